@@ -1,0 +1,134 @@
+/*
+ * adafortitran_amd.h -- C ABI of the MI355X (gfx950) AdaFortiTran forward path.
+ *
+ * The reference (BerkIGuler/AdaFortiTran) has no native layer: its boundary is the
+ * Python nn.Module surface in src/models/ (SURVEY.md 8b).  This header is the ABI
+ * that sits directly *below* that surface; each entry point names the reference
+ * interface it replaces.  The Python-side binding a maintainer adds is a ctypes
+ * stub (adafortitran_amd/_lib.py is that stub).
+ *
+ * Conventions
+ *   - plain C symbols, no C++/torch types; all tensors are raw DEVICE pointers owned
+ *     by the caller (PyTorch allocates inputs, outputs, weights and the workspace);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*, NULL =
+ *     default stream), never synchronises, allocates nothing, keeps no global state
+ *     (hipGraph-capturable); the caller's loss.item() is the sync point, as in
+ *     reference src/main/trainer.py:229,253,344;
+ *   - complex64 tensors are passed as float* to interleaved (re,im) pairs, i.e. the
+ *     memory of torch.view_as_real(x);
+ *   - return 0 on success; AFT_ERR_ARG / AFT_ERR_SHAPE -> the Python side raises
+ *     ValueError, AFT_ERR_HIP -> RuntimeError; aft_last_error() gives the text
+ *     (thread-local).
+ *   - inside the library a "plane" is one real-valued pass of the reference's
+ *     _forward_real_valued (fortitran.py:176-177): plane n = 2*frame + (0:Re | 1:Im).
+ */
+#ifndef ADAFORTITRAN_AMD_H
+#define ADAFORTITRAN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFT_ABI_VERSION 1
+#define AFT_MAX_LAYERS 32
+
+#define AFT_OK 0
+#define AFT_ERR_ARG 1   /* NULL pointer, bad batch, workspace too small ...          */
+#define AFT_ERR_SHAPE 2 /* configuration the kernels do not cover                    */
+#define AFT_ERR_HIP 3   /* a HIP runtime call or kernel launch failed                */
+
+#define AFT_ACT_RELU 0
+#define AFT_ACT_GELU 1 /* exact erf form, as activation="gelu" in encoders.py:44-51 */
+
+/* Shape of one estimator: system_config.yaml + model yaml
+ * (reference src/config/schemas.py:20-45,113-146; fortitran.py:52-81). */
+typedef struct aft_config {
+    int32_t num_scs, num_symbols;     /* OFDM grid S x T (120 x 14)                  */
+    int32_t pilot_scs, pilot_symbols; /* pilot grid (12 x 2)                         */
+    int32_t patch_scs, patch_symbols; /* patch (3 x 2): tokens = (S/p0)*(T/p1)       */
+    int32_t num_layers, model_dim, num_head;
+    int32_t activation;               /* AFT_ACT_*                                   */
+    int32_t adaptive;                 /* 1 = AdaFortiTran (adapter tokens), 0 = FortiTran */
+    int32_t hidden[3];                /* channel_adaptivity_hidden_sizes (adaptive only) */
+    int32_t reserved[2];
+} aft_config;
+
+/* One nn.TransformerEncoderLayer (post-LN), PyTorch layouts
+ * (reference blocks/encoders.py:44-55). */
+typedef struct aft_layer_weights {
+    const float *in_proj_w, *in_proj_b;   /* [3d,d] = [Wq;Wk;Wv], [3d]              */
+    const float *out_proj_w, *out_proj_b; /* [d,d], [d]                              */
+    const float *lin1_w, *lin1_b;         /* [2d,d], [2d]                            */
+    const float *lin2_w, *lin2_b;         /* [d,2d], [d]                             */
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b; /* [d] each                  */
+} aft_layer_weights;
+
+/* Every tensor of the reference state_dict, as device pointers to the tensors
+ * PyTorch already holds (no repacking, no ownership transfer). */
+typedef struct aft_weights {
+    const float *up_w, *up_b;        /* pilot_upsampler [S*T, Ps*Pt], [S*T]  (fortitran.py:86) */
+    const float *enh_w[4], *enh_b[4];/* initial_enhancer.conv_block.{0,2,4,6} (enhancers.py:12-20) */
+    const float *ref_w[4], *ref_b[4];/* final_refiner.conv_block.{0,2,4,6}                   */
+    const float *ada_w[3][3], *ada_b[3][3]; /* channel_adapter.{snr,ds,dop}_encoder.{0,2,4}
+                                               (channel_adaptivity.py:35-39); NULL if !adaptive */
+    const float *lin1_w, *lin1_b;    /* transformer_encoder.linear_1 [d, p(+6)], [d]          */
+    const float *pos;                /* positional table rows [>=tokens, d] (learnable or sinusoid) */
+    const float *lin2_w, *lin2_b;    /* transformer_encoder.linear_2 [p, d], [p]              */
+    aft_layer_weights layers[AFT_MAX_LAYERS];
+} aft_weights;
+
+int aft_version(void);
+const char *aft_last_error(void);
+
+/* Bytes of scratch aft_forward_f32 needs for `batch` frames (0 on a bad config). */
+size_t aft_workspace_bytes(const aft_config *cfg, int batch);
+
+/* Replaces BaseFortiTranEstimator.forward (reference src/models/fortitran.py:145-182):
+ * pilots complex64 [B,Ps,Pt] -> out complex64 [B,S,T].  snr/ds/dop are float32 [B]
+ * raw (un-normalised) channel conditions, NULL for FortiTran (meta_data[1..3],
+ * fortitran.py:166-170). */
+int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pilots,
+                    const float *snr, const float *ds, const float *dop, float *out,
+                    void *workspace, size_t workspace_bytes, int batch, void *stream);
+
+/* Replaces LinearEstimator.forward (reference src/models/linear.py:65-97), applied to
+ * the Re and Im planes separately: out[b,:,c] = W x[b,:,c] + bias. */
+int aft_linear_forward_f32(const float *weight, const float *bias, const float *pilots,
+                           float *out, int batch, int in_features, int out_features,
+                           void *stream);
+
+/* Replaces the metric of reference src/utils.py:164-180 + trainer.py:338-347:
+ * *sum_sq (device, float64) += sum |est-ref|^2 over n_complex complex elements.
+ * MSE = sum_sq / n_complex; dB = 10 log10 (utils.py:233-245). */
+int aft_mse_partial_f32(const float *est, const float *ref, double *sum_sq,
+                        long long n_complex, void *stream);
+
+/* ---- per-stage entry points (known-answer tests; same kernels as aft_forward_f32) ---- */
+
+/* S1+S2 (fortitran.py:203-209): pilots complex64 [B,Ps,Pt] -> conv_enhanced f32 [2B,S,T]. */
+int aft_stage_upsample_f32(const aft_config *cfg, const aft_weights *w, const float *pilots,
+                           float *conv_enhanced, int batch, void *stream);
+/* S4 (channel_adaptivity.py:59-63): snr/ds/dop [B] -> adapter tokens f32 [B,tokens,6]. */
+int aft_stage_adapter_f32(const aft_config *cfg, const aft_weights *w, const float *snr,
+                          const float *ds, const float *dop, float *tokens6, int batch,
+                          void *stream);
+/* S3+S4-concat+linear_1+pos (fortitran.py:212-217, encoders.py:67-68):
+ * conv_enhanced [2B,S,T] (+ tokens6 [B,tokens,6] or NULL) -> x f32 [2B*tokens, d]. */
+int aft_stage_embed_f32(const aft_config *cfg, const aft_weights *w, const float *conv_enhanced,
+                        const float *tokens6, float *x, int batch, void *stream);
+/* One nn.TransformerEncoderLayer in eval mode, in place on x [2B*tokens, d]
+ * (encoders.py:69).  `scratch` needs aft_workspace_bytes(cfg,batch) bytes. */
+int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int layer, float *x,
+                                void *scratch, size_t scratch_bytes, int batch, void *stream);
+/* linear_2 + S6 + S7 + S8 + complex recombination (encoders.py:70, fortitran.py:225-231,180):
+ * x [2B*tokens, d], conv_enhanced [2B,S,T] -> out complex64 [B,S,T]. */
+int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float *x,
+                       const float *conv_enhanced, float *out, int batch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAFORTITRAN_AMD_H */
