@@ -1,0 +1,74 @@
+"""ctypes binding of csrc/libaft_hip.so -- the stub a maintainer of the reference would add
+to call the C ABI of include/adafortitran_amd.h from Python.
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module
+raises, and every caller on a HIP device fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # imported first on purpose: binds libamdhip64.so.7 to the runtime torch already uses
+
+from . import _abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaft_hip.so")
+_lib = None
+
+
+class AftError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the library once and type its entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise AftError(
+            f"{_LIB_PATH} is missing: build it with `python -m adafortitran_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the HIP path.")
+    lib = C.CDLL(_LIB_PATH)
+    for name in _abi.EXPORTED_SYMBOLS:
+        if not hasattr(lib, name):
+            raise AftError(f"{_LIB_PATH} does not export {name}")
+    lib.aft_version.restype = C.c_int
+    lib.aft_last_error.restype = C.c_char_p
+    lib.aft_workspace_bytes.restype = C.c_size_t
+    lib.aft_workspace_bytes.argtypes = [C.POINTER(_abi.AftConfig), C.c_int]
+    vp, cfgp, wp = C.c_void_p, C.POINTER(_abi.AftConfig), C.POINTER(_abi.AftWeights)
+    lib.aft_forward_f32.argtypes = [cfgp, wp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
+    lib.aft_linear_forward_f32.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.aft_mse_partial_f32.argtypes = [vp, vp, vp, C.c_longlong, vp]
+    lib.aft_stage_upsample_f32.argtypes = [cfgp, wp, vp, vp, C.c_int, vp]
+    lib.aft_stage_adapter_f32.argtypes = [cfgp, wp, vp, vp, vp, vp, C.c_int, vp]
+    lib.aft_stage_embed_f32.argtypes = [cfgp, wp, vp, vp, vp, C.c_int, vp]
+    lib.aft_stage_encoder_layer_f32.argtypes = [cfgp, wp, C.c_int, vp, vp, C.c_size_t, C.c_int, vp]
+    lib.aft_stage_tail_f32.argtypes = [cfgp, wp, vp, vp, vp, C.c_int, vp]
+    for name in _abi.EXPORTED_SYMBOLS[3:]:
+        getattr(lib, name).restype = C.c_int
+    if lib.aft_version() != _abi.AFT_ABI_VERSION:
+        raise AftError(f"ABI mismatch: library {lib.aft_version()} vs binding {_abi.AFT_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """0 -> ok; argument/shape codes -> ValueError (the reference's convention for bad input,
+    fortitran.py:157-158, linear.py:79-83); HIP failures -> RuntimeError."""
+    if rc == _abi.AFT_OK:
+        return
+    msg = load().aft_last_error().decode(errors="replace")
+    if rc in (_abi.AFT_ERR_ARG, _abi.AFT_ERR_SHAPE):
+        raise ValueError(msg)
+    raise AftError(msg)
+
+
+def current_stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,147 @@
+"""Parameter containers + autograd (training) math of the estimator's building blocks.
+
+These nn.Modules exist for two reasons: (1) they own the parameters under exactly the
+reference's ``state_dict`` names, so checkpoints move both ways;
+(2) their ``forward`` is the differentiable PyTorch-ROCm path used under ``train()`` /
+autograd, where the forward-only HIP kernels do not apply (SURVEY.md 8b "Grad / mode").
+In ``eval()`` + ``no_grad()`` on a HIP device the estimator bypasses these forwards and
+calls the C ABI on the parameters' device pointers.
+
+Behavioural spec: reference src/models/blocks/{enhancers,patch_processors,
+channel_adaptivity,encoders,positional_encodings}.py.
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence, Tuple
+
+import torch
+from torch import nn
+
+
+class ConvEnhancer(nn.Module):
+    """3x3 conv stack 1->8->32->8->1 (ReLU between) under the key ``conv_block.{0,2,4,6}``
+    (reference blocks/enhancers.py:12-20)."""
+
+    WIDTHS = (1, 8, 32, 8, 1)
+
+    def __init__(self) -> None:
+        super().__init__()
+        layers = []
+        for i, (cin, cout) in enumerate(zip(self.WIDTHS[:-1], self.WIDTHS[1:])):
+            layers.append(nn.Conv2d(cin, cout, kernel_size=3, padding=1))
+            if i < len(self.WIDTHS) - 2:
+                layers.append(nn.ReLU())
+        self.conv_block = nn.Sequential(*layers)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.conv_block(x)
+
+
+class PatchEmbedding(nn.Module):
+    """[B,S,T] -> [B,tokens,p0*p1]; token = (sc//p0)*(T//p1) + sym//p1, feature =
+    (sc%p0)*p1 + sym%p1 (what nn.Unfold(kernel=stride=patch)+permute yields,
+    reference blocks/patch_processors.py:22,34-35) -- done here as a pure view/permute."""
+
+    def __init__(self, patch_size: Tuple[int, int] = (3, 2)) -> None:
+        super().__init__()
+        self.patch_size = tuple(patch_size)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        p0, p1 = self.patch_size
+        B, S, T = x.shape
+        return x.reshape(B, S // p0, p0, T // p1, p1).permute(0, 1, 3, 2, 4).reshape(B, (S // p0) * (T // p1), p0 * p1)
+
+
+class InversePatchEmbedding(nn.Module):
+    """Exact inverse of :class:`PatchEmbedding` (reference patch_processors.py:53-57,69-71:
+    non-overlapping Fold sums nothing)."""
+
+    def __init__(self, output_size: Tuple[int, int] = (120, 14), patch_size: Tuple[int, int] = (3, 2)) -> None:
+        super().__init__()
+        self.output_size = tuple(output_size)
+        self.patch_size = tuple(patch_size)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        (S, T), (p0, p1) = self.output_size, self.patch_size
+        B = x.shape[0]
+        return x.reshape(B, S // p0, T // p1, p0, p1).permute(0, 1, 3, 2, 4).reshape(B, S, T)
+
+
+class ChannelAdapter(nn.Module):
+    """Three MLPs (snr / ds / dop) 1->h0->h1->h2, ReLU between; each output viewed as
+    [B, h2/2, 2] and concatenated on the last axis -> [B, tokens, 6]
+    (reference blocks/channel_adaptivity.py:24-40,59-63)."""
+
+    def __init__(self, hidden_sizes: Sequence[int]) -> None:
+        super().__init__()
+        h0, h1, h2 = hidden_sizes
+
+        def mlp() -> nn.Sequential:
+            return nn.Sequential(nn.Linear(1, h0), nn.ReLU(), nn.Linear(h0, h1), nn.ReLU(), nn.Linear(h1, h2))
+
+        self.snr_encoder, self.ds_encoder, self.dop_encoder = mlp(), mlp(), mlp()
+
+    def forward(self, snr: torch.Tensor, delay_spread: torch.Tensor, doppler_shift: torch.Tensor) -> torch.Tensor:
+        B = snr.shape[0]
+        parts = [enc(v).reshape(B, -1, 2) for enc, v in ((self.snr_encoder, snr), (self.ds_encoder, delay_spread),
+                                                        (self.dop_encoder, doppler_shift))]
+        return torch.cat(parts, dim=2)
+
+
+class SinusoidalPositionalEncoding(nn.Module):
+    """Fixed table in buffer ``pe`` [1,max_len,d]: sin on even columns, cos on odd, base 1e4
+    (reference blocks/positional_encodings.py:5-38)."""
+
+    def __init__(self, max_len: int, d_model: int) -> None:
+        super().__init__()
+        pos = torch.arange(0, max_len).unsqueeze(1)
+        freq = torch.exp(torch.arange(0, d_model, 2) * (-torch.log(torch.tensor(10000.0)) / d_model))
+        table = torch.zeros(1, max_len, d_model)
+        table[0, :, 0::2] = torch.sin(pos * freq)
+        table[0, :, 1::2] = torch.cos(pos * freq)
+        self.register_buffer("pe", table)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x + self.pe[:, : x.size(1), :]
+
+
+class LearnablePositionalEncoding(nn.Module):
+    """Parameter ``position_embeddings`` [1,max_len,d], trunc-normal(std=0.02)
+    (reference blocks/positional_encodings.py:41-64)."""
+
+    def __init__(self, max_len: int, d_model: int) -> None:
+        super().__init__()
+        self.position_embeddings = nn.Parameter(torch.zeros(1, max_len, d_model))
+        nn.init.trunc_normal_(self.position_embeddings, std=0.02)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x + self.position_embeddings[:, : x.size(1), :]
+
+
+class TransformerEncoderForChannels(nn.Module):
+    """linear_1 -> + positional table -> L x post-LN encoder layers (FFN = 2d) -> linear_2
+    (reference blocks/encoders.py:7-70)."""
+
+    def __init__(self, input_dim: int, output_dim: int, model_dim: int = 128, num_head: int = 4,
+                 activation: str = "gelu", dropout: float = 0.1, num_layers: int = 3, max_len: int = 512,
+                 pos_encoding_type: str = "learnable") -> None:
+        super().__init__()
+        self.linear_1 = nn.Linear(input_dim, model_dim)
+        if pos_encoding_type == "learnable":
+            self.positional_encoding = LearnablePositionalEncoding(max_len, model_dim)
+        elif pos_encoding_type == "sinusoidal":
+            self.positional_encoding = SinusoidalPositionalEncoding(max_len, model_dim)
+        else:
+            raise ValueError("pos_encoding_type must be 'learnable' or 'sinusoidal'")
+        layer = nn.TransformerEncoderLayer(d_model=model_dim, nhead=num_head, dim_feedforward=2 * model_dim,
+                                           activation=activation, dropout=dropout, batch_first=True)
+        self.transformer = nn.TransformerEncoder(layer, num_layers=num_layers)
+        self.linear_2 = nn.Linear(model_dim, output_dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.linear_2(self.transformer(self.positional_encoding(self.linear_1(x))))
+
+
+__all__ = ["ChannelAdapter", "TransformerEncoderForChannels", "ConvEnhancer", "PatchEmbedding",
+           "InversePatchEmbedding", "SinusoidalPositionalEncoding", "LearnablePositionalEncoding"]

@@ -1,0 +1,48 @@
+"""Build the gfx950 shared library in-tree (adafortitran_amd/csrc/libaft_hip.so).
+
+    python -m adafortitran_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the built .so is git-ignored but
+travels with the tree to the GPU box.  gfx950 only: no other --offload-arch, no
+compatibility layers.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SOURCES = ("aft_api.hip", "k_chain.hip", "k_attn.hip", "k_conv.hip", "k_misc.hip")
+LIB = os.path.join(CSRC, "libaft_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _deps(src: str):
+    return [os.path.join(CSRC, src), os.path.join(CSRC, "aft_internal.h"),
+            os.path.join(CSRC, "..", "..", "include", "adafortitran_amd.h")]
+
+
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+    if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src)):
+        return obj
+    subprocess.run([HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj], check=True)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(lambda s: _compile(s, force), SOURCES))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
+                        "-Wl,-rpath,/opt/rocm/lib"], check=True)
+        if verbose:
+            print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

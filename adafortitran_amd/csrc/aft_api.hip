@@ -1,0 +1,237 @@
+// aft_api.hip -- the C ABI of include/adafortitran_amd.h: argument checking, workspace plan and
+// the launch sequence of one forward.  No allocation, no synchronisation, no global mutable state
+// besides a thread-local error string (hipGraph-capturable, re-entrant per stream).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "aft_internal.h"
+
+namespace aft {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int tokens_of(const aft_config &c) { return (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols); }
+
+int check_config(const aft_config *c) {
+    if (c == nullptr) {
+        set_error("aft_config is NULL");
+        return AFT_ERR_ARG;
+    }
+    if (c->num_scs <= 0 || c->num_symbols <= 0 || c->patch_scs <= 0 || c->patch_symbols <= 0 ||
+        c->num_scs % c->patch_scs || c->num_symbols % c->patch_symbols) {
+        set_error("OFDM grid %dx%d is not divisible by patch %dx%d", c->num_scs, c->num_symbols, c->patch_scs,
+                  c->patch_symbols);
+        return AFT_ERR_SHAPE;
+    }
+    if (c->pilot_scs <= 0 || c->pilot_symbols <= 0 || c->num_layers <= 0 || c->num_layers > AFT_MAX_LAYERS) {
+        set_error("bad pilot grid or layer count (layers=%d, max %d)", c->num_layers, AFT_MAX_LAYERS);
+        return AFT_ERR_SHAPE;
+    }
+    if (c->model_dim != 128 && c->model_dim != 256) {
+        set_error("model_dim %d not covered by the gfx950 kernels (128 or 256)", c->model_dim);
+        return AFT_ERR_SHAPE;
+    }
+    if (c->num_head <= 0 || c->model_dim % c->num_head || c->model_dim / c->num_head != kHeadDim) {
+        set_error("head dim must be %d (model_dim=%d, num_head=%d)", kHeadDim, c->model_dim, c->num_head);
+        return AFT_ERR_SHAPE;
+    }
+    if (c->num_scs % 4) {
+        set_error("num_scs=%d must be a multiple of 4 for the conv strips", c->num_scs);
+        return AFT_ERR_SHAPE;
+    }
+    if (c->activation != AFT_ACT_RELU && c->activation != AFT_ACT_GELU) {
+        set_error("unknown activation %d", c->activation);
+        return AFT_ERR_ARG;
+    }
+    if (c->adaptive && (c->hidden[0] <= 0 || c->hidden[1] <= 0 || c->hidden[2] != 2 * tokens_of(*c))) {
+        set_error("channel_adaptivity_hidden_sizes [%d,%d,%d]: last must be 2 x tokens (%d)", c->hidden[0],
+                  c->hidden[1], c->hidden[2], 2 * tokens_of(*c));
+        return AFT_ERR_SHAPE;
+    }
+    return AFT_OK;
+}
+
+static size_t align64(size_t floats) { return (floats + 63) / 64 * 64; }
+
+Workspace plan_workspace(const aft_config &c, int batch) {
+    Workspace ws{};
+    ws.tokens = tokens_of(c);
+    ws.tokpad = round_up(ws.tokens, kTile);
+    ws.planes = 2 * batch;
+    const size_t rows = (size_t)ws.planes * ws.tokens;
+    size_t off = 0;
+    ws.conv_enhanced = off; off += align64((size_t)ws.planes * c.num_scs * c.num_symbols);
+    ws.tokens6 = off;       off += align64((size_t)batch * ws.tokens * 6);
+    ws.x = off;             off += align64(rows * c.model_dim);
+    ws.attn = off;          off += align64(rows * c.model_dim);
+    const size_t per_head = (size_t)ws.planes * c.num_head * ws.tokpad * kHeadDim;
+    ws.q = off;             off += align64(per_head);
+    ws.k = off;             off += align64(per_head);
+    ws.vt = off;            off += align64(per_head);
+    ws.total_floats = off;
+    return ws;
+}
+
+static int hip_fail(const char *what, hipError_t e) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return AFT_ERR_HIP;
+}
+
+static int run_encoder(const aft_config &c, const aft_weights &w, const Workspace &ws, float *base, int first_layer,
+                       int last_layer, hipStream_t st) {
+    float *x = base + ws.x, *attn = base + ws.attn, *q = base + ws.q, *k = base + ws.k, *vt = base + ws.vt;
+    const int rows = ws.planes * ws.tokens;
+    hipError_t e;
+    // in-projection of the first layer (QKV-only pass of the chain kernel)
+    e = launch_chain(c, nullptr, &w.layers[first_layer], nullptr, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+    if (e != hipSuccess) return hip_fail("chain(qkv)", e);
+    for (int l = first_layer; l <= last_layer; ++l) {
+        e = launch_attention(c, q, k, vt, attn, ws.planes, ws.tokens, ws.tokpad, st);
+        if (e != hipSuccess) return hip_fail("attention", e);
+        const aft_layer_weights *next = l < last_layer ? &w.layers[l + 1] : nullptr;
+        e = launch_chain(c, &w.layers[l], next, attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+        if (e != hipSuccess) return hip_fail("chain(mlp)", e);
+    }
+    return AFT_OK;
+}
+
+}  // namespace aft
+
+using namespace aft;
+
+extern "C" {
+
+int aft_version(void) { return AFT_ABI_VERSION; }
+
+const char *aft_last_error(void) { return g_err; }
+
+size_t aft_workspace_bytes(const aft_config *cfg, int batch) {
+    if (check_config(cfg) != AFT_OK || batch <= 0) return 0;
+    return plan_workspace(*cfg, batch).total_floats * sizeof(float);
+}
+
+#define AFT_REQUIRE(cond, ...)        \
+    do {                              \
+        if (!(cond)) {                \
+            set_error(__VA_ARGS__);   \
+            return AFT_ERR_ARG;       \
+        }                             \
+    } while (0)
+
+int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pilots, const float *snr,
+                    const float *ds, const float *dop, float *out, void *workspace, size_t workspace_bytes,
+                    int batch, void *stream) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    AFT_REQUIRE(w && pilots && out && workspace, "NULL pointer argument");
+    AFT_REQUIRE(batch > 0, "batch must be positive (got %d)", batch);
+    // reference fortitran.py:157-158: meta_data is required when channel adaptation is enabled
+    AFT_REQUIRE(!cfg->adaptive || (snr && ds && dop), "meta_data is required when channel adaptation is enabled");
+    const Workspace ws = plan_workspace(*cfg, batch);
+    AFT_REQUIRE(workspace_bytes >= ws.total_floats * sizeof(float), "workspace too small: %zu < %zu bytes",
+                workspace_bytes, ws.total_floats * sizeof(float));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *base = static_cast<float *>(workspace);
+    hipError_t e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st);
+    if (e != hipSuccess) return hip_fail("upsample", e);
+    if (cfg->adaptive) {
+        e = launch_adapter(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, st);
+        if (e != hipSuccess) return hip_fail("adapter", e);
+    }
+    e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, base + ws.x,
+                     batch, st);
+    if (e != hipSuccess) return hip_fail("embed", e);
+    rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st);
+    if (rc != AFT_OK) return rc;
+    e = launch_tail(*cfg, *w, base + ws.x, base + ws.conv_enhanced, out, batch, st);
+    if (e != hipSuccess) return hip_fail("tail", e);
+    return AFT_OK;
+}
+
+int aft_linear_forward_f32(const float *weight, const float *bias, const float *pilots, float *out, int batch,
+                           int in_features, int out_features, void *stream) {
+    AFT_REQUIRE(weight && pilots && out, "NULL pointer argument");
+    AFT_REQUIRE(batch > 0 && in_features > 0 && out_features > 0, "bad sizes");
+    AFT_REQUIRE(in_features <= 8192, "in_features too large for the LDS-staged kernel");
+    hipError_t e = launch_linear(weight, bias, pilots, out, batch, in_features, out_features,
+                                 static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("linear", e);
+}
+
+int aft_mse_partial_f32(const float *est, const float *ref, double *sum_sq, long long n_complex, void *stream) {
+    AFT_REQUIRE(est && ref && sum_sq, "NULL pointer argument");
+    AFT_REQUIRE(n_complex >= 0, "negative element count");
+    if (n_complex == 0) return AFT_OK;
+    hipError_t e = launch_mse(est, ref, sum_sq, n_complex, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("mse", e);
+}
+
+int aft_stage_upsample_f32(const aft_config *cfg, const aft_weights *w, const float *pilots, float *conv_enhanced,
+                           int batch, void *stream) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    AFT_REQUIRE(w && pilots && conv_enhanced && batch > 0, "bad argument");
+    hipError_t e = launch_upsample(*cfg, *w, pilots, conv_enhanced, batch, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("upsample", e);
+}
+
+int aft_stage_adapter_f32(const aft_config *cfg, const aft_weights *w, const float *snr, const float *ds,
+                          const float *dop, float *tokens6, int batch, void *stream) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    AFT_REQUIRE(cfg->adaptive, "adapter stage needs an adaptive config");
+    AFT_REQUIRE(w && snr && ds && dop && tokens6 && batch > 0, "bad argument");
+    hipError_t e = launch_adapter(*cfg, *w, snr, ds, dop, tokens6, batch, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("adapter", e);
+}
+
+int aft_stage_embed_f32(const aft_config *cfg, const aft_weights *w, const float *conv_enhanced,
+                        const float *tokens6, float *x, int batch, void *stream) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    AFT_REQUIRE(w && conv_enhanced && x && batch > 0, "bad argument");
+    AFT_REQUIRE(!cfg->adaptive || tokens6, "adaptive config needs tokens6");
+    hipError_t e = launch_embed(*cfg, *w, conv_enhanced, tokens6, x, batch, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("embed", e);
+}
+
+int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int layer, float *x, void *scratch,
+                                size_t scratch_bytes, int batch, void *stream) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    AFT_REQUIRE(w && x && scratch && batch > 0, "bad argument");
+    AFT_REQUIRE(layer >= 0 && layer < cfg->num_layers, "layer %d out of range", layer);
+    Workspace ws = plan_workspace(*cfg, batch);
+    AFT_REQUIRE(scratch_bytes >= ws.total_floats * sizeof(float), "scratch too small");
+    // run on the caller's x: point the plan's x slot at it (offsets are relative to scratch)
+    float *base = static_cast<float *>(scratch);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = ws.planes * ws.tokens;
+    hipError_t e = launch_chain(*cfg, nullptr, &w->layers[layer], nullptr, x, base + ws.q, base + ws.k, base + ws.vt,
+                                rows, ws.tokens, ws.tokpad, st);
+    if (e != hipSuccess) return hip_fail("chain(qkv)", e);
+    e = launch_attention(*cfg, base + ws.q, base + ws.k, base + ws.vt, base + ws.attn, ws.planes, ws.tokens, ws.tokpad, st);
+    if (e != hipSuccess) return hip_fail("attention", e);
+    e = launch_chain(*cfg, &w->layers[layer], nullptr, base + ws.attn, x, nullptr, nullptr, nullptr, rows, ws.tokens,
+                     ws.tokpad, st);
+    return e == hipSuccess ? AFT_OK : hip_fail("chain(mlp)", e);
+}
+
+int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float *x, const float *conv_enhanced,
+                       float *out, int batch, void *stream) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    AFT_REQUIRE(w && x && conv_enhanced && out && batch > 0, "bad argument");
+    hipError_t e = launch_tail(*cfg, *w, x, conv_enhanced, out, batch, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("tail", e);
+}
+
+}  // extern "C"

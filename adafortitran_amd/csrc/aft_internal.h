@@ -1,0 +1,61 @@
+// Internal declarations shared by the gfx950 kernels and the C-ABI (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/adafortitran_amd.h"
+
+namespace aft {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kWave = 64;       // CDNA4 wavefront
+constexpr int kHeadDim = 32;    // model_dim / num_head for every config the kernels cover
+constexpr int kTile = 32;       // v_mfma_f32_32x32x2_f32 tile edge
+
+inline __host__ __device__ int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Device-resident scratch of one forward call; all offsets in floats, 256-B aligned.
+// Layout in HBM (DESIGN.md "data layout"):
+//   conv_enhanced [2B][S][T]            f32  kept for the S7 residual
+//   tokens6       [B][tokens][6]        f32  adapter features (adaptive only)
+//   x             [2B*tokens][d]        f32  token activations, row-major
+//   attn          [2B*tokens][d]        f32  attention output (heads concatenated)
+//   q, k          [2B][H][tokpad][32]   f32  per-head row-major, tokpad = tokens rounded to 32
+//   vt            [2B][H][32][tokpad]   f32  per-head V transposed (key index contiguous)
+struct Workspace {
+    size_t conv_enhanced, tokens6, x, attn, q, k, vt, total_floats;
+    int tokens, tokpad, planes;
+};
+
+Workspace plan_workspace(const aft_config &c, int batch);
+
+// error plumbing (thread-local message, see aft_api.hip)
+void set_error(const char *fmt, ...);
+int check_config(const aft_config *c);
+
+// ---- kernel launchers (each enqueues on `st`, returns hipError_t of the launch) ----
+hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots,
+                           float *conv_enhanced, int batch, hipStream_t st);
+hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
+                          const float *dop, float *tokens6, int batch, hipStream_t st);
+hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced,
+                        const float *tokens6, float *x, int batch, hipStream_t st);
+// Row-local chain on [rows, d]: (mlp) x <- LN2(x1 + FFN(x1)), x1 = LN1(x + attn Wo^T + bo);
+// (qkv) q,k,vt <- split(x Wqkv^T + b).  `mlp_w` may be NULL (QKV only), `qkv_w` may be NULL.
+hipError_t launch_chain(const aft_config &c, const aft_layer_weights *mlp_w, const aft_layer_weights *qkv_w,
+                        const float *attn, float *x, float *q, float *k, float *vt, int rows, int tokens,
+                        int tokpad, hipStream_t st);
+hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, float *attn,
+                            int planes, int tokens, int tokpad, hipStream_t st);
+hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
+                       float *out, int batch, hipStream_t st);
+hipError_t launch_linear(const float *weight, const float *bias, const float *pilots, float *out, int batch,
+                         int in_features, int out_features, hipStream_t st);
+hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long long n_complex, hipStream_t st);
+
+}  // namespace aft

@@ -1,0 +1,194 @@
+// k_misc.hip -- the small VALU stages: channel adapter, patch embedding + linear_1 + positional
+// table, the LinearEstimator, and the MSE metric.  None of them is MFMA-shaped (K = 1..42, 12, 24).
+#include "aft_internal.h"
+
+namespace aft {
+
+// ---------------------------------------------------------------------------------------------
+// ChannelAdapter (reference src/models/blocks/channel_adaptivity.py:24-40,59-63): three MLPs
+// Linear(1,h0)-ReLU-Linear(h0,h1)-ReLU-Linear(h1,h2) on the RAW snr / delay-spread / doppler
+// scalars; output element k of encoder e goes to token k/2, feature 2e + k%2.  Computed once per
+// frame (the reference recomputes it for the Re and Im pass with identical results).
+// grid = (B, 3 encoders), block = 256.
+// ---------------------------------------------------------------------------------------------
+struct AdapterArgs {
+    const float *cond[3];
+    const float *w[3][3], *b[3][3];
+    float *tokens6;
+    int h0, h1, h2, tokens;
+};
+
+__global__ __launch_bounds__(256) void adapter_kernel(const AdapterArgs a) {
+    extern __shared__ float sm[];
+    float *a0 = sm, *a1 = sm + a.h0;
+    const int b = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+    const float x = a.cond[e][b];
+    for (int i = tid; i < a.h0; i += 256) a0[i] = fmaxf(fmaf(a.w[e][0][i], x, a.b[e][0][i]), 0.f);
+    __syncthreads();
+    for (int i = tid; i < a.h1; i += 256) {
+        float acc = a.b[e][1][i];
+        for (int k = 0; k < a.h0; ++k) acc = fmaf(a.w[e][1][i * a.h0 + k], a0[k], acc);
+        a1[i] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int i = tid; i < a.h2; i += 256) {
+        float acc = a.b[e][2][i];
+        const float *wr = a.w[e][2] + (size_t)i * a.h1;
+        for (int k = 0; k < a.h1; ++k) acc = fmaf(wr[k], a1[k], acc);
+        a.tokens6[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)] = acc;
+    }
+}
+
+hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
+                          const float *dop, float *tokens6, int batch, hipStream_t st) {
+    AdapterArgs a{};
+    a.cond[0] = snr; a.cond[1] = ds; a.cond[2] = dop;
+    for (int e = 0; e < 3; ++e)
+        for (int j = 0; j < 3; ++j) { a.w[e][j] = w.ada_w[e][j]; a.b[e][j] = w.ada_b[e][j]; }
+    a.tokens6 = tokens6;
+    a.h0 = c.hidden[0]; a.h1 = c.hidden[1]; a.h2 = c.hidden[2];
+    a.tokens = (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols);
+    hipLaunchKernelGGL(adapter_kernel, dim3(batch, 3), dim3(256), sizeof(float) * (a.h0 + a.h1), st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// S3 + S4-concat + linear_1 + positional table (reference fortitran.py:212-217, encoders.py:67-68,
+// patch_processors.py:22,34-35, positional_encodings.py:38,64):
+//   x[n, t, :] = W1 [patch(n,t) ; tokens6(frame,t)] + b1 + pos[t, :]
+// The patch gather is pure addressing: feature f of token t is grid element
+// (sc, sym) = ((t / tw)*p0 + f / p1, (t % tw)*p1 + f % p1).
+// block = 256 threads = 8 tokens x 32 lanes; each lane produces d/32 consecutive outputs.
+// ---------------------------------------------------------------------------------------------
+struct EmbedArgs {
+    const float *conv_enhanced, *tokens6, *w1, *b1, *pos;
+    float *x;
+    int S, T, p0, p1, tokens, d, din, planes;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
+    extern __shared__ float sm[];  // W1 transposed [din][D]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.din * D; i += 256) sm[(i % a.din) * D + i / a.din] = a.w1[i];
+    __syncthreads();
+    constexpr int PER = D / 32;
+    const int tl = tid >> 5, lane32 = tid & 31;
+    const long row = (long)blockIdx.x * 8 + tl;
+    if (row >= (long)a.planes * a.tokens) return;
+    const int n = (int)(row / a.tokens), t = (int)(row % a.tokens);
+    const int tw = a.T / a.p1, p = a.p0 * a.p1;
+    float acc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) acc[i] = a.b1[lane32 * PER + i] + a.pos[(size_t)t * D + lane32 * PER + i];
+    for (int f = 0; f < a.din; ++f) {
+        float v;
+        if (f < p) {
+            const int sc = (t / tw) * a.p0 + f / a.p1, sym = (t % tw) * a.p1 + f % a.p1;
+            v = a.conv_enhanced[((size_t)n * a.S + sc) * a.T + sym];
+        } else {
+            v = a.tokens6[((size_t)(n >> 1) * a.tokens + t) * 6 + (f - p)];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) acc[i] = fmaf(sm[f * D + lane32 * PER + i], v, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) a.x[row * D + lane32 * PER + i] = acc[i];
+}
+
+hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced, const float *tokens6,
+                        float *x, int batch, hipStream_t st) {
+    EmbedArgs a{};
+    a.conv_enhanced = conv_enhanced; a.tokens6 = tokens6;
+    a.w1 = w.lin1_w; a.b1 = w.lin1_b; a.pos = w.pos; a.x = x;
+    a.S = c.num_scs; a.T = c.num_symbols; a.p0 = c.patch_scs; a.p1 = c.patch_symbols;
+    a.tokens = (a.S / a.p0) * (a.T / a.p1);
+    a.d = c.model_dim;
+    a.din = a.p0 * a.p1 + (c.adaptive ? 6 : 0);
+    a.planes = 2 * batch;
+    const long rows = (long)a.planes * a.tokens;
+    const int blocks = (int)((rows + 7) / 8);
+    const size_t lds = sizeof(float) * a.din * a.d;
+    if (c.model_dim == 128)
+        hipLaunchKernelGGL((embed_kernel<128>), dim3(blocks), dim3(256), lds, st, a);
+    else if (c.model_dim == 256)
+        hipLaunchKernelGGL((embed_kernel<256>), dim3(blocks), dim3(256), lds, st, a);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LinearEstimator (reference src/models/linear.py:65-97) applied plane-wise to complex pilots:
+// out[b, o, c] = sum_k W[o, k] x[b, k, c] + bias[o]  for c in {Re, Im}.
+// one thread per complex output element; x row staged in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                     const float *__restrict__ pilots, float *__restrict__ out,
+                                                     int in_f, int out_f) {
+    extern __shared__ float sm[];  // [in_f][2]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * in_f; i += 256) sm[i] = pilots[(size_t)b * 2 * in_f + i];
+    __syncthreads();
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= out_f) return;
+    const float bv = bias != nullptr ? bias[o] : 0.f;
+    float re = bv, im = bv;
+    const float *wr = w + (size_t)o * in_f;
+    for (int k = 0; k < in_f; ++k) {
+        re = fmaf(wr[k], sm[2 * k], re);
+        im = fmaf(wr[k], sm[2 * k + 1], im);
+    }
+    *reinterpret_cast<float2 *>(out + ((size_t)b * out_f + o) * 2) = make_float2(re, im);
+}
+
+hipError_t launch_linear(const float *weight, const float *bias, const float *pilots, float *out, int batch,
+                         int in_features, int out_features, hipStream_t st) {
+    hipLaunchKernelGGL(linear_kernel, dim3((out_features + 255) / 256, batch), dim3(256),
+                       sizeof(float) * 2 * in_features, st, weight, bias, pilots, out, in_features, out_features);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Metric (reference src/utils.py:164-180 + src/main/trainer.py:338-347): 2*MSELoss(cat(Re,Im))
+// == mean over complex elements of |est - ref|^2.  This kernel accumulates the SUM in float64
+// (one atomic per workgroup); the caller divides by the element count (and all-gathers across
+// ranks).  HBM-bound: 16 B per complex element, float4 loads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float *__restrict__ est, const float *__restrict__ ref,
+                                                  double *sum_sq, long long n_floats) {
+    double acc = 0.0;
+    const long long n4 = n_floats / 4;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 e = reinterpret_cast<const f32x4 *>(est)[i];
+        const f32x4 r = reinterpret_cast<const f32x4 *>(ref)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dlt = e[j] - r[j];
+            acc += (double)dlt * (double)dlt;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (long long i = n4 * 4 + threadIdx.x; i < n_floats; i += 256) {
+            const float dlt = est[i] - ref[i];
+            acc += (double)dlt * (double)dlt;
+        }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum_sq, part[0] + part[1] + part[2] + part[3]);
+}
+
+hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long long n_complex, hipStream_t st) {
+    const long long n_floats = 2 * n_complex;
+    long long blocks = (n_floats / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mse_kernel, dim3((int)blocks), dim3(256), 0, st, est, ref, sum_sq, n_floats);
+    return hipGetLastError();
+}
+
+}  // namespace aft

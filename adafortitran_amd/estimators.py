@@ -1,0 +1,219 @@
+"""Drop-in estimators: the reference's ``src/models`` module surface over the gfx950 C ABI.
+
+Kept byte-compatible with the reference where callers can see it:
+constructor ``(system_config, model_config)``, ``forward(pilot_symbols, meta_data=None)``,
+``get_model_info()`` keys, public attributes, ``state_dict`` keys/shapes, class identities
+(``AdaFortiTranEstimator`` is the trainer's dispatch key, reference trainer.py:185-193),
+exceptions (``ValueError`` for missing meta / bad shapes).
+
+Execution paths of ``forward``:
+  * HIP device, ``eval()`` and autograd off, float32 parameters  ->  ONE call into
+    ``aft_forward_f32`` (hand-written HIP).  A missing/failed extension RAISES here; there
+    is no silent PyTorch fallback for this case.
+  * ``train()`` or autograd on (the reference trainer's ``train_epoch``), CPU device, or
+    non-fp32 parameters -> the differentiable PyTorch composite in blocks.py.  This is the
+    autograd path, not a fallback: the HIP kernels are forward-only.
+"""
+from __future__ import annotations
+
+import logging
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _abi
+from .blocks import (ChannelAdapter, ConvEnhancer, InversePatchEmbedding, PatchEmbedding,
+                     TransformerEncoderForChannels)
+from .config import ModelConfig, SystemConfig, check_shape_coupling
+
+
+class BaseFortiTranEstimator(nn.Module):
+    """Pilot grid -> full OFDM grid estimator (reference src/models/fortitran.py:10-250)."""
+
+    def __init__(self, system_config: SystemConfig, model_config: ModelConfig,
+                 use_channel_adaptation: bool = False) -> None:
+        super().__init__()
+        self.system_config = system_config
+        self.model_config = model_config
+        self.use_channel_adaptation = use_channel_adaptation
+        self.device = torch.device(model_config.device)
+        self.logger = logging.getLogger(self.__class__.__name__)
+        self._engine = None
+        self._setup_dimensions()
+        self._build_architecture()
+        self.to(self.device)
+        self._log_initialization_info()
+
+    # ---- construction (fortitran.py:52-126) -------------------------------------------------
+    def _setup_dimensions(self) -> None:
+        sc, mc = self.system_config, self.model_config
+        self.ofdm_size = (sc.ofdm.num_scs, sc.ofdm.num_symbols)
+        self.pilot_size = (sc.pilot.num_scs, sc.pilot.num_symbols)
+        self.pilot_features = self.pilot_size[0] * self.pilot_size[1]
+        self.ofdm_features = self.ofdm_size[0] * self.ofdm_size[1]
+        self.patch_length = mc.patch_size[0] * mc.patch_size[1]
+        self.transformer_input_dim = self.patch_length
+        if self.use_channel_adaptation:
+            if mc.adaptive_token_length is None:
+                raise ValueError("adaptive_token_length must be set when channel adaptation is enabled")
+            if mc.channel_adaptivity_hidden_sizes is None:
+                raise ValueError("channel_adaptivity_hidden_sizes must be set when channel adaptation is enabled")
+            if len(mc.channel_adaptivity_hidden_sizes) != 3:
+                raise ValueError("channel_adaptivity_hidden_sizes must have exactly 3 values")
+            self.transformer_input_dim += mc.adaptive_token_length
+        check_shape_coupling(sc, mc, self.use_channel_adaptation)
+
+    def _build_architecture(self) -> None:
+        mc = self.model_config
+        self.pilot_upsampler = nn.Linear(self.pilot_features, self.ofdm_features)
+        self.initial_enhancer = ConvEnhancer()
+        self.patch_embedder = PatchEmbedding(tuple(mc.patch_size))
+        if self.use_channel_adaptation:
+            self.channel_adapter = ChannelAdapter(tuple(mc.channel_adaptivity_hidden_sizes))
+        self.transformer_encoder = TransformerEncoderForChannels(
+            input_dim=self.transformer_input_dim, output_dim=self.patch_length, model_dim=mc.model_dim,
+            num_head=mc.num_head, activation=mc.activation, dropout=mc.dropout, num_layers=mc.num_layers,
+            max_len=mc.max_seq_len, pos_encoding_type=mc.pos_encoding_type)
+        self.patch_reconstructor = InversePatchEmbedding(self.ofdm_size, tuple(mc.patch_size))
+        self.final_refiner = ConvEnhancer()
+
+    def _log_initialization_info(self) -> None:
+        info = self.get_model_info()
+        self.logger.info("%s initialized: adaptation=%s ofdm=%s pilots=%s patch=%s d=%s layers=%s device=%s "
+                         "params=%s trainable=%s", info["model_name"], info["channel_adaptation"], info["ofdm_size"],
+                         info["pilot_size"], info["patch_size"], info["model_dim"], info["num_layers"],
+                         info["device"], f"{info['total_parameters']:,}", f"{info['trainable_parameters']:,}")
+
+    # ---- engine management ------------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):  # .to()/.cuda()/.float() re-allocate parameters
+        self._engine = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._engine = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _hip_eligible(self) -> bool:
+        if self.training or torch.is_grad_enabled():
+            return False
+        p = self.pilot_upsampler.weight
+        return p.device.type == "cuda" and all(q.dtype == torch.float32 for q in self.parameters())
+
+    def _hip_engine(self):
+        from .hip_ops import HipEngine  # raises loudly if the extension is missing
+        tensors = {k: v for k, v in self.state_dict(keep_vars=True).items()}
+        for k, v in tensors.items():
+            if not v.is_contiguous():
+                raise ValueError(f"parameter {k} is not contiguous")
+        eng = self._engine
+        if eng is None or eng.signature() != tuple(v.data_ptr() for v in tensors.values() if v.is_floating_point()):
+            cfg = _abi.config_from_pydantic(self.system_config, self.model_config, self.use_channel_adaptation)
+            eng = HipEngine(cfg, {k: v.detach() for k, v in tensors.items()})
+            self._engine = eng
+        return eng
+
+    # ---- forward (fortitran.py:145-233) -----------------------------------------------------
+    def forward(self, pilot_symbols: torch.Tensor, meta_data: Optional[Tuple] = None) -> torch.Tensor:
+        if self.use_channel_adaptation and meta_data is None:
+            raise ValueError("meta_data is required when channel adaptation is enabled")
+        if not self.use_channel_adaptation and meta_data is not None:
+            self.logger.warning("meta_data provided but channel adaptation is disabled - ignoring meta_data")
+        conditions: Optional[List[torch.Tensor]] = None
+        if self.use_channel_adaptation:
+            _, snr, delay_spread, max_dop_shift, _, _ = meta_data
+            conditions = [t.to(self.device) for t in (snr, delay_spread, max_dop_shift)]
+        pilot_symbols = pilot_symbols.to(self.device)  # the model owns the H2D copy (fortitran.py:173)
+
+        if self._hip_eligible():
+            eng = self._hip_engine()
+            if conditions is None:
+                return eng.forward(pilot_symbols)
+            return eng.forward(pilot_symbols, *conditions)
+
+        real = self._forward_real_valued(pilot_symbols.real, conditions)
+        imag = self._forward_real_valued(pilot_symbols.imag, conditions)
+        return torch.complex(real, imag)
+
+    def _forward_real_valued(self, x: torch.Tensor, channel_conditions: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        """Differentiable composite of stages S1-S8 on one real plane batch [B,Ps,Pt]."""
+        B = x.shape[0]
+        grid = self.pilot_upsampler(x.reshape(B, -1)).view(B, 1, *self.ofdm_size)
+        conv_enhanced = self.initial_enhancer(grid).squeeze(1)
+        tokens = self.patch_embedder(conv_enhanced)
+        if self.use_channel_adaptation and channel_conditions is not None:
+            tokens = torch.cat((tokens, self.channel_adapter(*channel_conditions)), dim=2)
+        encoded = self.transformer_encoder(tokens)
+        combined = conv_enhanced + self.patch_reconstructor(encoded)
+        return self.final_refiner(combined.unsqueeze(1)).squeeze(1)
+
+    def get_model_info(self) -> dict:
+        mc = self.model_config
+        return {
+            "model_name": self.__class__.__name__,
+            "channel_adaptation": self.use_channel_adaptation,
+            "ofdm_size": self.ofdm_size,
+            "pilot_size": self.pilot_size,
+            "patch_size": mc.patch_size,
+            "patch_length": self.patch_length,
+            "transformer_input_dim": self.transformer_input_dim,
+            "model_dim": mc.model_dim,
+            "num_layers": mc.num_layers,
+            "device": str(self.device),
+            "total_parameters": sum(p.numel() for p in self.parameters()),
+            "trainable_parameters": sum(p.numel() for p in self.parameters() if p.requires_grad),
+        }
+
+
+class FortiTranEstimator(BaseFortiTranEstimator):
+    """No channel adaptation (reference src/models/fortitran.py:253-268)."""
+
+    def __init__(self, system_config: SystemConfig, model_config: ModelConfig) -> None:
+        super().__init__(system_config, model_config, use_channel_adaptation=False)
+
+
+class AdaFortiTranEstimator(BaseFortiTranEstimator):
+    """Adaptive tokens from SNR / delay spread / Doppler (reference src/models/adafortitran.py:5-22)."""
+
+    def __init__(self, system_config: SystemConfig, model_config: ModelConfig) -> None:
+        super().__init__(system_config, model_config, use_channel_adaptation=True)
+
+
+class LinearEstimator(nn.Module):
+    """Learned linear map pilots -> grid (reference src/models/linear.py:15-106).
+
+    The reference's real ``nn.Linear`` raises on the complex64 input its own dataset
+    produces.  This estimator accepts what the reference accepts (real
+    [B,Ps,Pt]) and additionally complex64, applying the real map to Re and Im separately
+    -- the only reading consistent with fortitran.py:176-180."""
+
+    def __init__(self, system_config: SystemConfig, model_config: ModelConfig) -> None:
+        super().__init__()
+        self.system_config = system_config
+        self.model_config = model_config
+        self.device = torch.device(model_config.device)
+        self.logger = logging.getLogger(__name__)
+        self.ofdm_size = (system_config.ofdm.num_scs, system_config.ofdm.num_symbols)
+        self.pilot_size = (system_config.pilot.num_scs, system_config.pilot.num_symbols)
+        self.linear = nn.Linear(self.pilot_size[0] * self.pilot_size[1], self.ofdm_size[0] * self.ofdm_size[1])
+        self.to(self.device)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        expected = (x.size(0), self.pilot_size[0], self.pilot_size[1])
+        if tuple(x.size()) != expected:
+            raise ValueError(f"Expected input shape {expected}, got {x.size()}")
+        x = x.to(self.device)
+        if x.is_complex():
+            w = self.linear.weight
+            if (w.device.type == "cuda" and not torch.is_grad_enabled() and x.dtype == torch.complex64
+                    and w.dtype == torch.float32):
+                from .hip_ops import linear_forward
+                return linear_forward(w.detach(), self.linear.bias.detach(), x, self.ofdm_size)
+            return torch.complex(self._plane(x.real), self._plane(x.imag))
+        return self._plane(x)
+
+    def _plane(self, x: torch.Tensor) -> torch.Tensor:
+        return self.linear(torch.flatten(x, start_dim=1)).reshape(-1, *self.ofdm_size)
+
+    def __repr__(self) -> str:
+        return f"LinearEstimator(\n  ofdm_size={self.ofdm_size},\n  pilot_size={self.pilot_size},\n  device={self.device}\n)"

@@ -1,0 +1,171 @@
+"""Thin Python layer over the C ABI: pointer tables from torch tensors, workspace cache,
+per-stage calls.  PyTorch is plumbing here (device memory + streams); the arithmetic is in
+csrc/*.hip.  Nothing in this module falls back to PyTorch math.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _abi, _lib
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dev_f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipEngine:
+    """Owns an ``aft_config``, the weight pointer table and a workspace for one model.
+
+    ``tensors`` maps reference ``state_dict`` keys to float32 CUDA
+    tensors; the engine keeps references so the device pointers stay valid.
+    """
+
+    def __init__(self, cfg: _abi.AftConfig, tensors: Dict[str, torch.Tensor]):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = next(iter(tensors.values())).device
+        if self.device.type != "cuda":
+            raise ValueError("HipEngine needs tensors on a HIP ('cuda') device")
+        self._keep = {}
+        for k, v in tensors.items():
+            if not v.is_floating_point():
+                continue
+            if v.dtype != torch.float32 or not v.is_contiguous():
+                raise ValueError(f"{k}: HIP path needs contiguous float32 (got {v.dtype})")
+            self._keep[k] = v
+        self.weights = _abi.make_weights(cfg, lambda k: self._keep[k].data_ptr(), pos_key=_abi.pos_key_of(self._keep))
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = 0
+
+    # -- helpers ---------------------------------------------------------------------------
+    @property
+    def tokens(self) -> int:
+        return self.cfg.tokens
+
+    def signature(self):
+        return tuple(v.data_ptr() for v in self._keep.values())
+
+    def workspace(self, batch: int) -> torch.Tensor:
+        if self._ws is None or batch > self._ws_batch:
+            nbytes = self.lib.aft_workspace_bytes(C.byref(self.cfg), batch)
+            if nbytes == 0:
+                _lib.check(self.lib.aft_forward_f32(C.byref(self.cfg), None, None, None, None, None, None, None, 0, batch, None))
+                raise ValueError("unsupported configuration")
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+        return self._ws
+
+    def _stream(self) -> int:
+        return _lib.current_stream_ptr(self.device)
+
+    # -- full forward ----------------------------------------------------------------------
+    def forward(self, pilots: torch.Tensor, snr=None, ds=None, dop=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """pilots complex64 [B,Ps,Pt] on the device -> complex64 [B,S,T] (same device, async)."""
+        c = self.cfg
+        if pilots.dtype != torch.complex64:
+            raise ValueError(f"pilot_symbols must be complex64, got {pilots.dtype}")
+        if pilots.dim() != 3 or pilots.shape[1] * pilots.shape[2] != c.pilot_scs * c.pilot_symbols:
+            raise ValueError(f"Expected pilot shape (B, {c.pilot_scs}, {c.pilot_symbols}), got {tuple(pilots.shape)}")
+        B = pilots.shape[0]
+        pil = torch.view_as_real(pilots.contiguous())
+        metas = [None, None, None]
+        if c.adaptive:
+            if snr is None or ds is None or dop is None:
+                raise ValueError("meta_data is required when channel adaptation is enabled")
+            metas = [_dev_f32(m.reshape(-1), self.device) for m in (snr, ds, dop)]
+            if any(m.numel() != B for m in metas):
+                raise ValueError("meta_data tensors must have one value per frame")
+        if out is None:
+            out = torch.empty((B, c.num_scs, c.num_symbols), dtype=torch.complex64, device=self.device)
+        ws = self.workspace(B)
+        rc = self.lib.aft_forward_f32(C.byref(c), C.byref(self.weights), pil.data_ptr(), _ptr(metas[0]), _ptr(metas[1]),
+                                      _ptr(metas[2]), torch.view_as_real(out).data_ptr(), ws.data_ptr(), ws.numel(),
+                                      B, self._stream())
+        _lib.check(rc)
+        return out
+
+    # -- per-stage entry points (tests) ----------------------------------------------------
+    def stage_upsample(self, pilots: torch.Tensor) -> torch.Tensor:
+        B = pilots.shape[0]
+        out = torch.empty((2 * B, self.cfg.num_scs, self.cfg.num_symbols), dtype=torch.float32, device=self.device)
+        pil = torch.view_as_real(pilots.contiguous())
+        _lib.check(self.lib.aft_stage_upsample_f32(C.byref(self.cfg), C.byref(self.weights), pil.data_ptr(),
+                                                   out.data_ptr(), B, self._stream()))
+        return out
+
+    def stage_adapter(self, snr, ds, dop) -> torch.Tensor:
+        m = [_dev_f32(t.reshape(-1), self.device) for t in (snr, ds, dop)]
+        B = m[0].numel()
+        out = torch.empty((B, self.tokens, 6), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.aft_stage_adapter_f32(C.byref(self.cfg), C.byref(self.weights), m[0].data_ptr(),
+                                                  m[1].data_ptr(), m[2].data_ptr(), out.data_ptr(), B, self._stream()))
+        return out
+
+    def stage_embed(self, conv_enhanced: torch.Tensor, tokens6: Optional[torch.Tensor]) -> torch.Tensor:
+        B = conv_enhanced.shape[0] // 2
+        x = torch.empty((2 * B, self.tokens, self.cfg.model_dim), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.aft_stage_embed_f32(C.byref(self.cfg), C.byref(self.weights), conv_enhanced.data_ptr(),
+                                                _ptr(tokens6), x.data_ptr(), B, self._stream()))
+        return x
+
+    def stage_encoder_layer(self, layer: int, x: torch.Tensor) -> torch.Tensor:
+        """x float32 [2B, tokens, d] -> new tensor, one post-LN encoder layer."""
+        y = x.contiguous().clone()
+        B = y.shape[0] // 2
+        ws = self.workspace(B)
+        _lib.check(self.lib.aft_stage_encoder_layer_f32(C.byref(self.cfg), C.byref(self.weights), layer, y.data_ptr(),
+                                                        ws.data_ptr(), ws.numel(), B, self._stream()))
+        return y
+
+    def stage_tail(self, x: torch.Tensor, conv_enhanced: torch.Tensor) -> torch.Tensor:
+        B = conv_enhanced.shape[0] // 2
+        out = torch.empty((B, self.cfg.num_scs, self.cfg.num_symbols), dtype=torch.complex64, device=self.device)
+        _lib.check(self.lib.aft_stage_tail_f32(C.byref(self.cfg), C.byref(self.weights), x.contiguous().data_ptr(),
+                                               conv_enhanced.contiguous().data_ptr(),
+                                               torch.view_as_real(out).data_ptr(), B, self._stream()))
+        return out
+
+
+def engine_from_numpy(cfg: _abi.AftConfig, state: Dict[str, np.ndarray], device="cuda:0") -> HipEngine:
+    """Upload a numpy state_dict (e.g. from ``synth.make_state_dict``) and build an engine."""
+    dev = torch.device(device)
+    tensors = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in state.items()}
+    return HipEngine(cfg, tensors)
+
+
+def linear_forward(weight: torch.Tensor, bias: Optional[torch.Tensor], pilots: torch.Tensor, ofdm_size) -> torch.Tensor:
+    """LinearEstimator on the HIP device, plane-wise on complex64 pilots [B,Ps,Pt]."""
+    lib = _lib.load()
+    if pilots.dtype != torch.complex64:
+        raise ValueError("pilots must be complex64")
+    B = pilots.shape[0]
+    out_f, in_f = weight.shape
+    if pilots[0].numel() != in_f or ofdm_size[0] * ofdm_size[1] != out_f:
+        raise ValueError("shape mismatch between pilots / weight / ofdm_size")
+    pil = torch.view_as_real(pilots.contiguous())
+    out = torch.empty((B, ofdm_size[0], ofdm_size[1]), dtype=torch.complex64, device=pilots.device)
+    _lib.check(lib.aft_linear_forward_f32(weight.contiguous().data_ptr(), _ptr(bias), pil.data_ptr(),
+                                          torch.view_as_real(out).data_ptr(), B, in_f, out_f,
+                                          _lib.current_stream_ptr(pilots.device)))
+    return out
+
+
+def mse_sum(est: torch.Tensor, ref: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Accumulate sum |est-ref|^2 (float64 device scalar) without a host sync."""
+    lib = _lib.load()
+    if est.dtype != torch.complex64 or ref.dtype != torch.complex64 or est.shape != ref.shape:
+        raise ValueError("est/ref must be complex64 tensors of equal shape")
+    if acc is None:
+        acc = torch.zeros(1, dtype=torch.float64, device=est.device)
+    e, r = torch.view_as_real(est.contiguous()), torch.view_as_real(ref.contiguous())
+    _lib.check(lib.aft_mse_partial_f32(e.data_ptr(), r.data_ptr(), acc.data_ptr(), est.numel(),
+                                       _lib.current_stream_ptr(est.device)))
+    return acc

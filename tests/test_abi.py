@@ -1,0 +1,58 @@
+"""The C-ABI library loads and exports every symbol include/adafortitran_amd.h declares
+(no compute calls: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from adafortitran_amd import _abi, _lib
+from helpers import DEFAULT_SPEC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "adafortitran_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(aft_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_binding_lists_every_header_symbol():
+    assert _header_symbols() == sorted(_abi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_all_symbols():
+    import torch  # noqa: F401  (binds libamdhip64.so.7 the way the product does)
+    assert os.path.exists(_lib.lib_path()), "build with python -m adafortitran_amd.build"
+    lib = ctypes.CDLL(_lib.lib_path())
+    for name in _header_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_loader_checks_version_and_host_only_calls():
+    lib = _lib.load()
+    assert lib.aft_version() == _abi.AFT_ABI_VERSION
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=(7, 42, 560))
+    nbytes = lib.aft_workspace_bytes(ctypes.byref(cfg), 128)
+    # conv_enhanced + tokens6 + x + attn + q + k + vt at B=128 (DESIGN.md data layout)
+    planes, tokens, tokpad, d = 256, 280, 288, 128
+    expect = 4 * (planes * 1680 + 128 * tokens * 6 + 2 * planes * tokens * d + 3 * planes * 4 * tokpad * 32)
+    assert expect <= nbytes <= expect + 7 * 256
+    bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3))
+    assert lib.aft_workspace_bytes(ctypes.byref(bad), 8) == 0
+    assert b"model_dim" in lib.aft_last_error()
+
+
+def test_struct_sizes_match_header():
+    assert ctypes.sizeof(_abi.AftConfig) == 16 * 4
+    assert ctypes.sizeof(_abi.AftLayerWeights) == 12 * 8
+    n_ptrs = 2 + 8 + 8 + 18 + 2 + 1 + 2
+    assert ctypes.sizeof(_abi.AftWeights) == n_ptrs * 8 + _abi.AFT_MAX_LAYERS * 12 * 8
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.AftError, match="no CPU or PyTorch fallback"):
+        _lib.load()

@@ -1,0 +1,142 @@
+"""Host-side mirror of the reference module surface, exercised on CPU (autograd composite):
+state_dict layout, class identities, error conventions, and the composite's numerics against
+the reference-generated golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import adafortitran_amd as A
+from adafortitran_amd import synth
+from helpers import Golden, TOL_ORACLE_OUT
+
+
+def _configs(spec, device="cpu"):
+    sc = A.SystemConfig(ofdm=dict(num_scs=spec["ofdm"][0], num_symbols=spec["ofdm"][1]),
+                        pilot=dict(num_scs=spec["pilot"][0], num_symbols=spec["pilot"][1]))
+    kw = dict(model_type="adafortitran" if spec.get("adaptive_hidden") else "fortitran",
+              patch_size=tuple(spec["patch"]), num_layers=spec["num_layers"], model_dim=spec["model_dim"],
+              num_head=spec["num_head"], activation=spec.get("activation", "gelu"),
+              max_seq_len=spec.get("max_seq_len", 512), pos_encoding_type=spec.get("pos_encoding_type", "learnable"),
+              device=device)
+    if spec.get("adaptive_hidden"):
+        kw.update(channel_adaptivity_hidden_sizes=list(spec["adaptive_hidden"]), adaptive_token_length=6)
+    return sc, A.ModelConfig(**kw)
+
+
+def build_model(g: Golden, device="cpu"):
+    sc, mc = _configs(g.spec, device)
+    cls = A.AdaFortiTranEstimator if g.adaptive else A.FortiTranEstimator
+    model = cls(sc, mc)
+    sd = {k: torch.from_numpy(v) for k, v in g.state_dict().items()}
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return model.eval()
+
+
+def golden_meta(g: Golden):
+    return synth.meta_tuple({k: g[k] for k in ("snr", "ds", "dop")}) if g.adaptive else None
+
+
+@pytest.mark.parametrize("name", ["T_tiny_ada", "T_tiny_forti", "D_forti", "A_ada", "AS_ada_sin_relu"])
+def test_composite_matches_reference(name):
+    g = Golden(name)
+    model = build_model(g)
+    with torch.no_grad():
+        meta = golden_meta(g)
+        out = model(torch.from_numpy(g["pilots"]), meta) if meta is not None else model(torch.from_numpy(g["pilots"]))
+    assert out.dtype == torch.complex64 and tuple(out.shape) == g["out"].shape
+    assert np.abs(out.numpy() - g["out"]).max() <= TOL_ORACLE_OUT
+
+
+def test_state_dict_layout_matches_appendix_a():
+    g = Golden("A_ada")
+    model = build_model(g)
+    want = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert got == want
+    assert len(got) == 113 and sum(p.numel() for p in model.parameters()) == 987_746 == g.meta["ref_params"]
+    f = build_model(Golden("D_forti"))
+    assert len(f.state_dict()) == 95 and sum(p.numel() for p in f.parameters()) == 913_688
+
+
+def test_class_identities_and_shim_imports():
+    from src.models import AdaFortiTranEstimator, FortiTranEstimator, LinearEstimator
+    from src.models.fortitran import BaseFortiTranEstimator
+    from src.models.blocks import ConvEnhancer, PatchEmbedding  # noqa: F401
+    from src.config import load_config
+    sc, mc = load_config("config/system_config.yaml", "config/adafortitran.yaml")
+    ada = AdaFortiTranEstimator(sc, mc)
+    sc2, mc2 = load_config("config/system_config.yaml", "config/fortitran.yaml")
+    forti = FortiTranEstimator(sc2, mc2)
+    assert isinstance(ada, BaseFortiTranEstimator) and isinstance(forti, BaseFortiTranEstimator)
+    assert not isinstance(forti, AdaFortiTranEstimator)   # trainer.py:185-193 dispatches on this
+    assert AdaFortiTranEstimator is A.AdaFortiTranEstimator and LinearEstimator is A.LinearEstimator
+    info = ada.get_model_info()
+    assert list(info) == ["model_name", "channel_adaptation", "ofdm_size", "pilot_size", "patch_size", "patch_length",
+                          "transformer_input_dim", "model_dim", "num_layers", "device", "total_parameters",
+                          "trainable_parameters"]
+    assert info["transformer_input_dim"] == 12 and ada.ofdm_size == (120, 14) and ada.pilot_size == (12, 2)
+
+
+def test_error_conventions():
+    g = Golden("T_tiny_ada")
+    model = build_model(g)
+    with pytest.raises(ValueError, match="meta_data is required"):
+        model(torch.from_numpy(g["pilots"]))                      # fortitran.py:157-158
+    sc, mc = _configs(g.spec)
+    with pytest.raises(ValueError):                                # adapter width must be 2 x tokens
+        A.AdaFortiTranEstimator(sc, mc.model_copy(update={"channel_adaptivity_hidden_sizes": [3, 5, 18]}))
+    with pytest.raises(ValueError):
+        A.AdaFortiTranEstimator(sc, mc.model_copy(update={"max_seq_len": 4}))
+    with pytest.raises(ValueError):                                # pydantic: extra keys forbidden
+        A.ModelConfig(patch_size=(3, 2), num_layers=1, model_dim=8, num_head=1, bogus=1)
+    with pytest.raises(ValueError):                                # fortitran must not carry adaptive fields
+        A.ModelConfig(model_type="fortitran", patch_size=(3, 2), num_layers=1, model_dim=8, num_head=1,
+                      adaptive_token_length=6)
+    with pytest.raises(ValueError):                                # pilots may not exceed the grid
+        A.SystemConfig(ofdm=dict(num_scs=4, num_symbols=4), pilot=dict(num_scs=8, num_symbols=2))
+    with pytest.raises(ValueError, match="Unsupported device"):
+        A.ModelConfig(patch_size=(3, 2), num_layers=1, model_dim=8, num_head=1, device="tpu")
+
+
+def test_forti_warns_on_meta(caplog):
+    g = Golden("T_tiny_forti")
+    model = build_model(g)
+    meta = synth.meta_tuple(synth.make_inputs(3, ofdm=(12, 4), pilot=(4, 2)))
+    with caplog.at_level("WARNING"), torch.no_grad():
+        model(torch.from_numpy(g["pilots"]), meta)                 # fortitran.py:160-161: warning, not error
+    assert any("ignoring meta_data" in r.message for r in caplog.records)
+
+
+def test_training_path_has_gradients():
+    g = Golden("T_tiny_ada")
+    model = build_model(g).train()
+    out = model(torch.from_numpy(g["pilots"]), golden_meta(g))
+    loss = torch.view_as_real(out).pow(2).mean()
+    loss.backward()
+    assert all(p.grad is not None for p in model.parameters())
+
+
+def test_linear_estimator_cpu():
+    g = Golden("L_linear")
+    sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
+    mc = A.ModelConfig(model_type="linear", patch_size=(3, 2), num_layers=1, model_dim=8, num_head=1)
+    model = A.LinearEstimator(sc, mc).eval()
+    seed = g.meta["seed"]
+    model.load_state_dict({"linear.weight": torch.from_numpy(synth.uniform_pm(seed, "linear.weight", (1680, 24), 1 / np.sqrt(24))),
+                           "linear.bias": torch.from_numpy(synth.uniform_pm(seed, "linear.bias", (1680,), 1 / np.sqrt(24)))})
+    with torch.no_grad():
+        out = model(torch.from_numpy(g["pilots"]))
+    assert np.abs(out.numpy() - g["out"]).max() <= 1e-6
+    with pytest.raises(ValueError, match="Expected input shape"):   # linear.py:79-83
+        model(torch.zeros(2, 5, 5))
+
+
+def test_synth_is_reproducible_and_shaped():
+    a = synth.make_inputs(4, seed=3)
+    b = synth.make_inputs(4, seed=3)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert a["pilots"].shape == (4, 12, 2) and a["pilots"].dtype == np.complex64
+    assert set(np.unique(a["snr"])) <= set(range(0, 31, 5))
+    big = synth.make_inputs(4096, seed=11)["pilots"]
+    assert abs(big.real.std() - 1.0) < 0.02 and abs(big.real.mean()) < 0.02

@@ -1,0 +1,190 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the hand-written HIP path, called through
+the C ABI, against (a) golden vectors produced by the reference itself and (b) the CPU oracle on
+the same seeded inputs.  Tolerances are the stated fp32 ones of SURVEY.md 8(d)."""
+import numpy as np
+import pytest
+import torch
+
+import adafortitran_amd as A
+from adafortitran_amd import _abi, synth
+from helpers import DEFAULT_SPEC, Golden, TOL_HIP_MSE, TOL_HIP_OUT, max_rel
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DEFAULT_SETS = ["D_forti", "A_ada", "DH_forti_hot", "AH_ada_mid", "AS_ada_sin_relu"]
+
+
+def _engine(g: Golden):
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    return engine_from_numpy(g.abi_config(), g.state_dict(), DEV)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _meta(g: Golden):
+    return [(_t(g[k]) if g.adaptive else None) for k in ("snr", "ds", "dop")]
+
+
+def test_extension_is_loaded_in_tree():
+    from adafortitran_amd import _lib
+    lib = _lib.load()
+    assert lib.aft_version() == _abi.AFT_ABI_VERSION
+    assert "/adafortitran_amd/csrc/libaft_hip.so" in _lib.lib_path()
+    maps = open("/proc/self/maps").read()
+    assert "libaft_hip.so" in maps
+
+
+@pytest.mark.parametrize("name", DEFAULT_SETS + ["C5_ada_large"])
+def test_forward_matches_reference_golden(name):
+    g = Golden(name)
+    eng = _engine(g)
+    out = eng.forward(_t(g["pilots"]), *_meta(g)).cpu().numpy()
+    ref = g["out"]
+    err = np.abs(out - ref).max()
+    assert err <= TOL_HIP_OUT * np.abs(ref).max(), (err, np.abs(ref).max())
+    # metric parity: |dMSE|/MSE against the reference's own 2*MSELoss(cat(Re,Im))
+    mse = np.mean(np.abs(out - g["target"]) ** 2)
+    assert abs(mse - g.meta["metric_2xmse"]) / g.meta["metric_2xmse"] <= TOL_HIP_MSE
+
+
+@pytest.mark.parametrize("name", ["D_forti", "A_ada", "DH_forti_hot", "AH_ada_mid"])
+def test_stages_match_golden_and_oracle(oracle_lib, name):
+    g = Golden(name)
+    eng = _engine(g)
+    orc = oracle_lib.Oracle(g.abi_config(), g.state_dict())
+    _, dump = orc.forward(g["pilots"], *g.meta_arrays(), dump=True)
+    ce = eng.stage_upsample(_t(g["pilots"]))
+    assert max_rel(ce.cpu().numpy(), g["conv_enhanced"]) <= TOL_HIP_OUT
+    tok6 = None
+    if g.adaptive:
+        tok6 = eng.stage_adapter(*_meta(g))
+        assert max_rel(tok6.cpu().numpy(), dump["tokens6"]) <= TOL_HIP_OUT
+    x0 = eng.stage_embed(_t(dump["conv_enhanced"]), None if tok6 is None else _t(dump["tokens6"]))
+    assert max_rel(x0.cpu().numpy(), dump["x0"]) <= TOL_HIP_OUT
+    if "x0_f0" in g:
+        assert max_rel(x0[:2].cpu().numpy(), g["x0_f0"]) <= TOL_HIP_OUT
+    # every encoder layer on the oracle's input of that layer (no error accumulation)
+    xin = dump["x0"]
+    for layer in range(g.spec["num_layers"]):
+        y = eng.stage_encoder_layer(layer, _t(xin)).cpu().numpy()
+        assert max_rel(y, dump["layer_out"][layer]) <= TOL_HIP_OUT, layer
+        xin = dump["layer_out"][layer]
+    if "layer_first_last_p0" in g:
+        L = g.spec["num_layers"]
+        y = eng.stage_encoder_layer(L - 1, _t(dump["layer_out"][L - 2])).cpu().numpy()
+        assert max_rel(y[0], g["layer_first_last_p0"][1]) <= 4 * TOL_HIP_OUT
+    out = eng.stage_tail(_t(dump["layer_out"][-1]), _t(dump["conv_enhanced"])).cpu().numpy()
+    assert np.abs(out - g["out"]).max() <= TOL_HIP_OUT * np.abs(g["out"]).max()
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("batch", [1, 3, 37])
+def test_ragged_batches_match_oracle(oracle_lib, adaptive, batch):
+    """batch sizes that leave partial 64-row tiles (2B*280 not a multiple of 64)."""
+    hid = (7, 42, 560) if adaptive else None
+    sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=4242, attn_gain=0.25 if adaptive else 32.0,
+                               head_gain=2.0)
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(batch, seed=777 + batch)
+    meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+    out = eng.forward(_t(inp["pilots"]), *meta).cpu().numpy()
+    orc = oracle_lib.Oracle(cfg, sd)
+    ref = orc.forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3))
+    assert np.abs(out - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+
+
+def test_full_size_batch128_properties(oracle_lib):
+    """BASELINE config 3 at full size: frames are independent (fortitran.py:176-177), so the
+    B=128 launch must reproduce (i) B=16 chunks bit-for-bit and (ii) the oracle on a sample."""
+    hid = (7, 42, 560)
+    sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=20251114)
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(128, seed=20251114)
+    meta = [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    pil = _t(inp["pilots"])
+    full = eng.forward(pil, *meta)
+    assert torch.isfinite(torch.view_as_real(full)).all()
+    for lo in (0, 48, 112):
+        part = eng.forward(pil[lo:lo + 16], *[m[lo:lo + 16] for m in meta])
+        assert torch.equal(torch.view_as_real(part), torch.view_as_real(full[lo:lo + 16]))
+    again = eng.forward(pil, *meta)
+    assert torch.equal(torch.view_as_real(again), torch.view_as_real(full))  # deterministic, no atomics
+    orc = oracle_lib.Oracle(cfg, sd)
+    idx = [0, 63, 127]
+    ref = orc.forward(inp["pilots"][idx], inp["snr"][idx], inp["ds"][idx], inp["dop"][idx])
+    got = full[idx].cpu().numpy()
+    assert np.abs(got - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+    # metric on device == oracle metric
+    from adafortitran_amd.hip_ops import mse_sum
+    tgt = _t(inp["target"])
+    dev_sum = mse_sum(full, tgt).item()
+    host_sum = oracle_lib.mse_sum(full.cpu().numpy(), inp["target"])
+    assert abs(dev_sum - host_sum) <= 1e-9 * host_sum
+
+
+@pytest.mark.parametrize("name", ["D_forti", "A_ada"])
+def test_module_surface_on_gpu(name):
+    """The drop-in nn.Module: CPU inputs in, device output out, HIP path under eval+no_grad,
+    autograd composite under train() -- both against the reference golden output."""
+    from test_estimators_cpu import _configs, golden_meta
+    g = Golden(name)
+    sc, mc = _configs(g.spec, device="cuda")
+    cls = A.AdaFortiTranEstimator if g.adaptive else A.FortiTranEstimator
+    model = cls(sc, mc)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()})
+    model.eval()
+    pil, meta = torch.from_numpy(g["pilots"]), golden_meta(g)       # CPU tensors, as the DataLoader yields
+    with torch.no_grad():
+        out = model(pil, meta) if meta is not None else model(pil)
+    assert out.device.type == "cuda" and out.dtype == torch.complex64
+    assert model._engine is not None                                # the C-ABI path ran
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_HIP_OUT * np.abs(g["out"]).max()
+    with torch.enable_grad():                                        # autograd path (PyTorch-ROCm composite)
+        out_g = model(pil, meta) if meta is not None else model(pil)
+        assert out_g.requires_grad
+    assert np.abs(out_g.detach().cpu().numpy() - g["out"]).max() <= 2 * TOL_HIP_OUT * np.abs(g["out"]).max()
+    if g.adaptive:
+        with pytest.raises(ValueError, match="meta_data is required"), torch.no_grad():
+            model(pil)
+
+
+def test_abi_error_codes():
+    g = Golden("A_ada")
+    eng = _engine(g)
+    with pytest.raises(ValueError, match="meta_data is required"):
+        eng.forward(_t(g["pilots"]))
+    with pytest.raises(ValueError, match="Expected pilot shape"):
+        eng.forward(_t(np.zeros((2, 5, 5), np.complex64)), *_meta(g))
+    from adafortitran_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    ws = eng.workspace(8)
+    pil = torch.view_as_real(_t(g["pilots"]))
+    m = _meta(g)
+    rc = lib.aft_forward_f32(C.byref(eng.cfg), C.byref(eng.weights), pil.data_ptr(), m[0].data_ptr(), m[1].data_ptr(),
+                             m[2].data_ptr(), pil.data_ptr(), ws.data_ptr(), 1024, 8, None)
+    assert rc == _abi.AFT_ERR_ARG and b"workspace too small" in lib.aft_last_error()
+
+
+def test_linear_and_mse_kernels(oracle_lib):
+    g = Golden("L_linear")
+    seed = g.meta["seed"]
+    w = synth.uniform_pm(seed, "linear.weight", (1680, 24), 1 / np.sqrt(24))
+    b = synth.uniform_pm(seed, "linear.bias", (1680,), 1 / np.sqrt(24))
+    from adafortitran_amd.hip_ops import linear_forward, mse_sum
+    out = linear_forward(_t(w), _t(b), _t(g["pilots"]), (120, 14)).cpu().numpy()
+    assert np.abs(out - g["out"]).max() <= 1e-5
+    for n in (1, 7, 1680 * 5 + 3):
+        rng = np.random.default_rng(n)
+        e = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        r = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        got = mse_sum(_t(e), _t(r)).item()
+        want = oracle_lib.mse_sum(e, r)
+        assert abs(got - want) <= 1e-9 * want
