@@ -234,4 +234,47 @@ int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float 
     return e == hipSuccess ? AFT_OK : hip_fail("tail", e);
 }
 
+int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int which, float *out, void *workspace,
+                           size_t workspace_bytes, int batch, int reps, void *stream) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    AFT_REQUIRE(w && workspace && batch > 0 && reps > 0, "bad argument");
+    const Workspace ws = plan_workspace(*cfg, batch);
+    AFT_REQUIRE(workspace_bytes >= ws.total_floats * sizeof(float), "workspace too small");
+    AFT_REQUIRE(cfg->num_layers >= 2 || which != AFT_KERNEL_CHAIN, "chain profile needs >= 2 layers");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *base = static_cast<float *>(workspace);
+    float *x = base + ws.x, *attn = base + ws.attn, *q = base + ws.q, *k = base + ws.k, *vt = base + ws.vt;
+    const int rows = ws.planes * ws.tokens;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < reps && e == hipSuccess; ++i) {
+        switch (which) {
+            case AFT_KERNEL_UPSAMPLE:
+                AFT_REQUIRE(out != nullptr, "upsample profile needs the pilots pointer in `out`");
+                e = launch_upsample(*cfg, *w, out, base + ws.conv_enhanced, batch, st);
+                break;
+            case AFT_KERNEL_EMBED:
+                e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, x, batch, st);
+                break;
+            case AFT_KERNEL_QKV:
+                e = launch_chain(*cfg, nullptr, &w->layers[0], nullptr, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+                break;
+            case AFT_KERNEL_ATTENTION:
+                e = launch_attention(*cfg, q, k, vt, attn, ws.planes, ws.tokens, ws.tokpad, st);
+                break;
+            case AFT_KERNEL_CHAIN:
+                e = launch_chain(*cfg, &w->layers[0], &w->layers[1], attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+                break;
+            case AFT_KERNEL_TAIL:
+                AFT_REQUIRE(out != nullptr, "tail profile needs an output buffer");
+                e = launch_tail(*cfg, *w, x, base + ws.conv_enhanced, out, batch, st);
+                break;
+            default:
+                set_error("unknown kernel id %d", which);
+                return AFT_ERR_ARG;
+        }
+    }
+    return e == hipSuccess ? AFT_OK : hip_fail("profile", e);
+}
+
 }  // extern "C"

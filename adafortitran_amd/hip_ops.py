@@ -134,6 +134,14 @@ class HipEngine:
         return out
 
 
+def profile_kernel(eng: HipEngine, which: str, batch: int, reps: int, io: Optional[torch.Tensor] = None) -> None:
+    """Enqueue ``reps`` launches of one kernel class on the current stream (bench.py roofline leg)."""
+    ws = eng.workspace(batch)
+    ptr = None if io is None else (torch.view_as_real(io) if io.is_complex() else io).data_ptr()
+    _lib.check(eng.lib.aft_profile_kernel_f32(C.byref(eng.cfg), C.byref(eng.weights), _abi.KERNEL_IDS[which], ptr,
+                                              ws.data_ptr(), ws.numel(), batch, reps, eng._stream()))
+
+
 def engine_from_numpy(cfg: _abi.AftConfig, state: Dict[str, np.ndarray], device="cuda:0") -> HipEngine:
     """Upload a numpy state_dict (e.g. from ``synth.make_state_dict``) and build an engine."""
     dev = torch.device(device)

@@ -128,6 +128,19 @@ int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int
 int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float *x,
                        const float *conv_enhanced, float *out, int batch, void *stream);
 
+/* ---- measurement hook (bench.py roofline leg; no reference counterpart) ----
+ * Launch ONE kernel class `reps` times back to back on `stream`, on the activations a previous
+ * aft_forward_f32 of the same (cfg, batch) left in `workspace`, so the caller can bracket it with
+ * events on that stream.  Same kernels, grids and arguments as inside aft_forward_f32. */
+#define AFT_KERNEL_UPSAMPLE 0   /* fused pilot-linear + initial ConvEnhancer                 */
+#define AFT_KERNEL_EMBED 1      /* patch gather + adapter concat + linear_1 + pos            */
+#define AFT_KERNEL_QKV 2        /* chain kernel, in-projection only (layer 0)                */
+#define AFT_KERNEL_ATTENTION 3  /* MFMA attention                                            */
+#define AFT_KERNEL_CHAIN 4      /* chain kernel: out-proj+LN1+FFN+LN2 (layer 0) + QKV (layer 1) */
+#define AFT_KERNEL_TAIL 5       /* linear_2 + fold + residual + final ConvEnhancer           */
+int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int which, float *out,
+                           void *workspace, size_t workspace_bytes, int batch, int reps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

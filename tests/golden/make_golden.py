@@ -134,6 +134,10 @@ def run_set(name, spec, batch, keep):
     }
     for k in keep:
         arrays[k] = avail[k]()
+    pe_key = "transformer_encoder.positional_encoding.pe"
+    if pe_key in sd:  # libm-dependent table: ship the rows the forward actually reads
+        ntok = (S // spec["patch"][0]) * (T // spec["patch"][1])
+        arrays["pe_rows"] = sd[pe_key][0, :ntok].copy()
     # metric fixture on the same (estimate, target) pair: 2*MSELoss(cat(Re,Im;dim=1)) and dB
     # (reference src/utils.py:164-180,233-245; src/main/trainer.py:338-347)
     tgt = torch.from_numpy(inp["target"])
