@@ -43,6 +43,10 @@ int check_config(const aft_config *c) {
         set_error("head dim must be %d (model_dim=%d, num_head=%d)", kHeadDim, c->model_dim, c->num_head);
         return AFT_ERR_SHAPE;
     }
+    if (tokens_of(*c) % 8 || tokens_of(*c) < 32) {
+        set_error("token count %d must be a multiple of 8 and >= 32 (fragment-packed q/k/v tiles)", tokens_of(*c));
+        return AFT_ERR_SHAPE;
+    }
     if (c->num_scs % 4) {
         set_error("num_scs=%d must be a multiple of 4 for the conv strips", c->num_scs);
         return AFT_ERR_SHAPE;
@@ -76,6 +80,7 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     ws.q = off;             off += align64(per_head);
     ws.k = off;             off += align64(per_head);
     ws.vt = off;            off += align64(per_head);
+    ws.wpack = off;         off += align64(packed_layer_floats(c.model_dim) * c.num_layers);
     ws.total_floats = off;
     return ws;
 }
@@ -89,15 +94,22 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
                        int last_layer, hipStream_t st) {
     float *x = base + ws.x, *attn = base + ws.attn, *q = base + ws.q, *k = base + ws.k, *vt = base + ws.vt;
     const int rows = ws.planes * ws.tokens;
+    const size_t pl = packed_layer_floats(c.model_dim);
+    float *wp = base + ws.wpack;
     hipError_t e;
+    // weights arrive in torch layout on every call (stateless ABI): re-lay them into fragment order
+    e = launch_pack_weights(c, w, wp + first_layer * pl, first_layer, last_layer - first_layer + 1, st);
+    if (e != hipSuccess) return hip_fail("pack_weights", e);
     // in-projection of the first layer (QKV-only pass of the chain kernel)
-    e = launch_chain(c, nullptr, &w.layers[first_layer], nullptr, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+    e = launch_chain(c, nullptr, nullptr, &w.layers[first_layer], wp + first_layer * pl, nullptr, x, q, k, vt, rows,
+                     ws.tokens, ws.tokpad, st);
     if (e != hipSuccess) return hip_fail("chain(qkv)", e);
     for (int l = first_layer; l <= last_layer; ++l) {
         e = launch_attention(c, q, k, vt, attn, ws.planes, ws.tokens, ws.tokpad, st);
         if (e != hipSuccess) return hip_fail("attention", e);
-        const aft_layer_weights *next = l < last_layer ? &w.layers[l + 1] : nullptr;
-        e = launch_chain(c, &w.layers[l], next, attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+        const bool more = l < last_layer;
+        e = launch_chain(c, &w.layers[l], wp + l * pl, more ? &w.layers[l + 1] : nullptr,
+                         more ? wp + (l + 1) * pl : nullptr, attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
         if (e != hipSuccess) return hip_fail("chain(mlp)", e);
     }
     return AFT_OK;
@@ -215,13 +227,16 @@ int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int
     float *base = static_cast<float *>(scratch);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int rows = ws.planes * ws.tokens;
-    hipError_t e = launch_chain(*cfg, nullptr, &w->layers[layer], nullptr, x, base + ws.q, base + ws.k, base + ws.vt,
-                                rows, ws.tokens, ws.tokpad, st);
+    float *wp = base + ws.wpack + layer * packed_layer_floats(cfg->model_dim);
+    hipError_t e = launch_pack_weights(*cfg, *w, wp, layer, 1, st);
+    if (e != hipSuccess) return hip_fail("pack_weights", e);
+    e = launch_chain(*cfg, nullptr, nullptr, &w->layers[layer], wp, nullptr, x, base + ws.q, base + ws.k, base + ws.vt,
+                     rows, ws.tokens, ws.tokpad, st);
     if (e != hipSuccess) return hip_fail("chain(qkv)", e);
     e = launch_attention(*cfg, base + ws.q, base + ws.k, base + ws.vt, base + ws.attn, ws.planes, ws.tokens, ws.tokpad, st);
     if (e != hipSuccess) return hip_fail("attention", e);
-    e = launch_chain(*cfg, &w->layers[layer], nullptr, base + ws.attn, x, nullptr, nullptr, nullptr, rows, ws.tokens,
-                     ws.tokpad, st);
+    e = launch_chain(*cfg, &w->layers[layer], wp, nullptr, nullptr, base + ws.attn, x, nullptr, nullptr, nullptr, rows,
+                     ws.tokens, ws.tokpad, st);
     return e == hipSuccess ? AFT_OK : hip_fail("chain(mlp)", e);
 }
 
@@ -257,13 +272,16 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                 e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, x, batch, st);
                 break;
             case AFT_KERNEL_QKV:
-                e = launch_chain(*cfg, nullptr, &w->layers[0], nullptr, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+                e = launch_chain(*cfg, nullptr, nullptr, &w->layers[0], base + ws.wpack, nullptr, x, q, k, vt, rows,
+                                 ws.tokens, ws.tokpad, st);
                 break;
             case AFT_KERNEL_ATTENTION:
                 e = launch_attention(*cfg, q, k, vt, attn, ws.planes, ws.tokens, ws.tokpad, st);
                 break;
             case AFT_KERNEL_CHAIN:
-                e = launch_chain(*cfg, &w->layers[0], &w->layers[1], attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+                e = launch_chain(*cfg, &w->layers[0], base + ws.wpack, &w->layers[1],
+                                 base + ws.wpack + packed_layer_floats(cfg->model_dim), attn, x, q, k, vt, rows,
+                                 ws.tokens, ws.tokpad, st);
                 break;
             case AFT_KERNEL_TAIL:
                 AFT_REQUIRE(out != nullptr, "tail profile needs an output buffer");

@@ -25,10 +25,11 @@ inline __host__ __device__ int round_up(int v, int m) { return (v + m - 1) / m *
 //   tokens6       [B][tokens][6]        f32  adapter features (adaptive only)
 //   x             [2B*tokens][d]        f32  token activations, row-major
 //   attn          [2B*tokens][d]        f32  attention output (heads concatenated)
-//   q, k          [2B][H][tokpad][32]   f32  per-head row-major, tokpad = tokens rounded to 32
-//   vt            [2B][H][32][tokpad]   f32  per-head V transposed (key index contiguous)
+//   q, k          [2B][H][tokpad/32][4 s][64 lanes][4]  f32  MFMA-fragment order: (key%32 + 32hh, d = 8s+4hh+j)
+//   vt            [2B][H][tokpad/32][4 g][64 lanes][4]  f32  fragment order: (d + 32hh, key = 32kt+8g+4hh+j)
+//   wpack         [L][8*d*d]            f32  encoder GEMM weights in MFMA-fragment order (rebuilt per call)
 struct Workspace {
-    size_t conv_enhanced, tokens6, x, attn, q, k, vt, total_floats;
+    size_t conv_enhanced, tokens6, x, attn, q, k, vt, wpack, total_floats;
     int tokens, tokpad, planes;
 };
 
@@ -47,9 +48,14 @@ hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *
                         const float *tokens6, float *x, int batch, hipStream_t st);
 // Row-local chain on [rows, d]: (mlp) x <- LN2(x1 + FFN(x1)), x1 = LN1(x + attn Wo^T + bo);
 // (qkv) q,k,vt <- split(x Wqkv^T + b).  `mlp_w` may be NULL (QKV only), `qkv_w` may be NULL.
-hipError_t launch_chain(const aft_config &c, const aft_layer_weights *mlp_w, const aft_layer_weights *qkv_w,
-                        const float *attn, float *x, float *q, float *k, float *vt, int rows, int tokens,
-                        int tokpad, hipStream_t st);
+// `*_packed` = that layer's block of the fragment-packed weight image (launch_pack_weights).
+hipError_t launch_chain(const aft_config &c, const aft_layer_weights *mlp_w, const float *mlp_packed,
+                        const aft_layer_weights *qkv_w, const float *qkv_packed, const float *attn, float *x,
+                        float *q, float *k, float *vt, int rows, int tokens, int tokpad, hipStream_t st);
+size_t packed_layer_floats(int d);
+// Re-lay the encoder GEMM weights of layers [first, first+count) into MFMA-fragment order.
+hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float *packed, int first_layer, int count,
+                               hipStream_t st);
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, float *attn,
                             int planes, int tokens, int tokpad, hipStream_t st);
 hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,

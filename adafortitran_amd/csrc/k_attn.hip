@@ -10,7 +10,8 @@
 //   * one WAVE owns one (plane, head, 32-query tile) task end to end; no LDS, no barriers:
 //     at 64 cycles per v_mfma_f32_32x32x2_f32 the matrix pipe needs only 16 operand bytes per
 //     lane per 256 cycles, which L1/L2 deliver directly (K and V^T of one head = 72 KB, hot in
-//     the XCD's L2 for all 9 query tiles of that head).
+//     the XCD's L2 for all 9 query tiles of that head).  q/k/vt are stored by the producer in
+//     fragment order, so each operand load is 1 KB contiguous per wave (16 TA accesses, not 64).
 //   * "swapped" products so the softmax row lives in ONE lane:  S^T = K Q^T  (A = K tile,
 //     B = Q^T) leaves lane (q, h) holding 16 of the 32 keys of query q per tile -> row max /
 //     row sum are register reductions + one cross-half exchange; then O^T = V^T P^T takes the
@@ -41,15 +42,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const float *__restrict__ q, 
     const int ph = task / nkt;  // plane * heads + head
     const int r = lane & 31, h = lane >> 5;
 
-    const float *qb = q + (size_t)ph * tokpad * kHeadDim;
-    const float *kb = k + (size_t)ph * tokpad * kHeadDim;
-    const float *vb = vt + (size_t)ph * kHeadDim * tokpad;
+    // q, k, vt arrive in MFMA-fragment order from k_chain.hip: [ph][tile][s or g][lane][4] -> every
+    // operand load below is one fully coalesced 1-KB global_load_dwordx4 per wave
+    const float *qb = q + (size_t)ph * tokpad * kHeadDim + lane * 4;
+    const float *kb = k + (size_t)ph * tokpad * kHeadDim + lane * 4;
+    const float *vb = vt + (size_t)ph * kHeadDim * tokpad + lane * 4;
 
     // B operand of S^T = K Q^T : lane (q = r, h) holds Q[q][8s + 4h + j], pre-scaled
     f32x4 qreg[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        qreg[s] = *reinterpret_cast<const f32x4 *>(qb + (size_t)(qt * kTile + r) * kHeadDim + 8 * s + 4 * h);
+        qreg[s] = *reinterpret_cast<const f32x4 *>(qb + qt * 1024 + s * 256);
         qreg[s] *= scale_log2e;
     }
 
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float *__restrict__ q, 
                 f32x4 kreg[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    kreg[s] = *reinterpret_cast<const f32x4 *>(kb + (size_t)(kt * kTile + r) * kHeadDim + 8 * s + 4 * h);
+                    kreg[s] = *reinterpret_cast<const f32x4 *>(kb + kt * 1024 + s * 256);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float *__restrict__ q, 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int key0 = kt * kTile + 8 * g + 4 * h;
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(vb + (size_t)r * tokpad + key0);
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(vb + kt * 1024 + g * 256);
                     if (ragged) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)

@@ -37,8 +37,10 @@ def test_loader_checks_version_and_host_only_calls():
     nbytes = lib.aft_workspace_bytes(ctypes.byref(cfg), 128)
     # conv_enhanced + tokens6 + x + attn + q + k + vt at B=128 (DESIGN.md data layout)
     planes, tokens, tokpad, d = 256, 280, 288, 128
-    expect = 4 * (planes * 1680 + 128 * tokens * 6 + 2 * planes * tokens * d + 3 * planes * 4 * tokpad * 32)
-    assert expect <= nbytes <= expect + 7 * 256
+    # conv_enhanced + tokens6 + x + attn + q + k + vt + fragment-packed encoder weights (6 layers x 8 d^2)
+    expect = 4 * (planes * 1680 + 128 * tokens * 6 + 2 * planes * tokens * d + 3 * planes * 4 * tokpad * 32
+                  + 6 * 8 * d * d)
+    assert expect <= nbytes <= expect + 8 * 256
     bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3))
     assert lib.aft_workspace_bytes(ctypes.byref(bad), 8) == 0
     assert b"model_dim" in lib.aft_last_error()

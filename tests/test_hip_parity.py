@@ -187,4 +187,4 @@ def test_linear_and_mse_kernels(oracle_lib):
         r = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
         got = mse_sum(_t(e), _t(r)).item()
         want = oracle_lib.mse_sum(e, r)
-        assert abs(got - want) <= 1e-9 * want
+        assert abs(got - want) <= 1e-6 * want   # device subtracts in fp32 (as torch does), oracle in fp64

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Quick per-kernel timing on the GPU box (events on the launch stream)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adafortitran_amd import _abi, synth
+from adafortitran_amd.hip_ops import engine_from_numpy, profile_kernel
+SPEC = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=6, model_dim=128, num_head=4)
+HID = (7, 42, 560)
+B = int(os.environ.get("AFT_BATCH", "128"))
+which = sys.argv[1:] or ["upsample", "embed", "qkv", "attention", "chain", "tail"]
+sd = synth.make_state_dict(**SPEC, adaptive_hidden=HID, seed=20251114)
+cfg = _abi.make_config(**SPEC, adaptive_hidden=HID)
+eng = engine_from_numpy(cfg, sd, "cuda:0")
+inp = synth.make_inputs(B, seed=20251114)
+dev = lambda a: torch.from_numpy(a).to("cuda:0")
+pil, meta = dev(inp["pilots"]), [dev(inp[k]) for k in ("snr", "ds", "dop")]
+out = torch.empty((B, 120, 14), dtype=torch.complex64, device="cuda:0")
+dbg = os.environ.pop("AFT_DBG", None)
+eng.forward(pil, *meta, out=out); torch.cuda.synchronize()
+if dbg: os.environ["AFT_DBG"] = dbg
+res = {}
+for name in which:
+    io = pil if name == "upsample" else (out if name == "tail" else None)
+    profile_kernel(eng, name, B, 3, io); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); profile_kernel(eng, name, B, 20, io); e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 20)
+    res[name] = round(best * 1e3, 1)
+print("AFT_DBG=%s" % dbg, res)
