@@ -25,11 +25,15 @@ def _deps(src: str):
             os.path.join(CSRC, "..", "..", "include", "adafortitran_amd.h")]
 
 
+DIAG = False  # --diag: -DAFT_DIAG_STAMPS (in-kernel phase stamps; never for the product build)
+
+
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(CSRC, src.replace(".hip", ".o"))
     if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src)):
         return obj
-    subprocess.run([HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj], check=True)
+    flags = FLAGS + (["-DAFT_DIAG_STAMPS"] if DIAG else [])
+    subprocess.run([HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj], check=True)
     return obj
 
 
@@ -45,4 +49,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    DIAG = "--diag" in sys.argv
+    build(force="--force" in sys.argv or DIAG, verbose=True)

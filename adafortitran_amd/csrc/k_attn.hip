@@ -24,23 +24,126 @@
 //     registers, query rows >= tokens are computed and dropped at the store.
 #include <math.h>
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "aft_internal.h"
 
 namespace aft {
 
+struct AttnState {
+    float m_run, l_run;
+    f32x16 oacc;
+};
+
+// One chunk of CH key tiles: S^T tiles -> online-softmax update -> O^T += V^T P^T.
+// TAIL = false: all CH tiles exist and are full (no masks, no bounds checks: the steady state);
+// TAIL = true : the final chunk -- tiles >= nkt are skipped, the ragged last tile is masked.
+template <int CH, bool TAIL>
+__device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4], const float *__restrict__ kb,
+                                           const float *__restrict__ vb, int c0, int nkt, int tokens, int h) {
+    f32x16 sacc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int kt = c0 + c;
+        sacc[c] = f32x16{0};
+        if (!TAIL || kt < nkt) {
+            f32x4 kreg[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kreg[s] = *reinterpret_cast<const f32x4 *>(kb + kt * 1024 + s * 256);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    sacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s][j], qreg[s][j], sacc[c], 0, 0, 0);
+            if (TAIL && kt * kTile + kTile > tokens) {  // ragged last tile: pad keys -> -inf
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * kTile + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (key >= tokens) sacc[c][e] = -INFINITY;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[c][e] = -INFINITY;
+        }
+    }
+    // running max over this chunk (lane-local over registers, then the other key half)
+    float cmax = sacc[0][0];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, sacc[c][e]);
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    const float m_new = fmaxf(st.m_run, cmax);  // finite: every chunk holds >= 1 real key
+    const float alpha = __builtin_amdgcn_exp2f(st.m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = __builtin_amdgcn_exp2f(sacc[c][e] - m_new);
+            sacc[c][e] = p;
+            psum += p;
+        }
+    psum += __shfl_xor(psum, 32);
+    st.l_run = st.l_run * alpha + psum;
+    st.m_run = m_new;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st.oacc[e] *= alpha;
+    // O^T += V^T P^T
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int kt = c0 + c;
+        if (!TAIL || kt < nkt) {
+            const bool ragged = TAIL && kt * kTile + kTile > tokens;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key0 = kt * kTile + 8 * g + 4 * h;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(vb + kt * 1024 + g * 256);
+                if (ragged) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (key0 + j >= tokens) v[j] = 0.f;  // workspace pad is never trusted
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    st.oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], sacc[c][4 * g + j], st.oacc, 0, 0, 0);
+            }
+        }
+    }
+}
+
+// launch bound (256, 3): <= 168 registers keeps accumulators in VGPRs (the MFMA's VGPR form) --
+// with the default 512-register budget hipcc parks them in AGPRs and pays ~2.5 v_accvgpr moves
+// per MFMA around the softmax, which on the fp32 matrix path comes straight out of MFMA time.
 template <int CH>
-__global__ __launch_bounds__(256) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
-                                                   const float *__restrict__ vt, float *__restrict__ out,
-                                                   int heads, int tokens, int tokpad, int model_dim,
-                                                   float scale_log2e, int ntasks) {
+__global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                      const float *__restrict__ vt, float *__restrict__ out,
+                                                      int heads, int tokens, int tokpad, int model_dim,
+                                                      float scale_log2e, int ntasks, unsigned long long *stamps) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = blockIdx.x * 4 + wave;
-    if (task >= ntasks) return;
+    // persistent waves with a static, balanced schedule: the grid is sized to the co-resident wave
+    // count and wave w takes tasks w, w + W, w + 2W ... (B=128: 9216 tasks over 3072 waves = exactly
+    // 3 each), so every SIMD finishes together -- a 40-us task has no tail to wait for.
+    const int total_waves = gridDim.x * 4;
     const int nkt = tokpad / kTile;
+    const int r = lane & 31, h = lane >> 5;
+#ifdef AFT_DIAG_STAMPS
+#define ASTAMP(i) do { if (stamps && lane == 0) stamps[(size_t)task * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+  for (int task = blockIdx.x * 4 + wave; task < ntasks; task += total_waves) {
+    ASTAMP(0);
+#ifdef AFT_DIAG_STAMPS
+    if (stamps && lane == 0) stamps[(size_t)task * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int qt = task % nkt;
     const int ph = task / nkt;  // plane * heads + head
-    const int r = lane & 31, h = lane >> 5;
 
     // q, k, vt arrive in MFMA-fragment order from k_chain.hip: [ph][tile][s or g][lane][4] -> every
     // operand load below is one fully coalesced 1-KB global_load_dwordx4 per wave
@@ -56,104 +159,78 @@ __global__ __launch_bounds__(256) void attn_kernel(const float *__restrict__ q, 
         qreg[s] *= scale_log2e;
     }
 
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x16 oacc = f32x16{0};
+    AttnState st;
+    st.m_run = -INFINITY;
+    st.l_run = 0.f;
+    st.oacc = f32x16{0};
 
-    for (int c0 = 0; c0 < nkt; c0 += CH) {
-        f32x16 sacc[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int kt = c0 + c;
-            sacc[c] = f32x16{0};
-            if (kt < nkt) {
-                f32x4 kreg[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    kreg[s] = *reinterpret_cast<const f32x4 *>(kb + kt * 1024 + s * 256);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        sacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s][j], qreg[s][j], sacc[c], 0, 0, 0);
-                if (kt * kTile + kTile > tokens) {  // ragged last tile: pad keys -> -inf
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = kt * kTile + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (key >= tokens) sacc[c][e] = -INFINITY;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[c][e] = -INFINITY;
-            }
-        }
-        // running max over this chunk (lane-local over registers, then the other key half)
-        float cmax = sacc[0][0];
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, sacc[c][e]);
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m_run, cmax);  // finite: every chunk holds >= 1 real key
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f(sacc[c][e] - m_new);
-                sacc[c][e] = p;
-                psum += p;
-            }
-        psum += __shfl_xor(psum, 32);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
-        // O^T += V^T P^T
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int kt = c0 + c;
-            if (kt < nkt) {
-                const bool ragged = kt * kTile + kTile > tokens;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int key0 = kt * kTile + 8 * g + 4 * h;
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(vb + kt * 1024 + g * 256);
-                    if (ragged) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (key0 + j >= tokens) v[j] = 0.f;  // workspace pad is never trusted
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], sacc[c][4 * g + j], oacc, 0, 0, 0);
-                }
-            }
-        }
-    }
+    int c0 = 0;
+    const int full_tiles = tokens / kTile;   // tiles with no padded key
+    ASTAMP(1);
+    for (; c0 + CH <= full_tiles; c0 += CH) attn_chunk<CH, false>(st, qreg, kb, vb, c0, nkt, tokens, h);
+    ASTAMP(2);
+    for (; c0 < nkt; c0 += CH) attn_chunk<CH, true>(st, qreg, kb, vb, c0, nkt, tokens, h);
+    ASTAMP(3);
 
     // O^T accumulator: lane = query r, register e = feature d = (e&3) + 8*(e>>2) + 4h
     const int qrow = qt * kTile + r;
     if (qrow < tokens) {
-        const float inv = 1.0f / l_run;
+        const float inv = 1.0f / st.l_run;
         const int plane = ph / heads, head = ph % heads;
         float *dst = out + ((size_t)plane * tokens + qrow) * model_dim + head * kHeadDim + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 o = {oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
+            f32x4 o = {st.oacc[4 * g] * inv, st.oacc[4 * g + 1] * inv, st.oacc[4 * g + 2] * inv, st.oacc[4 * g + 3] * inv};
             *reinterpret_cast<f32x4 *>(dst + 8 * g) = o;
         }
     }
+    ASTAMP(4);
+#ifdef AFT_DIAG_STAMPS
+    if (stamps && lane == 0) stamps[(size_t)task * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+  }
 }
 
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, float *attn,
                             int planes, int tokens, int tokpad, hipStream_t st) {
     const int ntasks = planes * c.num_head * (tokpad / kTile);
-    const int blocks = (ntasks + 3) / 4;
+    static int resident_blocks = 0;   // 256 CUs x 3 workgroups (launch bound: 3 waves / SIMD)
+    if (resident_blocks == 0) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident_blocks = 3 * cus;
+    }
+    const int blocks = std::min((ntasks + 3) / 4, resident_blocks);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)kHeadDim);
+#ifdef AFT_DIAG_STAMPS
+    if (getenv("AFT_STAMPS")) {   // per-task stamps + in-kernel clock (diagnostic build only)
+        static unsigned long long *dbuf = nullptr;
+        if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 8 * 16384);
+        (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 8 * 16384);
+        hipLaunchKernelGGL((attn_kernel<3>), dim3(blocks), dim3(256), 0, st, q, k, vt, attn, c.num_head, tokens,
+                           tokpad, c.model_dim, scale_log2e, ntasks, dbuf);
+        (void)hipDeviceSynchronize();
+        static int printed = 0;
+        if (printed++ < 2) {
+            std::vector<unsigned long long> hbuf(8 * 16384);
+            (void)hipMemcpy(hbuf.data(), dbuf, hbuf.size() * 8, hipMemcpyDeviceToHost);
+            double sum[5] = {0};
+            int n = ntasks < 16384 ? ntasks : 16384;
+            for (int t = 0; t < n; ++t)
+                for (int i = 1; i < 5; ++i) sum[i] += (double)(hbuf[t * 8 + i] - hbuf[t * 8 + i - 1]);
+            double clk = 0;
+            for (int t = 0; t < n; ++t)
+                clk += (double)(hbuf[t * 8 + 4] - hbuf[t * 8 + 0]) / (double)(hbuf[t * 8 + 5] - hbuf[t * 8 + 6]) * 100e6;
+            printf("in-kernel shader clock: %.3f GHz\n", clk / n / 1e9);
+            printf("attn stamps: mean per task: prologue=%.0f steady=%.0f tail=%.0f store=%.0f (cycles); MFMA ideal %d\n",
+                   sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, 288 * 64);
+        }
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((attn_kernel<3>), dim3(blocks), dim3(256), 0, st, q, k, vt, attn, c.num_head, tokens,
-                       tokpad, c.model_dim, scale_log2e, ntasks);
+                       tokpad, c.model_dim, scale_log2e, ntasks, (unsigned long long *)nullptr);
     return hipGetLastError();
 }
 

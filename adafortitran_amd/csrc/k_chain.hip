@@ -50,7 +50,6 @@ struct ChainShape {
     static constexpr int H_FLOATS = 2 * ROWS * LDA > ROWS * LDH ? 2 * ROWS * LDA : ROWS * LDH;
     static constexpr int LN_FLOATS = 6 * D;                    // gamma1, beta1, gamma2, beta2, q bias, k bias
     static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(ROWS * LDA + H_FLOATS + LN_FLOATS);
-    static constexpr size_t LDS_BYTES_QKV_ONLY = LDS_BYTES;   // same carve (bufB + params) keeps one code path
     static_assert(NT_D >= 1 && (D / 32) % CG == 0, "column split must be whole tiles");
     static_assert(CG == D / kHeadDim && NT_QKV == 3, "QKV epilogue: one head per wave (q, k, v tiles)");
 };
@@ -64,8 +63,7 @@ struct ChainArgs {
     const float *wqkv, *bqkv;
     float *q, *k, *vt;
     int rows, tokens, tokpad, heads, activation, do_mlp, do_qkv;
-    int dbg;  // EXPERIMENT bitmask (timing only)
-    unsigned long long *stamps;  // EXPERIMENT: per-workgroup phase stamps
+    unsigned long long *stamps;  // diagnostic build only (AFT_DIAG_STAMPS), else NULL
 };
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
@@ -180,7 +178,7 @@ __device__ __forceinline__ float group_sum(float v) {
 template <int D, int ROWS, int WAVES>
 __device__ __forceinline__ void layernorm_tile(const float *src, float *dst, int ld,
                                                const float *gamma, const float *beta,
-                                               float *gout, long row0, int rows, int wave, int lane, int dbg = 0) {
+                                               float *gout, long row0, int rows, int wave, int lane) {
     constexpr int RPW = ROWS / WAVES, LPR = 64 / RPW, VPL = D / LPR;
     static_assert(VPL % 4 == 0, "per-lane slice must be float4-able");
     const int row = wave * RPW + lane / LPR, c0 = (lane % LPR) * VPL;
@@ -195,14 +193,14 @@ __device__ __forceinline__ void layernorm_tile(const float *src, float *dst, int
             s += t[j];
         }
     }
-    const float mean = (dbg & 1) ? s : group_sum<LPR>(s) * (1.0f / D);
+    const float mean = group_sum<LPR>(s) * (1.0f / D);
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         v[i] -= mean;
         sq = fmaf(v[i], v[i], sq);
     }
-    const float rstd = (dbg & 1) ? sq : rsqrtf(group_sum<LPR>(sq) * (1.0f / D) + 1e-5f);
+    const float rstd = rsqrtf(group_sum<LPR>(sq) * (1.0f / D) + 1e-5f);
     const bool store = gout != nullptr && row0 + row < rows;
 #pragma unroll
     for (int i = 0; i < VPL; i += 4) {
@@ -244,10 +242,14 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
     const float *w2_lane = a.w2 + (size_t)(col0_d / 32) * (2 * D / 32) * 1024 + lane * 4;
     const float *wq_lane = a.wqkv + (size_t)(col0_qkv / 32) * (D / 32) * 1024 + lane * 4;
 
+#ifdef AFT_DIAG_STAMPS   // diagnostic build only (-DAFT_DIAG_STAMPS): per-phase s_memtime stamps of wave 0
 #define STAMP(i)                                                                              \
     do {                                                                                      \
-        if ((a.dbg & 32) && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
     STAMP(0);
     // per-column vectors are fetched ONCE, up front: a global load inside an epilogue would sit
     // behind an in-order vmcnt wait together with the weight prefetch and every earlier store
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
         }
         __syncthreads();
         STAMP(3);
-        layernorm_tile<D, S::ROWS, S::WAVES>(bufS, bufB, S::LDA, lnp, lnp + D, nullptr, row0, a.rows, wave, lane, a.dbg);
+        layernorm_tile<D, S::ROWS, S::WAVES>(bufS, bufB, S::LDA, lnp, lnp + D, nullptr, row0, a.rows, wave, lane);
         __syncthreads();
         STAMP(4);
         // ---- FFN up-projection + activation -> hidden tile in LDS ----
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
         }
         __syncthreads();
         STAMP(8);
-        layernorm_tile<D, S::ROWS, S::WAVES>(bufS, bufB, S::LDA, lnp + 2 * D, lnp + 3 * D, a.x, row0, a.rows, wave, lane, a.dbg);
+        layernorm_tile<D, S::ROWS, S::WAVES>(bufS, bufB, S::LDA, lnp + 2 * D, lnp + 3 * D, a.x, row0, a.rows, wave, lane);
         __syncthreads();
         STAMP(9);
     } else {
@@ -391,7 +393,6 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
         f32x16 acc[S::NT_QKV];
 #pragma unroll
         for (int t = 0; t < S::NT_QKV; ++t) acc[t] = f32x16{0};
-        const int col0 = col0_qkv;
         gemm_run<D, S::NT_QKV, 1, S::CG, 0x3>(ring_qkv, bufB + (rt * 32 + r) * S::LDA + 4 * h, wq_lane, acc);
         STAMP(10);
         // ---- epilogue: q, k, v of head `cg` for 32 token rows, written in MFMA-FRAGMENT order so that
@@ -462,9 +463,9 @@ static hipError_t launch_chain_t(const ChainArgs &args, hipStream_t st) {
         attr_set = true;
     }
     const int blocks = (args.rows + S::ROWS - 1) / S::ROWS;
-    size_t lds = args.do_mlp ? S::LDS_BYTES : S::LDS_BYTES_QKV_ONLY;   // more workgroups/CU for the QKV-only pass
-    if (args.dbg & 128) lds = 100 * 1024;   // EXPERIMENT: force one workgroup per CU
-    if (args.dbg & 32) {   // EXPERIMENT: phase stamps, printed on the host
+    const size_t lds = S::LDS_BYTES;
+#ifdef AFT_DIAG_STAMPS
+    if (getenv("AFT_STAMPS")) {   // phase stamps, printed on the host (never in the product build)
         static unsigned long long *dbuf = nullptr;
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 4096);
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
@@ -500,6 +501,7 @@ static hipError_t launch_chain_t(const ChainArgs &args, hipStream_t st) {
         }
         return hipGetLastError();
     }
+#endif
     hipLaunchKernelGGL((chain_kernel<D, RT, NWAVES, ACT>), dim3(blocks), dim3(S::THREADS), lds, st, args);
     return hipGetLastError();
 }
@@ -561,7 +563,6 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const f
     a.rows = rows; a.tokens = tokens; a.tokpad = tokpad;
     a.heads = c.num_head; a.activation = c.activation;
     a.do_mlp = m != nullptr; a.do_qkv = qw != nullptr;
-    { const char *e = getenv("AFT_DBG"); a.dbg = e ? atoi(e) : 0; }
     // d=128: 32-row tiles, 4 waves, 67 KB LDS -> two workgroups per CU overlap each other's
     // barrier/epilogue/LayerNorm phases; d=256: 32-row tiles, 8 waves, 133 KB LDS.
     const bool gelu = c.activation == AFT_ACT_GELU;

@@ -16,9 +16,9 @@ inp = synth.make_inputs(B, seed=20251114)
 dev = lambda a: torch.from_numpy(a).to("cuda:0")
 pil, meta = dev(inp["pilots"]), [dev(inp[k]) for k in ("snr", "ds", "dop")]
 out = torch.empty((B, 120, 14), dtype=torch.complex64, device="cuda:0")
-dbg = os.environ.pop("AFT_DBG", None)
+stamps = os.environ.pop("AFT_STAMPS", None)   # only meaningful with a --diag build
 eng.forward(pil, *meta, out=out); torch.cuda.synchronize()
-if dbg: os.environ["AFT_DBG"] = dbg
+if stamps: os.environ["AFT_STAMPS"] = stamps
 res = {}
 for name in which:
     io = pil if name == "upsample" else (out if name == "tail" else None)
@@ -29,4 +29,4 @@ for name in which:
         e0.record(); profile_kernel(eng, name, B, 20, io); e1.record(); e1.synchronize()
         best = min(best, e0.elapsed_time(e1) / 20)
     res[name] = round(best * 1e3, 1)
-print("AFT_DBG=%s" % dbg, res)
+print(res)
