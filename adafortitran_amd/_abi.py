@@ -122,4 +122,4 @@ EXPORTED_SYMBOLS = (
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",
     "aft_stage_tail_f32", "aft_profile_kernel_f32",
 )
-KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5}
+KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6}

@@ -283,6 +283,10 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                                  base + ws.wpack + packed_layer_floats(cfg->model_dim), attn, x, q, k, vt, rows,
                                  ws.tokens, ws.tokpad, st);
                 break;
+            case AFT_KERNEL_CHAIN_LAST:
+                e = launch_chain(*cfg, &w->layers[0], base + ws.wpack, nullptr, nullptr, attn, x, q, k, vt, rows,
+                                 ws.tokens, ws.tokpad, st);
+                break;
             case AFT_KERNEL_TAIL:
                 AFT_REQUIRE(out != nullptr, "tail profile needs an output buffer");
                 e = launch_tail(*cfg, *w, x, base + ws.conv_enhanced, out, batch, st);

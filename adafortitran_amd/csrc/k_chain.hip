@@ -214,7 +214,10 @@ __device__ __forceinline__ void layernorm_tile(const float *src, float *dst, int
     }
 }
 
-template <int D, int RT, int NWAVES, int ACT>
+// MLP / QKV select the three launch variants at compile time (distinct symbols in a profile):
+//   <true,true>  layer l's out-proj+LN1+FFN+LN2 and layer l+1's in-projection   (5 of 7 launches at L=6)
+//   <false,true> in-projection only (first layer)      <true,false> last layer, no in-projection
+template <int D, int RT, int NWAVES, int ACT, bool MLP, bool QKV>
 __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel(const ChainArgs a) {
     using S = ChainShape<D, RT, NWAVES>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
     // per-column vectors are fetched ONCE, up front: a global load inside an epilogue would sit
     // behind an in-order vmcnt wait together with the weight prefetch and every earlier store
     float bias_o[S::NT_D], bias_1[S::NT_FF], bias_2[S::NT_D], bias_q[S::NT_QKV];
-    if (a.do_mlp) {
+    if constexpr (MLP) {
 #pragma unroll
         for (int t = 0; t < S::NT_D; ++t) {
             bias_o[t] = a.bo[col0_d + t * 32 + r];
@@ -269,12 +272,12 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
             lnp[3 * D + i] = a.be2[i];
         }
     }
-    if (a.do_qkv) {
+    if constexpr (QKV) {
         for (int i = tid; i < 2 * D; i += S::THREADS) qkb[i] = a.bqkv[i];
 #pragma unroll
         for (int t = 0; t < S::NT_QKV; ++t) bias_q[t] = a.bqkv[t * D + col0_qkv + r];   // v tile: lane = feature
     }
-    if (a.do_mlp) {
+    if constexpr (MLP) {
         gemm_preload<D, S::NT_D, 2>(ring_d, wo_lane);   // in flight while the tiles are staged
         // ---- stage the attention-output tile (A operand of the out-projection) and the residual x ----
         // all loads first, then the LDS writes: one memory round trip for the whole tile
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
             for (int t = 0; t < S::NT_D; ++t) acc[t] = f32x16{0};
             const int col0 = col0_d;
             gemm_run<2 * D, S::NT_D, 2>(ring_d, bufH + (rt * 32 + r) * S::LDH + 4 * h, w2_lane, acc);
-            if (a.do_qkv) gemm_preload<D, S::NT_QKV, 1, S::CG>(ring_qkv, wq_lane);
+            if constexpr (QKV) gemm_preload<D, S::NT_QKV, 1, S::CG>(ring_qkv, wq_lane);
             STAMP(7);
             __syncthreads();   // every wave is done reading H before its bottom half becomes LN scratch
 #pragma unroll
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
         __syncthreads();
     }
 
-    if (a.do_qkv) {
+    if constexpr (QKV) {
         // ---- packed in-projection of the next attention: q,k row-major per head, v transposed ----
         f32x16 acc[S::NT_QKV];
 #pragma unroll
@@ -452,12 +455,12 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
     STAMP(11);
 }
 
-template <int D, int RT, int NWAVES, int ACT>
-static hipError_t launch_chain_t(const ChainArgs &args, hipStream_t st) {
+template <int D, int RT, int NWAVES, int ACT, bool MLP, bool QKV>
+static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
     using S = ChainShape<D, RT, NWAVES>;
     static bool attr_set = false;  // idempotent; races only repeat the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<D, RT, NWAVES, ACT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<D, RT, NWAVES, ACT, MLP, QKV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -471,12 +474,12 @@ static hipError_t launch_chain_t(const ChainArgs &args, hipStream_t st) {
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
         ChainArgs a2 = args;
         a2.stamps = dbuf;
-        hipLaunchKernelGGL((chain_kernel<D, RT, NWAVES, ACT>), dim3(blocks), dim3(S::THREADS), lds, st, a2);
+        hipLaunchKernelGGL((chain_kernel<D, RT, NWAVES, ACT, MLP, QKV>), dim3(blocks), dim3(S::THREADS), lds, st, a2);
         (void)hipDeviceSynchronize();
         static int printed = 0;
         if (printed == 0) {
             int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_kernel<D, RT, NWAVES, ACT>, S::THREADS, lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_kernel<D, RT, NWAVES, ACT, MLP, QKV>, S::THREADS, lds);
             printf("occupancy API: %d blocks/CU at %zu B LDS, %d threads\n", nb, lds, S::THREADS);
         }
         if (printed++ < 2) {
@@ -502,7 +505,7 @@ static hipError_t launch_chain_t(const ChainArgs &args, hipStream_t st) {
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((chain_kernel<D, RT, NWAVES, ACT>), dim3(blocks), dim3(S::THREADS), lds, st, args);
+    hipLaunchKernelGGL((chain_kernel<D, RT, NWAVES, ACT, MLP, QKV>), dim3(blocks), dim3(S::THREADS), lds, st, args);
     return hipGetLastError();
 }
 
@@ -538,6 +541,13 @@ hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float 
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, shifted, packed,
                        c.model_dim, count);
     return hipGetLastError();
+}
+
+template <int D, int RT, int NWAVES, int ACT>
+static hipError_t launch_chain_t(const ChainArgs &args, hipStream_t st) {
+    if (args.do_mlp && args.do_qkv) return launch_chain_v<D, RT, NWAVES, ACT, true, true>(args, st);
+    if (args.do_mlp) return launch_chain_v<D, RT, NWAVES, ACT, true, false>(args, st);
+    return launch_chain_v<D, RT, NWAVES, ACT, false, true>(args, st);
 }
 
 hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const float *m_packed,

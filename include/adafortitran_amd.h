@@ -138,6 +138,7 @@ int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float 
 #define AFT_KERNEL_ATTENTION 3  /* MFMA attention                                            */
 #define AFT_KERNEL_CHAIN 4      /* chain kernel: out-proj+LN1+FFN+LN2 (layer 0) + QKV (layer 1) */
 #define AFT_KERNEL_TAIL 5       /* linear_2 + fold + residual + final ConvEnhancer           */
+#define AFT_KERNEL_CHAIN_LAST 6 /* chain kernel of the last layer (no in-projection behind it) */
 int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int which, float *out,
                            void *workspace, size_t workspace_bytes, int batch, int reps, void *stream);
 

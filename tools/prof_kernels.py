@@ -23,7 +23,7 @@ inp = synth.make_inputs(B, seed=20251114)
 dev = lambda a: torch.from_numpy(a).to("cuda:0")  # noqa: E731
 pil, meta = dev(inp["pilots"]), [dev(inp[k]) for k in ("snr", "ds", "dop")]
 out = torch.empty((B, 120, 14), dtype=torch.complex64, device="cuda:0")
-for _ in range(3):
+for _ in range(int(os.environ.get("AFT_FWD", "3"))):
     eng.forward(pil, *meta, out=out)
 torch.cuda.synchronize()
 only = os.environ.get("AFT_ONLY")

@@ -10,7 +10,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(chain_kernel<[^>]*>|attn_kernel<[^>]*>|conv_stack_kernel|embed_kernel<[^>]*>|adapter_kernel|mse_kernel|linear_kernel)", name)
+    m = re.search(r"(chain_kernel<[^>]*>|attn_kernel<[^>]*>|conv_stack_kernel|embed_kernel<[^>]*>|adapter_kernel|mse_kernel|linear_kernel|pack_weights_kernel)", name)
     return m.group(1) if m else name[:60]
 
 
