@@ -27,5 +27,5 @@ python3 tools/summarize_prof.py "$OUT/bench_trace" > "$OUT/kernel_trace_summary.
 python3 tools/summarize_prof.py "$OUT"/pmc[0-9] "$OUT/pmc_attn" > "$OUT/pmc_summary.txt" 2>&1
 cp "$OUT"/bench_trace/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
 find "$OUT" -name "*.csv" -size +1M -delete
-tail -1 "$OUT/bench_trace.log" > "$OUT/bench_under_rocprof.json"
+grep -h "^{\"metric\"" "$OUT/bench_trace.log" | tail -1 > "$OUT/bench_under_rocprof.json"
 cat "$OUT/kernel_trace_summary.txt"; grep -A12 "chain_kernel" "$OUT/pmc_summary.txt" | head -80
