@@ -79,15 +79,22 @@ __device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4]
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
     const float m_new = fmaxf(st.m_run, cmax);  // finite: every chunk holds >= 1 real key
     const float alpha = __builtin_amdgcn_exp2f(st.m_run - m_new);
-    float psum = 0.f;
+    // exponentials: the shift and the row sum run on register PAIRS (v_pk_add_f32: two floats per
+    // lane per issue) -- VALU issue comes straight out of fp32-MFMA time on this path
+    const f32x2 m2 = {m_new, m_new};
+    f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float p = __builtin_amdgcn_exp2f(sacc[c][e] - m_new);
-            sacc[c][e] = p;
-            psum += p;
+        for (int e = 0; e < 16; e += 2) {
+            f32x2 t = f32x2{sacc[c][e], sacc[c][e + 1]} - m2;
+            t[0] = __builtin_amdgcn_exp2f(t[0]);
+            t[1] = __builtin_amdgcn_exp2f(t[1]);
+            sacc[c][e] = t[0];
+            sacc[c][e + 1] = t[1];
+            psum2 += t;
         }
+    float psum = psum2[0] + psum2[1];
     psum += __shfl_xor(psum, 32);
     st.l_run = st.l_run * alpha + psum;
     st.m_run = m_new;

@@ -156,6 +156,30 @@ __device__ __forceinline__ float activate(float v) {
     }
 }
 
+// Two activations at once: the polynomial runs on v_pk_fma_f32 (two floats per lane per issue).
+template <int ACT>
+__device__ __forceinline__ f32x2 activate2(f32x2 v) {
+    if constexpr (ACT == AFT_ACT_GELU) {
+        const f32x2 x = v * 0.70710678118654752440f;
+        const f32x2 t = {fminf(fabsf(x[0]), 4.0f), fminf(fabsf(x[1]), 4.0f)};
+        f32x2 p = {-4.535924745e-05f, -4.535924745e-05f};
+        p = __builtin_elementwise_fma(p, t, f32x2{4.455104063e-04f, 4.455104063e-04f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-1.489443355e-03f, -1.489443355e-03f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-7.746370393e-04f, -7.746370393e-04f});
+        p = __builtin_elementwise_fma(p, t, f32x2{2.825369500e-02f, 2.825369500e-02f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-1.484816223e-01f, -1.484816223e-01f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-9.184163809e-01f, -9.184163809e-01f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-1.627908587e+00f, -1.627908587e+00f});
+        p = p * t;
+        const f32x2 e = {copysignf(1.0f - __builtin_amdgcn_exp2f(p[0]), x[0]),
+                         copysignf(1.0f - __builtin_amdgcn_exp2f(p[1]), x[1])};
+        const f32x2 hv = v * 0.5f;
+        return __builtin_elementwise_fma(hv, e, hv);
+    } else {
+        return f32x2{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+    }
+}
+
 // Sum over groups of LPR consecutive lanes with DPP (no LDS crossbar): quad_perm xor-1, xor-2,
 // then row_half_mirror (8 lanes) and row_mirror (16 lanes).  Every lane ends with its group's sum.
 template <int LPR>
@@ -339,8 +363,11 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel
                 const int col = col0 + t * 32 + r;
                 const float bias = bias_1[t];
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    bufH[(rt * 32 + acc_row(e, h)) * S::LDH + col] = activate<ACT>(acc[t][e] + bias);
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 g = activate2<ACT>(f32x2{acc[t][e] + bias, acc[t][e + 1] + bias});
+                    bufH[(rt * 32 + acc_row(e, h)) * S::LDH + col] = g[0];
+                    bufH[(rt * 32 + acc_row(e + 1, h)) * S::LDH + col] = g[1];
+                }
             }
         }
         __syncthreads();
