@@ -108,6 +108,7 @@ __device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4]
             const bool ragged = TAIL && kt * kTile + kTile > tokens;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (ragged && kt * kTile + 8 * g >= tokens) continue;   // both halves of this k group are padding
                 const int key0 = kt * kTile + 8 * g + 4 * h;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(vb + kt * 1024 + g * 256);
                 if (ragged) {

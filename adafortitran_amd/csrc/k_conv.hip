@@ -24,7 +24,7 @@ namespace aft {
 
 struct ConvArgs {
     int mode;  // 0 = head (pilots -> conv_enhanced), 1 = tail (x, conv_enhanced -> complex out)
-    int S, T, band_rows, nbands;
+    int S, T, TP, band_rows, nbands;   // TP = padded LDS row stride (>= T+2)
     // head
     const float *pilots, *up_w, *up_b;
     int pf;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void conv8x8_strip(const float *__restrict__ src, int
 
 __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int S = a.S, T = a.T, TP = T + 2, LR = a.band_rows + 8;
+    const int S = a.S, T = a.T, TP = a.TP, LR = a.band_rows + 8;
     const int plane_stride = LR * TP;
     float *in0 = smem;                       // [LR][TP]
     float *bufA = in0 + plane_stride;        // [8][LR][TP]
@@ -216,18 +216,25 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 }
 
 // pick the largest row band (multiple of 4, divides S) whose strips fit 512 threads and 160 KB LDS
-static bool plan_bands(int S, int T, int extra_floats, int *band_rows, size_t *lds_bytes) {
+// Row stride: a wave's lanes are (column fastest, then 4-row strip), so strips sit 4*TP floats apart;
+// TP = T+2 = 16 puts every strip on the same banks (3-way conflicts measured: SQ_LDS_BANK_CONFLICT =
+// 66 % of LDS cycles).  T+4 staggers strips by 8 banks; fall back to T+2 when LDS would overflow.
+static bool plan_bands(int S, int T, int extra_floats, int *band_rows, int *tp, size_t *lds_bytes) {
     if (S % kStrip) return false;
     for (int nb = 1; nb <= S / kStrip; ++nb) {
         if (S % nb) continue;
         const int br = S / nb;
         if (br % kStrip) continue;
         const int LR = br + 8;
-        const size_t bytes = sizeof(float) * ((size_t)17 * LR * (T + 2) + extra_floats);
-        if ((LR / kStrip) * T <= kConvThreads && bytes <= 160 * 1024) {
-            *band_rows = br;
-            *lds_bytes = bytes;
-            return true;
+        if ((LR / kStrip) * T > kConvThreads) continue;
+        for (int pad = 4; pad >= 2; pad -= 2) {
+            const size_t bytes = sizeof(float) * ((size_t)17 * LR * (T + pad) + extra_floats);
+            if (bytes <= 160 * 1024) {
+                *band_rows = br;
+                *tp = T + pad;
+                *lds_bytes = bytes;
+                return true;
+            }
         }
     }
     return false;
@@ -235,7 +242,7 @@ static bool plan_bands(int S, int T, int extra_floats, int *band_rows, size_t *l
 
 static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStream_t st) {
     size_t lds = 0;
-    if (!plan_bands(a.S, a.T, extra_floats, &a.band_rows, &lds)) return hipErrorInvalidValue;
+    if (!plan_bands(a.S, a.T, extra_floats, &a.band_rows, &a.TP, &lds)) return hipErrorInvalidValue;
     a.nbands = a.S / a.band_rows;
     static bool attr_set = false;  // idempotent; a race only repeats the same call
     if (!attr_set) {
