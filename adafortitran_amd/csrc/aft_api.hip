@@ -75,7 +75,7 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     ws.conv_enhanced = off; off += align64((size_t)ws.planes * c.num_scs * c.num_symbols);
     ws.tokens6 = off;       off += align64((size_t)batch * ws.tokens * 6);
     ws.x = off;             off += align64(rows * c.model_dim);
-    ws.attn = off;          off += align64(rows * c.model_dim);
+    ws.attn = off;          off += align64((size_t)round_up((int)rows, kTile) * c.model_dim);
     const size_t per_head = (size_t)ws.planes * c.num_head * ws.tokpad * kHeadDim;
     ws.q = off;             off += align64(per_head);
     ws.k = off;             off += align64(per_head);
@@ -105,7 +105,7 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
                      ws.tokens, ws.tokpad, st);
     if (e != hipSuccess) return hip_fail("chain(qkv)", e);
     for (int l = first_layer; l <= last_layer; ++l) {
-        e = launch_attention(c, q, k, vt, attn, ws.planes, ws.tokens, ws.tokpad, st);
+        e = launch_attention(c, q, k, vt, w.layers[l].in_proj_b, attn, ws.planes, ws.tokens, ws.tokpad, st);
         if (e != hipSuccess) return hip_fail("attention", e);
         const bool more = l < last_layer;
         e = launch_chain(c, &w.layers[l], wp + l * pl, more ? &w.layers[l + 1] : nullptr,
@@ -233,7 +233,8 @@ int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int
     e = launch_chain(*cfg, nullptr, nullptr, &w->layers[layer], wp, nullptr, x, base + ws.q, base + ws.k, base + ws.vt,
                      rows, ws.tokens, ws.tokpad, st);
     if (e != hipSuccess) return hip_fail("chain(qkv)", e);
-    e = launch_attention(*cfg, base + ws.q, base + ws.k, base + ws.vt, base + ws.attn, ws.planes, ws.tokens, ws.tokpad, st);
+    e = launch_attention(*cfg, base + ws.q, base + ws.k, base + ws.vt, w->layers[layer].in_proj_b, base + ws.attn,
+                         ws.planes, ws.tokens, ws.tokpad, st);
     if (e != hipSuccess) return hip_fail("attention", e);
     e = launch_chain(*cfg, &w->layers[layer], wp, nullptr, nullptr, base + ws.attn, x, nullptr, nullptr, nullptr, rows,
                      ws.tokens, ws.tokpad, st);
@@ -276,7 +277,7 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                                  ws.tokens, ws.tokpad, st);
                 break;
             case AFT_KERNEL_ATTENTION:
-                e = launch_attention(*cfg, q, k, vt, attn, ws.planes, ws.tokens, ws.tokpad, st);
+                e = launch_attention(*cfg, q, k, vt, w->layers[0].in_proj_b, attn, ws.planes, ws.tokens, ws.tokpad, st);
                 break;
             case AFT_KERNEL_CHAIN:
                 e = launch_chain(*cfg, &w->layers[0], base + ws.wpack, &w->layers[1],

@@ -25,7 +25,7 @@ inline __host__ __device__ int round_up(int v, int m) { return (v + m - 1) / m *
 //   conv_enhanced [2B][S][T]            f32  kept for the S7 residual
 //   tokens6       [B][tokens][6]        f32  adapter features (adaptive only)
 //   x             [2B*tokens][d]        f32  token activations, row-major
-//   attn          [2B*tokens][d]        f32  attention output (heads concatenated)
+//   attn          [ceil(2B*tokens/32)][H][4 s][64 lanes][4]  f32  attention output in operand-fragment order
 //   q, k          [2B][H][tokpad/32][4 s][64 lanes][4]  f32  MFMA-fragment order: (key%32 + 32hh, d = 8s+4hh+j)
 //   vt            [2B][H][tokpad/32][4 g][64 lanes][4]  f32  fragment order: (d + 32hh, key = 32kt+8g+4hh+j)
 //   wpack         [L][8*d*d]            f32  encoder GEMM weights in MFMA-fragment order (rebuilt per call)
@@ -57,8 +57,9 @@ size_t packed_layer_floats(int d);
 // Re-lay the encoder GEMM weights of layers [first, first+count) into MFMA-fragment order.
 hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float *packed, int first_layer, int count,
                                hipStream_t st);
-hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, float *attn,
-                            int planes, int tokens, int tokpad, hipStream_t st);
+// qbias = the layer's in_proj_bias (first d entries are the query bias, applied at fragment load).
+hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
+                            float *attn, int planes, int tokens, int tokpad, hipStream_t st);
 hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
                        float *out, int batch, hipStream_t st);
 hipError_t launch_linear(const float *weight, const float *bias, const float *pilots, float *out, int batch,

@@ -129,8 +129,9 @@ __device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4]
 // per MFMA around the softmax, which on the fp32 matrix path comes straight out of MFMA time.
 template <int CH>
 __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
-                                                      const float *__restrict__ vt, float *__restrict__ out,
-                                                      int heads, int tokens, int tokpad, int model_dim,
+                                                      const float *__restrict__ vt, const float *__restrict__ qbias,
+                                                      float *__restrict__ out, int heads, int tokens, int tokpad,
+                                                      int model_dim,
                                                       float scale_log2e, int ntasks, unsigned long long *stamps) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -159,12 +160,15 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
     const float *kb = k + (size_t)ph * tokpad * kHeadDim + lane * 4;
     const float *vb = vt + (size_t)ph * kHeadDim * tokpad + lane * 4;
 
-    // B operand of S^T = K Q^T : lane (q = r, h) holds Q[q][8s + 4h + j], pre-scaled
+    // B operand of S^T = K Q^T : lane (q = r, h) holds Q[q][8s + 4h + j]; the query bias of the
+    // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
+    // a row constant to the logits, which softmax cancels), then everything is pre-scaled
     f32x4 qreg[4];
+    const float *bq = qbias + (ph % heads) * kHeadDim + 4 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         qreg[s] = *reinterpret_cast<const f32x4 *>(qb + qt * 1024 + s * 256);
-        qreg[s] *= scale_log2e;
+        qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
     }
 
     AttnState st;
@@ -180,16 +184,20 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
     for (; c0 < nkt; c0 += CH) attn_chunk<CH, true>(st, qreg, kb, vb, c0, nkt, tokens, h);
     ASTAMP(3);
 
-    // O^T accumulator: lane = query r, register e = feature d = (e&3) + 8*(e>>2) + 4h
+    // O^T accumulator: lane = query r, register e = feature d = (e&3) + 8*(e>>2) + 4h -- i.e. registers
+    // 4s..4s+3 are the operand-fragment element (s, h) of this head's feature block.  Stored in the
+    // fragment order k_chain.hip consumes: [global 32-row tile][head][s][lane = row%32 + 32h][4]
+    // (global rows = plane*tokens + q; a query tile straddles two row tiles when 32 does not divide tokens).
     const int qrow = qt * kTile + r;
     if (qrow < tokens) {
         const float inv = 1.0f / st.l_run;
         const int plane = ph / heads, head = ph % heads;
-        float *dst = out + ((size_t)plane * tokens + qrow) * model_dim + head * kHeadDim + 4 * h;
+        const unsigned grow = (unsigned)plane * tokens + qrow;
+        float *dst = out + ((size_t)(grow >> 5) * (model_dim / kHeadDim) + head) * 1024 + ((grow & 31) + 32 * h) * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 o = {st.oacc[4 * g] * inv, st.oacc[4 * g + 1] * inv, st.oacc[4 * g + 2] * inv, st.oacc[4 * g + 3] * inv};
-            *reinterpret_cast<f32x4 *>(dst + 8 * g) = o;
+            *reinterpret_cast<f32x4 *>(dst + g * 256) = o;
         }
     }
     ASTAMP(4);
@@ -199,8 +207,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
   }
 }
 
-hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, float *attn,
-                            int planes, int tokens, int tokpad, hipStream_t st) {
+hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
+                            float *attn, int planes, int tokens, int tokpad, hipStream_t st) {
     const int ntasks = planes * c.num_head * (tokpad / kTile);
     static int resident_blocks = 0;   // 256 CUs x 3 workgroups (launch bound: 3 waves / SIMD)
     if (resident_blocks == 0) {
@@ -216,7 +224,7 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
         static unsigned long long *dbuf = nullptr;
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 8 * 16384);
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 8 * 16384);
-        hipLaunchKernelGGL((attn_kernel<3>), dim3(blocks), dim3(256), 0, st, q, k, vt, attn, c.num_head, tokens,
+        hipLaunchKernelGGL((attn_kernel<3>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, c.num_head, tokens,
                            tokpad, c.model_dim, scale_log2e, ntasks, dbuf);
         (void)hipDeviceSynchronize();
         static int printed = 0;
@@ -237,7 +245,7 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((attn_kernel<3>), dim3(blocks), dim3(256), 0, st, q, k, vt, attn, c.num_head, tokens,
+    hipLaunchKernelGGL((attn_kernel<3>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, c.num_head, tokens,
                        tokpad, c.model_dim, scale_log2e, ntasks, (unsigned long long *)nullptr);
     return hipGetLastError();
 }

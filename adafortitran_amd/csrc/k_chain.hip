@@ -6,122 +6,113 @@
 //     x2 = LN2(x1 + act(x1 @ W1^T + b1) @ W2^T + b2)
 // and, fused behind it, the NEXT layer's packed in-projection (in_proj_weight [3d,d] =
 // [Wq;Wk;Wv]):   q,k,v = split(x2 @ Wqkv^T + bqkv)  written per head for k_attn.hip.
-// Everything between two attention calls is row-local, so one workgroup owns a tile of
-// ROWS token rows through all four GEMMs; activations never leave LDS in between.
+// Everything between two attention calls is row-local, so one workgroup owns a tile of 32 token
+// rows through all four GEMMs.
 //
-// MI355X mapping
-//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 cyc/SIMD, = fp32 vector peak 157 TF): fp32 parity
-//     is the contract, there is no xf32 on gfx950.
-//   * 8 waves / workgroup (2 per SIMD).  Wave w owns row tile  w / CG  and column group
-//     w % CG; A operand (activations) comes from LDS with ds_read_b128 (row stride K+4 floats
-//     -> conflict-free), B operand (weights, torch [out,in] layout, K contiguous) streams
-//     straight from L2 into registers with global_load_dwordx4, double-buffered per 32-deep
-//     k-block: every weight byte is read once per workgroup, nothing is re-staged.
-//   * k pairing: lane (r, h) feeds k = 8s + 4h + j to MFMA (s, j) for both operands, so one
-//     16-byte load serves four MFMAs.
-//   * LayerNorm: the pre-LN tile goes through LDS once; each wave then owns ROWS/8 rows, a
-//     row is D/64 values per lane, mean/var by wave-wide butterfly -- no atomics, no HBM.
-//   * HBM traffic per row: read attn + x (2*D*4 B), write x + q,k,v (4*D*4 B); weights
-//     (512 KB/layer at d=128) stay L2-resident.
+// MI355X mapping (round-1 design, see DESIGN.md 4.1 for the measurements behind each choice)
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (the parity contract; gfx950 has no xf32), 64 cycles per
+//     SIMD.  It shares the SIMD's issue with ordinary VALU work, so every VALU / LDS instruction
+//     removed from the epilogues is matrix time won.
+//   * W = d/32 waves per workgroup; wave w owns the 32-feature block w of EVERY activation tensor
+//     (out-proj tile w, hidden tiles 2w and 2w+1, q/k/v tile of head w).
+//   * every GEMM is computed TRANSPOSED: A operand = weight fragment (lane = output feature),
+//     B operand = activation fragment (lane = token row).  The accumulator then has lane = row and
+//     registers = features, and register e of lane half h is feature (e&3) + 8(e>>2) + 4h -- which
+//     is exactly the operand-fragment element (s = e>>2, j = e&3).  So a GEMM's output IS the next
+//     GEMM's operand for that feature block: bias, residual, GELU and LayerNorm all run on
+//     registers, and the only data that crosses waves is one fragment-ordered 4-KB block per wave
+//     per exchange (ds_write_b128 / ds_read_b128, lane-linear => conflict-free, no padding).
+//   * LayerNorm: each lane reduces its 16 features, pairs with the other half-wave (one
+//     cross-half exchange), the W per-wave partial (mean, M2) pairs meet in a 1-KB LDS table and are
+//     merged with Chan's formula -- two-pass accuracy without re-reading the tile.
+//   * weights: fragment-packed per call (pack_weights_kernel), streamed from L2 into a register
+//     ring PF k-blocks ahead of their MFMAs, the first fragments of the NEXT GEMM issued before the
+//     current epilogue; sched_barrier pins that order.
+//   * 5 workgroup barriers per tile (2 LN tables, x1 / hidden / x2 exchanges); LDS = 53 KB at
+//     d=128 => 3 workgroups per CU overlap each other's non-MFMA phases.
+//   * HBM per row: read attn + x, write x + q,k,v; weights (512 KB/layer at d=128) stay in L2.
+//   * K's in-projection bias is dropped: softmax_j(q.(k_j + b)) = softmax_j(q.k_j + q.b) and the
+//     row-constant q.b cancels (it only adds rounding error to the logits); Q's bias is applied by
+//     k_attn.hip when it loads the query fragment.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include <type_traits>
 
 #include "aft_internal.h"
 
 namespace aft {
 
-template <int D, int RT, int NWAVES>
+template <int D>
 struct ChainShape {
-    static constexpr int ROWS = 32 * RT;
-    static constexpr int WAVES = NWAVES;
-    static constexpr int THREADS = 64 * NWAVES;
-    static constexpr int CG = WAVES / RT;       // column groups
-    static constexpr int LDA = D + 4;           // padded row strides (floats)
-    static constexpr int LDH = 2 * D + 4;
-    static constexpr int NT_D = (D / 32) / CG;      // column tiles per wave for N = D
-    static constexpr int NT_FF = (2 * D / 32) / CG; // N = 2D
-    static constexpr int NT_QKV = (3 * D / 32) / CG;
-    // LDS plan (floats): [B: ROWS x LDA][H: ROWS x LDH]; the attention tile A aliases the upper half
-    // of H and both pre-LayerNorm scratch tiles alias its lower half (lifetimes in chain_kernel).
-    static constexpr int H_HALF = ROWS * LDA;                 // A starts right above the scratch tile
-    static constexpr int H_FLOATS = 2 * ROWS * LDA > ROWS * LDH ? 2 * ROWS * LDA : ROWS * LDH;
-    static constexpr int LN_FLOATS = 6 * D;                    // gamma1, beta1, gamma2, beta2, q bias, k bias
-    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(ROWS * LDA + H_FLOATS + LN_FLOATS);
-    static_assert(NT_D >= 1 && (D / 32) % CG == 0, "column split must be whole tiles");
-    static_assert(CG == D / kHeadDim && NT_QKV == 3, "QKV epilogue: one head per wave (q, k, v tiles)");
+    static constexpr int WAVES = D / 32;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int XB = WAVES * 1024;          // x1 / x2 exchange   [feature block][s][lane][4]
+    static constexpr int HB = 2 * WAVES * 1024;      // FFN hidden exchange [hidden block][s][lane][4]
+    static constexpr int ST = 32 * WAVES * 2;        // LayerNorm partials [row][wave]{mean, M2}
+    static constexpr int PAR = 8 * D;                // bo, g1, be1, b1[2D], b2, g2, be2
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(XB + HB + ST + PAR);
 };
 
 struct ChainArgs {
-    // MLP part (may be disabled)
-    const float *attn;  // [rows, D]
-    float *x;           // [rows, D] residual in, layer output out
-    const float *wo, *bo, *w1, *b1, *w2, *b2, *g1, *be1, *g2, *be2;   // wo/w1/w2/wqkv: PACKED copies
-    // QKV part (may be disabled)
-    const float *wqkv, *bqkv;
+    const float *attn;  // fragment-packed attention output [row tile][head][s][lane][4]
+    float *x;           // [rows, D] row-major: residual in, layer output out
+    const float *wo, *w1, *w2, *wqkv;                  // fragment-PACKED weights
+    const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;   // torch vectors
+    const float *bv;                                   // in_proj_bias + 2D (value bias)
     float *q, *k, *vt;
-    int rows, tokens, tokpad, heads, activation, do_mlp, do_qkv;
+    int rows, tokens, tokpad, heads;
     unsigned long long *stamps;  // diagnostic build only (AFT_DIAG_STAMPS), else NULL
 };
 
-__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
-
-// Weight-fragment ring of one wave: RING k-blocks (32 deep) x NT column tiles x 4 k-steps.
-//   w_lane = &W[col0 + r][4h] (global, torch [out,in] layout): lane (r,h) loads W[col][8s+4h..+3].
+// Weight-fragment ring of one wave: PF+1 k-blocks (32 deep) x NT tiles x 4 k-steps.
+// Packed layout (pack_weights_kernel): [tile][k-block][s][lane][4] so ONE global_load_dwordx4 of a
+// wave reads 1 KB contiguous (16 x 64-B TA accesses instead of 64 scattered ones; with the torch
+// [out,in] layout GRBM_TA_BUSY was 92 % and the matrix pipe starved).
 template <int NT, int PF>
 struct WRing {
     f32x4 b[PF + 1][NT][4];
 };
 
-// Packed weight layout (see pack_weights_kernel): [col tile][k-block][k-step s][lane][4 floats] so
-// that ONE global_load_dwordx4 of a wave reads 1 KB contiguous (16 x 64-B accesses in the TA
-// instead of 64 scattered ones: with the torch [out,in] layout the texture addresser, not the
-// matrix pipe, was the bottleneck -- GRBM_TA_BUSY 92 %, 61 cache accesses per load instruction).
-//   w_lane = packed + (first col tile) * (K/32) * 1024 + lane * 4
-template <int K, int NT, int PF, int TS = 1>
+template <int NKB, int NT, int PF, int TS>
 __device__ __forceinline__ void ring_load(WRing<NT, PF> &ring, const float *__restrict__ w_lane, int kb) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             ring.b[kb % (PF + 1)][t][s] =
-                *reinterpret_cast<const f32x4 *>(w_lane + (size_t)(t * TS * (K / 32) + kb) * 1024 + s * 256);
+                *reinterpret_cast<const f32x4 *>(w_lane + (size_t)(t * TS * NKB + kb) * 1024 + s * 256);
 }
 
-// Issue the first PF k-blocks of a GEMM's weights.  Called BEFORE the previous phase's epilogue /
-// barrier / LayerNorm so the L2 latency of a phase's first fragments hides under that work.
-template <int K, int NT, int PF, int TS = 1>
+// Issue the first PF k-blocks of a GEMM's weights -- called BEFORE the previous phase's epilogue /
+// barrier so their L2 latency hides under that work.
+template <int NKB, int NT, int PF, int TS>
 __device__ __forceinline__ void gemm_preload(WRing<NT, PF> &ring, const float *__restrict__ w_lane) {
 #pragma unroll
-    for (int p = 0; p < PF && p < K / 32; ++p) ring_load<K, NT, PF, TS>(ring, w_lane, p);
-    __builtin_amdgcn_sched_barrier(0);   // keep the loads here, ahead of the epilogue that follows
+    for (int p = 0; p < PF && p < NKB; ++p) ring_load<NKB, NT, PF, TS>(ring, w_lane, p);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc[t] += A_tile[32 x K] * W[tile t][K]^T for this wave; a_lane = &A[row r][4h] (LDS).
-// Fragments run PF k-blocks ahead of the MFMAs that consume them; sched_barrier pins the issue
-// order so the compiler cannot sink the loads back next to their use.  Activation and weight
-// fragments have the same (row, k) lane map, so passing them to the MFMA in the other order yields
-// the TRANSPOSED product: bit t of SWAP makes tile t come out as acc[feature][row] (lane = row).
-template <int K, int NT, int PF, int TS = 1, unsigned SWAP = 0>
-__device__ __forceinline__ void gemm_run(WRing<NT, PF> &ring, const float *a_lane, const float *__restrict__ w_lane,
-                                         f32x16 (&acc)[NT]) {
-    constexpr int NKB = K / 32;
+// acc[t] += W_tile[t] (32 features x 32*NKB) . act (32*NKB x 32 rows): transposed product, lane =
+// token row.  `act(kb, s)` yields this lane's activation fragment (registers or LDS).  Bit t of
+// NORMAL swaps the operands of tile t back (lane = feature), used for the V tile.
+template <int NKB, int NT, int PF, int TS, unsigned NORMAL, class Act>
+__device__ __forceinline__ void gemm_run(WRing<NT, PF> &ring, const float *__restrict__ w_lane, f32x16 (&acc)[NT],
+                                         Act act) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        if (kb + PF < NKB) ring_load<K, NT, PF, TS>(ring, w_lane, kb + PF);
+        if (kb + PF < NKB) ring_load<NKB, NT, PF, TS>(ring, w_lane, kb + PF);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(a_lane + kb * 32 + s * 8);
+            const f32x4 a = act(kb, s);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float wv = ring.b[kb % (PF + 1)][t][s][j];
-                    acc[t] = (SWAP >> t) & 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[j], acc[t], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wv, acc[t], 0, 0, 0);
+                    acc[t] = (NORMAL >> t) & 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wv, acc[t], 0, 0, 0)
+                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[j], acc[t], 0, 0, 0);
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -129,37 +120,12 @@ __device__ __forceinline__ void gemm_run(WRing<NT, PF> &ring, const float *a_lan
 }
 
 // erf(x) = sign(x) * (1 - 2^p(|x|)), p = degree-8 fit of log2(erfc(t)) on [0,4] with p(0) = 0
-// (erfc(4) = 1.5e-8 rounds to 0 against 1 in fp32).  Branch-free, 8 FMA + one v_exp_f32;
-// max |error| 1e-7 (<= 1 ulp of erf near 1) measured against scipy.special.erf on 4e5 points --
-// the libm erff it replaces cost ~40 VALU ops and a divergent branch per element.
-__device__ __forceinline__ float erf_poly(float x) {
-    const float t = fminf(fabsf(x), 4.0f);
-    float p = -4.535924745e-05f;
-    p = fmaf(p, t, 4.455104063e-04f);
-    p = fmaf(p, t, -1.489443355e-03f);
-    p = fmaf(p, t, -7.746370393e-04f);
-    p = fmaf(p, t, 2.825369500e-02f);
-    p = fmaf(p, t, -1.484816223e-01f);
-    p = fmaf(p, t, -9.184163809e-01f);
-    p = fmaf(p, t, -1.627908587e+00f);
-    return copysignf(1.0f - __builtin_amdgcn_exp2f(p * t), x);
-}
-
-template <int ACT>
-__device__ __forceinline__ float activate(float v) {
-    // exact-erf GELU (F.gelu default, activation="gelu") or ReLU -- schemas.py:128-131 allows both
-    if constexpr (ACT == AFT_ACT_GELU) {
-        const float hv = 0.5f * v;
-        return fmaf(hv, erf_poly(v * 0.70710678118654752440f), hv);
-    } else {
-        return fmaxf(v, 0.0f);
-    }
-}
-
-// Two activations at once: the polynomial runs on v_pk_fma_f32 (two floats per lane per issue).
+// (erfc(4) = 1.5e-8 rounds to 0 against 1 in fp32).  Branch-free; max |error| 1e-7 (<= 1 ulp of erf
+// near 1) against scipy.special.erf on 4e5 points -- libm erff cost ~40 VALU ops and a divergent
+// branch per element.  Two values at once: the polynomial runs on v_pk_fma_f32.
 template <int ACT>
 __device__ __forceinline__ f32x2 activate2(f32x2 v) {
-    if constexpr (ACT == AFT_ACT_GELU) {
+    if constexpr (ACT == AFT_ACT_GELU) {  // exact-erf GELU (F.gelu default, activation="gelu")
         const f32x2 x = v * 0.70710678118654752440f;
         const f32x2 t = {fminf(fabsf(x[0]), 4.0f), fminf(fabsf(x[1]), 4.0f)};
         f32x2 p = {-4.535924745e-05f, -4.535924745e-05f};
@@ -175,324 +141,283 @@ __device__ __forceinline__ f32x2 activate2(f32x2 v) {
                          copysignf(1.0f - __builtin_amdgcn_exp2f(p[1]), x[1])};
         const f32x2 hv = v * 0.5f;
         return __builtin_elementwise_fma(hv, e, hv);
-    } else {
+    } else {  // ReLU (schemas.py:128-131 allows both)
         return f32x2{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
     }
 }
 
-// Sum over groups of LPR consecutive lanes with DPP (no LDS crossbar): quad_perm xor-1, xor-2,
-// then row_half_mirror (8 lanes) and row_mirror (16 lanes).  Every lane ends with its group's sum.
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-    static_assert(LPR == 4 || LPR == 8 || LPR == 16, "group size");
-    auto dpp = [](float x, auto ctrl) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
-    };
-    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
-    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
-    if constexpr (LPR >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
-    if constexpr (LPR >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
-    return v;
-}
-
-// LayerNorm(eps=1e-5, biased variance) of ROWS rows held in `src` (row stride ld floats), result to
-// `dst` (same stride) and optionally to global rows.  A wave owns ROWS/WAVES rows and processes
-// them in ONE pass: LPR = 64/(ROWS/WAVES) lanes share a row, each lane holds D/LPR contiguous
-// values (ds_read_b128), the row statistics are two DPP group reductions.
-template <int D, int ROWS, int WAVES>
-__device__ __forceinline__ void layernorm_tile(const float *src, float *dst, int ld,
-                                               const float *gamma, const float *beta,
-                                               float *gout, long row0, int rows, int wave, int lane) {
-    constexpr int RPW = ROWS / WAVES, LPR = 64 / RPW, VPL = D / LPR;
-    static_assert(VPL % 4 == 0, "per-lane slice must be float4-able");
-    const int row = wave * RPW + lane / LPR, c0 = (lane % LPR) * VPL;
-    float v[VPL];
+// LayerNorm(eps = 1e-5, biased variance) over D features of the row this lane belongs to, given the
+// lane's 16 pre-norm values v (features fb + 8s + 4h + j).  Partial (mean, M2) of the wave's 32
+// features goes to `stats[row][wave]`; after the barrier every lane merges the W partials (Chan).
+template <int D>
+__device__ __forceinline__ void layernorm_rows(f32x16 &v, float *stats, const float *gamma, const float *beta,
+                                               int wave, int r, int h) {
+    constexpr int W = D / 32;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; i += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4 *>(src + row * ld + c0 + i);
+    for (int e = 0; e < 16; ++e) s += v[e];
+    const float mp = s * (1.0f / 16.0f);
+    float m2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[i + j] = t[j];
-            s += t[j];
-        }
+    for (int e = 0; e < 16; ++e) m2 = fmaf(v[e] - mp, v[e] - mp, m2);
+    // other half-wave holds the row's other 16 features of this block
+    const float mo = __shfl_xor(mp, 32), m2o = __shfl_xor(m2, 32);
+    const float dlt = mp - mo;
+    if (h == 0) *reinterpret_cast<float2 *>(stats + (r * W + wave) * 2) = make_float2(0.5f * (mp + mo), m2 + m2o + 8.0f * dlt * dlt);
+    __syncthreads();
+    float mean = 0.f, msum = 0.f;
+    float pm[W], pM[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        const float2 p = *reinterpret_cast<const float2 *>(stats + (r * W + u) * 2);
+        pm[u] = p.x;
+        pM[u] = p.y;
+        mean += p.x;
     }
-    const float mean = group_sum<LPR>(s) * (1.0f / D);
-    float sq = 0.f;
+    mean *= (1.0f / W);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        v[i] -= mean;
-        sq = fmaf(v[i], v[i], sq);
-    }
-    const float rstd = rsqrtf(group_sum<LPR>(sq) * (1.0f / D) + 1e-5f);
-    const bool store = gout != nullptr && row0 + row < rows;
+    for (int u = 0; u < W; ++u) msum += pM[u] + 32.0f * (pm[u] - mean) * (pm[u] - mean);
+    const float rstd = rsqrtf(msum * (1.0f / D) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < VPL; i += 4) {
-        const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + c0 + i);   // LDS copies
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + c0 + i);
-        f32x4 y;
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + 8 * s4 + 4 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + 8 * s4 + 4 * h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = v[i + j] * rstd * g[j] + b[j];
-        *reinterpret_cast<f32x4 *>(dst + row * ld + c0 + i) = y;
-        if (store) *reinterpret_cast<f32x4 *>(gout + (row0 + row) * (long)D + c0 + i) = y;
+        for (int j = 0; j < 4; ++j) v[4 * s4 + j] = (v[4 * s4 + j] - mean) * rstd * g[j] + b[j];
     }
 }
 
-// MLP / QKV select the three launch variants at compile time (distinct symbols in a profile):
-//   <true,true>  layer l's out-proj+LN1+FFN+LN2 and layer l+1's in-projection   (5 of 7 launches at L=6)
-//   <false,true> in-projection only (first layer)      <true,false> last layer, no in-projection
-template <int D, int RT, int NWAVES, int ACT, bool MLP, bool QKV>
-__global__ __launch_bounds__(64 * NWAVES, NWAVES == 4 ? 3 : 2) void chain_kernel(const ChainArgs a) {
-    using S = ChainShape<D, RT, NWAVES>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *bufB = smem;                       // x (residual) -> x1 (LN1 out) -> x2 (LN2 out) = QKV operand
-    float *bufH = bufB + S::ROWS * S::LDA;    // FFN hidden [ROWS][LDH]
-    float *bufA = bufH + S::H_HALF;           // attention tile (dead after the out-projection) = top of H
-    float *bufS = bufH;                       // pre-LayerNorm scratch [ROWS][LDA] = bottom of H
-    float *lnp = bufH + S::H_FLOATS;          // LayerNorm affine parameters (only with do_mlp)
-    float *qkb = lnp + 4 * D;                 // q and k in-proj bias [2][D] (per-feature = per-register in the swapped tiles)
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int rt = wave / S::CG, cg = wave % S::CG;
-    const long row0 = (long)blockIdx.x * S::ROWS;
-
-    WRing<S::NT_D, 2> ring_d;       // out-proj / FFN-down fragments
-    WRing<S::NT_FF, 1> ring_ff;     // FFN-up fragments
-    WRing<S::NT_QKV, 1> ring_qkv;   // in-projection fragments
-    const int col0_d = cg * S::NT_D * 32, col0_ff = cg * S::NT_FF * 32;
-    const int col0_qkv = cg * 32;   // wave cg owns head cg: column tiles cg (q), CG+cg (k), 2CG+cg (v)
-    // fragment-packed weights: [col tile][k-block][s][lane][4]
-    const float *wo_lane = a.wo + (size_t)(col0_d / 32) * (D / 32) * 1024 + lane * 4;
-    const float *w1_lane = a.w1 + (size_t)(col0_ff / 32) * (D / 32) * 1024 + lane * 4;
-    const float *w2_lane = a.w2 + (size_t)(col0_d / 32) * (2 * D / 32) * 1024 + lane * 4;
-    const float *wq_lane = a.wqkv + (size_t)(col0_qkv / 32) * (D / 32) * 1024 + lane * 4;
-
-#ifdef AFT_DIAG_STAMPS   // diagnostic build only (-DAFT_DIAG_STAMPS): per-phase s_memtime stamps of wave 0
-#define STAMP(i)                                                                              \
-    do {                                                                                      \
-        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+#ifdef AFT_DIAG_STAMPS  // diagnostic build only: per-phase s_memtime stamps of wave 0
+#define STAMP(i)                                                                                               \
+    do {                                                                                                       \
+        if (a.stamps && tid == 0) a.stamps[(size_t)tile * 16 + (i)] = __builtin_amdgcn_s_memtime();    \
     } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
+
+// MLP / QKV select the three launch variants at compile time (distinct symbols in a profile):
+//   <true,true>  layer l's out-proj+LN1+FFN+LN2 and layer l+1's in-projection   (5 of 7 launches at L=6)
+//   <false,true> in-projection only (first layer)      <true,false> last layer, no in-projection
+template <int D, int ACT, bool MLP, bool QKV>
+__global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const ChainArgs a) {
+    using S = ChainShape<D>;
+    constexpr int W = S::WAVES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xb = smem;              // x1 then x2, fragment order
+    float *hb = xb + S::XB;        // FFN hidden, fragment order
+    float *stats = hb + S::HB;     // LayerNorm partials
+    float *par = stats + S::ST;    // bo | g1 | be1 | b1[2D] | b2 | g2 | be2
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = feature block = head
+    const int r = lane & 31, h = lane >> 5;
+    const int fb = 32 * w;                                    // first feature of this wave's block
+
+    const float *wo_base = a.wo + (size_t)w * W * 1024 + lane * 4;
+    const float *w1_base = a.w1 + (size_t)(2 * w) * W * 1024 + lane * 4;
+    const float *w2_base = a.w2 + (size_t)w * (2 * W) * 1024 + lane * 4;
+    const float *wq_base = a.wqkv + (size_t)w * W * 1024 + lane * 4;   // tiles w, W+w, 2W+w (stride W tiles)
+
+    if constexpr (MLP) {
+        for (int i = tid; i < D; i += S::THREADS) {   // per-feature vectors -> LDS, once per workgroup
+            par[i] = a.bo[i];
+            par[D + i] = a.g1[i];
+            par[2 * D + i] = a.be1[i];
+            par[3 * D + i] = a.b1[i];
+            par[4 * D + i] = a.b1[D + i];
+            par[5 * D + i] = a.b2[i];
+            par[6 * D + i] = a.g2[i];
+            par[7 * D + i] = a.be2[i];
+        }
+        __syncthreads();
+    }
+    // persistent workgroups: the grid is sized to the co-resident count and each workgroup walks the
+    // row tiles with stride gridDim.x (no dispatch gaps, no launch tail; LDS buffers need no extra
+    // barrier between tiles: every re-write sits >= 1 barrier after the last read of the old data)
+    const int ntiles = (a.rows + 31) / 32;
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * 32;
+    const int grow = min(row0 + r, a.rows - 1);               // clamped: ragged last tile computes, never stores
+    const bool row_ok = row0 + r < a.rows;
+    float *xrow = a.x + (size_t)grow * D + fb + 4 * h;        // this lane's 16 features: + 8s + j
+    // the weight addresses do not depend on the tile: launder the pointers so LICM cannot hoist all
+    // 128 KB of this wave's fragment loads out of the tile loop (241 spilled VGPRs when it did)
+    const float *wo_lane = wo_base, *w1_lane = w1_base, *w2_lane = w2_base, *wq_lane = wq_base;
+    asm volatile("" : "+v"(wo_lane), "+v"(w1_lane), "+v"(w2_lane), "+v"(wq_lane));
     STAMP(0);
-    // per-column vectors are fetched ONCE, up front: a global load inside an epilogue would sit
-    // behind an in-order vmcnt wait together with the weight prefetch and every earlier store
-    float bias_o[S::NT_D], bias_1[S::NT_FF], bias_2[S::NT_D], bias_q[S::NT_QKV];
+    WRing<1, 2> ring_d;    // out-proj / FFN-down fragments   (declared per tile: nothing is live across tiles)
+    WRing<2, 1> ring_ff;   // FFN-up fragments
+    WRing<3, 1> ring_qkv;  // in-projection fragments (q, k, v tiles of head w)
+    f32x16 cur;   // this lane's 16 features of the current activation (operand layout)
     if constexpr (MLP) {
+        gemm_preload<W, 1, 2, 1>(ring_d, wo_lane);
+        // attention output of this row tile, all W feature blocks, straight into operand registers
+        f32x4 of[W][4];
+        const float *ap = a.attn + (size_t)tile * W * 1024 + lane * 4;
 #pragma unroll
-        for (int t = 0; t < S::NT_D; ++t) {
-            bias_o[t] = a.bo[col0_d + t * 32 + r];
-            bias_2[t] = a.b2[col0_d + t * 32 + r];
-        }
+        for (int kb = 0; kb < W; ++kb)
 #pragma unroll
-        for (int t = 0; t < S::NT_FF; ++t) bias_1[t] = a.b1[col0_ff + t * 32 + r];
-        for (int i = tid; i < D; i += S::THREADS) {
-            lnp[i] = a.g1[i];
-            lnp[D + i] = a.be1[i];
-            lnp[2 * D + i] = a.g2[i];
-            lnp[3 * D + i] = a.be2[i];
-        }
-    }
-    if constexpr (QKV) {
-        for (int i = tid; i < 2 * D; i += S::THREADS) qkb[i] = a.bqkv[i];
+            for (int s = 0; s < 4; ++s) of[kb][s] = *reinterpret_cast<const f32x4 *>(ap + kb * 1024 + s * 256);
+        f32x4 xres[4];
 #pragma unroll
-        for (int t = 0; t < S::NT_QKV; ++t) bias_q[t] = a.bqkv[t * D + col0_qkv + r];   // v tile: lane = feature
-    }
-    if constexpr (MLP) {
-        gemm_preload<D, S::NT_D, 2>(ring_d, wo_lane);   // in flight while the tiles are staged
-        // ---- stage the attention-output tile (A operand of the out-projection) and the residual x ----
-        // all loads first, then the LDS writes: one memory round trip for the whole tile
-        {
-            constexpr int ITER = S::ROWS * (D / 4) / S::THREADS;
-            f32x4 va[ITER], vx[ITER];
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int i = tid + it * S::THREADS, row = i / (D / 4), c4 = i % (D / 4);
-                const long grow = min(row0 + row, (long)a.rows - 1);
-                va[it] = *reinterpret_cast<const f32x4 *>(a.attn + grow * D + c4 * 4);
-                vx[it] = *reinterpret_cast<const f32x4 *>(a.x + grow * D + c4 * 4);
-            }
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int i = tid + it * S::THREADS, row = i / (D / 4), c4 = i % (D / 4);
-                *reinterpret_cast<f32x4 *>(bufA + row * S::LDA + c4 * 4) = va[it];
-                *reinterpret_cast<f32x4 *>(bufB + row * S::LDA + c4 * 4) = vx[it];
-            }
-        }
-        __syncthreads();
+        for (int s = 0; s < 4; ++s) xres[s] = *reinterpret_cast<const f32x4 *>(xrow + 8 * s);
         STAMP(1);
-        // ---- out-projection + bias + residual -> pre-LN1 scratch (bufH, stride LDA) ----
+        // ---- out-projection (transposed) + bias + residual ----
         {
-            f32x16 acc[S::NT_D];
+            f32x16 acc[1] = {f32x16{0}};
+            gemm_run<W, 1, 2, 1, 0>(ring_d, wo_lane, acc, [&](int kb, int s) { return of[kb][s]; });
+            gemm_preload<W, 2, 1, 1>(ring_ff, w1_lane);
 #pragma unroll
-            for (int t = 0; t < S::NT_D; ++t) acc[t] = f32x16{0};
-            const int col0 = col0_d;
-            gemm_run<D, S::NT_D, 2>(ring_d, bufA + (rt * 32 + r) * S::LDA + 4 * h, wo_lane, acc);
-            STAMP(2);
-            gemm_preload<D, S::NT_FF, 1>(ring_ff, w1_lane);   // next phase's first fragments
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(par + fb + 8 * s + 4 * h);
 #pragma unroll
-            for (int t = 0; t < S::NT_D; ++t) {
-                const int col = col0 + t * 32 + r;
-                const float bias = bias_o[t];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = rt * 32 + acc_row(e, h);
-                    bufS[row * S::LDA + col] = acc[t][e] + bias + bufB[row * S::LDA + col];
-                }
+                for (int j = 0; j < 4; ++j) cur[4 * s + j] = acc[0][4 * s + j] + b[j] + xres[s][j];
             }
         }
-        __syncthreads();
+        STAMP(2);
+        layernorm_rows<D>(cur, stats, par + D + fb, par + 2 * D + fb, w, r, h);   // -> x1 (kept: FFN residual)
         STAMP(3);
-        layernorm_tile<D, S::ROWS, S::WAVES>(bufS, bufB, S::LDA, lnp, lnp + D, nullptr, row0, a.rows, wave, lane);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
         __syncthreads();
         STAMP(4);
-        // ---- FFN up-projection + activation -> hidden tile in LDS ----
+        // ---- FFN up-projection + activation -> hidden blocks 2w, 2w+1 ----
         {
-            f32x16 acc[S::NT_FF];
-#pragma unroll
-            for (int t = 0; t < S::NT_FF; ++t) acc[t] = f32x16{0};
-            const int col0 = col0_ff;
-            gemm_run<D, S::NT_FF, 1>(ring_ff, bufB + (rt * 32 + r) * S::LDA + 4 * h, w1_lane, acc);
+            f32x16 acc[2] = {f32x16{0}, f32x16{0}};
+            gemm_run<W, 2, 1, 1, 0>(ring_ff, w1_lane, acc, [&](int kb, int s) {
+                return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+            });
+            gemm_preload<2 * W, 1, 2, 1>(ring_d, w2_lane);
             STAMP(5);
-            gemm_preload<2 * D, S::NT_D, 2>(ring_d, w2_lane);
 #pragma unroll
-            for (int t = 0; t < S::NT_FF; ++t) {
-                const int col = col0 + t * 32 + r;
-                const float bias = bias_1[t];
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const f32x2 g = activate2<ACT>(f32x2{acc[t][e] + bias, acc[t][e + 1] + bias});
-                    bufH[(rt * 32 + acc_row(e, h)) * S::LDH + col] = g[0];
-                    bufH[(rt * 32 + acc_row(e + 1, h)) * S::LDH + col] = g[1];
+                for (int s = 0; s < 4; ++s) {
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(par + 3 * D + 2 * fb + 32 * t + 8 * s + 4 * h);
+                    const f32x2 g0 = activate2<ACT>(f32x2{acc[t][4 * s] + b[0], acc[t][4 * s + 1] + b[1]});
+                    const f32x2 g1 = activate2<ACT>(f32x2{acc[t][4 * s + 2] + b[2], acc[t][4 * s + 3] + b[3]});
+                    *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = f32x4{g0[0], g0[1], g1[0], g1[1]};
                 }
-            }
         }
         __syncthreads();
         STAMP(6);
-        // ---- FFN down-projection + bias + residual(x1) -> pre-LN2 scratch (bufA) ----
+        // ---- FFN down-projection (transposed) + bias + residual(x1, registers) ----
         {
-            f32x16 acc[S::NT_D];
+            f32x16 acc[1] = {f32x16{0}};
+            gemm_run<2 * W, 1, 2, 1, 0>(ring_d, w2_lane, acc, [&](int kb, int s) {
+                return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
+            });
+            if constexpr (QKV) gemm_preload<W, 3, 1, W>(ring_qkv, wq_lane);
 #pragma unroll
-            for (int t = 0; t < S::NT_D; ++t) acc[t] = f32x16{0};
-            const int col0 = col0_d;
-            gemm_run<2 * D, S::NT_D, 2>(ring_d, bufH + (rt * 32 + r) * S::LDH + 4 * h, w2_lane, acc);
-            if constexpr (QKV) gemm_preload<D, S::NT_QKV, 1, S::CG>(ring_qkv, wq_lane);
-            STAMP(7);
-            __syncthreads();   // every wave is done reading H before its bottom half becomes LN scratch
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(par + 5 * D + fb + 8 * s + 4 * h);
 #pragma unroll
-            for (int t = 0; t < S::NT_D; ++t) {
-                const int col = col0 + t * 32 + r;
-                const float bias = bias_2[t];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = rt * 32 + acc_row(e, h);
-                    bufS[row * S::LDA + col] = acc[t][e] + bias + bufB[row * S::LDA + col];
-                }
+                for (int j = 0; j < 4; ++j) cur[4 * s + j] += acc[0][4 * s + j] + b[j];
             }
         }
-        __syncthreads();
+        STAMP(7);
+        layernorm_rows<D>(cur, stats, par + 6 * D + fb, par + 7 * D + fb, w, r, h);   // -> x2
         STAMP(8);
-        layernorm_tile<D, S::ROWS, S::WAVES>(bufS, bufB, S::LDA, lnp + 2 * D, lnp + 3 * D, a.x, row0, a.rows, wave, lane);
-        __syncthreads();
-        STAMP(9);
-    } else {
-        gemm_preload<D, S::NT_QKV, 1, S::CG>(ring_qkv, wq_lane);
-        {
-            constexpr int ITER = S::ROWS * (D / 4) / S::THREADS;
-            f32x4 vx[ITER];
+        if (row_ok) {
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int i = tid + it * S::THREADS, row = i / (D / 4), c4 = i % (D / 4);
-                const long grow = min(row0 + row, (long)a.rows - 1);
-                vx[it] = *reinterpret_cast<const f32x4 *>(a.x + grow * D + c4 * 4);
-            }
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int i = tid + it * S::THREADS, row = i / (D / 4), c4 = i % (D / 4);
-                *reinterpret_cast<f32x4 *>(bufB + row * S::LDA + c4 * 4) = vx[it];
-            }
+            for (int s = 0; s < 4; ++s)
+                *reinterpret_cast<f32x4 *>(xrow + 8 * s) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
         }
-        __syncthreads();
+    } else {
+        gemm_preload<W, 3, 1, W>(ring_qkv, wq_lane);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(xrow + 8 * s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[4 * s + j] = t[j];
+        }
     }
 
     if constexpr (QKV) {
-        // ---- packed in-projection of the next attention: q,k row-major per head, v transposed ----
-        f32x16 acc[S::NT_QKV];
+        const float bias_v = a.bv[fb + r];   // V tile: lane = feature (fetched before the barrier wait)
+        // publish x2 (or x0) for the in-projection.  x1 readers are all past the hidden-exchange barrier.
 #pragma unroll
-        for (int t = 0; t < S::NT_QKV; ++t) acc[t] = f32x16{0};
-        gemm_run<D, S::NT_QKV, 1, S::CG, 0x3>(ring_qkv, bufB + (rt * 32 + r) * S::LDA + 4 * h, wq_lane, acc);
+        for (int s = 0; s < 4; ++s)
+            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+        __syncthreads();
+        STAMP(9);
+        f32x16 acc[3] = {f32x16{0}, f32x16{0}, f32x16{0}};
+        gemm_run<W, 3, 1, W, 0x4>(ring_qkv, wq_lane, acc, [&](int kb, int s) {
+            return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+        });
         STAMP(10);
-        // ---- epilogue: q, k, v of head `cg` for 32 token rows, written in MFMA-FRAGMENT order so that
+        // ---- epilogue: q, k, v of head w for 32 token rows, written in MFMA-FRAGMENT order so that
         // k_attn.hip reads every operand with fully coalesced 1-KB loads:
         //   q, k : [plane*H + head][key tile][s][lane = key%32 + 32*hh][4]   value (key, d = 8s + 4hh + j)
         //   vt   : [plane*H + head][key tile][g][lane = d + 32*hh][4]        value (d, key = 32kt + 8g + 4hh + j)
-        // q/k tiles were computed transposed (lane = token row, registers = features): registers
-        // 4s..4s+3 of half hh are exactly one 16-byte fragment element; the v tile (lane = feature,
-        // registers = tokens) likewise.  32 lanes x 16 B = 512 B contiguous per store instruction.
-        const int base_row = (int)row0 + rt * 32;
-        const int plane0 = base_row / a.tokens, tok0 = base_row - plane0 * a.tokens;   // tok0 % 8 == 0
-        const int nkt = a.tokpad / kTile;
-        const unsigned head_stride = (unsigned)a.tokpad * kHeadDim;            // floats per (plane, head)
-        const unsigned ph0 = (unsigned)(plane0 * a.heads + cg);
-        const bool full = base_row + 32 <= a.rows;
-        // q / k : this lane's token
+        // q/k tiles (lane = token row, registers = features): registers 4s..4s+3 of half hh are one
+        // 16-byte fragment element; the v tile (lane = feature, registers = tokens) likewise.
+        const int plane0 = row0 / a.tokens, tok0 = row0 - plane0 * a.tokens;   // tok0 % 8 == 0
+        const unsigned head_stride = (unsigned)a.tokpad * kHeadDim;             // floats per (plane, head)
+        const unsigned ph0 = (unsigned)(plane0 * a.heads + w);
+        const bool full = row0 + 32 <= a.rows;
         {
             int tok = tok0 + r;
             unsigned ph = ph0;
             if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
             const unsigned lane_off = ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok & 31) + 32 * h) * 4;
-            const bool ok = full || base_row + r < a.rows;
+            if (full || row_ok) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float *dst = (t == 0 ? a.q : a.k) + lane_off;
-                // bias is per FEATURE = per register here
+                for (int t = 0; t < 2; ++t) {
+                    float *dst = (t == 0 ? a.q : a.k) + lane_off;
 #pragma unroll
-                for (int sgrp = 0; sgrp < 4; ++sgrp) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(qkb + t * D + cg * kHeadDim + 8 * sgrp + 4 * h);
-                    const f32x4 v = {acc[t][4 * sgrp] + bv[0], acc[t][4 * sgrp + 1] + bv[1], acc[t][4 * sgrp + 2] + bv[2],
-                                     acc[t][4 * sgrp + 3] + bv[3]};
-                    if (ok) *reinterpret_cast<f32x4 *>(dst + sgrp * 256) = v;
+                    for (int s = 0; s < 4; ++s)
+                        *reinterpret_cast<f32x4 *>(dst + s * 256) = f32x4{acc[t][4 * s], acc[t][4 * s + 1], acc[t][4 * s + 2], acc[t][4 * s + 3]};
                 }
             }
         }
-        // v : this lane's feature d = r, registers 4g..4g+3 = tokens tok0 + 8g + 4h + {0..3}
-        {
-            const float bias = bias_q[2];
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                int tok = tok0 + 8 * gq + 4 * h;
-                unsigned ph = ph0;
-                if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
-                const unsigned off = ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok >> 3) & 3) * 256 + (r + 32 * h) * 4;
-                const f32x4 v = {acc[2][4 * gq] + bias, acc[2][4 * gq + 1] + bias, acc[2][4 * gq + 2] + bias,
-                                 acc[2][4 * gq + 3] + bias};
-                if (full || base_row + 8 * gq + 4 * h + 3 < a.rows) *reinterpret_cast<f32x4 *>(a.vt + off) = v;
-                else {
+        for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = tokens tok0 + 8gq + 4h + {0..3}
+            int tok = tok0 + 8 * gq + 4 * h;
+            unsigned ph = ph0;
+            if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+            const unsigned off = ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok >> 3) & 3) * 256 + (r + 32 * h) * 4;
+            const f32x4 v = {acc[2][4 * gq] + bias_v, acc[2][4 * gq + 1] + bias_v, acc[2][4 * gq + 2] + bias_v,
+                             acc[2][4 * gq + 3] + bias_v};
+            if (full || row0 + 8 * gq + 4 * h + 3 < a.rows) {
+                *reinterpret_cast<f32x4 *>(a.vt + off) = v;
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (base_row + 8 * gq + 4 * h + j < a.rows) a.vt[off + j] = v[j];
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (row0 + 8 * gq + 4 * h + j < a.rows) a.vt[off + j] = v[j];
             }
         }
-        (void)nkt;
     }
     STAMP(11);
+    // cross-tile LDS hazards of the persistent loop.  <MLP,QKV>: every re-write sits behind a barrier
+    // that follows the last read (xb: LN1 barrier of the next tile; stats: the x2-exchange barrier; hb:
+    // two barriers).  <MLP,!QKV> has no x2-exchange barrier in front of the next tile's LN1 partials and
+    // <!MLP,QKV> re-writes xb right away while slower waves still read it: both need one more barrier.
+    if constexpr (!(MLP && QKV)) __syncthreads();
+  }
 }
 
-template <int D, int RT, int NWAVES, int ACT, bool MLP, bool QKV>
+template <int D, int ACT, bool MLP, bool QKV>
 static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
-    using S = ChainShape<D, RT, NWAVES>;
+    using S = ChainShape<D>;
     static bool attr_set = false;  // idempotent; races only repeat the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<D, RT, NWAVES, ACT, MLP, QKV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<D, ACT, MLP, QKV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int blocks = (args.rows + S::ROWS - 1) / S::ROWS;
+    static int resident = 0;   // co-resident workgroups: CUs x (3 at d=128 | 1 at d=256), see __launch_bounds__ / LDS
+    if (resident == 0) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident = cus * (D == 128 ? 3 : 1);
+    }
+    const int blocks = std::min((args.rows + 31) / 32, resident);
     const size_t lds = S::LDS_BYTES;
 #ifdef AFT_DIAG_STAMPS
     if (getenv("AFT_STAMPS")) {   // phase stamps, printed on the host (never in the product build)
@@ -501,38 +426,30 @@ static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
         ChainArgs a2 = args;
         a2.stamps = dbuf;
-        hipLaunchKernelGGL((chain_kernel<D, RT, NWAVES, ACT, MLP, QKV>), dim3(blocks), dim3(S::THREADS), lds, st, a2);
+        hipLaunchKernelGGL((chain_kernel<D, ACT, MLP, QKV>), dim3(blocks), dim3(S::THREADS), lds, st, a2);
         (void)hipDeviceSynchronize();
         static int printed = 0;
-        if (printed == 0) {
-            int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_kernel<D, RT, NWAVES, ACT, MLP, QKV>, S::THREADS, lds);
-            printf("occupancy API: %d blocks/CU at %zu B LDS, %d threads\n", nb, lds, S::THREADS);
-        }
         if (printed++ < 2) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_kernel<D, ACT, MLP, QKV>, S::THREADS, lds);
             std::vector<unsigned long long> h(16 * 4096);
             (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
-            unsigned long long t0 = ~0ull, t1 = 0;
             double sum[12] = {0};
-            for (int b = 0; b < blocks; ++b) {
-                t0 = std::min(t0, h[b * 16]);
-                t1 = std::max(t1, h[b * 16 + 11]);
+            const int nblk = std::min((args.rows + 31) / 32, 4096);
+            for (int b = 0; b < nblk; ++b)
                 for (int i = 1; i < 12; ++i) {
-                    unsigned long long prev = h[b * 16 + i - 1], cur = h[b * 16 + i];
-                    if (cur == 0 || prev == 0) { int k = i - 1; while (k > 0 && h[b * 16 + k] == 0) --k; prev = h[b * 16 + k]; }
-                    if (cur) sum[i] += (double)(cur - prev);
+                    int k = i - 1;
+                    while (k > 0 && h[b * 16 + k] == 0) --k;
+                    if (h[b * 16 + i]) sum[i] += (double)(h[b * 16 + i] - h[b * 16 + k]);
                 }
-            }
-            printf("chain stamps (100MHz ticks?): total span %llu ; mean per-phase:", (unsigned long long)(t1 - t0));
-            for (int i = 1; i < 12; ++i) printf(" [%d]=%.0f", i, sum[i] / blocks);
-            printf("\n  first 6 WG start offsets:");
-            for (int b = 0; b < 6; ++b) printf(" %llu", h[b * 16] - t0);
-            printf(" ... WG 768: %llu, WG 1536: %llu\n", h[768 * 16] - t0, h[1536 * 16] - t0);
+            printf("chain<%d,mlp=%d,qkv=%d> %d blocks/CU at %zu B LDS; mean cycles per phase:", D, (int)MLP, (int)QKV, nb, lds);
+            for (int i = 1; i < 12; ++i) printf(" [%d]=%.0f", i, sum[i] / nblk);
+            printf("\n");
         }
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((chain_kernel<D, RT, NWAVES, ACT, MLP, QKV>), dim3(blocks), dim3(S::THREADS), lds, st, args);
+    hipLaunchKernelGGL((chain_kernel<D, ACT, MLP, QKV>), dim3(blocks), dim3(S::THREADS), lds, st, args);
     return hipGetLastError();
 }
 
@@ -553,7 +470,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const aft_weights w, 
     else if ((off -= (size_t)3 * d * d) < (size_t)d * d) { src = lw.out_proj_w; K = d; }
     else if ((off -= (size_t)d * d) < (size_t)2 * d * d) { src = lw.lin1_w; K = d; }
     else { off -= (size_t)2 * d * d; src = lw.lin2_w; K = 2 * d; }
-    // off = (((ct*NKB + kb)*4 + s)*64 + lane)*4
+    // off = (((tile*NKB + kb)*4 + s)*64 + lane)*4 ; element (row = 32 tile + lane%32, k = 32kb + 8s + 4(lane/32) + j)
     const int lane = (int)(off / 4) % 64, s = (int)(off / 256) % 4;
     const int blk = (int)(off / 1024), nkb = K / 32, kb = blk % nkb, ct = blk / nkb;
     const int col = ct * 32 + (lane & 31), k = kb * 32 + s * 8 + (lane >> 5) * 4;
@@ -570,11 +487,11 @@ hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float 
     return hipGetLastError();
 }
 
-template <int D, int RT, int NWAVES, int ACT>
-static hipError_t launch_chain_t(const ChainArgs &args, hipStream_t st) {
-    if (args.do_mlp && args.do_qkv) return launch_chain_v<D, RT, NWAVES, ACT, true, true>(args, st);
-    if (args.do_mlp) return launch_chain_v<D, RT, NWAVES, ACT, true, false>(args, st);
-    return launch_chain_v<D, RT, NWAVES, ACT, false, true>(args, st);
+template <int D, int ACT>
+static hipError_t launch_chain_t(const ChainArgs &args, bool mlp, bool qkv, hipStream_t st) {
+    if (mlp && qkv) return launch_chain_v<D, ACT, true, true>(args, st);
+    if (mlp) return launch_chain_v<D, ACT, true, false>(args, st);
+    return launch_chain_v<D, ACT, false, true>(args, st);
 }
 
 hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const float *m_packed,
@@ -594,19 +511,17 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const f
     }
     if (qw != nullptr) {
         a.wqkv = q_packed;
-        a.bqkv = qw->in_proj_b;
+        a.bv = qw->in_proj_b + 2 * c.model_dim;
     }
     a.q = q; a.k = k; a.vt = vt;
     a.rows = rows; a.tokens = tokens; a.tokpad = tokpad;
-    a.heads = c.num_head; a.activation = c.activation;
-    a.do_mlp = m != nullptr; a.do_qkv = qw != nullptr;
-    // d=128: 32-row tiles, 4 waves, 67 KB LDS -> two workgroups per CU overlap each other's
-    // barrier/epilogue/LayerNorm phases; d=256: 32-row tiles, 8 waves, 133 KB LDS.
+    a.heads = c.num_head;
     const bool gelu = c.activation == AFT_ACT_GELU;
+    const bool mlp = m != nullptr, qkv = qw != nullptr;
     if (c.model_dim == 128)
-        return gelu ? launch_chain_t<128, 1, 4, AFT_ACT_GELU>(a, st) : launch_chain_t<128, 1, 4, AFT_ACT_RELU>(a, st);
+        return gelu ? launch_chain_t<128, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<128, AFT_ACT_RELU>(a, mlp, qkv, st);
     if (c.model_dim == 256)
-        return gelu ? launch_chain_t<256, 1, 8, AFT_ACT_GELU>(a, st) : launch_chain_t<256, 1, 8, AFT_ACT_RELU>(a, st);
+        return gelu ? launch_chain_t<256, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<256, AFT_ACT_RELU>(a, mlp, qkv, st);
     return hipErrorInvalidValue;
 }
 

@@ -129,6 +129,29 @@ def test_full_size_batch128_properties(oracle_lib):
     assert abs(dev_sum - host_sum) <= 1e-9 * host_sum
 
 
+def test_config5_persistent_tiles(oracle_lib):
+    """BASELINE config 5 shapes (240x28 grid, 12 layers, d=256, 8 heads, 1120 tokens) at B=16:
+    1120 row tiles over 256 resident workgroups, so every workgroup walks several tiles (the
+    persistent loop of k_chain.hip / k_attn.hip) -- determinism, chunk independence, oracle sample."""
+    g = Golden("C5_ada_large")
+    cfg, sd = g.abi_config(), g.state_dict()
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    B = 16
+    inp = synth.make_inputs(B, ofdm=(240, 28), pilot=(24, 4), seed=515)
+    meta = [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    pil = _t(inp["pilots"])
+    full = eng.forward(pil, *meta).clone()
+    again = eng.forward(pil, *meta)
+    assert torch.equal(torch.view_as_real(again), torch.view_as_real(full))
+    part = eng.forward(pil[12:16], *[m[12:16] for m in meta])
+    assert torch.equal(torch.view_as_real(part), torch.view_as_real(full[12:16]))
+    idx = [0, 15]
+    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"][idx], inp["snr"][idx], inp["ds"][idx], inp["dop"][idx])
+    got = full[idx].cpu().numpy()
+    assert np.abs(got - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("name", ["D_forti", "A_ada"])
 def test_module_surface_on_gpu(name):
     """The drop-in nn.Module: CPU inputs in, device output out, HIP path under eval+no_grad,
