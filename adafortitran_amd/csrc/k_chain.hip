@@ -28,8 +28,9 @@
 //   * weights: fragment-packed per call (pack_weights_kernel), streamed from L2 into a register
 //     ring PF k-blocks ahead of their MFMAs, the first fragments of the NEXT GEMM issued before the
 //     current epilogue; sched_barrier pins that order.
-//   * 5 workgroup barriers per tile (2 LN tables, x1 / hidden / x2 exchanges); LDS = 53 KB at
-//     d=128 => 3 workgroups per CU overlap each other's non-MFMA phases.
+//   * 5 workgroup barriers per tile (2 LN tables, x1 / hidden / x2 exchanges); biases enter as the
+//     accumulators' initial values; LDS = 51 KB at d=128 => 3 workgroups per CU (measured: the LDS
+//     allocator rounds up, 53 KB admitted only 2 although the occupancy API said 3).
 //   * HBM per row: read attn + x, write x + q,k,v; weights (512 KB/layer at d=128) stay in L2.
 //   * K's in-projection bias is dropped: softmax_j(q.(k_j + b)) = softmax_j(q.k_j + q.b) and the
 //     row-constant q.b cancels (it only adds rounding error to the logits); Q's bias is applied by
@@ -50,7 +51,7 @@ struct ChainShape {
     static constexpr int XB = WAVES * 1024;          // x1 / x2 exchange   [feature block][s][lane][4]
     static constexpr int HB = 2 * WAVES * 1024;      // FFN hidden exchange [hidden block][s][lane][4]
     static constexpr int ST = 32 * WAVES * 2;        // LayerNorm partials [row][wave]{mean, M2}
-    static constexpr int PAR = 8 * D;                // bo, g1, be1, b1[2D], b2, g2, be2
+    static constexpr int PAR = 4 * D;                // g1, be1, g2, be2 (biases ride in as accumulator initial values)
     static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(XB + HB + ST + PAR);
 };
 
@@ -187,6 +188,20 @@ __device__ __forceinline__ void layernorm_rows(f32x16 &v, float *stats, const fl
     }
 }
 
+// A GEMM's bias enters as the accumulator's initial value: in the transposed product register e of
+// lane half h is feature f0 + (e&3) + 8(e>>2) + 4h, so four 16-byte loads fill the accumulator
+// (no LDS copy of the bias vectors, no VALU add in the epilogue, issued long before the first MFMA).
+__device__ __forceinline__ f32x16 bias_acc(const float *__restrict__ bias_f0, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_f0 + 8 * s + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * s + j] = b[j];
+    }
+    return acc;
+}
+
 #ifdef AFT_DIAG_STAMPS  // diagnostic build only: per-phase s_memtime stamps of wave 0
 #define STAMP(i)                                                                                               \
     do {                                                                                                       \
@@ -207,28 +222,23 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     float *xb = smem;              // x1 then x2, fragment order
     float *hb = xb + S::XB;        // FFN hidden, fragment order
     float *stats = hb + S::HB;     // LayerNorm partials
-    float *par = stats + S::ST;    // bo | g1 | be1 | b1[2D] | b2 | g2 | be2
+    float *par = stats + S::ST;    // g1 | be1 | g2 | be2
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave = feature block = head
     const int r = lane & 31, h = lane >> 5;
     const int fb = 32 * w;                                    // first feature of this wave's block
 
-    const float *wo_base = a.wo + (size_t)w * W * 1024 + lane * 4;
-    const float *w1_base = a.w1 + (size_t)(2 * w) * W * 1024 + lane * 4;
-    const float *w2_base = a.w2 + (size_t)w * (2 * W) * 1024 + lane * 4;
-    const float *wq_base = a.wqkv + (size_t)w * W * 1024 + lane * 4;   // tiles w, W+w, 2W+w (stride W tiles)
+    const unsigned wo_off = (unsigned)w * W * 1024 + lane * 4, w1_off = (unsigned)(2 * w) * W * 1024 + lane * 4;
+    const unsigned w2_off = (unsigned)w * (2 * W) * 1024 + lane * 4;
+    const unsigned wq_off = (unsigned)w * W * 1024 + lane * 4;   // tiles w, W+w, 2W+w (stride W tiles)
 
     if constexpr (MLP) {
-        for (int i = tid; i < D; i += S::THREADS) {   // per-feature vectors -> LDS, once per workgroup
-            par[i] = a.bo[i];
-            par[D + i] = a.g1[i];
-            par[2 * D + i] = a.be1[i];
-            par[3 * D + i] = a.b1[i];
-            par[4 * D + i] = a.b1[D + i];
-            par[5 * D + i] = a.b2[i];
-            par[6 * D + i] = a.g2[i];
-            par[7 * D + i] = a.be2[i];
+        for (int i = tid; i < D; i += S::THREADS) {   // LayerNorm affine vectors -> LDS, once per workgroup
+            par[i] = a.g1[i];
+            par[D + i] = a.be1[i];
+            par[2 * D + i] = a.g2[i];
+            par[3 * D + i] = a.be2[i];
         }
         __syncthreads();
     }
@@ -244,14 +254,26 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     float *xrow = a.x + (size_t)grow * D + fb + 4 * h;        // this lane's 16 features: + 8s + j
     // the weight addresses do not depend on the tile: launder the pointers so LICM cannot hoist all
     // 128 KB of this wave's fragment loads out of the tile loop (241 spilled VGPRs when it did)
-    const float *wo_lane = wo_base, *w1_lane = w1_base, *w2_lane = w2_base, *wq_lane = wq_base;
-    asm volatile("" : "+v"(wo_lane), "+v"(w1_lane), "+v"(w2_lane), "+v"(wq_lane));
+    // (launder the OFFSET, not the pointer: a laundered pointer loses its address space and the loads
+    //  become flat_load, whose out-of-order return forces vmcnt(0)+lgkmcnt(0) waits)
+    unsigned lo = 0;
+    asm volatile("" : "+v"(lo));
+    const float *wo_lane = a.wo + (wo_off + lo), *w1_lane = a.w1 + (w1_off + lo);
+    const float *w2_lane = a.w2 + (w2_off + lo), *wq_lane = a.wqkv + (wq_off + lo);
     STAMP(0);
+#ifdef AFT_DIAG_STAMPS
+    if (a.stamps && tid == 0) {
+        a.stamps[(size_t)tile * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[(size_t)tile * 16 + 14] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                           __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_ID, XCC_ID
+    }
+#endif
     WRing<1, 2> ring_d;    // out-proj / FFN-down fragments   (declared per tile: nothing is live across tiles)
     WRing<2, 1> ring_ff;   // FFN-up fragments
     WRing<3, 1> ring_qkv;  // in-projection fragments (q, k, v tiles of head w)
     f32x16 cur;   // this lane's 16 features of the current activation (operand layout)
     if constexpr (MLP) {
+        f32x16 acc_o[1] = {bias_acc(a.bo + fb, h)};
         gemm_preload<W, 1, 2, 1>(ring_d, wo_lane);
         // attention output of this row tile, all W feature blocks, straight into operand registers
         f32x4 of[W][4];
@@ -265,19 +287,15 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
         for (int s = 0; s < 4; ++s) xres[s] = *reinterpret_cast<const f32x4 *>(xrow + 8 * s);
         STAMP(1);
         // ---- out-projection (transposed) + bias + residual ----
-        {
-            f32x16 acc[1] = {f32x16{0}};
-            gemm_run<W, 1, 2, 1, 0>(ring_d, wo_lane, acc, [&](int kb, int s) { return of[kb][s]; });
-            gemm_preload<W, 2, 1, 1>(ring_ff, w1_lane);
+        gemm_run<W, 1, 2, 1, 0>(ring_d, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
+        f32x16 acc_h[2] = {bias_acc(a.b1 + 2 * fb, h), bias_acc(a.b1 + 2 * fb + 32, h)};
+        gemm_preload<W, 2, 1, 1>(ring_ff, w1_lane);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(par + fb + 8 * s + 4 * h);
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cur[4 * s + j] = acc[0][4 * s + j] + b[j] + xres[s][j];
-            }
-        }
+            for (int j = 0; j < 4; ++j) cur[4 * s + j] = acc_o[0][4 * s + j] + xres[s][j];
         STAMP(2);
-        layernorm_rows<D>(cur, stats, par + D + fb, par + 2 * D + fb, w, r, h);   // -> x1 (kept: FFN residual)
+        layernorm_rows<D>(cur, stats, par + fb, par + D + fb, w, r, h);   // -> x1 (kept: FFN residual)
         STAMP(3);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -285,41 +303,31 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
         __syncthreads();
         STAMP(4);
         // ---- FFN up-projection + activation -> hidden blocks 2w, 2w+1 ----
-        {
-            f32x16 acc[2] = {f32x16{0}, f32x16{0}};
-            gemm_run<W, 2, 1, 1, 0>(ring_ff, w1_lane, acc, [&](int kb, int s) {
-                return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
-            });
-            gemm_preload<2 * W, 1, 2, 1>(ring_d, w2_lane);
-            STAMP(5);
+        gemm_run<W, 2, 1, 1, 0>(ring_ff, w1_lane, acc_h, [&](int kb, int s) {
+            return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+        });
+        f32x16 acc_d[1] = {bias_acc(a.b2 + fb, h)};
+        gemm_preload<2 * W, 1, 2, 1>(ring_d, w2_lane);
+        STAMP(5);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const f32x4 b = *reinterpret_cast<const f32x4 *>(par + 3 * D + 2 * fb + 32 * t + 8 * s + 4 * h);
-                    const f32x2 g0 = activate2<ACT>(f32x2{acc[t][4 * s] + b[0], acc[t][4 * s + 1] + b[1]});
-                    const f32x2 g1 = activate2<ACT>(f32x2{acc[t][4 * s + 2] + b[2], acc[t][4 * s + 3] + b[3]});
-                    *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = f32x4{g0[0], g0[1], g1[0], g1[1]};
-                }
-        }
+            for (int s = 0; s < 4; ++s) {
+                const f32x2 g0 = activate2<ACT>(f32x2{acc_h[t][4 * s], acc_h[t][4 * s + 1]});
+                const f32x2 g1 = activate2<ACT>(f32x2{acc_h[t][4 * s + 2], acc_h[t][4 * s + 3]});
+                *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = f32x4{g0[0], g0[1], g1[0], g1[1]};
+            }
         __syncthreads();
         STAMP(6);
         // ---- FFN down-projection (transposed) + bias + residual(x1, registers) ----
-        {
-            f32x16 acc[1] = {f32x16{0}};
-            gemm_run<2 * W, 1, 2, 1, 0>(ring_d, w2_lane, acc, [&](int kb, int s) {
-                return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
-            });
-            if constexpr (QKV) gemm_preload<W, 3, 1, W>(ring_qkv, wq_lane);
+        gemm_run<2 * W, 1, 2, 1, 0>(ring_d, w2_lane, acc_d, [&](int kb, int s) {
+            return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
+        });
+        if constexpr (QKV) gemm_preload<W, 3, 1, W>(ring_qkv, wq_lane);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(par + 5 * D + fb + 8 * s + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cur[4 * s + j] += acc[0][4 * s + j] + b[j];
-            }
-        }
+        for (int e = 0; e < 16; ++e) cur[e] += acc_d[0][e];
         STAMP(7);
-        layernorm_rows<D>(cur, stats, par + 6 * D + fb, par + 7 * D + fb, w, r, h);   // -> x2
+        layernorm_rows<D>(cur, stats, par + 2 * D + fb, par + 3 * D + fb, w, r, h);   // -> x2
         STAMP(8);
         if (row_ok) {
 #pragma unroll
@@ -339,14 +347,21 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     if constexpr (QKV) {
         const float bias_v = a.bv[fb + r];   // V tile: lane = feature (fetched before the barrier wait)
         // publish x2 (or x0) for the in-projection.  x1 readers are all past the hidden-exchange barrier.
+        // The QKV-only variant has one barrier per tile, so it alternates between two exchange buffers
+        // (xb / the idle hidden buffer): a re-write then sits two barriers behind the last read.
+        float *xq = xb;
+        if constexpr (!MLP) xq = (((tile - (int)blockIdx.x) / (int)gridDim.x) & 1) ? hb : xb;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+            *reinterpret_cast<f32x4 *>(xq + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
         __syncthreads();
         STAMP(9);
-        f32x16 acc[3] = {f32x16{0}, f32x16{0}, f32x16{0}};
+        f32x16 vinit;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) vinit[e] = bias_v;
+        f32x16 acc[3] = {f32x16{0}, f32x16{0}, vinit};
         gemm_run<W, 3, 1, W, 0x4>(ring_qkv, wq_lane, acc, [&](int kb, int s) {
-            return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+            return *reinterpret_cast<const f32x4 *>(xq + (kb * 4 + s) * 256 + lane * 4);
         });
         STAMP(10);
         // ---- epilogue: q, k, v of head w for 32 token rows, written in MFMA-FRAGMENT order so that
@@ -380,8 +395,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
             unsigned ph = ph0;
             if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
             const unsigned off = ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok >> 3) & 3) * 256 + (r + 32 * h) * 4;
-            const f32x4 v = {acc[2][4 * gq] + bias_v, acc[2][4 * gq + 1] + bias_v, acc[2][4 * gq + 2] + bias_v,
-                             acc[2][4 * gq + 3] + bias_v};
+            const f32x4 v = {acc[2][4 * gq], acc[2][4 * gq + 1], acc[2][4 * gq + 2], acc[2][4 * gq + 3]};
             if (full || row0 + 8 * gq + 4 * h + 3 < a.rows) {
                 *reinterpret_cast<f32x4 *>(a.vt + off) = v;
             } else {
@@ -392,11 +406,14 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
         }
     }
     STAMP(11);
+#ifdef AFT_DIAG_STAMPS
+    if (a.stamps && tid == 0) a.stamps[(size_t)tile * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
     // cross-tile LDS hazards of the persistent loop.  <MLP,QKV>: every re-write sits behind a barrier
     // that follows the last read (xb: LN1 barrier of the next tile; stats: the x2-exchange barrier; hb:
-    // two barriers).  <MLP,!QKV> has no x2-exchange barrier in front of the next tile's LN1 partials and
-    // <!MLP,QKV> re-writes xb right away while slower waves still read it: both need one more barrier.
-    if constexpr (!(MLP && QKV)) __syncthreads();
+    // two barriers).  <!MLP,QKV> double-buffers its exchange (above).  <MLP,!QKV> has no x2-exchange
+    // barrier in front of the next tile's LN1 partials: one more barrier.
+    if constexpr (MLP && !QKV) __syncthreads();
   }
 }
 
@@ -445,6 +462,22 @@ static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
             printf("chain<%d,mlp=%d,qkv=%d> %d blocks/CU at %zu B LDS; mean cycles per phase:", D, (int)MLP, (int)QKV, nb, lds);
             for (int i = 1; i < 12; ++i) printf(" [%d]=%.0f", i, sum[i] / nblk);
             printf("\n");
+            // residency: busy tile-time per (xcc, hw cu id) / kernel span (memrealtime = 100 MHz)
+            unsigned long long t0 = ~0ull, t1 = 0;
+            std::vector<double> busy(8 * 4096, 0.0);
+            std::vector<int> cnt(8 * 4096, 0);
+            for (int b = 0; b < nblk; ++b) {
+                const unsigned long long s0 = h[b * 16 + 12], s1 = h[b * 16 + 13], id = h[b * 16 + 14];
+                t0 = std::min(t0, s0); t1 = std::max(t1, s1);
+                const unsigned hw = (unsigned)(id >> 32), xcc = (unsigned)id & 7;
+                const unsigned cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (((hw >> 12) & 1) << 7);   // cu_id, se_id, sh_id
+                busy[xcc * 4096 + cu] += (double)(s1 - s0);
+                cnt[xcc * 4096 + cu]++;
+            }
+            int ncu = 0, mn = 1 << 30, mx = 0; double tot = 0;
+            for (size_t i = 0; i < busy.size(); ++i) if (cnt[i]) { ++ncu; tot += busy[i]; mn = std::min(mn, cnt[i]); mx = std::max(mx, cnt[i]); }
+            printf("  span %.1f us; %d distinct CUs; tiles/CU min %d max %d; mean concurrent workgroups per CU %.2f; mean tile time %.1f us\n",
+                   (t1 - t0) / 100.0, ncu, mn, mx, tot / ncu / (double)(t1 - t0), tot / nblk / 100.0);
         }
         return hipGetLastError();
     }
