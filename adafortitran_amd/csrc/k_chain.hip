@@ -75,22 +75,33 @@ struct WRing {
     f32x4 b[PF + 1][NT][4];
 };
 
+// All hot loads go through a buffer resource (SRD + 32-bit byte offset), not global_load with 64-bit
+// per-lane addresses: micro-benchmarked on MI355X (tools/micro/mfma_feed2.hip, NT=3 feed loop) the
+// global_load form drops from 136 to 104 TFLOP/s as 1 -> 3 workgroups per CU stream weights, the
+// buffer_load form goes 137 -> 149 TFLOP/s.
+using Srd = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ Srd make_srd(const float *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 srd_load(Srd r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
 template <int NKB, int NT, int PF, int TS>
-__device__ __forceinline__ void ring_load(WRing<NT, PF> &ring, const float *__restrict__ w_lane, int kb) {
+__device__ __forceinline__ void ring_load(WRing<NT, PF> &ring, Srd w, unsigned w_lane, int kb) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            ring.b[kb % (PF + 1)][t][s] =
-                *reinterpret_cast<const f32x4 *>(w_lane + (size_t)(t * TS * NKB + kb) * 1024 + s * 256);
+            ring.b[kb % (PF + 1)][t][s] = srd_load(w, w_lane + (unsigned)((t * TS * NKB + kb) * 1024 + s * 256) * 4);
 }
 
 // Issue the first PF k-blocks of a GEMM's weights -- called BEFORE the previous phase's epilogue /
 // barrier so their L2 latency hides under that work.
 template <int NKB, int NT, int PF, int TS>
-__device__ __forceinline__ void gemm_preload(WRing<NT, PF> &ring, const float *__restrict__ w_lane) {
+__device__ __forceinline__ void gemm_preload(WRing<NT, PF> &ring, Srd w, unsigned w_lane) {
 #pragma unroll
-    for (int p = 0; p < PF && p < NKB; ++p) ring_load<NKB, NT, PF, TS>(ring, w_lane, p);
+    for (int p = 0; p < PF && p < NKB; ++p) ring_load<NKB, NT, PF, TS>(ring, w, w_lane, p);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -98,11 +109,10 @@ __device__ __forceinline__ void gemm_preload(WRing<NT, PF> &ring, const float *_
 // token row.  `act(kb, s)` yields this lane's activation fragment (registers or LDS).  Bit t of
 // NORMAL swaps the operands of tile t back (lane = feature), used for the V tile.
 template <int NKB, int NT, int PF, int TS, unsigned NORMAL, class Act>
-__device__ __forceinline__ void gemm_run(WRing<NT, PF> &ring, const float *__restrict__ w_lane, f32x16 (&acc)[NT],
-                                         Act act) {
+__device__ __forceinline__ void gemm_run(WRing<NT, PF> &ring, Srd w, unsigned w_lane, f32x16 (&acc)[NT], Act act) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        if (kb + PF < NKB) ring_load<NKB, NT, PF, TS>(ring, w_lane, kb + PF);
+        if (kb + PF < NKB) ring_load<NKB, NT, PF, TS>(ring, w, w_lane, kb + PF);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -229,6 +239,8 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     const int r = lane & 31, h = lane >> 5;
     const int fb = 32 * w;                                    // first feature of this wave's block
 
+    const Srd srd_wo = make_srd(a.wo), srd_w1 = make_srd(a.w1), srd_w2 = make_srd(a.w2), srd_wq = make_srd(a.wqkv);
+    const Srd srd_attn = make_srd(a.attn);
     const unsigned wo_off = (unsigned)w * W * 1024 + lane * 4, w1_off = (unsigned)(2 * w) * W * 1024 + lane * 4;
     const unsigned w2_off = (unsigned)w * (2 * W) * 1024 + lane * 4;
     const unsigned wq_off = (unsigned)w * W * 1024 + lane * 4;   // tiles w, W+w, 2W+w (stride W tiles)
@@ -254,12 +266,12 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     float *xrow = a.x + (size_t)grow * D + fb + 4 * h;        // this lane's 16 features: + 8s + j
     // the weight addresses do not depend on the tile: launder the pointers so LICM cannot hoist all
     // 128 KB of this wave's fragment loads out of the tile loop (241 spilled VGPRs when it did)
-    // (launder the OFFSET, not the pointer: a laundered pointer loses its address space and the loads
+    // (launder an OFFSET, never a pointer: a laundered pointer loses its address space and the loads
     //  become flat_load, whose out-of-order return forces vmcnt(0)+lgkmcnt(0) waits)
     unsigned lo = 0;
     asm volatile("" : "+v"(lo));
-    const float *wo_lane = a.wo + (wo_off + lo), *w1_lane = a.w1 + (w1_off + lo);
-    const float *w2_lane = a.w2 + (w2_off + lo), *wq_lane = a.wqkv + (wq_off + lo);
+    const unsigned wo_lane = (wo_off + lo) * 4, w1_lane = (w1_off + lo) * 4, w2_lane = (w2_off + lo) * 4,
+                   wq_lane = (wq_off + lo) * 4;   // byte offsets into the packed weight blocks
     STAMP(0);
 #ifdef AFT_DIAG_STAMPS
     if (a.stamps && tid == 0) {
@@ -274,22 +286,22 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     f32x16 cur;   // this lane's 16 features of the current activation (operand layout)
     if constexpr (MLP) {
         f32x16 acc_o[1] = {bias_acc(a.bo + fb, h)};
-        gemm_preload<W, 1, 2, 1>(ring_d, wo_lane);
+        gemm_preload<W, 1, 2, 1>(ring_d, srd_wo, wo_lane);
         // attention output of this row tile, all W feature blocks, straight into operand registers
         f32x4 of[W][4];
-        const float *ap = a.attn + (size_t)tile * W * 1024 + lane * 4;
+        const unsigned ap = ((unsigned)tile * W * 1024 + lane * 4) * 4;
 #pragma unroll
         for (int kb = 0; kb < W; ++kb)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) of[kb][s] = *reinterpret_cast<const f32x4 *>(ap + kb * 1024 + s * 256);
+            for (int s = 0; s < 4; ++s) of[kb][s] = srd_load(srd_attn, ap + (kb * 1024 + s * 256) * 4);
         f32x4 xres[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) xres[s] = *reinterpret_cast<const f32x4 *>(xrow + 8 * s);
         STAMP(1);
         // ---- out-projection (transposed) + bias + residual ----
-        gemm_run<W, 1, 2, 1, 0>(ring_d, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
+        gemm_run<W, 1, 2, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
         f32x16 acc_h[2] = {bias_acc(a.b1 + 2 * fb, h), bias_acc(a.b1 + 2 * fb + 32, h)};
-        gemm_preload<W, 2, 1, 1>(ring_ff, w1_lane);
+        gemm_preload<W, 2, 1, 1>(ring_ff, srd_w1, w1_lane);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -303,11 +315,11 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
         __syncthreads();
         STAMP(4);
         // ---- FFN up-projection + activation -> hidden blocks 2w, 2w+1 ----
-        gemm_run<W, 2, 1, 1, 0>(ring_ff, w1_lane, acc_h, [&](int kb, int s) {
+        gemm_run<W, 2, 1, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
         });
         f32x16 acc_d[1] = {bias_acc(a.b2 + fb, h)};
-        gemm_preload<2 * W, 1, 2, 1>(ring_d, w2_lane);
+        gemm_preload<2 * W, 1, 2, 1>(ring_d, srd_w2, w2_lane);
         STAMP(5);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -320,10 +332,10 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
         __syncthreads();
         STAMP(6);
         // ---- FFN down-projection (transposed) + bias + residual(x1, registers) ----
-        gemm_run<2 * W, 1, 2, 1, 0>(ring_d, w2_lane, acc_d, [&](int kb, int s) {
+        gemm_run<2 * W, 1, 2, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
         });
-        if constexpr (QKV) gemm_preload<W, 3, 1, W>(ring_qkv, wq_lane);
+        if constexpr (QKV) gemm_preload<W, 3, 1, W>(ring_qkv, srd_wq, wq_lane);
 #pragma unroll
         for (int e = 0; e < 16; ++e) cur[e] += acc_d[0][e];
         STAMP(7);
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
                 *reinterpret_cast<f32x4 *>(xrow + 8 * s) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
         }
     } else {
-        gemm_preload<W, 3, 1, W>(ring_qkv, wq_lane);
+        gemm_preload<W, 3, 1, W>(ring_qkv, srd_wq, wq_lane);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f32x4 t = *reinterpret_cast<const f32x4 *>(xrow + 8 * s);
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
 #pragma unroll
         for (int e = 0; e < 16; ++e) vinit[e] = bias_v;
         f32x16 acc[3] = {f32x16{0}, f32x16{0}, vinit};
-        gemm_run<W, 3, 1, W, 0x4>(ring_qkv, wq_lane, acc, [&](int kb, int s) {
+        gemm_run<W, 3, 1, W, 0x4>(ring_qkv, srd_wq, wq_lane, acc, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(xq + (kb * 4 + s) * 256 + lane * 4);
         });
         STAMP(10);
