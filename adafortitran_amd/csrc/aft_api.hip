@@ -145,6 +145,8 @@ int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pi
     if (rc != AFT_OK) return rc;
     AFT_REQUIRE(w && pilots && out && workspace, "NULL pointer argument");
     AFT_REQUIRE(batch > 0, "batch must be positive (got %d)", batch);
+    AFT_REQUIRE((size_t)2 * batch * tokens_of(*cfg) * cfg->model_dim * sizeof(float) < ((size_t)1 << 31),
+                "batch %d too large for 32-bit buffer offsets (split the batch)", batch);
     // reference fortitran.py:157-158: meta_data is required when channel adaptation is enabled
     AFT_REQUIRE(!cfg->adaptive || (snr && ds && dop), "meta_data is required when channel adaptation is enabled");
     const Workspace ws = plan_workspace(*cfg, batch);

@@ -33,6 +33,17 @@
 
 namespace aft {
 
+// Buffer-resource loads (SRD + 32-bit byte offset): with several waves per SIMD streaming operands,
+// global_load's 64-bit per-lane addressing throttles the fp32 MFMA stream (tools/micro/mfma_feed2.hip:
+// 104 vs 149 TFLOP/s at 3 workgroups/CU); buffer_load does not.
+using Srd = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ Srd make_srd(const float *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 srd_load(Srd r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
 struct AttnState {
     float m_run, l_run;
     f32x16 oacc;
@@ -42,8 +53,8 @@ struct AttnState {
 // TAIL = false: all CH tiles exist and are full (no masks, no bounds checks: the steady state);
 // TAIL = true : the final chunk -- tiles >= nkt are skipped, the ragged last tile is masked.
 template <int CH, bool TAIL>
-__device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4], const float *__restrict__ kb,
-                                           const float *__restrict__ vb, int c0, int nkt, int tokens, int h) {
+__device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4], Srd ks, Srd vs, unsigned kb,
+                                           unsigned vb, int c0, int nkt, int tokens, int h) {
     f32x16 sacc[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -52,7 +63,7 @@ __device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4]
         if (!TAIL || kt < nkt) {
             f32x4 kreg[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) kreg[s] = *reinterpret_cast<const f32x4 *>(kb + kt * 1024 + s * 256);
+            for (int s = 0; s < 4; ++s) kreg[s] = srd_load(ks, kb + (unsigned)(kt * 1024 + s * 256) * 4);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -110,7 +121,7 @@ __device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4]
             for (int g = 0; g < 4; ++g) {
                 if (ragged && kt * kTile + 8 * g >= tokens) continue;   // both halves of this k group are padding
                 const int key0 = kt * kTile + 8 * g + 4 * h;
-                f32x4 v = *reinterpret_cast<const f32x4 *>(vb + kt * 1024 + g * 256);
+                f32x4 v = srd_load(vs, vb + (unsigned)(kt * 1024 + g * 256) * 4);
                 if (ragged) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -138,6 +149,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
     // persistent waves with a static, balanced schedule: the grid is sized to the co-resident wave
     // count and wave w takes tasks w, w + W, w + 2W ... (B=128: 9216 tasks over 3072 waves = exactly
     // 3 each), so every SIMD finishes together -- a 40-us task has no tail to wait for.
+    const Srd qs = make_srd(q), ks = make_srd(k), vs = make_srd(vt);
     const int total_waves = gridDim.x * 4;
     const int nkt = tokpad / kTile;
     const int r = lane & 31, h = lane >> 5;
@@ -156,9 +168,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
 
     // q, k, vt arrive in MFMA-fragment order from k_chain.hip: [ph][tile][s or g][lane][4] -> every
     // operand load below is one fully coalesced 1-KB global_load_dwordx4 per wave
-    const float *qb = q + (size_t)ph * tokpad * kHeadDim + lane * 4;
-    const float *kb = k + (size_t)ph * tokpad * kHeadDim + lane * 4;
-    const float *vb = vt + (size_t)ph * kHeadDim * tokpad + lane * 4;
+    const unsigned hb = ((unsigned)ph * tokpad * kHeadDim + lane * 4) * 4;   // byte offset of this (plane, head)
+    const unsigned kb = hb, vb = hb;
 
     // B operand of S^T = K Q^T : lane (q = r, h) holds Q[q][8s + 4h + j]; the query bias of the
     // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
     const float *bq = qbias + (ph % heads) * kHeadDim + 4 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        qreg[s] = *reinterpret_cast<const f32x4 *>(qb + qt * 1024 + s * 256);
+        qreg[s] = srd_load(qs, hb + (unsigned)(qt * 1024 + s * 256) * 4);
         qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
     }
 
@@ -179,9 +190,9 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
     int c0 = 0;
     const int full_tiles = tokens / kTile;   // tiles with no padded key
     ASTAMP(1);
-    for (; c0 + CH <= full_tiles; c0 += CH) attn_chunk<CH, false>(st, qreg, kb, vb, c0, nkt, tokens, h);
+    for (; c0 + CH <= full_tiles; c0 += CH) attn_chunk<CH, false>(st, qreg, ks, vs, kb, vb, c0, nkt, tokens, h);
     ASTAMP(2);
-    for (; c0 < nkt; c0 += CH) attn_chunk<CH, true>(st, qreg, kb, vb, c0, nkt, tokens, h);
+    for (; c0 < nkt; c0 += CH) attn_chunk<CH, true>(st, qreg, ks, vs, kb, vb, c0, nkt, tokens, h);
     ASTAMP(3);
 
     // O^T accumulator: lane = query r, register e = feature d = (e&3) + 8*(e>>2) + 4h -- i.e. registers
