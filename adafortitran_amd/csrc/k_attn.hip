@@ -43,6 +43,9 @@ __device__ __forceinline__ Srd make_srd(const float *p) {
 __device__ __forceinline__ f32x4 srd_load(Srd r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+__device__ __forceinline__ void srd_store(Srd r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, byte_off, 0, 0);
+}
 
 struct AttnState {
     float m_run, l_run;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
     // persistent waves with a static, balanced schedule: the grid is sized to the co-resident wave
     // count and wave w takes tasks w, w + W, w + 2W ... (B=128: 9216 tasks over 3072 waves = exactly
     // 3 each), so every SIMD finishes together -- a 40-us task has no tail to wait for.
-    const Srd qs = make_srd(q), ks = make_srd(k), vs = make_srd(vt);
+    const Srd qs = make_srd(q), ks = make_srd(k), vs = make_srd(vt), os = make_srd(out);
     const int total_waves = gridDim.x * 4;
     const int nkt = tokpad / kTile;
     const int r = lane & 31, h = lane >> 5;
@@ -204,11 +207,11 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ 
         const float inv = 1.0f / st.l_run;
         const int plane = ph / heads, head = ph % heads;
         const unsigned grow = (unsigned)plane * tokens + qrow;
-        float *dst = out + ((size_t)(grow >> 5) * (model_dim / kHeadDim) + head) * 1024 + ((grow & 31) + 32 * h) * 4;
+        const unsigned dst = (((grow >> 5) * (unsigned)(model_dim / kHeadDim) + head) * 1024 + ((grow & 31) + 32 * h) * 4) * 4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 o = {st.oacc[4 * g] * inv, st.oacc[4 * g + 1] * inv, st.oacc[4 * g + 2] * inv, st.oacc[4 * g + 3] * inv};
-            *reinterpret_cast<f32x4 *>(dst + g * 256) = o;
+            srd_store(os, dst + g * 1024, o);
         }
     }
     ASTAMP(4);

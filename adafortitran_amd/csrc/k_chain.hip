@@ -86,6 +86,9 @@ __device__ __forceinline__ Srd make_srd(const float *p) {
 __device__ __forceinline__ f32x4 srd_load(Srd r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+__device__ __forceinline__ void srd_store(Srd r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, byte_off, 0, 0);
+}
 
 template <int NKB, int NT, int PF, int TS>
 __device__ __forceinline__ void ring_load(WRing<NT, PF> &ring, Srd w, unsigned w_lane, int kb) {
@@ -201,11 +204,11 @@ __device__ __forceinline__ void layernorm_rows(f32x16 &v, float *stats, const fl
 // A GEMM's bias enters as the accumulator's initial value: in the transposed product register e of
 // lane half h is feature f0 + (e&3) + 8(e>>2) + 4h, so four 16-byte loads fill the accumulator
 // (no LDS copy of the bias vectors, no VALU add in the epilogue, issued long before the first MFMA).
-__device__ __forceinline__ f32x16 bias_acc(const float *__restrict__ bias_f0, int h) {
+__device__ __forceinline__ f32x16 bias_acc(Srd bias, int f0, int h) {
     f32x16 acc;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_f0 + 8 * s + 4 * h);
+        const f32x4 b = srd_load(bias, (unsigned)(f0 + 8 * s + 4 * h) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[4 * s + j] = b[j];
     }
@@ -240,7 +243,9 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     const int fb = 32 * w;                                    // first feature of this wave's block
 
     const Srd srd_wo = make_srd(a.wo), srd_w1 = make_srd(a.w1), srd_w2 = make_srd(a.w2), srd_wq = make_srd(a.wqkv);
-    const Srd srd_attn = make_srd(a.attn);
+    const Srd srd_attn = make_srd(a.attn), srd_x = make_srd(a.x);
+    const Srd srd_bo = make_srd(a.bo), srd_b1 = make_srd(a.b1), srd_b2 = make_srd(a.b2);
+    const Srd srd_q = make_srd(a.q), srd_k = make_srd(a.k), srd_vt = make_srd(a.vt);
     const unsigned wo_off = (unsigned)w * W * 1024 + lane * 4, w1_off = (unsigned)(2 * w) * W * 1024 + lane * 4;
     const unsigned w2_off = (unsigned)w * (2 * W) * 1024 + lane * 4;
     const unsigned wq_off = (unsigned)w * W * 1024 + lane * 4;   // tiles w, W+w, 2W+w (stride W tiles)
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     const int row0 = tile * 32;
     const int grow = min(row0 + r, a.rows - 1);               // clamped: ragged last tile computes, never stores
     const bool row_ok = row0 + r < a.rows;
-    float *xrow = a.x + (size_t)grow * D + fb + 4 * h;        // this lane's 16 features: + 8s + j
+    const unsigned xrow = ((unsigned)grow * D + fb + 4 * h) * 4;   // byte offset of this lane's 16 features: + 32s + 4j
     // the weight addresses do not depend on the tile: launder the pointers so LICM cannot hoist all
     // 128 KB of this wave's fragment loads out of the tile loop (241 spilled VGPRs when it did)
     // (launder an OFFSET, never a pointer: a laundered pointer loses its address space and the loads
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
     WRing<3, 1> ring_qkv;  // in-projection fragments (q, k, v tiles of head w)
     f32x16 cur;   // this lane's 16 features of the current activation (operand layout)
     if constexpr (MLP) {
-        f32x16 acc_o[1] = {bias_acc(a.bo + fb, h)};
+        f32x16 acc_o[1] = {bias_acc(srd_bo, fb, h)};
         gemm_preload<W, 1, 2, 1>(ring_d, srd_wo, wo_lane);
         // attention output of this row tile, all W feature blocks, straight into operand registers
         f32x4 of[W][4];
@@ -296,11 +301,11 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
             for (int s = 0; s < 4; ++s) of[kb][s] = srd_load(srd_attn, ap + (kb * 1024 + s * 256) * 4);
         f32x4 xres[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xres[s] = *reinterpret_cast<const f32x4 *>(xrow + 8 * s);
+        for (int s = 0; s < 4; ++s) xres[s] = srd_load(srd_x, xrow + 32 * s);
         STAMP(1);
         // ---- out-projection (transposed) + bias + residual ----
         gemm_run<W, 1, 2, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
-        f32x16 acc_h[2] = {bias_acc(a.b1 + 2 * fb, h), bias_acc(a.b1 + 2 * fb + 32, h)};
+        f32x16 acc_h[2] = {bias_acc(srd_b1, 2 * fb, h), bias_acc(srd_b1, 2 * fb + 32, h)};
         gemm_preload<W, 2, 1, 1>(ring_ff, srd_w1, w1_lane);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
         gemm_run<W, 2, 1, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
         });
-        f32x16 acc_d[1] = {bias_acc(a.b2 + fb, h)};
+        f32x16 acc_d[1] = {bias_acc(srd_b2, fb, h)};
         gemm_preload<2 * W, 1, 2, 1>(ring_d, srd_w2, w2_lane);
         STAMP(5);
 #pragma unroll
@@ -344,13 +349,13 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
         if (row_ok) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                *reinterpret_cast<f32x4 *>(xrow + 8 * s) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+                srd_store(srd_x, xrow + 32 * s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
         }
     } else {
         gemm_preload<W, 3, 1, W>(ring_qkv, srd_wq, wq_lane);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(xrow + 8 * s);
+            const f32x4 t = srd_load(srd_x, xrow + 32 * s);
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = t[j];
         }
@@ -394,10 +399,10 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
             if (full || row_ok) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    float *dst = (t == 0 ? a.q : a.k) + lane_off;
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
-                        *reinterpret_cast<f32x4 *>(dst + s * 256) = f32x4{acc[t][4 * s], acc[t][4 * s + 1], acc[t][4 * s + 2], acc[t][4 * s + 3]};
+                        srd_store(t == 0 ? srd_q : srd_k, (lane_off + s * 256) * 4,
+                                  f32x4{acc[t][4 * s], acc[t][4 * s + 1], acc[t][4 * s + 2], acc[t][4 * s + 3]});
                 }
             }
         }
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
             const unsigned off = ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok >> 3) & 3) * 256 + (r + 32 * h) * 4;
             const f32x4 v = {acc[2][4 * gq], acc[2][4 * gq + 1], acc[2][4 * gq + 2], acc[2][4 * gq + 3]};
             if (full || row0 + 8 * gq + 4 * h + 3 < a.rows) {
-                *reinterpret_cast<f32x4 *>(a.vt + off) = v;
+                srd_store(srd_vt, off * 4, v);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
