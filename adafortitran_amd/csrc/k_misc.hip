@@ -66,31 +66,38 @@ struct EmbedArgs {
     int S, T, p0, p1, tokens, d, din, planes;
 };
 
-template <int D>
+template <int D, bool ADAPTIVE>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     extern __shared__ float sm[];  // W1 transposed [din][D]
     const int tid = threadIdx.x;
     for (int i = tid; i < a.din * D; i += 256) sm[(i % a.din) * D + i / a.din] = a.w1[i];
-    __syncthreads();
     constexpr int PER = D / 32;
     const int tl = tid >> 5, lane32 = tid & 31;
     const long row = (long)blockIdx.x * 8 + tl;
-    if (row >= (long)a.planes * a.tokens) return;
-    const int n = (int)(row / a.tokens), t = (int)(row % a.tokens);
+    const bool live = row < (long)a.planes * a.tokens;
+    const int n = live ? (int)(row / a.tokens) : 0, t = live ? (int)(row % a.tokens) : 0;
     const int tw = a.T / a.p1, p = a.p0 * a.p1;
+    // all inputs of this token first (independent loads in flight together), then the FMAs
+    float vin[12];
+    const float *ce = a.conv_enhanced + ((size_t)n * a.S + (t / tw) * a.p0) * a.T + (t % tw) * a.p1;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) vin[f] = f < p ? ce[(f / a.p1) * a.T + f % a.p1] : 0.f;
+    if constexpr (ADAPTIVE) {
+        const float *tk = a.tokens6 + ((size_t)(n >> 1) * a.tokens + t) * 6;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) vin[6 + f] = tk[f];
+    }
     float acc[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) acc[i] = a.b1[lane32 * PER + i] + a.pos[(size_t)t * D + lane32 * PER + i];
-    for (int f = 0; f < a.din; ++f) {
-        float v;
-        if (f < p) {
-            const int sc = (t / tw) * a.p0 + f / a.p1, sym = (t % tw) * a.p1 + f % a.p1;
-            v = a.conv_enhanced[((size_t)n * a.S + sc) * a.T + sym];
-        } else {
-            v = a.tokens6[((size_t)(n >> 1) * a.tokens + t) * 6 + (f - p)];
-        }
+    __syncthreads();
+    if (!live) return;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) acc[i] = fmaf(sm[f * D + lane32 * PER + i], v, acc[i]);
+    for (int f = 0; f < (ADAPTIVE ? 12 : 6); ++f) {
+        if (f < 6 && f >= p) continue;
+        const int frow = f < 6 ? f : p + (f - 6);   // row of W1^T: patch features then adapter features
+#pragma unroll
+        for (int i = 0; i < PER; ++i) acc[i] = fmaf(sm[frow * D + lane32 * PER + i], vin[f], acc[i]);
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) a.x[row * D + lane32 * PER + i] = acc[i];
@@ -109,10 +116,15 @@ hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *
     const long rows = (long)a.planes * a.tokens;
     const int blocks = (int)((rows + 7) / 8);
     const size_t lds = sizeof(float) * a.din * a.d;
-    if (c.model_dim == 128)
-        hipLaunchKernelGGL((embed_kernel<128>), dim3(blocks), dim3(256), lds, st, a);
+    if (a.p0 * a.p1 > 6) return hipErrorInvalidValue;   // patch features are unrolled up to 6 (3x2)
+    if (c.model_dim == 128 && c.adaptive)
+        hipLaunchKernelGGL((embed_kernel<128, true>), dim3(blocks), dim3(256), lds, st, a);
+    else if (c.model_dim == 128)
+        hipLaunchKernelGGL((embed_kernel<128, false>), dim3(blocks), dim3(256), lds, st, a);
+    else if (c.model_dim == 256 && c.adaptive)
+        hipLaunchKernelGGL((embed_kernel<256, true>), dim3(blocks), dim3(256), lds, st, a);
     else if (c.model_dim == 256)
-        hipLaunchKernelGGL((embed_kernel<256>), dim3(blocks), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((embed_kernel<256, false>), dim3(blocks), dim3(256), lds, st, a);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
