@@ -241,7 +241,7 @@ def main() -> None:
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded over {world} rank(s)"},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "mse_db_vs_random_target": round(10 * np.log10(mse), 4),
-            "roofline": {"kernel": "chain_kernel<128,1,4,GELU,MLP=true,QKV=true> (out-proj+LN1+FFN+LN2 + next layer's QKV)",
+            "roofline": {"kernel": "chain_kernel<128,GELU,MLP=true,QKV=true> (out-proj+LN1+FFN+LN2 + next layer's QKV)",
                          "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": load_pmc_traffic(),

@@ -17,7 +17,7 @@ for name in ("kernel_stats.csv", "kernel_trace_summary.txt", "pmc_summary.txt", 
 text = open(os.path.join(src, "pmc_summary.txt")).read()
 vals = {}
 for block in re.split(r"\n  (?=\S)", text):
-    if block.startswith("chain_kernel<128, 1, 4, 1, true, true>"):
+    if block.startswith("chain_kernel<128, 1, true, true>"):
         for m in re.finditer(r"(\w+)\s+mean=\s*([\d.]+)", block):
             vals.setdefault(m.group(1), float(m.group(2)))
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
@@ -26,7 +26,7 @@ alg = {"read_attn_plus_x": 2 * rows * d * 4, "read_packed_weights_2_layers": 2 *
        "write_x": rows * d * 4, "write_q_k_vt": 3 * planes * heads * tokpad * 32 * 4}
 out = {
     "round": tag,
-    "kernel": "chain_kernel<128,1,4,GELU,MLP=true,QKV=true>, B=128 frames (71,680 token rows)",
+    "kernel": "chain_kernel<128,GELU,MLP=true,QKV=true>, B=128 frames (71,680 token rows)",
     "source": f"profiles/{tag}_pmc_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 50 launches",
     "FETCH_SIZE_KB_mean": fetch_kb, "WRITE_SIZE_KB_mean": write_kb,
     "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced (16 B/lane) reads -> x2; "
