@@ -13,7 +13,9 @@ import torch  # imported first on purpose: binds libamdhip64.so.7 to the runtime
 
 from . import _abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libaft_hip.so")
+# AFT_LIB_PATH: explicit override for A/B-ing kernel variants (tools/); default = the in-tree build
+_LIB_PATH = os.environ.get("AFT_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                           "libaft_hip.so")
 _lib = None
 
 

@@ -47,6 +47,10 @@ __device__ __forceinline__ void srd_store(Srd r, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, byte_off, 0, 0);
 }
 
+#ifndef AFT_ATTN_WAVES
+#define AFT_ATTN_WAVES 3   // waves per SIMD the register budget is capped for (and the persistent grid sized to)
+#endif
+
 struct AttnState {
     float m_run, l_run;
     f32x16 oacc;
@@ -142,7 +146,7 @@ __device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4]
 // with the default 512-register budget hipcc parks them in AGPRs and pays ~2.5 v_accvgpr moves
 // per MFMA around the softmax, which on the fp32 matrix path comes straight out of MFMA time.
 template <int CH>
-__global__ __launch_bounds__(256, 3) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
+__global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                       const float *__restrict__ vt, const float *__restrict__ qbias,
                                                       float *__restrict__ out, int heads, int tokens, int tokpad,
                                                       int model_dim,
@@ -229,7 +233,7 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        resident_blocks = 3 * cus;
+        resident_blocks = AFT_ATTN_WAVES * cus;
     }
     const int blocks = std::min((ntasks + 3) / 4, resident_blocks);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)kHeadDim);

@@ -178,6 +178,35 @@ def test_module_surface_on_gpu(name):
             model(pil)
 
 
+def test_stream_and_graph_semantics():
+    """The ABI is asynchronous on the caller's stream and allocation-free: it runs on a side
+    stream and inside a captured hipGraph (after one warm call that sets kernel attributes)."""
+    g = Golden("A_ada")
+    eng = _engine(g)
+    pil, meta = _t(g["pilots"]), _meta(g)
+    ref = eng.forward(pil, *meta).clone()                      # warm call on the default stream
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out_side = eng.forward(pil, *meta).clone()
+    side.synchronize()
+    assert torch.equal(torch.view_as_real(out_side), torch.view_as_real(ref))
+    static_out = torch.empty_like(ref)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.forward(pil, *meta, out=static_out)
+    static_out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(static_out), torch.view_as_real(ref))
+    pil2 = _t(np.ascontiguousarray(g["pilots"][::-1]))         # new inputs through the same buffers
+    pil.copy_(pil2)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = eng.forward(pil2, *meta)
+    assert torch.equal(torch.view_as_real(static_out), torch.view_as_real(want))
+
+
 def test_abi_error_codes():
     g = Golden("A_ada")
     eng = _engine(g)
