@@ -41,9 +41,13 @@ constexpr int kStrip = 4;  // rows per thread
 
 // one 8-in -> 8-out 3x3 group on a 4-row strip: acc[row][o] += sum_ci sum_tap win * w
 // wbase points at w[o = 0][ci = 0][0][0] of the group; strides in floats.
+// The FMAs run on ROW PAIRS (v_pk_fma_f32: rows (0,1) and (2,3) of the strip share the weight), which
+// halves the VALU issue of the 288 FMAs per input channel; the 6-row window is kept twice, as
+// even-aligned pairs (0,1),(2,3),(4,5) and odd-aligned pairs (1,2),(3,4), so every tap's two rows are
+// one register pair.
 __device__ __forceinline__ void conv8x8_strip(const float *__restrict__ src, int plane_stride, int TP, int lr0,
                                               int LR, int col, const float *__restrict__ wbase, int w_o_stride,
-                                              int w_ci_stride, float (&acc)[kStrip][8]) {
+                                              int w_ci_stride, f32x2 (&acc)[2][8]) {
     int rows[kStrip + 2];
 #pragma unroll
     for (int i = 0; i < kStrip + 2; ++i) rows[i] = min(max(lr0 - 1 + i, 0), LR - 1) * TP + col;
@@ -55,6 +59,12 @@ __device__ __forceinline__ void conv8x8_strip(const float *__restrict__ src, int
         for (int i = 0; i < kStrip + 2; ++i)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) win[i][dx] = sp[rows[i] + dx];  // col is the padded index of x-1
+        // pair[i][dx] = (win[i], win[i+1]) for i = 0..4
+        f32x2 pr[5][3];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) pr[i][dx] = f32x2{win[i][dx], win[i + 1][dx]};
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             const float *wp = wbase + o * w_o_stride + ci * w_ci_stride;
@@ -63,8 +73,9 @@ __device__ __forceinline__ void conv8x8_strip(const float *__restrict__ src, int
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const float wv = wp[dy * 3 + dx];
-#pragma unroll
-                    for (int rr = 0; rr < kStrip; ++rr) acc[rr][o] = fmaf(win[rr + dy][dx], wv, acc[rr][o]);
+                    const f32x2 w2 = {wv, wv};
+                    acc[0][o] = __builtin_elementwise_fma(pr[dy][dx], w2, acc[0][o]);      // rows 0,1 use window rows dy, dy+1
+                    acc[1][o] = __builtin_elementwise_fma(pr[2 + dy][dx], w2, acc[1][o]);  // rows 2,3 use window rows 2+dy, 3+dy
                 }
         }
     }
@@ -151,21 +162,21 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     for (int rr = 0; rr < kStrip; ++rr) any_valid |= (gr0 + lr0 + rr >= 0 && gr0 + lr0 + rr < S);
     const bool work = active && any_valid;
 
-    float acc3[kStrip][8];
+    f32x2 acc3[2][8];   // [row pair][out channel]
 #pragma unroll
-    for (int rr = 0; rr < kStrip; ++rr)
+    for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-        for (int o = 0; o < 8; ++o) acc3[rr][o] = 0.f;
+        for (int o = 0; o < 8; ++o) acc3[pp][o] = f32x2{0.f, 0.f};
 
 #pragma unroll 1
     for (int g = 0; g < 4; ++g) {
         if (work) {
-            float acc2[kStrip][8];
+            f32x2 acc2[2][8];
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 const float bias = a.cb[1][8 * g + o];
-#pragma unroll
-                for (int rr = 0; rr < kStrip; ++rr) acc2[rr][o] = bias;
+                acc2[0][o] = f32x2{bias, bias};
+                acc2[1][o] = f32x2{bias, bias};
             }
             conv8x8_strip(bufA, plane_stride, TP, lr0, LR, col, a.cw[1] + (size_t)(8 * g) * 72, 72, 9, acc2);
 #pragma unroll
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                 const int lr = lr0 + rr, gr = gr0 + lr;
                 if (lr >= 2 && lr < LR - 2 && gr >= 0 && gr < S) {
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) bufB[o * plane_stride + lr * TP + col + 1] = fmaxf(acc2[rr][o], 0.f);
+                    for (int o = 0; o < 8; ++o) bufB[o * plane_stride + lr * TP + col + 1] = fmaxf(acc2[rr >> 1][o][rr & 1], 0.f);
                 }
             }
         }
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
             const bool ok = lr >= 3 && lr < LR - 3 && gr >= 0 && gr < S;
 #pragma unroll
             for (int o = 0; o < 8; ++o)
-                bufA[o * plane_stride + lr * TP + col + 1] = ok ? fmaxf(acc3[rr][o] + a.cb[2][o], 0.f) : 0.f;
+                bufA[o * plane_stride + lr * TP + col + 1] = ok ? fmaxf(acc3[rr >> 1][o][rr & 1] + a.cb[2][o], 0.f) : 0.f;
         }
     }
     __syncthreads();
