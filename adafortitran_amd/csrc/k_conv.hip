@@ -36,8 +36,8 @@ struct ConvArgs {
     float *out_complex;  // tail: [B][S][T][2]
 };
 
-constexpr int kConvThreads = 512;
-constexpr int kStrip = 4;  // rows per thread
+constexpr int kConvThreads = 1024;  // 16 waves: 4 per SIMD hide the LDS / scalar-load latency of the tap loops
+constexpr int kStrip = 2;         // rows per thread (one v_pk_fma row pair)
 
 // one 8-in -> 8-out 3x3 group on a 4-row strip: acc[row][o] += sum_ci sum_tap win * w
 // wbase points at w[o = 0][ci = 0][0][0] of the group; strides in floats.
@@ -47,7 +47,7 @@ constexpr int kStrip = 4;  // rows per thread
 // one register pair.
 __device__ __forceinline__ void conv8x8_strip(const float *__restrict__ src, int plane_stride, int TP, int lr0,
                                               int LR, int col, const float *__restrict__ wbase, int w_o_stride,
-                                              int w_ci_stride, f32x2 (&acc)[2][8]) {
+                                              int w_ci_stride, f32x2 (&acc)[kStrip / 2][8]) {
     int rows[kStrip + 2];
 #pragma unroll
     for (int i = 0; i < kStrip + 2; ++i) rows[i] = min(max(lr0 - 1 + i, 0), LR - 1) * TP + col;
@@ -59,10 +59,10 @@ __device__ __forceinline__ void conv8x8_strip(const float *__restrict__ src, int
         for (int i = 0; i < kStrip + 2; ++i)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) win[i][dx] = sp[rows[i] + dx];  // col is the padded index of x-1
-        // pair[i][dx] = (win[i], win[i+1]) for i = 0..4
-        f32x2 pr[5][3];
+        // pair[i][dx] = (win[i], win[i+1]) for i = 0..kStrip
+        f32x2 pr[kStrip + 1][3];
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < kStrip + 1; ++i)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) pr[i][dx] = f32x2{win[i][dx], win[i + 1][dx]};
 #pragma unroll
@@ -74,8 +74,9 @@ __device__ __forceinline__ void conv8x8_strip(const float *__restrict__ src, int
                 for (int dx = 0; dx < 3; ++dx) {
                     const float wv = wp[dy * 3 + dx];
                     const f32x2 w2 = {wv, wv};
-                    acc[0][o] = __builtin_elementwise_fma(pr[dy][dx], w2, acc[0][o]);      // rows 0,1 use window rows dy, dy+1
-                    acc[1][o] = __builtin_elementwise_fma(pr[2 + dy][dx], w2, acc[1][o]);  // rows 2,3 use window rows 2+dy, 3+dy
+#pragma unroll
+                    for (int pp = 0; pp < kStrip / 2; ++pp)   // rows 2pp, 2pp+1 use window rows 2pp+dy, 2pp+dy+1
+                        acc[pp][o] = __builtin_elementwise_fma(pr[2 * pp + dy][dx], w2, acc[pp][o]);
                 }
         }
     }
@@ -162,21 +163,21 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     for (int rr = 0; rr < kStrip; ++rr) any_valid |= (gr0 + lr0 + rr >= 0 && gr0 + lr0 + rr < S);
     const bool work = active && any_valid;
 
-    f32x2 acc3[2][8];   // [row pair][out channel]
+    f32x2 acc3[kStrip / 2][8];   // [row pair][out channel]
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+    for (int pp = 0; pp < kStrip / 2; ++pp)
 #pragma unroll
         for (int o = 0; o < 8; ++o) acc3[pp][o] = f32x2{0.f, 0.f};
 
 #pragma unroll 1
     for (int g = 0; g < 4; ++g) {
         if (work) {
-            f32x2 acc2[2][8];
+            f32x2 acc2[kStrip / 2][8];
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 const float bias = a.cb[1][8 * g + o];
-                acc2[0][o] = f32x2{bias, bias};
-                acc2[1][o] = f32x2{bias, bias};
+#pragma unroll
+                for (int pp = 0; pp < kStrip / 2; ++pp) acc2[pp][o] = f32x2{bias, bias};
             }
             conv8x8_strip(bufA, plane_stride, TP, lr0, LR, col, a.cw[1] + (size_t)(8 * g) * 72, 72, 9, acc2);
 #pragma unroll
