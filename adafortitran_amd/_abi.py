@@ -120,6 +120,6 @@ EXPORTED_SYMBOLS = (
     "aft_version", "aft_last_error", "aft_workspace_bytes", "aft_forward_f32",
     "aft_linear_forward_f32", "aft_mse_partial_f32", "aft_stage_upsample_f32",
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",
-    "aft_stage_tail_f32", "aft_profile_kernel_f32",
+    "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",
 )
 KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6}

@@ -54,6 +54,8 @@ def load():
     lib.aft_stage_encoder_layer_f32.argtypes = [cfgp, wp, C.c_int, vp, vp, C.c_size_t, C.c_int, vp]
     lib.aft_stage_tail_f32.argtypes = [cfgp, wp, vp, vp, vp, C.c_int, vp]
     lib.aft_profile_kernel_f32.argtypes = [cfgp, wp, C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
+    lib.aft_pilot_gather_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.aft_ls_mse_db_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     for name in _abi.EXPORTED_SYMBOLS[3:]:
         getattr(lib, name).restype = C.c_int
     if lib.aft_version() != _abi.AFT_ABI_VERSION:

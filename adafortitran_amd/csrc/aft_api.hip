@@ -188,6 +188,22 @@ int aft_mse_partial_f32(const float *est, const float *ref, double *sum_sq, long
     return e == hipSuccess ? AFT_OK : hip_fail("mse", e);
 }
 
+int aft_pilot_gather_f32(const float *hzero_ls, float *pilots, int *counts, int batch, int grid_elems, int expected,
+                         void *stream) {
+    AFT_REQUIRE(hzero_ls && pilots && counts, "NULL pointer argument");
+    AFT_REQUIRE(batch > 0 && grid_elems > 0 && expected > 0 && expected <= grid_elems, "bad sizes");
+    hipError_t e = launch_pilot_gather(hzero_ls, pilots, counts, batch, grid_elems, expected,
+                                       static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("pilot_gather", e);
+}
+
+int aft_ls_mse_db_f32(const float *ls, const float *ideal, float *db, int batch, int grid_elems, void *stream) {
+    AFT_REQUIRE(ls && ideal && db, "NULL pointer argument");
+    AFT_REQUIRE(batch > 0 && grid_elems > 0, "bad sizes");
+    hipError_t e = launch_ls_mse_db(ls, ideal, db, batch, grid_elems, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("ls_mse_db", e);
+}
+
 int aft_stage_upsample_f32(const aft_config *cfg, const aft_weights *w, const float *pilots, float *conv_enhanced,
                            int batch, void *stream) {
     int rc = check_config(cfg);

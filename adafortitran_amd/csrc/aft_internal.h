@@ -64,6 +64,9 @@ hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x
                        float *out, int batch, hipStream_t st);
 hipError_t launch_linear(const float *weight, const float *bias, const float *pilots, float *out, int batch,
                          int in_features, int out_features, hipStream_t st);
+hipError_t launch_pilot_gather(const float *hzero_ls, float *pilots, int *counts, int batch, int grid_elems,
+                               int expected, hipStream_t st);
+hipError_t launch_ls_mse_db(const float *ls, const float *ideal, float *db, int batch, int grid_elems, hipStream_t st);
 hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long long n_complex, hipStream_t st);
 
 }  // namespace aft

@@ -203,4 +203,63 @@ hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long l
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pilot extraction (reference src/data/dataset.py:116-139): per frame, compact the non-zero complex
+// entries of the sparse LS grid in row-major order.  One wave per frame; order is kept with a
+// ballot + prefix popcount per 64-element step (no atomics, deterministic).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pilot_gather_kernel(const float2 *__restrict__ grid, float2 *__restrict__ pilots,
+                                                           int *__restrict__ counts, int batch, int n, int expected) {
+    const int lane = threadIdx.x & 63;
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= batch) return;
+    const float2 *src = grid + (size_t)frame * n;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        float2 v = make_float2(0.f, 0.f);
+        if (i < n) v = src[i];
+        const bool nz = i < n && (v.x != 0.f || v.y != 0.f);   // complex != 0, as torch compares it
+        const unsigned long long m = __ballot(nz);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (nz && pos < expected) pilots[(size_t)frame * expected + pos] = v;
+        base += __popcll(m);
+    }
+    if (lane == 0) counts[frame] = base;
+}
+
+hipError_t launch_pilot_gather(const float *hzero_ls, float *pilots, int *counts, int batch, int grid_elems,
+                               int expected, hipStream_t st) {
+    hipLaunchKernelGGL(pilot_gather_kernel, dim3((batch + 3) / 4), dim3(256), 0, st,
+                       reinterpret_cast<const float2 *>(hzero_ls), reinterpret_cast<float2 *>(pilots), counts, batch,
+                       grid_elems, expected);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LS-baseline metric (reference src/utils.py:248-261, applied per file by get_ls_mse_per_folder
+// :264-303): db[b] = 10 log10(mean |ls - ideal|^2).  One wave per frame, float64 accumulation.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ls_mse_db_kernel(const float2 *__restrict__ ls, const float2 *__restrict__ ideal,
+                                                        float *__restrict__ db, int batch, int n) {
+    const int lane = threadIdx.x & 63;
+    const int frame = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= batch) return;
+    double acc = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const float2 a = ls[(size_t)frame * n + i], b = ideal[(size_t)frame * n + i];
+        const double dr = (double)a.x - (double)b.x, di = (double)a.y - (double)b.y;
+        acc += dr * dr + di * di;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) db[frame] = (float)(10.0 * log10(acc / (double)n));
+}
+
+hipError_t launch_ls_mse_db(const float *ls, const float *ideal, float *db, int batch, int grid_elems, hipStream_t st) {
+    hipLaunchKernelGGL(ls_mse_db_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, reinterpret_cast<const float2 *>(ls),
+                       reinterpret_cast<const float2 *>(ideal), db, batch, grid_elems);
+    return hipGetLastError();
+}
+
 }  // namespace aft

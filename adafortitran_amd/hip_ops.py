@@ -128,8 +128,9 @@ class HipEngine:
     def stage_tail(self, x: torch.Tensor, conv_enhanced: torch.Tensor) -> torch.Tensor:
         B = conv_enhanced.shape[0] // 2
         out = torch.empty((B, self.cfg.num_scs, self.cfg.num_symbols), dtype=torch.complex64, device=self.device)
-        _lib.check(self.lib.aft_stage_tail_f32(C.byref(self.cfg), C.byref(self.weights), x.contiguous().data_ptr(),
-                                               conv_enhanced.contiguous().data_ptr(),
+        x, conv_enhanced = x.contiguous(), conv_enhanced.contiguous()    # keep both alive across the launch
+        _lib.check(self.lib.aft_stage_tail_f32(C.byref(self.cfg), C.byref(self.weights), x.data_ptr(),
+                                               conv_enhanced.data_ptr(),
                                                torch.view_as_real(out).data_ptr(), B, self._stream()))
         return out
 
@@ -159,8 +160,9 @@ def linear_forward(weight: torch.Tensor, bias: Optional[torch.Tensor], pilots: t
     if pilots[0].numel() != in_f or ofdm_size[0] * ofdm_size[1] != out_f:
         raise ValueError("shape mismatch between pilots / weight / ofdm_size")
     pil = torch.view_as_real(pilots.contiguous())
+    weight = weight.contiguous()
     out = torch.empty((B, ofdm_size[0], ofdm_size[1]), dtype=torch.complex64, device=pilots.device)
-    _lib.check(lib.aft_linear_forward_f32(weight.contiguous().data_ptr(), _ptr(bias), pil.data_ptr(),
+    _lib.check(lib.aft_linear_forward_f32(weight.data_ptr(), _ptr(bias), pil.data_ptr(),
                                           torch.view_as_real(out).data_ptr(), B, in_f, out_f,
                                           _lib.current_stream_ptr(pilots.device)))
     return out
@@ -177,3 +179,38 @@ def mse_sum(est: torch.Tensor, ref: torch.Tensor, acc: Optional[torch.Tensor] = 
     _lib.check(lib.aft_mse_partial_f32(e.data_ptr(), r.data_ptr(), acc.data_ptr(), est.numel(),
                                        _lib.current_stream_ptr(est.device)))
     return acc
+
+
+def pilot_gather(hzero_ls: torch.Tensor, pilot_size) -> torch.Tensor:
+    """Sparse LS grid complex64 [B,S,T] (zeros off the pilot positions) -> pilots complex64
+    [B,Ps,Pt], the non-zero entries in row-major order (reference dataset.py:116-139).  Raises the
+    reference's ValueError when a frame does not hold exactly Ps*Pt non-zero entries."""
+    lib = _lib.load()
+    if hzero_ls.dtype != torch.complex64 or hzero_ls.dim() != 3:
+        raise ValueError("hzero_ls must be complex64 [B, S, T]")
+    B, n = hzero_ls.shape[0], hzero_ls.shape[1] * hzero_ls.shape[2]
+    expected = int(pilot_size[0]) * int(pilot_size[1])
+    src = torch.view_as_real(hzero_ls.contiguous())
+    out = torch.zeros((B, pilot_size[0], pilot_size[1]), dtype=torch.complex64, device=hzero_ls.device)
+    counts = torch.empty(B, dtype=torch.int32, device=hzero_ls.device)
+    _lib.check(lib.aft_pilot_gather_f32(src.data_ptr(), torch.view_as_real(out).data_ptr(), counts.data_ptr(), B, n,
+                                        expected, _lib.current_stream_ptr(hzero_ls.device)))
+    bad = (counts != expected).nonzero()
+    if bad.numel():
+        i = int(bad[0])
+        raise ValueError(f"Expected {expected} pilot values, got {int(counts[i])} (frame {i})")
+    return out
+
+
+def ls_mse_db(ls: torch.Tensor, ideal: torch.Tensor) -> torch.Tensor:
+    """Per-frame LS-baseline MSE in dB, float32 [B] (reference utils.py:248-261 per file)."""
+    lib = _lib.load()
+    if ls.dtype != torch.complex64 or ideal.dtype != torch.complex64 or ls.shape != ideal.shape or ls.dim() != 3:
+        raise ValueError("ls / ideal must be complex64 [B, S, T] of equal shape")
+    B, n = ls.shape[0], ls.shape[1] * ls.shape[2]
+    db = torch.empty(B, dtype=torch.float32, device=ls.device)
+    ls, ideal = ls.contiguous(), ideal.contiguous()      # held until after the launch is enqueued
+    _lib.check(lib.aft_ls_mse_db_f32(torch.view_as_real(ls).data_ptr(),
+                                     torch.view_as_real(ideal).data_ptr(), db.data_ptr(), B, n,
+                                     _lib.current_stream_ptr(ls.device)))
+    return db

@@ -1,0 +1,139 @@
+"""Data ingest on either side of the forward path.
+
+The reference reads ONE ``.mat`` file per sample with ``scipy.io.loadmat`` and extracts the pilots
+with a boolean mask on the host (reference src/data/dataset.py:95-190, src/utils.py:68-110); once
+the model runs at > 10^4 frames/s that is the end-to-end bottleneck.  Here a folder of ``.mat`` files
+(same file-name convention, same ``H`` variable) is packed ONCE into a contiguous ``.npz`` and batches
+are cut from it; the non-zero-pilot gather and the LS-baseline metric run on the GPU
+(``aft_pilot_gather_f32`` / ``aft_ls_mse_db_f32``).  Batches come out in exactly the format the
+reference's ``DataLoader`` yields: ``(pilots cfloat[B,Ps,Pt], H cfloat[B,S,T], meta 6-tuple)`` with
+``meta = (file_no, snr, ds, dop, n: float32 [B,1] each, [tuple of B channel-type strings])``.
+"""
+from __future__ import annotations
+
+import os
+import re
+from pathlib import Path
+from typing import Dict, Iterator, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+_NAME = re.compile(r"(\d+)_SNR-(\d+)_DS-(\d+)_DOP-(\d+)_N-(\d+)_([A-Z\-]+)\.mat")
+
+
+def parse_filename(file_name: str) -> Tuple[float, float, float, float, float, str]:
+    """``{no}_SNR-{snr}_DS-{ds}_DOP-{dop}_N-{n}_{type}.mat`` -> numbers + channel type
+    (reference src/utils.py:68-110; same ``re.match`` semantics, same error text)."""
+    m = _NAME.match(file_name)
+    if not m:
+        raise ValueError("Cannot extract file information.")
+    return (float(int(m.group(1))), float(int(m.group(2))), float(int(m.group(3))), float(int(m.group(4))),
+            float(int(m.group(5))), m.group(6))
+
+
+def pack_mat_folder(folder: Union[str, Path], out_path: Optional[Union[str, Path]] = None) -> Dict[str, np.ndarray]:
+    """Read every ``*.mat`` of ``folder`` (variable ``H`` [S,T,>=2] complex: [:,:,0] ideal channel,
+    [:,:,1] LS estimate at the pilot positions and zero elsewhere, optional [:,:,2] full LS estimate,
+    reference dataset.py:3-21, utils.py:283-288) into contiguous arrays; optionally save as ``.npz``."""
+    import scipy.io as sio
+    folder = Path(folder)
+    if not folder.exists():
+        raise FileNotFoundError(f"Data directory not found: {folder}")
+    files = sorted(folder.glob("*.mat"), key=lambda p: p.name)   # the reference's glob order is unspecified (B13)
+    if not files:
+        raise ValueError(f"No .mat files found in {folder}")
+    ideal, sparse, full, meta, ctype = [], [], [], [], []
+    for f in files:
+        mat = sio.loadmat(f)
+        if "H" not in mat or mat["H"].shape[-1] < 2:
+            raise ValueError(f"Error processing file {f}: Invalid .mat file format: missing required data")
+        H = mat["H"]
+        ideal.append(H[:, :, 0].astype(np.complex64))
+        sparse.append(H[:, :, 1].astype(np.complex64))
+        if H.shape[-1] > 2:
+            full.append(H[:, :, 2].astype(np.complex64))
+        *nums, ct = parse_filename(f.name)
+        meta.append(nums)
+        ctype.append(ct)
+    # loadmat hands back Fortran-ordered planes and np.stack keeps that order: force row-major
+    packed = {"h_ideal": np.ascontiguousarray(np.stack(ideal)), "h_ls_sparse": np.ascontiguousarray(np.stack(sparse)),
+              "meta": np.asarray(meta, dtype=np.float32), "channel_type": np.asarray(ctype)}
+    if len(full) == len(files):
+        packed["h_ls_full"] = np.ascontiguousarray(np.stack(full))
+    if out_path is not None:
+        np.savez(out_path, **packed)
+    return packed
+
+
+def extract_pilots_host(h_ls_sparse: np.ndarray, pilot_size: Tuple[int, int]) -> np.ndarray:
+    """CPU path of the pilot gather (used when the tensors live on the CPU)."""
+    B = h_ls_sparse.shape[0]
+    expected = pilot_size[0] * pilot_size[1]
+    out = np.empty((B, pilot_size[0], pilot_size[1]), np.complex64)
+    for b in range(B):
+        nz = h_ls_sparse[b][h_ls_sparse[b] != 0]
+        if nz.size != expected:
+            raise ValueError(f"Expected {expected} pilot values, got {nz.size} (frame {b})")
+        out[b] = nz.reshape(pilot_size)
+    return out
+
+
+class PackedLoader:
+    """Iterates a packed folder in file order (``shuffle=False`` as in the reference's test loaders,
+    dataset.py:254-260) and yields reference-format batches.  On a HIP device the pilots are gathered
+    by the GPU kernel and both pilots and targets stay on the device."""
+
+    def __init__(self, packed: Union[str, Path, Dict[str, np.ndarray]], pilot_size: Tuple[int, int], batch_size: int,
+                 device: Union[str, torch.device] = "cpu") -> None:
+        if not isinstance(packed, dict):
+            z = np.load(packed, allow_pickle=False)
+            packed = {k: z[k] for k in z.files}
+        self.p = packed
+        self.pilot_size = tuple(pilot_size)
+        self.batch_size = int(batch_size)
+        self.device = torch.device(device)
+        self.n = packed["h_ideal"].shape[0]
+
+    def __len__(self) -> int:
+        return (self.n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, tuple]]:
+        for lo in range(0, self.n, self.batch_size):
+            hi = min(lo + self.batch_size, self.n)
+            ideal = torch.from_numpy(self.p["h_ideal"][lo:hi])
+            sparse = self.p["h_ls_sparse"][lo:hi]
+            if self.device.type == "cuda":
+                from .hip_ops import pilot_gather
+                ideal = ideal.to(self.device)
+                pilots = pilot_gather(torch.from_numpy(sparse).to(self.device), self.pilot_size)
+            else:
+                pilots = torch.from_numpy(extract_pilots_host(sparse, self.pilot_size))
+            m = torch.from_numpy(self.p["meta"][lo:hi])
+            meta = (m[:, 0:1], m[:, 1:2], m[:, 2:3], m[:, 3:4], m[:, 4:5],
+                    [tuple(str(c) for c in self.p["channel_type"][lo:hi])])
+            yield pilots, ideal, meta
+
+
+def ls_mse_db_per_frame(h_ls_full: torch.Tensor, h_ideal: torch.Tensor) -> torch.Tensor:
+    """10 log10(mean |LS - ideal|^2) per frame (reference utils.py:248-261)."""
+    if h_ls_full.device.type == "cuda":
+        from .hip_ops import ls_mse_db
+        return ls_mse_db(h_ls_full, h_ideal.to(h_ls_full.device))
+    d = (h_ls_full - h_ideal).abs().double() ** 2
+    return (10.0 * torch.log10(d.mean(dim=(1, 2)))).float()
+
+
+def get_ls_mse_per_folder(folders_dir: Union[str, Path], device: Union[str, torch.device] = "cpu") -> Dict[int, float]:
+    """{int(val): mean over files of the per-file LS MSE in dB} for sub-folders named ``prefix_val``,
+    sorted by val -- the reference's get_ls_mse_per_folder (utils.py:264-303), with the per-file
+    reductions done in one kernel per folder."""
+    out: Dict[int, float] = {}
+    for folder in sorted(os.listdir(folders_dir), key=lambda s: int(s.split("_")[1])):
+        packed = pack_mat_folder(os.path.join(folders_dir, folder))
+        if "h_ls_full" not in packed:
+            raise ValueError(f"{folder}: 'H' has no [:,:,2] LS-estimate slice")
+        ls = torch.from_numpy(packed["h_ls_full"]).to(device)
+        ideal = torch.from_numpy(packed["h_ideal"]).to(device)
+        out[int(folder.split("_")[1])] = float(ls_mse_db_per_frame(ls, ideal).double().mean())
+    return out

@@ -106,6 +106,21 @@ int aft_linear_forward_f32(const float *weight, const float *bias, const float *
 int aft_mse_partial_f32(const float *est, const float *ref, double *sum_sq,
                         long long n_complex, void *stream);
 
+/* ---- the data formats either side of the path ---- */
+
+/* Replaces the boolean-mask pilot extraction of MatDataset._process_channel_data (reference
+ * src/data/dataset.py:116-139): hzero_ls complex64 [B, grid_elems] is the LS estimate with zeros at
+ * non-pilot positions; the non-zero entries (re != 0 or im != 0) of each frame are compacted in
+ * row-major order into pilots complex64 [B, expected].  counts[b] (device int32) receives the number
+ * of non-zero entries found, so the caller can raise the reference's ValueError when it differs from
+ * `expected` (dataset.py:128-132); at most `expected` values are written per frame. */
+int aft_pilot_gather_f32(const float *hzero_ls, float *pilots, int *counts, int batch, int grid_elems,
+                         int expected, void *stream);
+
+/* Replaces utils.mse (reference src/utils.py:248-261) as get_ls_mse_per_folder applies it per file
+ * (:264-303): db[b] = 10 log10( mean_i |ls[b,i] - ideal[b,i]|^2 ), complex64 [B, grid_elems] inputs. */
+int aft_ls_mse_db_f32(const float *ls, const float *ideal, float *db, int batch, int grid_elems, void *stream);
+
 /* ---- per-stage entry points (known-answer tests; same kernels as aft_forward_f32) ---- */
 
 /* S1+S2 (fortitran.py:203-209): pilots complex64 [B,Ps,Pt] -> conv_enhanced f32 [2B,S,T]. */

@@ -178,6 +178,58 @@ def run_linear(name, batch, seed):
     print(f"{name}: B={batch} complex input raises: {bool(complex_raises)}")
 
 
+def run_ingest(name, seed):
+    """f2/f4 fixtures: synthetic .mat trees run through the REFERENCE's MatDataset / extract_values /
+    get_ls_mse_per_folder (prettytable is stubbed in-process: it is only needed by an unrelated
+    pretty-printer of src/utils.py)."""
+    import shutil
+    import tempfile
+    import types
+    import scipy.io as sio
+    sys.modules.setdefault("prettytable", types.SimpleNamespace(PrettyTable=object))
+    from src.data.dataset import MatDataset          # reference
+    from src.utils import extract_values, get_ls_mse_per_folder
+    from src.config.schemas import PilotParams
+    rng = np.random.default_rng(seed)
+    root = tempfile.mkdtemp(prefix="aft_ingest_")
+    arrays = {}
+    try:
+        folders = {"SNR_10": 3, "SNR_0": 2}
+        names, pilots_ref, ideal_ref, meta_ref = [], [], [], []
+        for folder, count in folders.items():
+            os.makedirs(os.path.join(root, folder))
+            for i in range(count):
+                H = np.zeros((120, 14, 3), np.complex128)
+                H[:, :, 0] = rng.standard_normal((120, 14)) + 1j * rng.standard_normal((120, 14))
+                H[:, :, 2] = H[:, :, 0] + 0.1 * (rng.standard_normal((120, 14)) + 1j * rng.standard_normal((120, 14)))
+                sc = np.arange(2, 120, 10)[:12]      # 12 pilot subcarriers, symbols 3 and 10
+                for s_ in sc:
+                    for t_ in (3, 10):
+                        H[s_, t_, 1] = H[s_, t_, 2]
+                snr = int(folder.split("_")[1])
+                fname = f"{i + 1}_SNR-{snr}_DS-{50 * (i + 1)}_DOP-{200 * (i + 1)}_N-3_TDL-A.mat"
+                sio.savemat(os.path.join(root, folder, fname), {"H": H})
+                arrays[f"H__{folder}__{fname}"] = H.astype(np.complex64)
+        for folder in folders:
+            ds = MatDataset(os.path.join(root, folder), PilotParams(num_scs=12, num_symbols=2))
+            order = sorted(range(len(ds)), key=lambda k: ds.file_list[k].name)
+            for k in order:
+                hp, hi, meta = ds[k]
+                names.append(f"{folder}/{ds.file_list[k].name}")
+                pilots_ref.append(hp.numpy()); ideal_ref.append(hi.numpy())
+                meta_ref.append([float(t.item()) for t in meta[:5]])
+                assert extract_values(ds.file_list[k].name)[5] == meta[5]
+        ls = get_ls_mse_per_folder(root)
+        arrays.update(names=np.asarray(names), pilots=np.stack(pilots_ref), ideal=np.stack(ideal_ref),
+                      meta=np.asarray(meta_ref, np.float32), ls_keys=np.asarray(list(ls.keys())),
+                      ls_vals=np.asarray(list(ls.values()), np.float64))
+        arrays["meta_json"] = np.frombuffer(json.dumps(dict(seed=seed, torch=torch.__version__)).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **arrays)
+        print(f"{name}: {len(names)} files, LS dB {dict(ls)}")
+    finally:
+        shutil.rmtree(root)
+
+
 DEFAULT = dict(ofdm=[120, 14], pilot=[12, 2], patch=[3, 2], num_layers=6, model_dim=128, num_head=4, seed=20251114)
 SETS = {
     # tiny: every stage dumped
@@ -211,5 +263,7 @@ if __name__ == "__main__":
         run_set(nm, spec, batch, keep)
     if not only or "L_linear" in only:
         run_linear("L_linear", 32, 31)
+    if not only or "I_ingest" in only:
+        run_ingest("I_ingest", 77)
     leftovers = [os.path.join(r, f) for r, _d, fs in os.walk(REF) for f in fs if f.endswith(".pyc") and "cpython-310" in f]
     assert not leftovers, f"bytecode leaked into the reference mount: {leftovers}"
