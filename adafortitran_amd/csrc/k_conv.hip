@@ -10,21 +10,30 @@
 //   ConvEnhancer (blocks/enhancers.py:12-20): 3x3 cross-correlations, zero padding 1,
 //              channels 1->8->32->8->1, ReLU after the first three.
 //
-// MI355X mapping: one workgroup (8 waves) per (plane, row band).  The whole receptive field
-// lives in LDS: the 1-channel input, one 8-channel buffer (conv1 out, later conv3 out) and one
-// 8-channel buffer holding ONE group of 8 of conv2's 32 output channels at a time; conv3's
-// 8 outputs x 4 rows per thread accumulate in registers across the four groups, so the 32-channel
-// tensor (250 KB/plane) never exists.  Weights are wave-uniform -> scalar loads feeding v_fma
-// from SGPRs.  Each thread owns a 4-row x 1-column strip and slides a 6x3 window, 18 LDS reads
-// per 288 FMAs.  HBM traffic per plane = compulsory only (pilots / x rows in, one plane out).
-// Bands carry a 4-row halo (4 stacked 3x3 convs); the default 120x14 grid is one band.
+// MI355X mapping: one workgroup (8 waves) per (plane, row band); the whole receptive field lives in
+// LDS as [channel][symbol column + 1][subcarrier row], rows contiguous, so a wave's 32 pixel lanes
+// always read consecutive banks.  conv1 (1->8) and conv4 (8->1) are 4 % of the FLOPs and run on the
+// VALU.  conv2 (8->32) and conv3 (32->8) are implicit GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32):
+//   conv2  A = weights [co 32][k = (kx, ky, ci)]  B = conv1 output read straight from LDS at the
+//          tap's offset (one ds_read_b32 per MFMA, pixel = lane)      K = 72  -> 36 MFMAs / column
+//   conv3  the accumulator of conv2 has lane = pixel, register = channel, i.e. it already IS the
+//          B operand of conv3 for the centre row tap; the ky = -1/+1 taps are the same registers
+//          moved one lane (DPP wave shift), so the 32-channel tensor never leaves registers.
+//          The kx taps are folded into M: row (kx, co) of the product is the contribution of input
+//          column t' to output column t'-kx+1, so the three row groups are three output columns in
+//          flight; rotating the accumulator registers by 4 between columns sums them for free.
+//          M = 24 of 32 rows used, K = 96 -> 48 MFMAs / column.
+// A wave owns a tile of 32 rows (30 of them valid conv3 outputs: one halo lane per side replaces
+// any cross-wave exchange) over half of the symbol columns; weights fragments stay in registers for
+// the whole kernel.  HBM traffic per plane = compulsory only (pilots / x rows in, one plane out).
+// Bands carry a 4-row halo (4 stacked 3x3 convs); the default 120x14 grid is one band, 4 tiles.
 #include "aft_internal.h"
 
 namespace aft {
 
 struct ConvArgs {
     int mode;  // 0 = head (pilots -> conv_enhanced), 1 = tail (x, conv_enhanced -> complex out)
-    int S, T, TP, band_rows, nbands;   // TP = padded LDS row stride (>= T+2)
+    int S, T, SP, band_rows, nbands, ntiles, nseg, arena, extra;   // SP = LDS row-vector length (>= band_rows + 8)
     // head
     const float *pilots, *up_w, *up_b;
     int pf;
@@ -36,68 +45,37 @@ struct ConvArgs {
     float *out_complex;  // tail: [B][S][T][2]
 };
 
-constexpr int kConvThreads = 1024;  // 16 waves: 4 per SIMD hide the LDS / scalar-load latency of the tap loops
-constexpr int kStrip = 2;         // rows per thread (one v_pk_fma row pair)
+constexpr int kConvThreads = 512;
+constexpr int kConvWaves = kConvThreads / 64;
+constexpr int kTileRows = 30;   // valid conv3 rows per 32-lane tile
 
-// one 8-in -> 8-out 3x3 group on a 4-row strip: acc[row][o] += sum_ci sum_tap win * w
-// wbase points at w[o = 0][ci = 0][0][0] of the group; strides in floats.
-// The FMAs run on ROW PAIRS (v_pk_fma_f32: rows (0,1) and (2,3) of the strip share the weight), which
-// halves the VALU issue of the 288 FMAs per input channel; the 6-row window is kept twice, as
-// even-aligned pairs (0,1),(2,3),(4,5) and odd-aligned pairs (1,2),(3,4), so every tap's two rows are
-// one register pair.
-__device__ __forceinline__ void conv8x8_strip(const float *__restrict__ src, int plane_stride, int TP, int lr0,
-                                              int LR, int col, const float *__restrict__ wbase, int w_o_stride,
-                                              int w_ci_stride, f32x2 (&acc)[kStrip / 2][8]) {
-    int rows[kStrip + 2];
-#pragma unroll
-    for (int i = 0; i < kStrip + 2; ++i) rows[i] = min(max(lr0 - 1 + i, 0), LR - 1) * TP + col;
-#pragma unroll 1
-    for (int ci = 0; ci < 8; ++ci) {
-        const float *sp = src + ci * plane_stride;
-        float win[kStrip + 2][3];
-#pragma unroll
-        for (int i = 0; i < kStrip + 2; ++i)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) win[i][dx] = sp[rows[i] + dx];  // col is the padded index of x-1
-        // pair[i][dx] = (win[i], win[i+1]) for i = 0..kStrip
-        f32x2 pr[kStrip + 1][3];
-#pragma unroll
-        for (int i = 0; i < kStrip + 1; ++i)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) pr[i][dx] = f32x2{win[i][dx], win[i + 1][dx]};
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const float *wp = wbase + o * w_o_stride + ci * w_ci_stride;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float wv = wp[dy * 3 + dx];
-                    const f32x2 w2 = {wv, wv};
-#pragma unroll
-                    for (int pp = 0; pp < kStrip / 2; ++pp)   // rows 2pp, 2pp+1 use window rows 2pp+dy, 2pp+dy+1
-                        acc[pp][o] = __builtin_elementwise_fma(pr[2 * pp + dy][dx], w2, acc[pp][o]);
-                }
-        }
-    }
+__device__ __forceinline__ float lane_from_below(float v) {   // lane i <- lane i-1 (DPP wave_shr:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_from_above(float v) {   // lane i <- lane i+1 (DPP wave_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int S = a.S, T = a.T, TP = a.TP, LR = a.band_rows + 8;
-    const int plane_stride = LR * TP;
-    float *in0 = smem;                       // [LR][TP]
-    float *bufA = in0 + plane_stride;        // [8][LR][TP]
-    float *bufB = bufA + 8 * plane_stride;   // [8][LR][TP]
-    float *small = bufB + 8 * plane_stride;  // head: pilot plane [pf]; tail: lin2 weights [p][d] + bias [p]
+    const int S = a.S, T = a.T, SP = a.SP, LR = a.band_rows + 8;
+    const int col_stride = SP, plane = (T + 2) * SP;
+    float *in0 = smem;                 // [T+2][SP]      column index = symbol + 1
+    float *c1 = in0 + plane;           // [8][T+2][SP]   conv1 output
+    float *c3 = c1 + 8 * plane;        // [8][T+2][SP]   conv3 output
 
     const int tid = threadIdx.x;
     const int n = blockIdx.x / a.nbands, band = blockIdx.x % a.nbands;
     const int frame = n >> 1, part = n & 1;
     const int gr0 = band * a.band_rows - 4;  // global row of local row 0
 
-    // ---- zero LDS (padding columns, rows outside the plane, unwritten halo rows) ----
-    for (int i = tid; i < 17 * plane_stride; i += kConvThreads) smem[i] = 0.f;
+    // ---- stage the conv2/conv3 weights through LDS (coalesced), gather the MFMA A fragments ----
+    // conv2.weight [32][8][3][3] and conv3.weight [8][32][3][3] are 2304 floats each.
+    float *small = smem + a.arena;     // head: pilot plane [pf]; tail: lin2 weights [p][d] + bias [p]
+    for (int i = tid; i < 2304; i += kConvThreads) {
+        smem[i] = a.cw[1][i];
+        smem[2304 + i] = a.cw[2][i];
+    }
     if (a.mode == 0) {
         for (int i = tid; i < a.pf; i += kConvThreads) small[i] = a.pilots[((size_t)frame * a.pf + i) * 2 + part];
     } else {
@@ -105,148 +83,282 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         for (int i = tid; i < p * a.d; i += kConvThreads) small[i] = a.lin2_w[i];
         for (int i = tid; i < p; i += kConvThreads) small[p * a.d + i] = a.lin2_b[i];
     }
+    const int lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    float bias3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias3[e] = a.cb[2][e + 4 * h];
+    __syncthreads();
+    float wa2[36], wa3[48];
+#pragma unroll
+    for (int kb = 0; kb < 36; ++kb) {        // k slot (kb, h): tap = kb>>2 = kx*3+ky, ci = 4h + (kb&3); row = co = j
+        const int tap = kb >> 2, kx = tap / 3, ky = tap % 3, ci = 4 * h + (kb & 3);
+        wa2[kb] = smem[(j * 8 + ci) * 9 + ky * 3 + kx];
+    }
+    {
+        const int kx = min(j >> 3, 2), co = j & 7;   // row j = (kx, co); rows 24..31 are padding
+        const float keep = j < 24 ? 1.f : 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 48; ++kb) {    // k slot (kb, h): ky = kb>>4, ci = C-layout row of register kb&15
+            const int ky = kb >> 4, e = kb & 15, ci = (e & 3) + 8 * (e >> 2) + 4 * h;
+            wa3[kb] = keep * smem[2304 + ((co * 32 + ci) * 3 + ky) * 3 + kx];
+        }
+    }
+    __syncthreads();
+    // ---- zero LDS (border columns, rows outside the plane, halo rows nobody writes); the conv2
+    //      bias in accumulator-register order sits behind `small` ----
+    {
+        f32x4 *z = reinterpret_cast<f32x4 *>(smem);
+        const int n4 = (17 * plane + 3) >> 2;   // arena is a multiple of 4 floats
+        for (int i = tid; i < n4; i += kConvThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float *bias2 = small + a.extra;    // [2 halves][16]
+    if (tid < 32) bias2[tid] = a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
     __syncthreads();
 
     // ---- input plane ----
-    for (int i = tid; i < LR * T; i += kConvThreads) {
-        const int lr = i / T, t = i % T, gr = gr0 + lr;
-        if (gr < 0 || gr >= S) continue;
-        float v;
-        if (a.mode == 0) {  // pilot_upsampler row (gr*T + t): idx = sc*T + sym (view(B,1,S,T))
-            const int pix = gr * T + t;
-            const float *wr = a.up_w + (size_t)pix * a.pf;
-            v = a.up_b[pix];
-            for (int kk = 0; kk < a.pf; ++kk) v = fmaf(wr[kk], small[kk], v);
-        } else {            // linear_2 feature f of token tk + conv_enhanced residual
-            const int tk = (gr / a.p0) * (T / a.p1) + t / a.p1, f = (gr % a.p0) * a.p1 + t % a.p1;
-            const float *xr = a.x + ((size_t)n * a.tokens + tk) * a.d;
-            const float *wr = small + f * a.d;
-            float acc = small[a.p0 * a.p1 * a.d + f];
-            for (int e = 0; e < a.d; e += 4) {
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + e);
-                acc = fmaf(xv[0], wr[e], acc);
-                acc = fmaf(xv[1], wr[e + 1], acc);
-                acc = fmaf(xv[2], wr[e + 2], acc);
-                acc = fmaf(xv[3], wr[e + 3], acc);
+    if (a.mode == 0) {   // pilot_upsampler row (gr*T + t): idx = sc*T + sym (view(B,1,S,T))
+        if (a.pf == 24) {   // default pilot grid: four pixels per pass, all 24 row loads in flight before the FMAs
+            for (int i0 = tid; i0 < LR * T; i0 += 4 * kConvThreads) {
+                f32x4 wv[4][6];
+                float bv[4];
+                int dsti[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * kConvThreads, t = i / LR, lr = i - t * LR, gr = gr0 + lr;
+                    const bool ok = i < LR * T && gr >= 0 && gr < S;
+                    const int pix = ok ? gr * T + t : 0;
+                    dsti[u] = ok ? (t + 1) * col_stride + lr : -1;
+                    const f32x4 *wr = reinterpret_cast<const f32x4 *>(a.up_w + (size_t)pix * 24);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) wv[u][q] = wr[q];
+                    bv[u] = a.up_b[pix];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v = bv[u];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4 *>(small + 4 * q);
+                        v = fmaf(wv[u][q][0], pv[0], v);
+                        v = fmaf(wv[u][q][1], pv[1], v);
+                        v = fmaf(wv[u][q][2], pv[2], v);
+                        v = fmaf(wv[u][q][3], pv[3], v);
+                    }
+                    if (dsti[u] >= 0) in0[dsti[u]] = v;
+                }
             }
-            v = acc + a.resid[((size_t)n * S + gr) * T + t];
+        } else {
+            for (int i = tid; i < LR * T; i += kConvThreads) {
+                const int t = i / LR, lr = i - t * LR, gr = gr0 + lr;
+                if (gr < 0 || gr >= S) continue;
+                const int pix = gr * T + t;
+                const float *wr = a.up_w + (size_t)pix * a.pf;
+                float v = a.up_b[pix];
+                for (int kk = 0; kk < a.pf; ++kk) v = fmaf(wr[kk], small[kk], v);
+                in0[(t + 1) * col_stride + lr] = v;
+            }
         }
-        in0[lr * TP + t + 1] = v;
+    } else {
+        // linear_2 + inverse patch map + conv_enhanced residual.  One thread per token: its x row is read
+        // once (d floats) and dotted with the p weight rows (LDS, wave-uniform address -> broadcast), in
+        // groups of up to 8 features.  Feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1).
+        const int p0 = a.p0, p1 = a.p1, p = p0 * p1, tpr = T / p1;
+        const int g_lo = max(gr0, 0) / p0, g_hi = (min(gr0 + LR, S) - 1) / p0;
+        const int items = (g_hi - g_lo + 1) * tpr;
+        for (int i = tid; i < items; i += kConvThreads) {
+            const int g = g_lo + i / tpr, tc = i % tpr;
+            const float *xr = a.x + ((size_t)n * a.tokens + g * tpr + tc) * a.d;
+            for (int f0 = 0; f0 < p; f0 += 8) {
+                float acc[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = f0 + q < p ? small[p * a.d + f0 + q] : 0.f;
+                for (int e0 = 0; e0 < a.d; e0 += 16) {
+                    f32x4 xv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const f32x4 *>(xr + e0 + 4 * u);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (f0 + q >= p) break;
+                        const float *wr = small + (f0 + q) * a.d + e0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + 4 * u);
+                            acc[q] = fmaf(xv[u][0], wv[0], acc[q]);
+                            acc[q] = fmaf(xv[u][1], wv[1], acc[q]);
+                            acc[q] = fmaf(xv[u][2], wv[2], acc[q]);
+                            acc[q] = fmaf(xv[u][3], wv[3], acc[q]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int f = f0 + q;
+                    if (f >= p) break;
+                    const int gr = g * p0 + f / p1, t = tc * p1 + f % p1, lr = gr - gr0;
+                    if (lr >= 0 && lr < LR && gr < S)
+                        in0[(t + 1) * col_stride + lr] = acc[q] + a.resid[((size_t)n * S + gr) * T + t];
+                }
+            }
+        }
     }
     __syncthreads();
 
     // ---- conv1: 1 -> 8, ReLU, rows [1, LR-1) ----
-    for (int i = tid; i < LR * T; i += kConvThreads) {
-        const int lr = i / T, t = i % T, gr = gr0 + lr;
-        if (lr < 1 || lr >= LR - 1 || gr < 0 || gr >= S) continue;
-        float win[3][3];
+    for (int i = tid; i < (LR - 2) * T; i += kConvThreads) {
+        const int t = i / (LR - 2), lr = 1 + i - t * (LR - 2), gr = gr0 + lr;
+        if (gr < 0 || gr >= S) continue;
+        float win[3][3];  // [ky][kx]
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) win[dy][dx] = in0[(lr - 1 + dy) * TP + t + dx];
+            for (int kx = 0; kx < 3; ++kx) win[ky][kx] = in0[(t + kx) * col_stride + lr - 1 + ky];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             float acc = a.cb[0][o];
 #pragma unroll
             for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[k9 / 3][k9 % 3], a.cw[0][o * 9 + k9], acc);
-            bufA[o * plane_stride + lr * TP + t + 1] = fmaxf(acc, 0.f);
+            c1[o * plane + (t + 1) * col_stride + lr] = fmaxf(acc, 0.f);
         }
     }
     __syncthreads();
 
-    // ---- conv2 (8 -> 32, ReLU) in four 8-channel groups, conv3 (32 -> 8) accumulated in registers ----
-    const int ngroups = (LR / kStrip) * T;
-    const bool active = tid < ngroups;
-    const int lr0 = (tid / T) * kStrip, col = tid % T;  // padded column index of x-1 is `col`
-    bool any_valid = false;
-#pragma unroll
-    for (int rr = 0; rr < kStrip; ++rr) any_valid |= (gr0 + lr0 + rr >= 0 && gr0 + lr0 + rr < S);
-    const bool work = active && any_valid;
+    // ---- conv2 + conv3 on the matrix cores ----
+    const int r3lo = band == 0 ? 4 : 3;   // first local row whose conv3 output is needed and inside the plane
+    for (int task = wave; task < a.ntiles * a.nseg; task += kConvWaves) {
+        const int tile = task / a.nseg, seg = task - tile * a.nseg;
+        const int ta = seg * T / a.nseg, tb = (seg + 1) * T / a.nseg;   // output columns [ta, tb)
+        const int tlo = max(ta - 1, 0), thi = min(tb, T - 1);           // conv2 columns needed
+        const int r = r3lo + kTileRows * tile - 1 + j;                   // this lane's local row
+        const int gr = gr0 + r;
+        const bool ok2 = gr >= 0 && gr < S;                              // conv2 output inside the plane (else zero padding)
+        const float relu_hi = ok2 ? __builtin_inff() : 0.f;
+        const bool ok3 = ok2 && j >= 1 && j <= kTileRows && r < LR - 3;
+        const float *bsrc = c1 + (4 * h) * plane + r - 1;                // + c*plane + (t'+kx)*col_stride + ky
+        float *dst = c3 + (4 * h) * plane + r;
 
-    f32x2 acc3[kStrip / 2][8];   // [row pair][out channel]
+        f32x16 acc3;
 #pragma unroll
-    for (int pp = 0; pp < kStrip / 2; ++pp)
-#pragma unroll
-        for (int o = 0; o < 8; ++o) acc3[pp][o] = f32x2{0.f, 0.f};
+        for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
 
-#pragma unroll 1
-    for (int g = 0; g < 4; ++g) {
-        if (work) {
-            f32x2 acc2[kStrip / 2][8];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const float bias = a.cb[1][8 * g + o];
-#pragma unroll
-                for (int pp = 0; pp < kStrip / 2; ++pp) acc2[pp][o] = f32x2{bias, bias};
+        auto store_col = [&](int tout, float v0, float v1, float v2, float v3) {
+            if (tout >= ta && tout < tb && ok3) {
+                float *p = dst + (tout + 1) * col_stride;
+                p[0 * plane] = fmaxf(v0 + bias3[0], 0.f);
+                p[1 * plane] = fmaxf(v1 + bias3[1], 0.f);
+                p[2 * plane] = fmaxf(v2 + bias3[2], 0.f);
+                p[3 * plane] = fmaxf(v3 + bias3[3], 0.f);
             }
-            conv8x8_strip(bufA, plane_stride, TP, lr0, LR, col, a.cw[1] + (size_t)(8 * g) * 72, 72, 9, acc2);
+        };
+        // B operand slot kb of conv2 column tcol: channel 4h + (kb&3), tap (kx, ky) = ((kb>>2)/3, (kb>>2)%3)
+        auto b_at = [&](int kb, int tcol) {
+            const int tap = kb >> 2, kx = tap / 3, ky = tap % 3;
+            return bsrc[(kb & 3) * plane + (tcol + kx) * col_stride + ky];
+        };
+        float b[36];
 #pragma unroll
-            for (int rr = 0; rr < kStrip; ++rr) {
-                const int lr = lr0 + rr, gr = gr0 + lr;
-                if (lr >= 2 && lr < LR - 2 && gr >= 0 && gr < S) {
+        for (int kb = 0; kb < 36; ++kb) b[kb] = b_at(kb, tlo);
+#pragma unroll 1
+        for (int tcol = tlo; tcol <= thi; ++tcol) {
+            f32x16 acc2;
+            {
+                const f32x4 *bp = reinterpret_cast<const f32x4 *>(bias2 + 16 * h);
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) bufB[o * plane_stride + lr * TP + col + 1] = fmaxf(acc2[rr >> 1][o][rr & 1], 0.f);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = bp[q];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc2[4 * q + u] = v[u];
                 }
             }
-        }
-        __syncthreads();
-        if (work)  // conv3 weights [8][32][3][3]: o stride 288, ci stride 9, channel offset 8g
-            conv8x8_strip(bufB, plane_stride, TP, lr0, LR, col, a.cw[2] + (size_t)(8 * g) * 9, 288, 9, acc3);
-        __syncthreads();
-    }
-
-    // ---- conv3 epilogue: bias + ReLU -> bufA (conv1 output is dead), rows [3, LR-3) ----
-    if (work) {
+            // conv2: each operand register is refilled for the next column as soon as its MFMA has issued
+            const int tnext = min(tcol + 1, thi);
 #pragma unroll
-        for (int rr = 0; rr < kStrip; ++rr) {
-            const int lr = lr0 + rr, gr = gr0 + lr;
-            const bool ok = lr >= 3 && lr < LR - 3 && gr >= 0 && gr < S;
+            for (int kb = 0; kb < 36; ++kb) {
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[kb], b[kb], acc2, 0, 0, 0);
+                b[kb] = b_at(kb, tnext);
+            }
+            // registers 8..11 hold output column tcol-2, complete since the previous column's MFMAs
+            store_col(tcol - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
 #pragma unroll
-            for (int o = 0; o < 8; ++o)
-                bufA[o * plane_stride + lr * TP + col + 1] = ok ? fmaxf(acc3[rr >> 1][o][rr & 1] + a.cb[2][o], 0.f) : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                acc3[8 + e] = acc3[4 + e];
+                acc3[4 + e] = acc3[e];
+                acc3[e] = 0.f;
+            }
+            float x2[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);   // ReLU, or 0 outside the plane
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[16 + e], x2[e], acc3, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[e], lane_from_below(x2[e]), acc3, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[32 + e], lane_from_above(x2[e]), acc3, 0, 0, 0);
         }
+        store_col(thi - 1, acc3[8], acc3[9], acc3[10], acc3[11]);
+        store_col(thi, acc3[4], acc3[5], acc3[6], acc3[7]);   // only stored when thi == T-1 (column T is zero padding)
     }
     __syncthreads();
 
-    // ---- conv4: 8 -> 1, no activation, rows of this band only ----
-    for (int i = tid; i < a.band_rows * T; i += kConvThreads) {
-        const int lr = 4 + i / T, t = i % T, gr = gr0 + lr;
+    // ---- conv4: 8 -> 1, no activation, rows of this band only; one thread = one row x 4 columns ----
+    const int tstrips = (T + 3) >> 2;
+    for (int i = tid; i < a.band_rows * tstrips; i += kConvThreads) {
+        const int ts = i / a.band_rows, lr = 4 + i - ts * a.band_rows, gr = gr0 + lr, t0 = 4 * ts;
         if (gr >= S) continue;
-        float acc = a.cb[3][0];
+        float acc[4];
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci)
+        for (int q = 0; q < 4; ++q) acc[q] = a.cb[3][0];
+#pragma unroll 2
+        for (int ci = 0; ci < 8; ++ci) {
+            float win[3][6];   // [ky][column t0-1 .. t0+4]; columns past T+1 are never used by a stored output
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    acc = fmaf(bufA[ci * plane_stride + (lr - 1 + dy) * TP + t + dx], a.cw[3][ci * 9 + dy * 3 + dx], acc);
-        if (a.mode == 0)
-            a.out_plane[((size_t)n * S + gr) * T + t] = acc;
-        else
-            a.out_complex[(((size_t)frame * S + gr) * T + t) * 2 + part] = acc;
+                for (int c = 0; c < 6; ++c) win[ky][c] = c3[ci * plane + min(t0 + c, T + 1) * col_stride + lr - 1 + ky];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float w = a.cw[3][ci * 9 + ky * 3 + kx];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(win[ky][q + kx], w, acc[q]);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = t0 + q;
+            if (t >= T) break;
+            if (a.mode == 0)
+                a.out_plane[((size_t)n * S + gr) * T + t] = acc[q];
+            else
+                a.out_complex[(((size_t)frame * S + gr) * T + t) * 2 + part] = acc[q];
+        }
     }
 }
 
-// pick the largest row band (multiple of 4, divides S) whose strips fit 512 threads and 160 KB LDS
-// Row stride: a wave's lanes are (column fastest, then 4-row strip), so strips sit 4*TP floats apart;
-// TP = T+2 = 16 puts every strip on the same banks (3-way conflicts measured: SQ_LDS_BANK_CONFLICT =
-// 66 % of LDS cycles).  T+4 staggers strips by 8 banks; fall back to T+2 when LDS would overflow.
-static bool plan_bands(int S, int T, int extra_floats, int *band_rows, int *tp, size_t *lds_bytes) {
-    if (S % kStrip) return false;
-    for (int nb = 1; nb <= S / kStrip; ++nb) {
+// Largest row band (divides S) whose 17 channel planes fit 160 KB of LDS.  A band needs conv3 rows
+// [-1, band_rows+1) around it, covered by 30-row tiles; SP spans the last tile's halo lane.
+static bool plan_bands(int S, int T, int extra_floats, ConvArgs *a, size_t *lds_bytes) {
+    const int extra = (extra_floats + 3) & ~3;
+    for (int nb = 1; nb <= S; ++nb) {
         if (S % nb) continue;
         const int br = S / nb;
-        if (br % kStrip) continue;
-        const int LR = br + 8;
-        if ((LR / kStrip) * T > kConvThreads) continue;
-        for (int pad = 4; pad >= 2; pad -= 2) {
-            const size_t bytes = sizeof(float) * ((size_t)17 * LR * (T + pad) + extra_floats);
-            if (bytes <= 160 * 1024) {
-                *band_rows = br;
-                *tp = T + pad;
-                *lds_bytes = bytes;
-                return true;
-            }
+        const int rows3 = nb == 1 ? br : br + 2;
+        const int ntiles = (rows3 + kTileRows - 1) / kTileRows;
+        const int sp = std::max(br + 8, 4 + kTileRows * ntiles + 2);
+        const int arena = (std::max(17 * (T + 2) * sp, 2 * 2304) + 3) & ~3;   // also stages the conv2/conv3 weights
+        const size_t bytes = sizeof(float) * ((size_t)arena + extra + 32);
+        if (bytes <= 160 * 1024) {
+            a->band_rows = br;
+            a->nbands = nb;
+            a->ntiles = ntiles;
+            a->nseg = T >= 8 ? 2 : 1;
+            a->SP = sp;
+            a->arena = arena;
+            a->extra = extra;
+            *lds_bytes = bytes;
+            return true;
         }
     }
     return false;
@@ -254,8 +366,7 @@ static bool plan_bands(int S, int T, int extra_floats, int *band_rows, int *tp, 
 
 static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStream_t st) {
     size_t lds = 0;
-    if (!plan_bands(a.S, a.T, extra_floats, &a.band_rows, &a.TP, &lds)) return hipErrorInvalidValue;
-    a.nbands = a.S / a.band_rows;
+    if (!plan_bands(a.S, a.T, extra_floats, &a, &lds)) return hipErrorInvalidValue;
     static bool attr_set = false;  // idempotent; a race only repeats the same call
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stack_kernel),
