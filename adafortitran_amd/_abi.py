@@ -37,6 +37,18 @@ class AftLayerWeights(C.Structure):
         "lin2_w", "lin2_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b")]
 
 
+LAYER_FIELDS = ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b",
+                "lin2_w", "lin2_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b")
+#: nn.TransformerEncoderLayer parameter names in LAYER_FIELDS order
+LAYER_PARAM_NAMES = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                     "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+                     "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+class AftLayerGrads(C.Structure):
+    _fields_ = [(n, _fp) for n in LAYER_FIELDS]
+
+
 class AftWeights(C.Structure):
     _fields_ = [
         ("up_w", _fp), ("up_b", _fp),
@@ -121,5 +133,9 @@ EXPORTED_SYMBOLS = (
     "aft_linear_forward_f32", "aft_mse_partial_f32", "aft_stage_upsample_f32",
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",
     "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",
+    "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
+    "aft_encoder_layer_fwd_train_f32", "aft_encoder_layer_bwd_f32",
 )
+#: size queries (return size_t, not a status code)
+SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes")
 KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6}

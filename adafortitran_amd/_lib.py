@@ -56,8 +56,17 @@ def load():
     lib.aft_profile_kernel_f32.argtypes = [cfgp, wp, C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     lib.aft_pilot_gather_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_ls_mse_db_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
-    for name in _abi.EXPORTED_SYMBOLS[3:]:
-        getattr(lib, name).restype = C.c_int
+    lwp, lgp = C.POINTER(_abi.AftLayerWeights), C.POINTER(_abi.AftLayerGrads)
+    for name in ("aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes"):
+        getattr(lib, name).restype = C.c_size_t
+        getattr(lib, name).argtypes = [cfgp, C.c_int]
+    lib.aft_encoder_layer_fwd_train_f32.argtypes = [cfgp, lwp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
+                                                    C.c_float, C.c_uint64, vp]
+    lib.aft_encoder_layer_bwd_f32.argtypes = [cfgp, lwp, vp, vp, C.c_size_t, vp, vp, lgp, C.c_int, vp, C.c_size_t,
+                                              C.c_int, C.c_float, C.c_uint64, vp]
+    for name in _abi.EXPORTED_SYMBOLS:
+        if name not in _abi.SIZE_SYMBOLS + ("aft_version", "aft_last_error"):
+            getattr(lib, name).restype = C.c_int
     if lib.aft_version() != _abi.AFT_ABI_VERSION:
         raise AftError(f"ABI mismatch: library {lib.aft_version()} vs binding {_abi.AFT_ABI_VERSION}")
     _lib = lib

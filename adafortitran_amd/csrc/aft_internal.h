@@ -69,4 +69,31 @@ hipError_t launch_pilot_gather(const float *hzero_ls, float *pilots, int *counts
 hipError_t launch_ls_mse_db(const float *ls, const float *ideal, float *db, int batch, int grid_elems, hipStream_t st);
 hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long long n_complex, hipStream_t st);
 
+
+// ---- training path: row-major GEMMs, attention with saved LSE, row-wise pieces ----
+constexpr int kGemmMaxSlices = 128;   // split of the token-row reduction in weight / bias gradients
+int gemm_split_slices(int rows);
+int ln_bwd_blocks(int rows);
+// op 0: C = A[M][K] B[N][K]^T + bias;  op 1: C = A[M][K] B[K][N]   (accumulate: C += ...)
+hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,
+                       int ldb, int ldc, bool accumulate, hipStream_t st);
+hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slices, int M, int N, int R, int lda, int ldb,
+                          bool accumulate, hipStream_t st);
+hipError_t launch_colsum(const float *x, float *out, float *slices, int rows, int n, int ld, bool accumulate, hipStream_t st);
+hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, size_t stride, bool accumulate, hipStream_t st);
+hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o, float *lse, int planes, int tokens,
+                                 float dropout_p, uint32_t seed, hipStream_t st);
+hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const float *o, const float *d_o, const float *lse,
+                                 float *dsum, float *dqkv, int planes, int tokens, float dropout_p, uint32_t seed,
+                                 hipStream_t st);
+hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamma, const float *beta, float *s_out,
+                             float *stats, float *out, int rows, int n, float eps, float dropout_p, uint32_t seed,
+                             hipStream_t st);
+hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, const float *gamma, float *ds, float *dbranch,
+                         float *dgamma, float *dbeta, float *slices, int rows, int n, float dropout_p, uint32_t seed,
+                         bool accumulate, hipStream_t st);
+hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dropout_p, uint32_t seed, hipStream_t st);
+hipError_t launch_act_bwd(int act, const float *a, float *dh, size_t n, float dropout_p, uint32_t seed, hipStream_t st);
+hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t st);
+
 }  // namespace aft

@@ -1,0 +1,186 @@
+// aft_train.hip -- C-ABI of the encoder layer's training forward / backward.
+//
+// One nn.TransformerEncoderLayer (post-LN, reference src/models/blocks/encoders.py:44-55) in
+// train() mode as two calls: the forward keeps what the backward needs in a caller-owned "tape",
+// the backward turns d(loss)/d(x_out) into d(loss)/d(x_in) and the gradients of the layer's twelve
+// parameter tensors.  Everything row-major fp32, rows = 2B * tokens.  The caller (PyTorch autograd,
+// adafortitran_amd/training.py) owns x_in, the tape and the gradient tensors.
+#include <cstdarg>
+
+#include "aft_internal.h"
+
+namespace aft {
+
+namespace {
+
+size_t al64(size_t floats) { return (floats + 63) / 64 * 64; }
+
+struct Tape {   // offsets in floats
+    size_t qkv, attn, lse, s1, st1, x1, a, s2, st2, total;
+};
+struct Scratch {
+    size_t g1, g2, gff, hd, dqkv, dsum, slices, total;
+};
+
+int tokens_of_cfg(const aft_config &c) { return (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols); }
+
+Tape plan_tape(const aft_config &c, int batch) {
+    const size_t rows = (size_t)2 * batch * tokens_of_cfg(c), d = c.model_dim, ff = 2 * d;
+    Tape t{};
+    size_t off = 0;
+    t.qkv = off;  off += al64(rows * 3 * d);
+    t.attn = off; off += al64(rows * d);
+    t.lse = off;  off += al64(rows * c.num_head);
+    t.s1 = off;   off += al64(rows * d);
+    t.st1 = off;  off += al64(rows * 2);
+    t.x1 = off;   off += al64(rows * d);
+    t.a = off;    off += al64(rows * ff);
+    t.s2 = off;   off += al64(rows * d);
+    t.st2 = off;  off += al64(rows * 2);
+    t.total = off;
+    return t;
+}
+
+Scratch plan_scratch(const aft_config &c, int batch) {
+    const size_t rows = (size_t)2 * batch * tokens_of_cfg(c), d = c.model_dim, ff = 2 * d;
+    Scratch s{};
+    size_t off = 0;
+    s.g1 = off;     off += al64(rows * d);
+    s.g2 = off;     off += al64(rows * d);
+    s.gff = off;    off += al64(rows * ff);
+    s.hd = off;     off += al64(rows * ff);
+    s.dqkv = off;   off += al64(rows * 3 * d);
+    s.dsum = off;   off += al64(rows * c.num_head);
+    s.slices = off; off += al64((size_t)kGemmMaxSlices * 3 * d * d);
+    s.total = off;
+    return s;
+}
+
+uint32_t site_seed(uint64_t seed, uint32_t site) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (site + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)(z ^ (z >> 31));
+}
+
+thread_local const char *g_step = "";
+int fail(hipError_t e) {
+    set_error("%s: %s", g_step, hipGetErrorString(e));
+    return AFT_ERR_HIP;
+}
+#define STEP(name, call)                     \
+    do {                                     \
+        g_step = name;                       \
+        hipError_t e_ = (call);              \
+        if (e_ != hipSuccess) return fail(e_); \
+    } while (0)
+
+int check_train(const aft_config *cfg, int batch, float dropout_p) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    if (batch <= 0 || !(dropout_p >= 0.f && dropout_p < 1.f)) {
+        set_error("bad batch %d or dropout %g", batch, (double)dropout_p);
+        return AFT_ERR_ARG;
+    }
+    if ((size_t)2 * batch * tokens_of_cfg(*cfg) * 3 * cfg->model_dim >= ((size_t)1 << 32)) {
+        set_error("batch %d: dropout counters are 32-bit", batch);
+        return AFT_ERR_ARG;
+    }
+    return AFT_OK;
+}
+
+}  // namespace
+
+}  // namespace aft
+
+using namespace aft;
+
+extern "C" {
+
+size_t aft_encoder_tape_bytes(const aft_config *cfg, int batch) {
+    if (check_config(cfg) != AFT_OK || batch <= 0) return 0;
+    return plan_tape(*cfg, batch).total * sizeof(float);
+}
+
+size_t aft_encoder_train_scratch_bytes(const aft_config *cfg, int batch) {
+    if (check_config(cfg) != AFT_OK || batch <= 0) return 0;
+    return plan_scratch(*cfg, batch).total * sizeof(float);
+}
+
+int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
+                                    void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
+                                    float dropout_p, uint64_t seed, void *stream) {
+    int rc = check_train(cfg, batch, dropout_p);
+    if (rc != AFT_OK) return rc;
+    if (!w || !x_in || !x_out || !tape || !scratch) { set_error("NULL pointer argument"); return AFT_ERR_ARG; }
+    const Tape t = plan_tape(*cfg, batch);
+    const Scratch s = plan_scratch(*cfg, batch);
+    if (tape_bytes < t.total * sizeof(float) || scratch_bytes < s.total * sizeof(float)) {
+        set_error("tape or scratch too small");
+        return AFT_ERR_ARG;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *tp = static_cast<float *>(tape), *sc = static_cast<float *>(scratch);
+    const int tokens = tokens_of_cfg(*cfg), planes = 2 * batch, rows = planes * tokens, d = cfg->model_dim, ff = 2 * d;
+    float *o = sc + s.g1;   // projection outputs before the residual joins
+
+    STEP("qkv", launch_gemm(0, x_in, w->in_proj_w, tp + t.qkv, w->in_proj_b, rows, 3 * d, d, d, d, 3 * d, false, st));
+    STEP("attention", launch_attn_train_fwd(*cfg, tp + t.qkv, tp + t.attn, tp + t.lse, planes, tokens, dropout_p,
+                                            site_seed(seed, 0), st));
+    STEP("out_proj", launch_gemm(0, tp + t.attn, w->out_proj_w, o, w->out_proj_b, rows, d, d, d, d, d, false, st));
+    STEP("norm1", launch_add_ln_fwd(x_in, o, w->norm1_w, w->norm1_b, tp + t.s1, tp + t.st1, tp + t.x1, rows, d, 1e-5f,
+                                    dropout_p, site_seed(seed, 1), st));
+    STEP("linear1", launch_gemm(0, tp + t.x1, w->lin1_w, tp + t.a, w->lin1_b, rows, ff, d, d, d, ff, false, st));
+    STEP("activation", launch_act_fwd(cfg->activation, tp + t.a, sc + s.hd, (size_t)rows * ff, dropout_p, site_seed(seed, 2), st));
+    STEP("linear2", launch_gemm(0, sc + s.hd, w->lin2_w, o, w->lin2_b, rows, d, ff, ff, ff, d, false, st));
+    STEP("norm2", launch_add_ln_fwd(tp + t.x1, o, w->norm2_w, w->norm2_b, tp + t.s2, tp + t.st2, x_out, rows, d, 1e-5f,
+                                    dropout_p, site_seed(seed, 3), st));
+    return AFT_OK;
+}
+
+int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, const void *tape,
+                              size_t tape_bytes, const float *dx_out, float *dx_in, const aft_layer_grads *g,
+                              int accumulate, void *scratch, size_t scratch_bytes, int batch, float dropout_p,
+                              uint64_t seed, void *stream) {
+    int rc = check_train(cfg, batch, dropout_p);
+    if (rc != AFT_OK) return rc;
+    if (!w || !x_in || !tape || !dx_out || !dx_in || !g || !scratch) { set_error("NULL pointer argument"); return AFT_ERR_ARG; }
+    const Tape t = plan_tape(*cfg, batch);
+    const Scratch s = plan_scratch(*cfg, batch);
+    if (tape_bytes < t.total * sizeof(float) || scratch_bytes < s.total * sizeof(float)) {
+        set_error("tape or scratch too small");
+        return AFT_ERR_ARG;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *tp = static_cast<const float *>(tape);
+    float *sc = static_cast<float *>(scratch);
+    const int tokens = tokens_of_cfg(*cfg), planes = 2 * batch, rows = planes * tokens, d = cfg->model_dim, ff = 2 * d;
+    const bool acc = accumulate != 0;
+    float *g1 = sc + s.g1, *g2 = sc + s.g2, *gff = sc + s.gff, *hd = sc + s.hd, *dqkv = sc + s.dqkv, *sl = sc + s.slices;
+
+    // LN2: g1 = d(x1) through the residual, g2 = d(linear2 output) (dropout 3 applied)
+    STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, sl, rows, d,
+                                    dropout_p, site_seed(seed, 3), acc, st));
+    STEP("activation (recompute)", launch_act_fwd(cfg->activation, tp + t.a, hd, (size_t)rows * ff, dropout_p, site_seed(seed, 2), st));
+    STEP("linear2 wgrad", launch_gemm_tn(g2, hd, g->lin2_w, sl, d, ff, rows, d, ff, acc, st));
+    STEP("linear2 bgrad", launch_colsum(g2, g->lin2_b, sl, rows, d, d, acc, st));
+    STEP("linear2 dgrad", launch_gemm(1, g2, w->lin2_w, gff, nullptr, rows, ff, d, d, ff, ff, false, st));
+    STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, (size_t)rows * ff, dropout_p, site_seed(seed, 2), st));
+    STEP("linear1 wgrad", launch_gemm_tn(gff, tp + t.x1, g->lin1_w, sl, ff, d, rows, ff, d, acc, st));
+    STEP("linear1 bgrad", launch_colsum(gff, g->lin1_b, sl, rows, ff, ff, acc, st));
+    STEP("linear1 dgrad", launch_gemm(1, gff, w->lin1_w, g1, nullptr, rows, d, ff, ff, d, d, true, st));
+    // LN1: dx_in = d(x_in) through the residual, g2 = d(out_proj output) (dropout 1 applied)
+    STEP("norm1 bwd", launch_ln_bwd(g1, tp + t.s1, tp + t.st1, w->norm1_w, dx_in, g2, g->norm1_w, g->norm1_b, sl, rows, d,
+                                    dropout_p, site_seed(seed, 1), acc, st));
+    STEP("out_proj wgrad", launch_gemm_tn(g2, tp + t.attn, g->out_proj_w, sl, d, d, rows, d, d, acc, st));
+    STEP("out_proj bgrad", launch_colsum(g2, g->out_proj_b, sl, rows, d, d, acc, st));
+    STEP("out_proj dgrad", launch_gemm(1, g2, w->out_proj_w, g1, nullptr, rows, d, d, d, d, d, false, st));
+    STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,
+                                                dropout_p, site_seed(seed, 0), st));
+    STEP("in_proj wgrad", launch_gemm_tn(dqkv, x_in, g->in_proj_w, sl, 3 * d, d, rows, 3 * d, d, acc, st));
+    STEP("in_proj bgrad", launch_colsum(dqkv, g->in_proj_b, sl, rows, 3 * d, 3 * d, acc, st));
+    STEP("in_proj dgrad", launch_gemm(1, dqkv, w->in_proj_w, dx_in, nullptr, rows, d, 3 * d, 3 * d, d, d, true, st));
+    return AFT_OK;
+}
+
+}  // extern "C"

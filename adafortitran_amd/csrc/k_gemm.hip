@@ -1,0 +1,198 @@
+// k_gemm.hip -- row-major fp32 GEMMs on v_mfma_f32_32x32x2_f32 for the training path.
+//
+// The inference path keeps activations in MFMA-fragment order and never needs a general GEMM.  The
+// backward pass does: every nn.Linear of the encoder (reference src/models/blocks/encoders.py:44-55,
+// torch.nn.TransformerEncoderLayer) needs, besides y = x W^T + b,
+//     dgrad  dx = dy W          (NN)
+//     wgrad  dW = dy^T x        (TN, reduction over all token rows)
+// with every operand in PyTorch's row-major layout.  One kernel, three operand modes:
+//     NT  C[M][N] = A[M][K] . B[N][K]^T (+ bias[N])
+//     NN  C[M][N] = A[M][K] . B[K][N]
+//     TN  C[M][N] = A[K][M]^T . B[K][N]      K = token rows, split over blockIdx.z into partial
+//                                            slices that reduce_slices_kernel sums (deterministic)
+// Tiling: 128x128 output tile per workgroup (4 waves, each 2x2 MFMA tiles), K step 16.  Both
+// operands are staged in LDS k-major ([k][m], row stride 132 floats) so that a fragment read is
+// 32 consecutive floats per half-wave -- conflict-free for A and B alike -- and the global->LDS
+// transposition of k-contiguous sources lands on 64 distinct banks.  Global loads of step i+1 are in
+// flight during the 32 MFMAs per wave of step i (register staging, two LDS buffers, one barrier).
+#include "aft_internal.h"
+
+namespace aft {
+
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
+
+// tile element (x, k), source contiguous in k:  src[(x0 + x) * ld + k0 + k]
+__device__ __forceinline__ void load_kc(const float *__restrict__ src, int ld, int x0, int xlim, int k0, int klim,
+                                        int tid, f32x4 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, x = e >> 2, kq = e & 3;
+        const bool ok = x0 + x < xlim && k0 + 4 * kq < klim;
+        v[u] = ok ? *reinterpret_cast<const f32x4 *>(src + (size_t)(x0 + x) * ld + k0 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void store_kc(float *__restrict__ lds, int tid, const f32x4 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, x = e >> 2, kq = e & 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lds[(4 * kq + c) * GLD + x] = v[u][c];
+    }
+}
+// tile element (x, k), source contiguous in x:  src[(k0 + k) * ld + x0 + x]
+__device__ __forceinline__ void load_xc(const float *__restrict__ src, int ld, int x0, int xlim, int k0, int klim,
+                                        int tid, f32x4 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, k = e >> 5, xq = e & 31;
+        const bool ok = k0 + k < klim && x0 + 4 * xq < xlim;
+        v[u] = ok ? *reinterpret_cast<const f32x4 *>(src + (size_t)(k0 + k) * ld + x0 + 4 * xq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void store_xc(float *__restrict__ lds, int tid, const f32x4 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, k = e >> 5, xq = e & 31;
+        *reinterpret_cast<f32x4 *>(lds + k * GLD + 4 * xq) = v[u];
+    }
+}
+
+// OP: 0 = NT, 1 = NN, 2 = TN (see header).  M, N multiples of 4; K multiple of 4 for NT/NN.
+template <int OP>
+__global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                   float *__restrict__ C, const float *__restrict__ bias, int M, int N,
+                                                   int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
+                                                   int accumulate) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int kbeg = blockIdx.z * k_chunk, kend = min(K, kbeg + k_chunk);
+    C += (size_t)blockIdx.z * c_slice;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    auto fetch = [&](int k0) {
+        if constexpr (OP == 2) load_xc(A, lda, m0, M, k0, kend, tid, ra); else load_kc(A, lda, m0, M, k0, kend, tid, ra);
+        if constexpr (OP == 0) load_kc(B, ldb, n0, N, k0, kend, tid, rb); else load_xc(B, ldb, n0, N, k0, kend, tid, rb);
+    };
+    auto stage = [&](int buf) {
+        if constexpr (OP == 2) store_xc(As[buf], tid, ra); else store_kc(As[buf], tid, ra);
+        if constexpr (OP == 0) store_kc(Bs[buf], tid, rb); else store_xc(Bs[buf], tid, rb);
+    };
+
+    const int nsteps = (kend - kbeg + GBK - 1) / GBK;
+    if (nsteps > 0) {
+        fetch(kbeg);
+        stage(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nsteps; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nsteps) fetch(kbeg + (it + 1) * GBK);
+        const float *as = As[buf] + h * GLD + wm * 64 + j;
+        const float *bs = Bs[buf] + h * GLD + wn * 64 + j;
+#pragma unroll
+        for (int kb = 0; kb < GBK / 2; ++kb) {
+            const float a0 = as[2 * kb * GLD], a1 = as[2 * kb * GLD + 32];
+            const float b0 = bs[2 * kb * GLD], b1 = bs[2 * kb * GLD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (it + 1 < nsteps) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int col = n0 + wn * 64 + tj * 32 + j;
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                float *p = C + (size_t)row * ldc + col;
+                float v = acc[ti][tj][e] + bv;
+                if (accumulate) v += *p;
+                *p = v;
+            }
+        }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_z slices[z * stride + i]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restrict__ slices, float *__restrict__ out,
+                                                            int n, int nz, size_t stride, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int z = 0; z < nz; ++z) s += slices[(size_t)z * stride + i];
+    out[i] = s;
+}
+
+hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, size_t stride, bool accumulate,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, st, slices, out, n, nz, stride, (int)accumulate);
+    return hipGetLastError();
+}
+
+// column sums of a row-major [rows][n] matrix (bias gradients): one slice per row chunk
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ slices, int rows,
+                                                     int n, int ld, int chunk) {
+    const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+    __shared__ float part[4][64];
+    float s = 0.f;
+    if (col < n)
+        for (int r = r0 + rq; r < r1; r += 4) s += x[(size_t)r * ld + col];
+    part[rq][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rq == 0 && col < n) slices[(size_t)blockIdx.y * n + col] = part[0][col & 63] + part[1][col & 63] + part[2][col & 63] + part[3][col & 63];
+}
+
+int gemm_split_slices(int rows) { return std::max(1, std::min(kGemmMaxSlices, rows / 256)); }
+
+hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,
+                       int ldb, int ldc, bool accumulate, hipStream_t st) {
+    const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, 1);
+    if (op == 0)
+        hipLaunchKernelGGL(gemm_kernel<0>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0, (int)accumulate);
+    else if (op == 1)
+        hipLaunchKernelGGL(gemm_kernel<1>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0, (int)accumulate);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// dW[M][N] (+)= A[R][M]^T . B[R][N]; `slices` holds gemm_split_slices(R) * M * N floats
+hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slices, int M, int N, int R, int lda, int ldb,
+                          bool accumulate, hipStream_t st) {
+    const int nz = gemm_split_slices(R);
+    const int chunk = ((R + nz - 1) / nz + GBK - 1) / GBK * GBK;
+    const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, nz);
+    hipLaunchKernelGGL(gemm_kernel<2>, grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb, N,
+                       chunk, (size_t)M * N, 0);
+    return launch_reduce_slices(slices, C, M * N, nz, (size_t)M * N, accumulate, st);
+}
+
+// db[n] (+)= sum_r x[r][n]; `slices` holds gemm_split_slices(rows) * n floats
+hipError_t launch_colsum(const float *x, float *out, float *slices, int rows, int n, int ld, bool accumulate, hipStream_t st) {
+    const int nz = gemm_split_slices(rows);
+    const int chunk = (rows + nz - 1) / nz;
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, x, slices, rows, n, ld, chunk);
+    return launch_reduce_slices(slices, out, n, nz, (size_t)n, accumulate, st);
+}
+
+}  // namespace aft

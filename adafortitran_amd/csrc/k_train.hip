@@ -1,0 +1,234 @@
+// k_train.hip -- row-wise pieces of the encoder layer's training forward / backward:
+// residual + dropout + LayerNorm (forward keeps the pre-norm sum and the row statistics), LayerNorm
+// backward, activation (+ dropout) forward / backward, dropout scaling of a gradient.
+//
+// Reference semantics: torch.nn.TransformerEncoderLayer, norm_first = False
+// (reference src/models/blocks/encoders.py:44-55):
+//     x1 = LN1(x + drop(attn_proj));   x2 = LN2(x1 + drop(W2 drop(act(W1 x1 + b1)) + b2))
+// LayerNorm: biased variance, eps inside the square root.  All tensors row-major [rows][n], fp32.
+// HBM-bound elementwise work: one wave per row (n = 128 or 256 -> 2 or 4 floats per lane), row
+// reductions by DPP/shuffle butterflies; the column reductions of the LayerNorm weight gradients go
+// through per-workgroup partial slices and the shared deterministic slice reduction.
+#include "aft_internal.h"
+
+namespace aft {
+
+__device__ __forceinline__ uint32_t tmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float tdrop(uint32_t seed, uint32_t idx, uint32_t threshold, float keep_scale) {
+    return tmix32(idx * 0x9E3779B1u ^ seed) >= threshold ? keep_scale : 0.f;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// s = res + drop(y);  out = LN(s) * gamma + beta;  keeps s, mean, rstd.   NPL = n / 64 floats per lane
+template <int NPL>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float *__restrict__ res, const float *__restrict__ y,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         float *__restrict__ s_out, float *__restrict__ stats,
+                                                         float *__restrict__ out, int rows, float eps, uint32_t seed,
+                                                         uint32_t threshold, float keep_scale) {
+    constexpr int N = NPL * 64;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[NPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int col = lane + 64 * q;
+        float t = y[(size_t)row * N + col];
+        if (threshold) t *= tdrop(seed, (uint32_t)row * N + col, threshold, keep_scale);
+        v[q] = res[(size_t)row * N + col] + t;
+        sum += v[q];
+    }
+    const float mean = wave_sum(sum) * (1.f / N);
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) var += (v[q] - mean) * (v[q] - mean);
+    const float rstd = rsqrtf(wave_sum(var) * (1.f / N) + eps);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int col = lane + 64 * q;
+        s_out[(size_t)row * N + col] = v[q];
+        out[(size_t)row * N + col] = (v[q] - mean) * rstd * gamma[col] + beta[col];
+    }
+    if (lane == 0) {
+        stats[2 * (size_t)row] = mean;
+        stats[2 * (size_t)row + 1] = rstd;
+    }
+}
+
+// ds = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-workgroup partial sums of
+// dgamma = sum dy * xhat and dbeta = sum dy into slices[block][2n].  If `dres` is given, ds is also
+// multiplied by the dropout factor of the forward's `y` branch and written there (the gradient of y).
+template <int NPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ s,
+                                                     const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                     float *__restrict__ ds, float *__restrict__ dbranch,
+                                                     float *__restrict__ slices, int rows, int rows_per_block, uint32_t seed,
+                                                     uint32_t threshold, float keep_scale) {
+    constexpr int N = NPL * 64;
+    __shared__ float part[4][2 * N];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float dg[NPL], db[NPL], gm[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        dg[q] = 0.f;
+        db[q] = 0.f;
+        gm[q] = gamma[lane + 64 * q];
+    }
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+        float g[NPL], xh[NPL], a = 0.f, b = 0.f;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int col = lane + 64 * q;
+            const float d = dy[(size_t)row * N + col];
+            xh[q] = (s[(size_t)row * N + col] - mean) * rstd;
+            g[q] = d * gm[q];
+            a += g[q];
+            b += g[q] * xh[q];
+            dg[q] += d * xh[q];
+            db[q] += d;
+        }
+        a = wave_sum(a) * (1.f / N);
+        b = wave_sum(b) * (1.f / N);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int col = lane + 64 * q;
+            const float v = rstd * (g[q] - a - xh[q] * b);
+            ds[(size_t)row * N + col] = v;
+            if (dbranch)
+                dbranch[(size_t)row * N + col] = threshold ? v * tdrop(seed, (uint32_t)row * N + col, threshold, keep_scale) : v;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        part[wave][lane + 64 * q] = dg[q];
+        part[wave][N + lane + 64 * q] = db[q];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * N; i += 256)
+        slices[(size_t)blockIdx.x * 2 * N + i] = part[0][i] + part[1][i] + part[2][i] + part[3][i];
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+// h = drop(act(a))       ACT: 0 = relu, 1 = gelu (exact erf form, torch default)
+template <int ACT>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ a, float *__restrict__ hout, size_t n4,
+                                                      uint32_t seed, uint32_t threshold, float keep_scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i];
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = ACT ? gelu_exact(x[c]) : fmaxf(x[c], 0.f);
+        if (threshold) v *= tdrop(seed, (uint32_t)(4 * i + c), threshold, keep_scale);
+        r[c] = v;
+    }
+    reinterpret_cast<f32x4 *>(hout)[i] = r;
+}
+
+// da = dh * dropfactor * act'(a)   (in place on dh)
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ a, float *__restrict__ dh, size_t n4,
+                                                      uint32_t seed, uint32_t threshold, float keep_scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i];
+    f32x4 g = reinterpret_cast<f32x4 *>(dh)[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v = g[c] * (ACT ? gelu_grad(x[c]) : (x[c] > 0.f ? 1.f : 0.f));
+        if (threshold) v *= tdrop(seed, (uint32_t)(4 * i + c), threshold, keep_scale);
+        g[c] = v;
+    }
+    reinterpret_cast<f32x4 *>(dh)[i] = g;
+}
+
+// out = a + b   (gradient joins of the two residual branches)
+__global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                  float *__restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i], y = reinterpret_cast<const f32x4 *>(b)[i];
+    reinterpret_cast<f32x4 *>(out)[i] = x + y;
+}
+
+static inline uint32_t drop_threshold(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+static inline float drop_keep(float p) { return p > 0.f ? 1.f / (1.f - p) : 1.f; }
+
+hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamma, const float *beta, float *s_out,
+                             float *stats, float *out, int rows, int n, float eps, float dropout_p, uint32_t seed,
+                             hipStream_t st) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    const uint32_t th = drop_threshold(dropout_p);
+    const float ks = drop_keep(dropout_p);
+    if (n == 128)
+        hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else if (n == 256)
+        hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+int ln_bwd_blocks(int rows) { return std::max(1, std::min(kGemmMaxSlices, rows / 64)); }
+
+// dgamma / dbeta (+)= column sums; `slices` holds ln_bwd_blocks(rows) * 2n floats
+hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, const float *gamma, float *ds, float *dbranch,
+                         float *dgamma, float *dbeta, float *slices, int rows, int n, float dropout_p, uint32_t seed,
+                         bool accumulate, hipStream_t st) {
+    const int nb = ln_bwd_blocks(rows), rpb = (rows + nb - 1) / nb;
+    const uint32_t th = drop_threshold(dropout_p);
+    const float ks = drop_keep(dropout_p);
+    if (n == 128)
+        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else if (n == 256)
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else
+        return hipErrorInvalidValue;
+    // slices[b][0..n) = dgamma partials, [n..2n) = dbeta partials
+    hipError_t e = launch_reduce_slices(slices, dgamma, n, nb, 2 * n, accumulate, st);
+    if (e != hipSuccess) return e;
+    return launch_reduce_slices(slices + n, dbeta, n, nb, 2 * n, accumulate, st);
+}
+
+hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dropout_p, uint32_t seed, hipStream_t st) {
+    const size_t n4 = n / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+    if (act)
+        hipLaunchKernelGGL(act_fwd_kernel<1>, grid, block, 0, st, a, h, n4, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
+    else
+        hipLaunchKernelGGL(act_fwd_kernel<0>, grid, block, 0, st, a, h, n4, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
+    return hipGetLastError();
+}
+
+hipError_t launch_act_bwd(int act, const float *a, float *dh, size_t n, float dropout_p, uint32_t seed, hipStream_t st) {
+    const size_t n4 = n / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+    if (act)
+        hipLaunchKernelGGL(act_bwd_kernel<1>, grid, block, 0, st, a, dh, n4, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<0>, grid, block, 0, st, a, dh, n4, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
+    return hipGetLastError();
+}
+
+hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t st) {
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, b, out, n4);
+    return hipGetLastError();
+}
+
+}  // namespace aft

@@ -121,6 +121,40 @@ int aft_pilot_gather_f32(const float *hzero_ls, float *pilots, int *counts, int 
  * (:264-303): db[b] = 10 log10( mean_i |ls[b,i] - ideal[b,i]|^2 ), complex64 [B, grid_elems] inputs. */
 int aft_ls_mse_db_f32(const float *ls, const float *ideal, float *db, int batch, int grid_elems, void *stream);
 
+/* ---- training path of the encoder ---- */
+
+/* Gradients of one nn.TransformerEncoderLayer: same fields and shapes as aft_layer_weights,
+ * writable.  These are the .grad tensors autograd hands to the optimizer
+ * (reference src/main/trainer.py:195-233, loss.backward()). */
+typedef struct aft_layer_grads {
+    float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b;
+    float *lin1_w, *lin1_b, *lin2_w, *lin2_b;
+    float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} aft_layer_grads;
+
+/* Bytes of the per-layer activation tape the training forward fills and the backward reads, and
+ * of the scratch either call needs (both 0 on a bad config). */
+size_t aft_encoder_tape_bytes(const aft_config *cfg, int batch);
+size_t aft_encoder_train_scratch_bytes(const aft_config *cfg, int batch);
+
+/* Replaces nn.TransformerEncoderLayer.forward in train() mode (reference blocks/encoders.py:44-55,
+ * called from encoders.py:69): x_in f32 [2B*tokens, d] -> x_out (may not alias x_in, which the
+ * backward reads again).  Dropout with probability `dropout_p` at the layer's four sites (attention
+ * probabilities, after out_proj, after the activation, after linear2) from a counter-based
+ * generator keyed by `seed`; the backward must be given the same seed.  dropout_p = 0 reproduces
+ * the eval-mode layer. */
+int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
+                                    void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
+                                    float dropout_p, uint64_t seed, void *stream);
+
+/* Replaces autograd's backward through that layer: dx_out = dL/dx_out [2B*tokens, d] ->
+ * dx_in = dL/dx_in (may alias dx_out) and the twelve parameter gradients in `grads`
+ * (overwritten, or added to when accumulate != 0). */
+int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, const void *tape,
+                              size_t tape_bytes, const float *dx_out, float *dx_in, const aft_layer_grads *grads,
+                              int accumulate, void *scratch, size_t scratch_bytes, int batch, float dropout_p,
+                              uint64_t seed, void *stream);
+
 /* ---- per-stage entry points (known-answer tests; same kernels as aft_forward_f32) ---- */
 
 /* S1+S2 (fortitran.py:203-209): pilots complex64 [B,Ps,Pt] -> conv_enhanced f32 [2B,S,T]. */
