@@ -17,6 +17,7 @@ from typing import Sequence, Tuple
 
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 
 class ConvEnhancer(nn.Module):
@@ -140,7 +141,32 @@ class TransformerEncoderForChannels(nn.Module):
         self.linear_2 = nn.Linear(model_dim, output_dim)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.linear_2(self.transformer(self.positional_encoding(self.linear_1(x))))
+        h = self.positional_encoding(self.linear_1(x))
+        if self._hip_train_eligible(h):
+            # grad-enabled forward on the HIP device: hand-written forward/backward kernels for the
+            # encoder layers (training.py); everything else differentiates through PyTorch-ROCm.
+            from . import _abi
+            from .training import encoder_stack_train
+            layer0 = self.transformer.layers[0]
+            cfg = _abi.make_config(ofdm=(h.shape[1], 1), pilot=(1, 1), patch=(1, 1), num_layers=len(self.transformer.layers),
+                                   model_dim=h.shape[2], num_head=layer0.self_attn.num_heads,
+                                   activation="gelu" if layer0.activation is F.gelu else "relu")
+            h = encoder_stack_train(h, list(self.transformer.layers), cfg, layer0.dropout.p if self.training else 0.0)
+        else:
+            h = self.transformer(h)
+        return self.linear_2(h)
+
+    #: set to False to differentiate the encoder through PyTorch-ROCm autograd instead (A/B tests)
+    hip_training = True
+
+    def _hip_train_eligible(self, h: torch.Tensor) -> bool:
+        if not (self.hip_training and h.device.type == "cuda" and torch.is_grad_enabled() and h.dtype == torch.float32):
+            return False
+        layer0 = self.transformer.layers[0]
+        d, heads, tokens = h.shape[2], layer0.self_attn.num_heads, h.shape[1]
+        return (d in (128, 256) and d // heads == 32 and tokens % 8 == 0 and tokens >= 32 and h.shape[0] % 2 == 0
+                and layer0.activation in (F.gelu, F.relu) and not layer0.norm_first
+                and layer0.linear1.out_features == 2 * d)
 
 
 __all__ = ["ChannelAdapter", "TransformerEncoderForChannels", "ConvEnhancer", "PatchEmbedding",

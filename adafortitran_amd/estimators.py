@@ -131,6 +131,15 @@ class BaseFortiTranEstimator(nn.Module):
                 return eng.forward(pilot_symbols)
             return eng.forward(pilot_symbols, *conditions)
 
+        if pilot_symbols.device.type == "cuda" and torch.is_grad_enabled():
+            # training on the HIP device: the Re and Im planes go through the network as ONE batch of
+            # 2B planes (same per-sample arithmetic as the reference's two passes, fortitran.py:176-177),
+            # which is what the encoder's training kernels are laid out for
+            B = pilot_symbols.shape[0]
+            stacked = torch.cat((pilot_symbols.real, pilot_symbols.imag), dim=0)
+            cond2 = None if conditions is None else [torch.cat((c, c), dim=0) for c in conditions]
+            out = self._forward_real_valued(stacked, cond2)
+            return torch.complex(out[:B], out[B:])
         real = self._forward_real_valued(pilot_symbols.real, conditions)
         imag = self._forward_real_valued(pilot_symbols.imag, conditions)
         return torch.complex(real, imag)
