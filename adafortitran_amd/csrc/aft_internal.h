@@ -71,7 +71,9 @@ hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long l
 
 
 // ---- training path: row-major GEMMs, attention with saved LSE, row-wise pieces ----
-constexpr int kGemmMaxSlices = 128;   // split of the token-row reduction in weight / bias gradients
+constexpr int kGemmMaxSlices = 128;   // split of the token-row reduction in weight gradients
+constexpr int kColsumMaxSlices = 1024; // ... in bias / LayerNorm-parameter gradients (one slice per workgroup)
+int colsum_slices(int rows);
 int gemm_split_slices(int rows);
 int ln_bwd_blocks(int rows);
 // op 0: C = A[M][K] B[N][K]^T + bias;  op 1: C = A[M][K] B[K][N]   (accumulate: C += ...)
@@ -90,10 +92,11 @@ hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamm
                              float *stats, float *out, int rows, int n, float eps, float dropout_p, uint32_t seed,
                              hipStream_t st);
 hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, const float *gamma, float *ds, float *dbranch,
-                         float *dgamma, float *dbeta, float *slices, int rows, int n, float dropout_p, uint32_t seed,
-                         bool accumulate, hipStream_t st);
+                         float *dgamma, float *dbeta, float *dbias, float *slices, int rows, int n, float dropout_p,
+                         uint32_t seed, bool accumulate, hipStream_t st);
 hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dropout_p, uint32_t seed, hipStream_t st);
-hipError_t launch_act_bwd(int act, const float *a, float *dh, size_t n, float dropout_p, uint32_t seed, hipStream_t st);
+hipError_t launch_act_bwd(int act, const float *a, float *dh, float *dbias, float *slices, int rows, int n, float dropout_p,
+                          uint32_t seed, bool accumulate, hipStream_t st);
 hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t st);
 
 }  // namespace aft

@@ -51,7 +51,7 @@ Scratch plan_scratch(const aft_config &c, int batch) {
     s.hd = off;     off += al64(rows * ff);
     s.dqkv = off;   off += al64(rows * 3 * d);
     s.dsum = off;   off += al64(rows * c.num_head);
-    s.slices = off; off += al64((size_t)kGemmMaxSlices * 3 * d * d);
+    s.slices = off; off += al64(std::max((size_t)kGemmMaxSlices * 3 * d * d, (size_t)kColsumMaxSlices * 3 * d));
     s.total = off;
     return s;
 }
@@ -159,21 +159,19 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     float *g1 = sc + s.g1, *g2 = sc + s.g2, *gff = sc + s.gff, *hd = sc + s.hd, *dqkv = sc + s.dqkv, *sl = sc + s.slices;
 
     // LN2: g1 = d(x1) through the residual, g2 = d(linear2 output) (dropout 3 applied)
-    STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, sl, rows, d,
-                                    dropout_p, site_seed(seed, 3), acc, st));
+    STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, g->lin2_b, sl,
+                                    rows, d, dropout_p, site_seed(seed, 3), acc, st));
     STEP("activation (recompute)", launch_act_fwd(cfg->activation, tp + t.a, hd, (size_t)rows * ff, dropout_p, site_seed(seed, 2), st));
     STEP("linear2 wgrad", launch_gemm_tn(g2, hd, g->lin2_w, sl, d, ff, rows, d, ff, acc, st));
-    STEP("linear2 bgrad", launch_colsum(g2, g->lin2_b, sl, rows, d, d, acc, st));
     STEP("linear2 dgrad", launch_gemm(1, g2, w->lin2_w, gff, nullptr, rows, ff, d, d, ff, ff, false, st));
-    STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, (size_t)rows * ff, dropout_p, site_seed(seed, 2), st));
+    STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, g->lin1_b, sl, rows, ff, dropout_p, site_seed(seed, 2),
+                                          acc, st));
     STEP("linear1 wgrad", launch_gemm_tn(gff, tp + t.x1, g->lin1_w, sl, ff, d, rows, ff, d, acc, st));
-    STEP("linear1 bgrad", launch_colsum(gff, g->lin1_b, sl, rows, ff, ff, acc, st));
     STEP("linear1 dgrad", launch_gemm(1, gff, w->lin1_w, g1, nullptr, rows, d, ff, ff, d, d, true, st));
     // LN1: dx_in = d(x_in) through the residual, g2 = d(out_proj output) (dropout 1 applied)
-    STEP("norm1 bwd", launch_ln_bwd(g1, tp + t.s1, tp + t.st1, w->norm1_w, dx_in, g2, g->norm1_w, g->norm1_b, sl, rows, d,
-                                    dropout_p, site_seed(seed, 1), acc, st));
+    STEP("norm1 bwd", launch_ln_bwd(g1, tp + t.s1, tp + t.st1, w->norm1_w, dx_in, g2, g->norm1_w, g->norm1_b, g->out_proj_b, sl,
+                                    rows, d, dropout_p, site_seed(seed, 1), acc, st));
     STEP("out_proj wgrad", launch_gemm_tn(g2, tp + t.attn, g->out_proj_w, sl, d, d, rows, d, d, acc, st));
-    STEP("out_proj bgrad", launch_colsum(g2, g->out_proj_b, sl, rows, d, d, acc, st));
     STEP("out_proj dgrad", launch_gemm(1, g2, w->out_proj_w, g1, nullptr, rows, d, d, d, d, d, false, st));
     STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,
                                                 dropout_p, site_seed(seed, 0), st));

@@ -132,19 +132,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
         }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_z slices[z * stride + i]   (fixed order: deterministic)
+// out[i] = (accumulate ? out[i] : 0) + sum_z slices[z * stride + i].  64 columns per workgroup, the
+// slice index split over the 4 waves, four loads in flight per thread; fixed summation order
+// (deterministic run to run).
 __global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restrict__ slices, float *__restrict__ out,
                                                             int n, int nz, size_t stride, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = accumulate ? out[i] : 0.f;
-    for (int z = 0; z < nz; ++z) s += slices[(size_t)z * stride + i];
-    out[i] = s;
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, zq = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int z = zq;
+        for (; z + 12 < nz; z += 16) {
+            s0 += slices[(size_t)z * stride + i];
+            s1 += slices[(size_t)(z + 4) * stride + i];
+            s2 += slices[(size_t)(z + 8) * stride + i];
+            s3 += slices[(size_t)(z + 12) * stride + i];
+        }
+        for (; z < nz; z += 4) s0 += slices[(size_t)z * stride + i];
+    }
+    part[zq][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zq == 0 && i < n) {
+        const float s = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        out[i] = accumulate ? out[i] + s : s;
+    }
 }
 
 hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, size_t stride, bool accumulate,
                                 hipStream_t st) {
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, st, slices, out, n, nz, stride, (int)accumulate);
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 63) / 64), dim3(256), 0, st, slices, out, n, nz, stride, (int)accumulate);
     return hipGetLastError();
 }
 
@@ -152,17 +168,26 @@ hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, 
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, float *__restrict__ slices, int rows,
                                                      int n, int ld, int chunk) {
     const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+    const int c = threadIdx.x & 63, col = blockIdx.x * 64 + c, rq = threadIdx.x >> 6;
     __shared__ float part[4][64];
-    float s = 0.f;
-    if (col < n)
-        for (int r = r0 + rq; r < r1; r += 4) s += x[(size_t)r * ld + col];
-    part[rq][threadIdx.x & 63] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < n) {
+        int r = r0 + rq;
+        for (; r + 12 < r1; r += 16) {
+            s0 += x[(size_t)r * ld + col];
+            s1 += x[(size_t)(r + 4) * ld + col];
+            s2 += x[(size_t)(r + 8) * ld + col];
+            s3 += x[(size_t)(r + 12) * ld + col];
+        }
+        for (; r < r1; r += 4) s0 += x[(size_t)r * ld + col];
+    }
+    part[rq][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (rq == 0 && col < n) slices[(size_t)blockIdx.y * n + col] = part[0][col & 63] + part[1][col & 63] + part[2][col & 63] + part[3][col & 63];
+    if (rq == 0 && col < n) slices[(size_t)blockIdx.y * n + col] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 int gemm_split_slices(int rows) { return std::max(1, std::min(kGemmMaxSlices, rows / 256)); }
+int colsum_slices(int rows) { return std::max(1, std::min(kColsumMaxSlices, rows / 64)); }
 
 hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,
                        int ldb, int ldc, bool accumulate, hipStream_t st) {
@@ -187,9 +212,9 @@ hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slice
     return launch_reduce_slices(slices, C, M * N, nz, (size_t)M * N, accumulate, st);
 }
 
-// db[n] (+)= sum_r x[r][n]; `slices` holds gemm_split_slices(rows) * n floats
+// db[n] (+)= sum_r x[r][n]; `slices` holds colsum_slices(rows) * n floats
 hipError_t launch_colsum(const float *x, float *out, float *slices, int rows, int n, int ld, bool accumulate, hipStream_t st) {
-    const int nz = gemm_split_slices(rows);
+    const int nz = colsum_slices(rows);
     const int chunk = (rows + nz - 1) / nz;
     hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, nz), dim3(256), 0, st, x, slices, rows, n, ld, chunk);
     return launch_reduce_slices(slices, out, n, nz, (size_t)n, accumulate, st);

@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float *__restrict
 }
 
 // ds = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-workgroup partial sums of
-// dgamma = sum dy * xhat and dbeta = sum dy into slices[block][2n].  If `dres` is given, ds is also
-// multiplied by the dropout factor of the forward's `y` branch and written there (the gradient of y).
+// dgamma = sum dy * xhat and dbeta = sum dy into slices[block][3n].  ds times the dropout factor of the
+// forward's `y` branch is the gradient of y: written to `dbranch`, its column sums (the bias gradient of
+// the linear layer that produced y) into the third n of the slice.
 template <int NPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ s,
                                                      const float *__restrict__ stats, const float *__restrict__ gamma,
@@ -73,14 +74,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
                                                      float *__restrict__ slices, int rows, int rows_per_block, uint32_t seed,
                                                      uint32_t threshold, float keep_scale) {
     constexpr int N = NPL * 64;
-    __shared__ float part[4][2 * N];
+    __shared__ float part[4][3 * N];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    float dg[NPL], db[NPL], gm[NPL];
+    float dg[NPL], db[NPL], dbr[NPL], gm[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         dg[q] = 0.f;
         db[q] = 0.f;
+        dbr[q] = 0.f;
         gm[q] = gamma[lane + 64 * q];
     }
     for (int row = r0 + wave; row < r1; row += 4) {
@@ -104,18 +106,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
             const int col = lane + 64 * q;
             const float v = rstd * (g[q] - a - xh[q] * b);
             ds[(size_t)row * N + col] = v;
-            if (dbranch)
-                dbranch[(size_t)row * N + col] = threshold ? v * tdrop(seed, (uint32_t)row * N + col, threshold, keep_scale) : v;
+            const float vb = threshold ? v * tdrop(seed, (uint32_t)row * N + col, threshold, keep_scale) : v;
+            dbranch[(size_t)row * N + col] = vb;
+            dbr[q] += vb;
         }
     }
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         part[wave][lane + 64 * q] = dg[q];
         part[wave][N + lane + 64 * q] = db[q];
+        part[wave][2 * N + lane + 64 * q] = dbr[q];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * N; i += 256)
-        slices[(size_t)blockIdx.x * 2 * N + i] = part[0][i] + part[1][i] + part[2][i] + part[3][i];
+    for (int i = threadIdx.x; i < 3 * N; i += 256)
+        slices[(size_t)blockIdx.x * 3 * N + i] = part[0][i] + part[1][i] + part[2][i] + part[3][i];
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -140,21 +144,36 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ 
     reinterpret_cast<f32x4 *>(hout)[i] = r;
 }
 
-// da = dh * dropfactor * act'(a)   (in place on dh)
+// da = dh * dropfactor * act'(a)   (in place on dh), [rows][n]; column sums of da (the bias gradient of
+// linear1) per workgroup into slices[block][n].  A thread owns 4 adjacent columns and every
+// (256 / (n/4))-th row of the workgroup's row chunk.
 template <int ACT>
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ a, float *__restrict__ dh, size_t n4,
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ a, float *__restrict__ dh,
+                                                      float *__restrict__ slices, int rows, int n, int rows_per_block,
                                                       uint32_t seed, uint32_t threshold, float keep_scale) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i];
-    f32x4 g = reinterpret_cast<f32x4 *>(dh)[i];
+    __shared__ f32x4 part[256];
+    const int groups = n >> 2, cg = threadIdx.x % groups, rsub = threadIdx.x / groups, rstep = 256 / groups;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int row = r0 + rsub; row < r1; row += rstep) {
+        const size_t i = ((size_t)row * n >> 2) + cg;
+        const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i];
+        f32x4 g = reinterpret_cast<f32x4 *>(dh)[i];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float v = g[c] * (ACT ? gelu_grad(x[c]) : (x[c] > 0.f ? 1.f : 0.f));
-        if (threshold) v *= tdrop(seed, (uint32_t)(4 * i + c), threshold, keep_scale);
-        g[c] = v;
+        for (int c = 0; c < 4; ++c) {
+            float v = g[c] * (ACT ? gelu_grad(x[c]) : (x[c] > 0.f ? 1.f : 0.f));
+            if (threshold) v *= tdrop(seed, (uint32_t)(4 * i + c), threshold, keep_scale);
+            g[c] = v;
+        }
+        reinterpret_cast<f32x4 *>(dh)[i] = g;
+        sum += g;
     }
-    reinterpret_cast<f32x4 *>(dh)[i] = g;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (rsub == 0) {
+        for (int q = 1; q < rstep; ++q) sum += part[q * groups + cg];
+        reinterpret_cast<f32x4 *>(slices + (size_t)blockIdx.x * n)[cg] = sum;
+    }
 }
 
 // out = a + b   (gradient joins of the two residual branches)
@@ -184,12 +203,12 @@ hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamm
     return hipGetLastError();
 }
 
-int ln_bwd_blocks(int rows) { return std::max(1, std::min(kGemmMaxSlices, rows / 64)); }
+int ln_bwd_blocks(int rows) { return std::max(1, std::min(kColsumMaxSlices, rows / 32)); }
 
-// dgamma / dbeta (+)= column sums; `slices` holds ln_bwd_blocks(rows) * 2n floats
+// dgamma / dbeta / dbias (+)= column sums; `slices` holds ln_bwd_blocks(rows) * 3n floats
 hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, const float *gamma, float *ds, float *dbranch,
-                         float *dgamma, float *dbeta, float *slices, int rows, int n, float dropout_p, uint32_t seed,
-                         bool accumulate, hipStream_t st) {
+                         float *dgamma, float *dbeta, float *dbias, float *slices, int rows, int n, float dropout_p,
+                         uint32_t seed, bool accumulate, hipStream_t st) {
     const int nb = ln_bwd_blocks(rows), rpb = (rows + nb - 1) / nb;
     const uint32_t th = drop_threshold(dropout_p);
     const float ks = drop_keep(dropout_p);
@@ -199,10 +218,12 @@ hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, co
         hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
     else
         return hipErrorInvalidValue;
-    // slices[b][0..n) = dgamma partials, [n..2n) = dbeta partials
-    hipError_t e = launch_reduce_slices(slices, dgamma, n, nb, 2 * n, accumulate, st);
+    // slices[b][0..n) = dgamma partials, [n..2n) = dbeta partials, [2n..3n) = branch bias gradient
+    hipError_t e = launch_reduce_slices(slices, dgamma, n, nb, 3 * n, accumulate, st);
     if (e != hipSuccess) return e;
-    return launch_reduce_slices(slices + n, dbeta, n, nb, 2 * n, accumulate, st);
+    e = launch_reduce_slices(slices + n, dbeta, n, nb, 3 * n, accumulate, st);
+    if (e != hipSuccess) return e;
+    return launch_reduce_slices(slices + 2 * n, dbias, n, nb, 3 * n, accumulate, st);
 }
 
 hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dropout_p, uint32_t seed, hipStream_t st) {
@@ -215,14 +236,16 @@ hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dro
     return hipGetLastError();
 }
 
-hipError_t launch_act_bwd(int act, const float *a, float *dh, size_t n, float dropout_p, uint32_t seed, hipStream_t st) {
-    const size_t n4 = n / 4;
-    const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+// dbias (+)= column sums of da; `slices` holds ln_bwd_blocks(rows) * n floats; n = 256 or 512
+hipError_t launch_act_bwd(int act, const float *a, float *dh, float *dbias, float *slices, int rows, int n, float dropout_p,
+                          uint32_t seed, bool accumulate, hipStream_t st) {
+    if (n % 4 || 256 % (n / 4)) return hipErrorInvalidValue;
+    const int nb = ln_bwd_blocks(rows), rpb = (rows + nb - 1) / nb;
     if (act)
-        hipLaunchKernelGGL(act_bwd_kernel<1>, grid, block, 0, st, a, dh, n4, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
+        hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, a, dh, slices, rows, n, rpb, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
     else
-        hipLaunchKernelGGL(act_bwd_kernel<0>, grid, block, 0, st, a, dh, n4, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
-    return hipGetLastError();
+        hipLaunchKernelGGL(act_bwd_kernel<0>, dim3(nb), dim3(256), 0, st, a, dh, slices, rows, n, rpb, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
+    return launch_reduce_slices(slices, dbias, n, nb, (size_t)n, accumulate, st);
 }
 
 hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t st) {
