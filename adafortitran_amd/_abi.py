@@ -134,7 +134,7 @@ EXPORTED_SYMBOLS = (
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",
     "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",
     "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
-    "aft_encoder_layer_fwd_train_f32", "aft_encoder_layer_bwd_f32",
+    "aft_encoder_layer_fwd_train_f32", "aft_encoder_layer_bwd_f32", "aft_adam_step_f32",
 )
 #: size queries (return size_t, not a status code)
 SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes")

@@ -98,5 +98,7 @@ hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dro
 hipError_t launch_act_bwd(int act, const float *a, float *dh, float *dbias, float *slices, int rows, int n, float dropout_p,
                           uint32_t seed, bool accumulate, hipStream_t st);
 hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t st);
+hipError_t launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
+                       float wd, float grad_scale, int step, hipStream_t st);
 
 }  // namespace aft

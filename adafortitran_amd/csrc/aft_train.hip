@@ -181,4 +181,13 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     return AFT_OK;
 }
 
+int aft_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float grad_scale, int step, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) { set_error("bad Adam argument"); return AFT_ERR_ARG; }
+    if (n == 0) return AFT_OK;
+    STEP("adam", launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step,
+                             static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
 }  // extern "C"

@@ -185,6 +185,31 @@ __global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, c
     reinterpret_cast<f32x4 *>(out)[i] = x + y;
 }
 
+// torch.optim.Adam (reference src/main/trainer.py:407-413, no amsgrad), one pass over a flat parameter shard:
+//   g = grad * grad_scale + wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+//   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float grad_scale, float inv_bc1, float inv_sqrt_bc2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float pw = p[i];
+    const float gr = g[i] * grad_scale + wd * pw;
+    const float mn = b1 * m[i] + (1.f - b1) * gr;
+    const float vn = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mn;
+    v[i] = vn;
+    p[i] = pw - lr * inv_bc1 * mn / (sqrtf(vn) * inv_sqrt_bc2 + eps);
+}
+
+hipError_t launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
+                       float wd, float grad_scale, int step, hipStream_t st) {
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd,
+                       grad_scale, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    return hipGetLastError();
+}
+
 static inline uint32_t drop_threshold(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
 static inline float drop_keep(float p) { return p > 0.f ? 1.f / (1.f - p) : 1.f; }
 

@@ -155,6 +155,12 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
                               int accumulate, void *scratch, size_t scratch_bytes, int batch, float dropout_p,
                               uint64_t seed, void *stream);
 
+/* Replaces torch.optim.Adam.step (reference src/main/trainer.py:407-413; amsgrad off) on one flat
+ * float32 shard of n elements: grad is first multiplied by grad_scale (1/world_size after a
+ * sum-reduce-scatter), weight_decay is the L2 form Adam uses; `step` is the 1-based step count. */
+int aft_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float grad_scale, int step, void *stream);
+
 /* ---- per-stage entry points (known-answer tests; same kernels as aft_forward_f32) ---- */
 
 /* S1+S2 (fortitran.py:203-209): pilots complex64 [B,Ps,Pt] -> conv_enhanced f32 [2B,S,T]. */

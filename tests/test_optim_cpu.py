@@ -1,0 +1,69 @@
+"""Flat-buffer Adam and the sharded data-parallel step on CPU: single process against
+torch.optim.Adam, and world_size 2 over gloo against the single-process result on the full batch."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from adafortitran_amd.optim import ShardedFlatAdam
+
+
+def _net(seed=0):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(6, 17), torch.nn.GELU(), torch.nn.Linear(17, 3))
+
+
+def _data(n=8, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 6, generator=g), torch.randn(n, 3, generator=g)
+
+
+def test_flat_adam_matches_torch_adam():
+    a, b = _net(), _net()
+    x, y = _data()
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2, weight_decay=1e-3)
+    opt = ShardedFlatAdam(b.parameters(), lr=1e-2, weight_decay=1e-3)
+    for _ in range(5):
+        for net, o in ((a, ref), (b, opt)):
+            o.zero_grad()
+            torch.nn.functional.mse_loss(net(x), y).backward()
+            o.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _net()
+    x, y = _data()
+    lo, hi = rank * len(x) // world, (rank + 1) * len(x) // world
+    opt = ShardedFlatAdam(net.parameters(), lr=1e-2)
+    for _ in range(4):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()   # equal shards: mean of means = global mean
+        opt.step()
+    out[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_world_size_2_matches_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    net = _net()
+    x, y = _data()
+    ref = torch.optim.Adam(net.parameters(), lr=1e-2)
+    for _ in range(4):
+        ref.zero_grad()
+        torch.nn.functional.mse_loss(net(x), y).backward()
+        ref.step()
+    want = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    assert np.allclose(out[0], out[1], rtol=0, atol=0)          # ranks hold identical parameters
+    assert np.allclose(out[0], want, rtol=1e-5, atol=1e-7)

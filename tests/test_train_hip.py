@@ -182,3 +182,21 @@ def test_training_reduces_the_loss_with_dropout():
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < 0.5 * losses[0], losses
+
+
+def test_fused_adam_matches_torch_adam_on_device():
+    from adafortitran_amd.optim import ShardedFlatAdam
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.GELU(), torch.nn.Linear(300, 7)).cuda()
+    b = torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.GELU(), torch.nn.Linear(300, 7)).cuda()
+    b.load_state_dict(a.state_dict())
+    x, y = torch.randn(32, 64, device="cuda"), torch.randn(32, 7, device="cuda")
+    ref = torch.optim.Adam(a.parameters(), lr=3e-3, weight_decay=1e-3)
+    opt = ShardedFlatAdam(b.parameters(), lr=3e-3, weight_decay=1e-3)
+    for _ in range(6):
+        for net, o in ((a, ref), (b, opt)):
+            o.zero_grad()
+            torch.nn.functional.mse_loss(net(x), y).backward()
+            o.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=2e-5, atol=1e-6)

@@ -28,16 +28,21 @@ def main():
     ap.add_argument("--model", default="adafortitran")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--only", default="", help="hip | torch")
+    ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"], help="flat = ShardedFlatAdam (fused kernel)")
     a = ap.parse_args()
     torch.manual_seed(0)
     model = build(a.model, a.dropout).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    if a.optimizer == "flat":
+        from adafortitran_amd.optim import ShardedFlatAdam
+        opt = ShardedFlatAdam(model.parameters(), lr=1e-3)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     inp = synth.make_inputs(a.batch, seed=1)
     pil, tgt = torch.from_numpy(inp["pilots"]).cuda(), torch.from_numpy(inp["target"]).cuda()
     meta = synth.meta_tuple(inp) if a.model == "adafortitran" else None
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad()
         out = model(pil, meta) if meta is not None else model(pil)
         loss = torch.nn.functional.mse_loss(torch.view_as_real(out), torch.view_as_real(tgt))
         loss.backward()
