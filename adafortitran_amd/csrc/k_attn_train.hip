@@ -9,7 +9,8 @@
 //     dQ   = dS K / sqrt(dh)                 dK = dS^T Q / sqrt(dh)
 // Operands are PyTorch row-major: qkv [rows][3d] (q | k | v column blocks), o / dO [rows][d].
 //
-// MI355X mapping: one wave per 32-row tile of one (plane, head); no LDS, no barriers.  Everything is
+// MI355X mapping: one wave per 32-row tile of one (plane, head), three such waves per workgroup sharing
+// the tiles they all walk through LDS.  Everything is
 // v_mfma_f32_32x32x2_f32 (exact fp32).  An MFMA accumulator has lane = column, register = row, so it
 // can be fed back as the B operand of a product that contracts over its ROW index.  Each pass picks
 // the orientation of S that makes that true:
@@ -89,48 +90,128 @@ __device__ __forceinline__ void store_transposed(float *__restrict__ base, int l
         *reinterpret_cast<f32x4 *>(p + 8 * q) = f32x4{acc[4 * q] * mul, acc[4 * q + 1] * mul, acc[4 * q + 2] * mul, acc[4 * q + 3] * mul};
 }
 
-// ---- forward: one wave per (plane, head, query tile) ----
-__global__ __launch_bounds__(256) void attn_train_fwd_kernel(const AttnTrainArgs a) {
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= a.planes * a.heads * a.ntiles) return;
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int qt = task % a.ntiles, ph = task / a.ntiles, head = ph % a.heads, plane = ph / a.heads;
+// ---- LDS staging shared by the three kernels ----
+// A workgroup is kAtWaves waves working on consecutive "own" tiles of one (plane, head); all of them
+// walk the same sequence of "other" tiles, so each other-tile (32 rows x 32 head features of up to two
+// matrices, plus two per-row scalars) is fetched from HBM/L2 once per workgroup, coalesced, into LDS
+// (row stride 36 floats), double-buffered: the loads of tile t+1 are in flight during the MFMAs of t.
+constexpr int kAtWaves = 3, kAtThreads = 64 * kAtWaves, kAtLd = 36;
+constexpr int kAtTileFloats = 32 * kAtLd;
+
+struct StageRegs { f32x4 a[2], b[2]; float s0, s1; };
+
+// fetch tile `tile` of matrices A, B ([tokens][ld], already offset to the head's columns) and of the
+// per-row scalars s0, s1 (may be NULL) into registers; rows >= tokens read as zero
+__device__ __forceinline__ void stage_fetch(StageRegs &r, const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                            int ldb, const float *__restrict__ s0, const float *__restrict__ s1, int tile,
+                                            int tokens, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + kAtThreads * u;   // vec4 index 0..255: row = e >> 3, quad = e & 7
+        const int row = e >> 3, q4 = e & 7, tok = tile * 32 + row;
+        const bool ok = e < 256 && tok < tokens;
+        r.a[u] = ok ? *reinterpret_cast<const f32x4 *>(A + (size_t)tok * lda + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        r.b[u] = ok ? *reinterpret_cast<const f32x4 *>(B + (size_t)tok * ldb + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int tok = tile * 32 + (tid & 31);
+    r.s0 = (s0 && tid < 32 && tok < tokens) ? s0[tok] : 0.f;
+    r.s1 = (s1 && tid < 32 && tok < tokens) ? s1[tok] : 0.f;
+}
+// buf: [A tile][B tile][s0 32][s1 32]
+__device__ __forceinline__ void stage_store(const StageRegs &r, float *__restrict__ buf, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + kAtThreads * u, row = e >> 3, q4 = e & 7;
+        if (e < 256) {
+            *reinterpret_cast<f32x4 *>(buf + row * kAtLd + 4 * q4) = r.a[u];
+            *reinterpret_cast<f32x4 *>(buf + kAtTileFloats + row * kAtLd + 4 * q4) = r.b[u];
+        }
+    }
+    if (tid < 32) {
+        buf[2 * kAtTileFloats + tid] = r.s0;
+        buf[2 * kAtTileFloats + 32 + tid] = r.s1;
+    }
+}
+constexpr int kAtBufFloats = 2 * kAtTileFloats + 64;
+
+// operand fragments out of a staged tile: lane <-> row (rowfrag) or lane <-> feature (colfrag)
+__device__ __forceinline__ void lds_rowfrag(const float *__restrict__ t, int j, int h, float (&f)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(t + j * kAtLd + 8 * q + 4 * h);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f[4 * q + c] = v[c];
+    }
+}
+__device__ __forceinline__ void lds_colfrag(const float *__restrict__ t, int j, int h, float (&f)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) f[r] = t[rowmap(r, h) * kAtLd + j];
+}
+// per-row scalars of the accumulator rows this lane half holds: rows rowmap(r, h), r = 0..15
+__device__ __forceinline__ void lds_rowscalars(const float *__restrict__ s, int h, float (&f)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(s + 8 * q + 4 * h);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f[4 * q + c] = v[c];
+    }
+}
+
+// ---- forward: own = query tile, walks the key tiles (staged: K, V) ----
+__global__ __launch_bounds__(kAtThreads) void attn_train_fwd_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
+    const int ph = blockIdx.x / groups, qt = (blockIdx.x % groups) * kAtWaves + wave;
+    const int head = ph % a.heads, plane = ph / a.heads;
+    const bool active = qt < a.ntiles;
     const int ld = 3 * a.d;
     const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * 32;
     const float *kb = qb + a.d, *vb = qb + 2 * a.d;
     const int query = qt * 32 + j;
 
     float qf[16];
-    load_rowfrag(qb, ld, query, a.tokens, h, a.scale2, qf);
+    load_rowfrag(qb, ld, active ? query : 0, a.tokens, h, a.scale2, qf);
     float m = -__builtin_inff(), l = 0.f;
     f32x16 o = zero16();
     const uint32_t idx0 = ((uint32_t)ph * a.tokens + min(query, a.tokens - 1)) * a.tokens;
+    StageRegs sr;
+    stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, 0, a.tokens, tid);
+    stage_store(sr, lds[0], tid);
+    __syncthreads();
     for (int kt = 0; kt < a.ntiles; ++kt) {
-        float kf[16], vt[16];
-        load_rowfrag(kb, ld, kt * 32 + j, a.tokens, h, 1.f, kf);
-        load_colfrag(vb, ld, kt, a.tokens, j, h, vt);
-        f32x16 s = mma16(kf, qf, zero16());               // [row = key][col = query]
-        float mx = -__builtin_inff();
+        const float *buf = lds[kt & 1];
+        if (kt + 1 < a.ntiles) stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, kt + 1, a.tokens, tid);
+        if (active) {
+            float kf[16], vt[16];
+            lds_rowfrag(buf, j, h, kf);
+            lds_colfrag(buf + kAtTileFloats, j, h, vt);
+            f32x16 s = mma16(kf, qf, zero16());               // [row = key][col = query]
+            float mx = -__builtin_inff();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (kt * 32 + rowmap(r, h) >= a.tokens) s[r] = -__builtin_inff();
-            mx = fmaxf(mx, s[r]);
+            for (int r = 0; r < 16; ++r) {
+                if (kt * 32 + rowmap(r, h) >= a.tokens) s[r] = -__builtin_inff();
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx), alpha = exp2f(m - mn);
+            float p[16], sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = exp2f(s[r] - mn);
+                sum += p[r];
+                if (a.threshold) p[r] *= drop_factor(a.seed, idx0 + kt * 32 + rowmap(r, h), a.threshold, a.keep_scale);
+            }
+            l = l * alpha + sum;
+            m = mn;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] *= alpha;
+            o = mma16(vt, p, o);                              // [row = feature][col = query]
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m, mx), alpha = exp2f(m - mn);
-        float p[16], sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p[r] = exp2f(s[r] - mn);
-            sum += p[r];
-            if (a.threshold) p[r] *= drop_factor(a.seed, idx0 + kt * 32 + rowmap(r, h), a.threshold, a.keep_scale);
-        }
-        l = l * alpha + sum;
-        m = mn;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] *= alpha;
-        o = mma16(vt, p, o);                              // [row = feature][col = query]
+        if (kt + 1 < a.ntiles) stage_store(sr, lds[(kt + 1) & 1], tid);
+        __syncthreads();
     }
+    if (!active) return;
     l += __shfl_xor(l, 32);
     store_transposed(a.out + (size_t)plane * a.tokens * a.d + head * 32, a.d, query, a.tokens, h, o, 1.f / l);
     if (h == 0 && query < a.tokens) a.lse[(size_t)ph * a.tokens + query] = m + log2f(l);
@@ -151,89 +232,119 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const AttnTrainArgs 
     a.dsum[((size_t)plane * a.heads + head) * a.tokens + tok] = s;
 }
 
-// ---- dK, dV: one wave per (plane, head, key tile), loop over query tiles ----
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnTrainArgs a) {
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= a.planes * a.heads * a.ntiles) return;
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int kt = task % a.ntiles, ph = task / a.ntiles, head = ph % a.heads, plane = ph / a.heads;
+// ---- dK, dV: own = key tile, walks the query tiles (staged: Q, dO, lse, D) ----
+__global__ __launch_bounds__(kAtThreads) void attn_bwd_kv_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
+    const int ph = blockIdx.x / groups, kt = (blockIdx.x % groups) * kAtWaves + wave;
+    const int head = ph % a.heads, plane = ph / a.heads;
+    const bool active = kt < a.ntiles;
     const int ld = 3 * a.d;
     const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * 32;
     const float *kb = qb + a.d, *vb = qb + 2 * a.d;
     const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * 32;
     const float *lse = a.lse + (size_t)ph * a.tokens, *dsum = a.dsum + (size_t)ph * a.tokens;
     const int key = kt * 32 + j;
-    const bool key_ok = key < a.tokens;
+    const bool key_ok = active && key < a.tokens;
+    const int keyc = min(key, a.tokens - 1);
 
     float kf[16], vf[16];
-    load_rowfrag(kb, ld, key, a.tokens, h, a.scale2, kf);   // B operands: lane <-> key
-    load_rowfrag(vb, ld, key, a.tokens, h, 1.f, vf);
+    load_rowfrag(kb, ld, active ? key : 0, a.tokens, h, a.scale2, kf);   // B operands: lane <-> key
+    load_rowfrag(vb, ld, active ? key : 0, a.tokens, h, 1.f, vf);
     f32x16 dv = zero16(), dk = zero16();
+    StageRegs sr;
+    stage_fetch(sr, qb, ld, dob, a.d, lse, dsum, 0, a.tokens, tid);
+    stage_store(sr, lds[0], tid);
+    __syncthreads();
     for (int qt = 0; qt < a.ntiles; ++qt) {
-        float qf[16], dof[16], qT[16], doT[16];
-        load_rowfrag(qb, ld, qt * 32 + j, a.tokens, h, 1.f, qf);      // A operands: lane <-> query
-        load_rowfrag(dob, a.d, qt * 32 + j, a.tokens, h, 1.f, dof);
-        load_colfrag(qb, ld, qt, a.tokens, j, h, qT);                  // A operands: lane <-> feature
-        load_colfrag(dob, a.d, qt, a.tokens, j, h, doT);
-        const f32x16 s = mma16(qf, kf, zero16());                      // [row = query][col = key]
-        const f32x16 dp = mma16(dof, vf, zero16());
-        float pd[16], ds[16];
+        const float *buf = lds[qt & 1];
+        if (qt + 1 < a.ntiles) stage_fetch(sr, qb, ld, dob, a.d, lse, dsum, qt + 1, a.tokens, tid);
+        if (active) {
+            float qf[16], dof[16], ls[16], dsm[16];
+            lds_rowfrag(buf, j, h, qf);                                    // A operands: lane <-> query
+            lds_rowfrag(buf + kAtTileFloats, j, h, dof);
+            lds_rowscalars(buf + 2 * kAtTileFloats, h, ls);
+            lds_rowscalars(buf + 2 * kAtTileFloats + 32, h, dsm);
+            const f32x16 s = mma16(qf, kf, zero16());                      // [row = query][col = key]
+            const f32x16 dp = mma16(dof, vf, zero16());
+            float pd[16], ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int query = qt * 32 + rowmap(r, h);
-            const bool ok = key_ok && query < a.tokens;
-            const int qc = min(query, a.tokens - 1);
-            const float p = ok ? exp2f(s[r] - lse[qc]) : 0.f;
-            const float f = a.threshold ? drop_factor(a.seed, ((uint32_t)ph * a.tokens + qc) * a.tokens + min(key, a.tokens - 1),
-                                                      a.threshold, a.keep_scale) : 1.f;
-            pd[r] = p * f;
-            ds[r] = p * (dp[r] * f - dsum[qc]);
+            for (int r = 0; r < 16; ++r) {
+                const int query = qt * 32 + rowmap(r, h);
+                const bool ok = key_ok && query < a.tokens;
+                const float p = ok ? exp2f(s[r] - ls[r]) : 0.f;
+                const float f = a.threshold ? drop_factor(a.seed, ((uint32_t)ph * a.tokens + min(query, a.tokens - 1)) * a.tokens + keyc,
+                                                          a.threshold, a.keep_scale) : 1.f;
+                pd[r] = p * f;
+                ds[r] = p * (dp[r] * f - dsm[r]);
+            }
+            float qT[16], doT[16];
+            lds_colfrag(buf, j, h, qT);                                    // A operands: lane <-> feature
+            lds_colfrag(buf + kAtTileFloats, j, h, doT);
+            dv = mma16(doT, pd, dv);                                       // [row = feature][col = key]
+            dk = mma16(qT, ds, dk);
         }
-        dv = mma16(doT, pd, dv);                                       // [row = feature][col = key]
-        dk = mma16(qT, ds, dk);
+        if (qt + 1 < a.ntiles) stage_store(sr, lds[(qt + 1) & 1], tid);
+        __syncthreads();
     }
+    if (!active) return;
     float *dst = a.out + (size_t)plane * a.tokens * ld + head * 32;
     store_transposed(dst + a.d, ld, key, a.tokens, h, dk, a.scale);
     store_transposed(dst + 2 * a.d, ld, key, a.tokens, h, dv, 1.f);
 }
 
-// ---- dQ: one wave per (plane, head, query tile), loop over key tiles ----
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnTrainArgs a) {
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= a.planes * a.heads * a.ntiles) return;
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int qt = task % a.ntiles, ph = task / a.ntiles, head = ph % a.heads, plane = ph / a.heads;
+// ---- dQ: own = query tile, walks the key tiles (staged: K, V) ----
+__global__ __launch_bounds__(kAtThreads) void attn_bwd_q_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
+    const int ph = blockIdx.x / groups, qt = (blockIdx.x % groups) * kAtWaves + wave;
+    const int head = ph % a.heads, plane = ph / a.heads;
+    const bool active = qt < a.ntiles;
     const int ld = 3 * a.d;
     const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * 32;
     const float *kb = qb + a.d, *vb = qb + 2 * a.d;
     const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * 32;
     const int query = qt * 32 + j, qc = min(query, a.tokens - 1);
-    const bool q_ok = query < a.tokens;
+    const bool q_ok = active && query < a.tokens;
     const float lse = a.lse[(size_t)ph * a.tokens + qc], dsum = a.dsum[(size_t)ph * a.tokens + qc];
     const uint32_t idx0 = ((uint32_t)ph * a.tokens + qc) * a.tokens;
 
     float qf[16], dof[16];
-    load_rowfrag(qb, ld, query, a.tokens, h, a.scale2, qf);   // B operands: lane <-> query
-    load_rowfrag(dob, a.d, query, a.tokens, h, 1.f, dof);
+    load_rowfrag(qb, ld, active ? query : 0, a.tokens, h, a.scale2, qf);   // B operands: lane <-> query
+    load_rowfrag(dob, a.d, active ? query : 0, a.tokens, h, 1.f, dof);
     f32x16 dq = zero16();
+    StageRegs sr;
+    stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, 0, a.tokens, tid);
+    stage_store(sr, lds[0], tid);
+    __syncthreads();
     for (int kt = 0; kt < a.ntiles; ++kt) {
-        float kf[16], vf[16], kT[16];
-        load_rowfrag(kb, ld, kt * 32 + j, a.tokens, h, 1.f, kf);      // A operands: lane <-> key
-        load_rowfrag(vb, ld, kt * 32 + j, a.tokens, h, 1.f, vf);
-        load_colfrag(kb, ld, kt, a.tokens, j, h, kT);                  // A operand: lane <-> feature
-        const f32x16 s = mma16(kf, qf, zero16());                      // [row = key][col = query]
-        const f32x16 dp = mma16(vf, dof, zero16());
-        float ds[16];
+        const float *buf = lds[kt & 1];
+        if (kt + 1 < a.ntiles) stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, kt + 1, a.tokens, tid);
+        if (active) {
+            float kf[16], vf[16];
+            lds_rowfrag(buf, j, h, kf);                                    // A operands: lane <-> key
+            lds_rowfrag(buf + kAtTileFloats, j, h, vf);
+            const f32x16 s = mma16(kf, qf, zero16());                      // [row = key][col = query]
+            const f32x16 dp = mma16(vf, dof, zero16());
+            float ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + rowmap(r, h);
-            const bool ok = q_ok && key < a.tokens;
-            const float p = ok ? exp2f(s[r] - lse) : 0.f;
-            const float f = a.threshold ? drop_factor(a.seed, idx0 + min(key, a.tokens - 1), a.threshold, a.keep_scale) : 1.f;
-            ds[r] = p * (dp[r] * f - dsum);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + rowmap(r, h);
+                const bool ok = q_ok && key < a.tokens;
+                const float p = ok ? exp2f(s[r] - lse) : 0.f;
+                const float f = a.threshold ? drop_factor(a.seed, idx0 + min(key, a.tokens - 1), a.threshold, a.keep_scale) : 1.f;
+                ds[r] = p * (dp[r] * f - dsum);
+            }
+            float kT[16];
+            lds_colfrag(buf, j, h, kT);                                    // A operand: lane <-> feature
+            dq = mma16(kT, ds, dq);                                        // [row = feature][col = query]
         }
-        dq = mma16(kT, ds, dq);                                        // [row = feature][col = query]
+        if (kt + 1 < a.ntiles) stage_store(sr, lds[(kt + 1) & 1], tid);
+        __syncthreads();
     }
+    if (!active) return;
     store_transposed(a.out + (size_t)plane * a.tokens * ld + head * 32, ld, query, a.tokens, h, dq, a.scale);
 }
 
@@ -254,8 +365,8 @@ hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o
                                  float dropout_p, uint32_t seed, hipStream_t st) {
     AttnTrainArgs a = make_args(c, planes, tokens, dropout_p, seed);
     a.qkv = qkv; a.out = o; a.lse = lse;
-    const int tasks = planes * a.heads * a.ntiles;
-    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((tasks + 3) / 4), dim3(256), 0, st, a);
+    const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
+    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(wgs), dim3(kAtThreads), 0, st, a);
     return hipGetLastError();
 }
 
@@ -264,10 +375,10 @@ hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const fl
                                  hipStream_t st) {
     AttnTrainArgs a = make_args(c, planes, tokens, dropout_p, seed);
     a.qkv = qkv; a.o = o; a.d_o = d_o; a.lse = const_cast<float *>(lse); a.dsum = dsum; a.out = dqkv;
-    const int tasks = planes * a.heads * a.ntiles;
+    const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((planes * tokens * a.heads + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((tasks + 3) / 4), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((tasks + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(wgs), dim3(kAtThreads), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(wgs), dim3(kAtThreads), 0, st, a);
     return hipGetLastError();
 }
 

@@ -22,43 +22,49 @@ namespace aft {
 constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
 
 // tile element (x, k), source contiguous in k:  src[(x0 + x) * ld + k0 + k]
+template <int NU>
 __device__ __forceinline__ void load_kc(const float *__restrict__ src, int ld, int x0, int xlim, int k0, int klim,
-                                        int tid, f32x4 (&v)[2]) {
+                                        int tid, f32x4 (&v)[NU]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u, x = e >> 2, kq = e & 3;
         const bool ok = x0 + x < xlim && k0 + 4 * kq < klim;
         v[u] = ok ? *reinterpret_cast<const f32x4 *>(src + (size_t)(x0 + x) * ld + k0 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
-__device__ __forceinline__ void store_kc(float *__restrict__ lds, int tid, const f32x4 (&v)[2]) {
+template <int NU>
+__device__ __forceinline__ void store_kc(float *__restrict__ lds, int tid, const f32x4 (&v)[NU]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u, x = e >> 2, kq = e & 3;
 #pragma unroll
         for (int c = 0; c < 4; ++c) lds[(4 * kq + c) * GLD + x] = v[u][c];
     }
 }
 // tile element (x, k), source contiguous in x:  src[(k0 + k) * ld + x0 + x]
+template <int NU>   // NU = 2: 128-wide tile (32 vec4 per k row); NU = 1: 64-wide tile (16 vec4 per k row)
 __device__ __forceinline__ void load_xc(const float *__restrict__ src, int ld, int x0, int xlim, int k0, int klim,
-                                        int tid, f32x4 (&v)[2]) {
+                                        int tid, f32x4 (&v)[NU]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int e = tid + 256 * u, k = e >> 5, xq = e & 31;
+    for (int u = 0; u < NU; ++u) {
+        const int e = tid + 256 * u, k = e >> (3 + NU), xq = e & (16 * NU - 1);
         const bool ok = k0 + k < klim && x0 + 4 * xq < xlim;
         v[u] = ok ? *reinterpret_cast<const f32x4 *>(src + (size_t)(k0 + k) * ld + x0 + 4 * xq) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
-__device__ __forceinline__ void store_xc(float *__restrict__ lds, int tid, const f32x4 (&v)[2]) {
+template <int NU>
+__device__ __forceinline__ void store_xc(float *__restrict__ lds, int tid, const f32x4 (&v)[NU]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int e = tid + 256 * u, k = e >> 5, xq = e & 31;
+    for (int u = 0; u < NU; ++u) {
+        const int e = tid + 256 * u, k = e >> (3 + NU), xq = e & (16 * NU - 1);
         *reinterpret_cast<f32x4 *>(lds + k * GLD + 4 * xq) = v[u];
     }
 }
 
 // OP: 0 = NT, 1 = NN, 2 = TN (see header).  M, N multiples of 4; K multiple of 4 for NT/NN.
-template <int OP>
+// BM = rows of C per workgroup: 128 (each wave 64x64) or 64 (each wave 32x64), the latter for launches
+// whose 128-row tiling would leave the 256 CUs with two workgroups each.
+template <int OP, int BM>
 __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                    float *__restrict__ C, const float *__restrict__ bias, int M, int N,
                                                    int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
@@ -67,19 +73,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    constexpr int TI = BM / 64, NUA = BM / 64;   // MFMA row tiles per wave; A-tile vec4 per thread
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GBN;
     const int kbeg = blockIdx.z * k_chunk, kend = min(K, kbeg + k_chunk);
     C += (size_t)blockIdx.z * c_slice;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TI; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[NUA], rb[2];
     auto fetch = [&](int k0) {
         if constexpr (OP == 2) load_xc(A, lda, m0, M, k0, kend, tid, ra); else load_kc(A, lda, m0, M, k0, kend, tid, ra);
         if constexpr (OP == 0) load_kc(B, ldb, n0, N, k0, kend, tid, rb); else load_xc(B, ldb, n0, N, k0, kend, tid, rb);
@@ -98,23 +105,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     for (int it = 0; it < nsteps; ++it) {
         const int buf = it & 1;
         if (it + 1 < nsteps) fetch(kbeg + (it + 1) * GBK);
-        const float *as = As[buf] + h * GLD + wm * 64 + j;
+        const float *as = As[buf] + h * GLD + wm * (BM / 2) + j;
         const float *bs = Bs[buf] + h * GLD + wn * 64 + j;
 #pragma unroll
         for (int kb = 0; kb < GBK / 2; ++kb) {
-            const float a0 = as[2 * kb * GLD], a1 = as[2 * kb * GLD + 32];
             const float b0 = bs[2 * kb * GLD], b1 = bs[2 * kb * GLD + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+                const float av = as[2 * kb * GLD + 32 * ti];
+                acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[ti][0], 0, 0, 0);
+                acc[ti][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[ti][1], 0, 0, 0);
+            }
         }
         if (it + 1 < nsteps) stage(buf ^ 1);
         __syncthreads();
     }
 
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
             const int col = n0 + wn * 64 + tj * 32 + j;
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
             const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int row = m0 + wm * (BM / 2) + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row >= M) continue;
                 float *p = C + (size_t)row * ldc + col;
                 float v = acc[ti][tj][e] + bv;
@@ -189,15 +197,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
 int gemm_split_slices(int rows) { return std::max(1, std::min(kGemmMaxSlices, rows / 256)); }
 int colsum_slices(int rows) { return std::max(1, std::min(kColsumMaxSlices, rows / 64)); }
 
+template <int OP, int BM>
+static void gemm_go(const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda, int ldb,
+                    int ldc, bool accumulate, hipStream_t st) {
+    const dim3 grid((N + GBN - 1) / GBN, (M + BM - 1) / BM, 1);
+    hipLaunchKernelGGL((gemm_kernel<OP, BM>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
+                       (int)accumulate);
+}
+
 hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,
                        int ldb, int ldc, bool accumulate, hipStream_t st) {
-    const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, 1);
-    if (op == 0)
-        hipLaunchKernelGGL(gemm_kernel<0>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0, (int)accumulate);
-    else if (op == 1)
-        hipLaunchKernelGGL(gemm_kernel<1>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0, (int)accumulate);
-    else
+    const bool small = (long long)((M + 127) / 128) * ((N + GBN - 1) / GBN) < 1024;   // < 4 workgroups per CU
+    if (op == 0) {
+        if (small) gemm_go<0, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
+        else gemm_go<0, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
+    } else if (op == 1) {
+        if (small) gemm_go<1, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
+        else gemm_go<1, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
+    } else {
         return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
@@ -207,7 +226,7 @@ hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slice
     const int nz = gemm_split_slices(R);
     const int chunk = ((R + nz - 1) / nz + GBK - 1) / GBK * GBK;
     const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, nz);
-    hipLaunchKernelGGL(gemm_kernel<2>, grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb, N,
+    hipLaunchKernelGGL((gemm_kernel<2, 128>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb, N,
                        chunk, (size_t)M * N, 0);
     return launch_reduce_slices(slices, C, M * N, nz, (size_t)M * N, accumulate, st);
 }
