@@ -79,6 +79,9 @@ class ShardedFlatAdam:
         self.steps = 0
         # one ExponentialLR-style hook: the reference multiplies lr by 0.995 per epoch (trainer.py:414)
         self.param_groups = [{"lr": lr}]
+        if self.flat.data.device.type == "cuda":
+            from . import training
+            training.ACCUMULATE_INTO_GRAD = True   # the encoder backward adds into the flat grad views
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.flat.zero_grad()

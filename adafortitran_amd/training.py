@@ -23,6 +23,13 @@ import torch
 from . import _abi, _lib
 
 
+#: When True (set by optim.ShardedFlatAdam, whose .grad tensors are views into one flat buffer), the
+#: backward adds the parameter gradients straight into the existing ``.grad`` tensors and reports
+#: "no gradient" to autograd, which saves autograd's own 12 accumulate kernels per layer.  Leave it
+#: False with optimizers / wrappers that rely on autograd's AccumulateGrad hooks (torch DDP).
+ACCUMULATE_INTO_GRAD = False
+
+
 def _layer_struct(cls, tensors: Sequence[torch.Tensor]):
     st = cls()
     for name, t in zip(_abi.LAYER_FIELDS, tensors):
@@ -40,6 +47,7 @@ class HipEncoderLayerFunction(torch.autograd.Function):
         if x.dtype != torch.float32 or x.device.type != "cuda":
             raise ValueError("the HIP training path needs float32 tensors on the HIP device")
         x = x.contiguous()
+        param_objs = params
         params = tuple(p.detach().contiguous() for p in params)
         planes = x.shape[0]
         batch = planes // 2
@@ -52,6 +60,7 @@ class HipEncoderLayerFunction(torch.autograd.Function):
             scratch.data_ptr(), scratch.numel(), batch, float(dropout_p), int(seed), _lib.current_stream_ptr(x.device)))
         ctx.save_for_backward(x, tape, *params)
         ctx.cfg, ctx.dropout_p, ctx.seed, ctx.batch = cfg, float(dropout_p), int(seed), batch
+        ctx.param_objs = param_objs
         return out
 
     @staticmethod
@@ -60,15 +69,19 @@ class HipEncoderLayerFunction(torch.autograd.Function):
         x, tape, *params = ctx.saved_tensors
         cfg = ctx.cfg
         grad_out = grad_out.contiguous()
-        grads = [torch.empty_like(p) for p in params]
+        direct = ACCUMULATE_INTO_GRAD and all(
+            p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.param_objs)
+        grads = [p.grad for p in ctx.param_objs] if direct else [torch.empty_like(p) for p in params]
         dx = torch.empty_like(x)
         scratch = torch.empty(lib.aft_encoder_train_scratch_bytes(C.byref(cfg), ctx.batch), dtype=torch.uint8, device=x.device)
         w = _layer_struct(_abi.AftLayerWeights, params)
         g = _layer_struct(_abi.AftLayerGrads, grads)
         _lib.check(lib.aft_encoder_layer_bwd_f32(
             C.byref(cfg), C.byref(w), x.data_ptr(), tape.data_ptr(), tape.numel(), grad_out.data_ptr(), dx.data_ptr(),
-            C.byref(g), 0, scratch.data_ptr(), scratch.numel(), ctx.batch, ctx.dropout_p, ctx.seed,
+            C.byref(g), int(direct), scratch.data_ptr(), scratch.numel(), ctx.batch, ctx.dropout_p, ctx.seed,
             _lib.current_stream_ptr(x.device)))
+        if direct:
+            return (dx, None, None, None) + (None,) * len(params)
         return (dx, None, None, None, *grads)
 
 

@@ -200,3 +200,27 @@ def test_fused_adam_matches_torch_adam_on_device():
             o.step()
     for p, q in zip(a.parameters(), b.parameters()):
         assert torch.allclose(p, q, rtol=2e-5, atol=1e-6)
+
+
+def test_direct_gradient_accumulation_matches_autograd_accumulation():
+    """ShardedFlatAdam lets the encoder backward add into the flat .grad views; same gradients as the
+    autograd-accumulated path."""
+    from adafortitran_amd import synth, training
+    from adafortitran_amd.optim import FlatParameters
+    torch.manual_seed(0)
+    model = _model("fortitran", 0.0).train()
+    pil = torch.from_numpy(synth.make_inputs(4, seed=9)["pilots"]).cuda()
+    tgt = torch.from_numpy(synth.make_inputs(4, seed=9)["target"]).cuda()
+
+    def grads(direct):
+        training.ACCUMULATE_INTO_GRAD = direct
+        flat.zero_grad()
+        torch.nn.functional.mse_loss(torch.view_as_real(model(pil)), torch.view_as_real(tgt)).backward()
+        return flat.grad.clone()
+
+    flat = FlatParameters(model.parameters())
+    try:
+        a, b = grads(False), grads(True)
+    finally:
+        training.ACCUMULATE_INTO_GRAD = False
+    assert _rel(b, a) <= 1e-6

@@ -22,7 +22,11 @@ done
 unset AFT_ONLY
 export AFT_ONLY=attention
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d "$OUT/pmc_attn" -- python3 "$REPO/tools/prof_kernels.py" > "$OUT/pmc_attn.log" 2>&1
+# training step: kernel trace of the HIP-encoder path + the A/B line against PyTorch-ROCm autograd
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_trace" -- python3 "$REPO/tools/train_bench.py" --only hip --steps 10 --warmup 3 > "$OUT/train_trace.log" 2>&1
+python3 "$REPO/tools/train_bench.py" --steps 20 --warmup 5 2>/dev/null | grep "^{" | tail -1 > "$OUT/train_bench_line.json"
 cd "$REPO"
+python3 tools/train_step_breakdown.py "$OUT/train_trace" > "$OUT/train_kernel_trace_summary.txt" 2>&1
 python3 tools/summarize_prof.py "$OUT/bench_trace" > "$OUT/kernel_trace_summary.txt" 2>&1
 python3 tools/summarize_prof.py "$OUT"/pmc[0-9] "$OUT/pmc_attn" > "$OUT/pmc_summary.txt" 2>&1
 cp "$OUT"/bench_trace/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
