@@ -71,10 +71,10 @@ hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long l
 
 
 // ---- training path: row-major GEMMs, attention with saved LSE, row-wise pieces ----
-constexpr int kGemmMaxSlices = 128;   // split of the token-row reduction in weight gradients
+constexpr int kGemmMaxSlices = 256;   // split of the token-row reduction in weight gradients
 constexpr int kColsumMaxSlices = 1024; // ... in bias / LayerNorm-parameter gradients (one slice per workgroup)
 int colsum_slices(int rows);
-int gemm_split_slices(int rows);
+int gemm_split_slices(int rows, int tiles);
 int ln_bwd_blocks(int rows);
 // op 0: C = A[M][K] B[N][K]^T + bias;  op 1: C = A[M][K] B[K][N]   (accumulate: C += ...)
 hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,

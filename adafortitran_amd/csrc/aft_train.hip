@@ -51,7 +51,7 @@ Scratch plan_scratch(const aft_config &c, int batch) {
     s.hd = off;     off += al64(rows * ff);
     s.dqkv = off;   off += al64(rows * 3 * d);
     s.dsum = off;   off += al64(rows * c.num_head);
-    s.slices = off; off += al64(std::max((size_t)kGemmMaxSlices * 3 * d * d, (size_t)kColsumMaxSlices * 3 * d));
+    s.slices = off; off += al64(std::max((size_t)(512 + 6) * 128 * 128, (size_t)kColsumMaxSlices * 3 * 2 * d));   // wgrad: tiles * slices <= 512 + tiles
     s.total = off;
     return s;
 }

@@ -194,11 +194,11 @@ __global__ __launch_bounds__(kAtThreads) void attn_train_fwd_kernel(const AttnTr
                 mx = fmaxf(mx, s[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m, mx), alpha = exp2f(m - mn);
+            const float mn = fmaxf(m, mx), alpha = __builtin_amdgcn_exp2f(m - mn);
             float p[16], sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[r] = exp2f(s[r] - mn);
+                p[r] = __builtin_amdgcn_exp2f(s[r] - mn);
                 sum += p[r];
                 if (a.threshold) p[r] *= drop_factor(a.seed, idx0 + kt * 32 + rowmap(r, h), a.threshold, a.keep_scale);
             }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kAtThreads) void attn_bwd_kv_kernel(const AttnTrain
             for (int r = 0; r < 16; ++r) {
                 const int query = qt * 32 + rowmap(r, h);
                 const bool ok = key_ok && query < a.tokens;
-                const float p = ok ? exp2f(s[r] - ls[r]) : 0.f;
+                const float p = ok ? __builtin_amdgcn_exp2f(s[r] - ls[r]) : 0.f;
                 const float f = a.threshold ? drop_factor(a.seed, ((uint32_t)ph * a.tokens + min(query, a.tokens - 1)) * a.tokens + keyc,
                                                           a.threshold, a.keep_scale) : 1.f;
                 pd[r] = p * f;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kAtThreads) void attn_bwd_q_kernel(const AttnTrainA
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + rowmap(r, h);
                 const bool ok = q_ok && key < a.tokens;
-                const float p = ok ? exp2f(s[r] - lse) : 0.f;
+                const float p = ok ? __builtin_amdgcn_exp2f(s[r] - lse) : 0.f;
                 const float f = a.threshold ? drop_factor(a.seed, idx0 + min(key, a.tokens - 1), a.threshold, a.keep_scale) : 1.f;
                 ds[r] = p * (dp[r] * f - dsum);
             }

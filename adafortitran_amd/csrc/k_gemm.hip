@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
     if (rq == 0 && col < n) slices[(size_t)blockIdx.y * n + col] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
-int gemm_split_slices(int rows) { return std::max(1, std::min(kGemmMaxSlices, rows / 256)); }
+// enough slices to put two workgroups on every CU whatever the number of output tiles, never fewer than 128 rows each
+int gemm_split_slices(int rows, int tiles) {
+    return std::max(1, std::min(std::min(kGemmMaxSlices, (512 + tiles - 1) / tiles), rows / 128));
+}
 int colsum_slices(int rows) { return std::max(1, std::min(kColsumMaxSlices, rows / 64)); }
 
 template <int OP, int BM>
@@ -220,10 +223,11 @@ hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const f
     return hipGetLastError();
 }
 
-// dW[M][N] (+)= A[R][M]^T . B[R][N]; `slices` holds gemm_split_slices(R) * M * N floats
+// dW[M][N] (+)= A[R][M]^T . B[R][N]; `slices` holds up to kGemmMaxSlices * 128*128 * tiles floats (<= 512 tiles*slices)
 hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slices, int M, int N, int R, int lda, int ldb,
                           bool accumulate, hipStream_t st) {
-    const int nz = gemm_split_slices(R);
+    const int tiles = ((N + GBN - 1) / GBN) * ((M + GBM - 1) / GBM);
+    const int nz = gemm_split_slices(R, tiles);
     const int chunk = ((R + nz - 1) / nz + GBK - 1) / GBK * GBK;
     const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, nz);
     hipLaunchKernelGGL((gemm_kernel<2, 128>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb, N,
