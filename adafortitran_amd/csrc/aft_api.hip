@@ -47,8 +47,8 @@ int check_config(const aft_config *c) {
         set_error("token count %d must be a multiple of 8 and >= 32 (fragment-packed q/k/v tiles)", tokens_of(*c));
         return AFT_ERR_SHAPE;
     }
-    if (c->num_scs % 4) {
-        set_error("num_scs=%d must be a multiple of 4 for the conv strips", c->num_scs);
+    if (c->patch_scs * c->patch_symbols > kMaxPatchFeatures) {
+        set_error("patch %dx%d has more than %d elements", c->patch_scs, c->patch_symbols, kMaxPatchFeatures);
         return AFT_ERR_SHAPE;
     }
     if (c->activation != AFT_ACT_RELU && c->activation != AFT_ACT_GELU) {

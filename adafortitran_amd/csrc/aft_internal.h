@@ -17,6 +17,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kWave = 64;       // CDNA4 wavefront
 constexpr int kHeadDim = 32;    // model_dim / num_head for every config the kernels cover
 constexpr int kTile = 32;       // v_mfma_f32_32x32x2_f32 tile edge
+constexpr int kMaxPatchFeatures = 16;   // patch_scs * patch_symbols the embedding kernel unrolls
 
 inline __host__ __device__ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

@@ -66,7 +66,8 @@ struct EmbedArgs {
     int S, T, p0, p1, tokens, d, din, planes;
 };
 
-template <int D, bool ADAPTIVE>
+// PMAX = unroll bound of the patch features: 6 (the default 3x2 patch and smaller) or 16
+template <int D, bool ADAPTIVE, int PMAX>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     extern __shared__ float sm[];  // W1 transposed [din][D]
     const int tid = threadIdx.x;
@@ -78,14 +79,14 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     const int n = live ? (int)(row / a.tokens) : 0, t = live ? (int)(row % a.tokens) : 0;
     const int tw = a.T / a.p1, p = a.p0 * a.p1;
     // all inputs of this token first (independent loads in flight together), then the FMAs
-    float vin[12];
+    float vin[PMAX + 6];
     const float *ce = a.conv_enhanced + ((size_t)n * a.S + (t / tw) * a.p0) * a.T + (t % tw) * a.p1;
 #pragma unroll
-    for (int f = 0; f < 6; ++f) vin[f] = f < p ? ce[(f / a.p1) * a.T + f % a.p1] : 0.f;
+    for (int f = 0; f < PMAX; ++f) vin[f] = f < p ? ce[(f / a.p1) * a.T + f % a.p1] : 0.f;
     if constexpr (ADAPTIVE) {
         const float *tk = a.tokens6 + ((size_t)(n >> 1) * a.tokens + t) * 6;
 #pragma unroll
-        for (int f = 0; f < 6; ++f) vin[6 + f] = tk[f];
+        for (int f = 0; f < 6; ++f) vin[PMAX + f] = tk[f];
     }
     float acc[PER];
 #pragma unroll
@@ -93,9 +94,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     __syncthreads();
     if (!live) return;
 #pragma unroll
-    for (int f = 0; f < (ADAPTIVE ? 12 : 6); ++f) {
-        if (f < 6 && f >= p) continue;
-        const int frow = f < 6 ? f : p + (f - 6);   // row of W1^T: patch features then adapter features
+    for (int f = 0; f < (ADAPTIVE ? PMAX + 6 : PMAX); ++f) {
+        if (f < PMAX && f >= p) continue;
+        const int frow = f < PMAX ? f : p + (f - PMAX);   // row of W1^T: patch features then adapter features
 #pragma unroll
         for (int i = 0; i < PER; ++i) acc[i] = fmaf(sm[frow * D + lane32 * PER + i], vin[f], acc[i]);
     }
@@ -116,17 +117,19 @@ hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *
     const long rows = (long)a.planes * a.tokens;
     const int blocks = (int)((rows + 7) / 8);
     const size_t lds = sizeof(float) * a.din * a.d;
-    if (a.p0 * a.p1 > 6) return hipErrorInvalidValue;   // patch features are unrolled up to 6 (3x2)
-    if (c.model_dim == 128 && c.adaptive)
-        hipLaunchKernelGGL((embed_kernel<128, true>), dim3(blocks), dim3(256), lds, st, a);
-    else if (c.model_dim == 128)
-        hipLaunchKernelGGL((embed_kernel<128, false>), dim3(blocks), dim3(256), lds, st, a);
-    else if (c.model_dim == 256 && c.adaptive)
-        hipLaunchKernelGGL((embed_kernel<256, true>), dim3(blocks), dim3(256), lds, st, a);
-    else if (c.model_dim == 256)
-        hipLaunchKernelGGL((embed_kernel<256, false>), dim3(blocks), dim3(256), lds, st, a);
-    else
-        return hipErrorInvalidValue;
+    const bool small = a.p0 * a.p1 <= 6;
+    if (a.p0 * a.p1 > kMaxPatchFeatures) return hipErrorInvalidValue;   // check_config rejects these
+#define AFT_EMBED(D_, A_)                                                                              \
+    do {                                                                                               \
+        if (small) hipLaunchKernelGGL((embed_kernel<D_, A_, 6>), dim3(blocks), dim3(256), lds, st, a); \
+        else hipLaunchKernelGGL((embed_kernel<D_, A_, kMaxPatchFeatures>), dim3(blocks), dim3(256), lds, st, a); \
+    } while (0)
+    if (c.model_dim == 128 && c.adaptive) AFT_EMBED(128, true);
+    else if (c.model_dim == 128) AFT_EMBED(128, false);
+    else if (c.model_dim == 256 && c.adaptive) AFT_EMBED(256, true);
+    else if (c.model_dim == 256) AFT_EMBED(256, false);
+    else return hipErrorInvalidValue;
+#undef AFT_EMBED
     return hipGetLastError();
 }
 

@@ -129,6 +129,26 @@ def test_full_size_batch128_properties(oracle_lib):
     assert abs(dev_sum - host_sum) <= 1e-9 * host_sum
 
 
+@pytest.mark.parametrize("ofdm,pilot,patch,adaptive", [((30, 8), (6, 2), (3, 2), True), ((66, 12), (11, 3), (3, 3), False),
+                                                        ((150, 8), (10, 2), (5, 2), True)])
+def test_other_grid_geometries_match_oracle(oracle_lib, ofdm, pilot, patch, adaptive):
+    """Grids whose row count is not a multiple of 4 / of the 30-row conv tiles, other patch shapes, a
+    grid taller than the default (one band, five conv tiles): conv tiling, patch addressing, ragged
+    attention tiles."""
+    tokens = (ofdm[0] // patch[0]) * (ofdm[1] // patch[1])
+    spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=2, model_dim=128, num_head=4)
+    hid = (5, 9, 2 * tokens) if adaptive else None
+    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=99)
+    cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(5, ofdm=ofdm, pilot=pilot, seed=31)
+    meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+    out = eng.forward(_t(inp["pilots"]), *meta).cpu().numpy()
+    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3))
+    assert np.abs(out - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+
+
 def test_config5_persistent_tiles(oracle_lib):
     """BASELINE config 5 shapes (240x28 grid, 12 layers, d=256, 8 heads, 1120 tokens) at B=16:
     1120 row tiles over 256 resident workgroups, so every workgroup walks several tiles (the
