@@ -43,8 +43,8 @@ int check_config(const aft_config *c) {
         set_error("head dim must be %d (model_dim=%d, num_head=%d)", kHeadDim, c->model_dim, c->num_head);
         return AFT_ERR_SHAPE;
     }
-    if (tokens_of(*c) % 8 || tokens_of(*c) < 32) {
-        set_error("token count %d must be a multiple of 8 and >= 32 (fragment-packed q/k/v tiles)", tokens_of(*c));
+    if (tokens_of(*c) < 32) {
+        set_error("token count %d must be >= 32 (one MFMA tile of keys)", tokens_of(*c));
         return AFT_ERR_SHAPE;
     }
     if (c->patch_scs * c->patch_symbols > kMaxPatchFeatures) {

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
         //   vt   : [plane*H + head][key tile][g][lane = d + 32*hh][4]        value (d, key = 32kt + 8g + 4hh + j)
         // q/k tiles (lane = token row, registers = features): registers 4s..4s+3 of half hh are one
         // 16-byte fragment element; the v tile (lane = feature, registers = tokens) likewise.
-        const int plane0 = row0 / a.tokens, tok0 = row0 - plane0 * a.tokens;   // tok0 % 8 == 0
+        const int plane0 = row0 / a.tokens, tok0 = row0 - plane0 * a.tokens;
         const unsigned head_stride = (unsigned)a.tokpad * kHeadDim;             // floats per (plane, head)
         const unsigned ph0 = (unsigned)(plane0 * a.heads + w);
         const bool full = row0 + 32 <= a.rows;
@@ -411,14 +411,23 @@ __global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const Ch
             int tok = tok0 + 8 * gq + 4 * h;
             unsigned ph = ph0;
             if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
-            const unsigned off = ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok >> 3) & 3) * 256 + (r + 32 * h) * 4;
             const f32x4 v = {acc[2][4 * gq], acc[2][4 * gq + 1], acc[2][4 * gq + 2], acc[2][4 * gq + 3]};
-            if (full || row0 + 8 * gq + 4 * h + 3 < a.rows) {
+            const bool in_rows = full || row0 + 8 * gq + 4 * h + 3 < a.rows;
+            if ((tok & 3) == 0 && tok + 3 < a.tokens && in_rows) {
+                // the four tokens are one fragment element (key = 32kt + 8g + 4hh + j) of one plane
+                const unsigned off = ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok >> 3) & 3) * 256 +
+                                     (r + 32 * ((tok >> 2) & 1)) * 4;
                 srd_store(srd_vt, off * 4, v);
-            } else {
+            } else {   // token counts that are not a multiple of 4, plane boundaries, the last partial row tile
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (row0 + 8 * gq + 4 * h + j < a.rows) a.vt[off + j] = v[j];
+                for (int j = 0; j < 4; ++j) {
+                    int tj = tok + j;
+                    unsigned pj = ph;
+                    if (tj >= a.tokens) { tj -= a.tokens; pj += a.heads; }
+                    if (row0 + 8 * gq + 4 * h + j < a.rows)
+                        a.vt[pj * head_stride + (unsigned)(tj >> 5) * 1024 + ((tj >> 3) & 3) * 256 +
+                             (r + 32 * ((tj >> 2) & 1)) * 4 + (tj & 3)] = v[j];
+                }
             }
         }
     }

@@ -130,11 +130,13 @@ def test_full_size_batch128_properties(oracle_lib):
 
 
 @pytest.mark.parametrize("ofdm,pilot,patch,adaptive", [((30, 8), (6, 2), (3, 2), True), ((66, 12), (11, 3), (3, 3), False),
-                                                        ((150, 8), (10, 2), (5, 2), True)])
+                                                        ((150, 8), (10, 2), (5, 2), True),
+                                                        ((120, 14), (12, 2), (4, 2), True), ((120, 14), (12, 2), (2, 2), False),
+                                                        ((54, 14), (6, 2), (3, 2), False)])
 def test_other_grid_geometries_match_oracle(oracle_lib, ofdm, pilot, patch, adaptive):
     """Grids whose row count is not a multiple of 4 / of the 30-row conv tiles, other patch shapes, a
     grid taller than the default (one band, five conv tiles): conv tiling, patch addressing, ragged
-    attention tiles."""
+    attention tiles; token counts that are not a multiple of 8 or 4 (210, 420, 126)."""
     tokens = (ofdm[0] // patch[0]) * (ofdm[1] // patch[1])
     spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=2, model_dim=128, num_head=4)
     hid = (5, 9, 2 * tokens) if adaptive else None
