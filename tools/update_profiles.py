@@ -11,7 +11,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 for name in ("kernel_stats.csv", "kernel_trace_summary.txt", "pmc_summary.txt", "bench_under_rocprof.json",
-             "train_kernel_trace_summary.txt", "train_bench_line.json"):
+             "train_kernel_trace_summary.txt", "train_bench_line.json", "flow_timeline.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join("profiles", f"{tag}_{name}"))
