@@ -84,6 +84,8 @@ hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slice
                           bool accumulate, hipStream_t st);
 hipError_t launch_colsum(const float *x, float *out, float *slices, int rows, int n, int ld, bool accumulate, hipStream_t st);
 hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, size_t stride, bool accumulate, hipStream_t st);
+hipError_t launch_reduce_slices3(const float *slices, float *out0, float *out1, float *out2, int n, int nout, int nz,
+                                 size_t stride, bool accumulate, hipStream_t st);
 hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o, float *lse, int planes, int tokens,
                                  float dropout_p, uint32_t seed, hipStream_t st);
 hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const float *o, const float *d_o, const float *lse,

@@ -141,35 +141,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_z slices[z * stride + i].  64 columns per workgroup, the
-// slice index split over the 4 waves, four loads in flight per thread; fixed summation order
-// (deterministic run to run).
-__global__ __launch_bounds__(256) void reduce_slices_kernel(const float *__restrict__ slices, float *__restrict__ out,
-                                                            int n, int nz, size_t stride, int accumulate) {
+// slice index split over the 4 waves, eight loads in flight per thread; fixed summation order
+// (deterministic run to run).  Up to three outputs of n columns each, laid side by side in a slice
+// (LayerNorm backward: dgamma | dbeta | bias gradient), in one launch.
+struct ReduceArgs {
+    const float *slices;
+    float *out[3];
+    int n, nout, nz, accumulate;
+    size_t stride;
+};
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const ReduceArgs a) {
     __shared__ float part[4][64];
-    const int c = threadIdx.x & 63, zq = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < n) {
+    const int c = threadIdx.x & 63, zq = threadIdx.x >> 6, i = blockIdx.x * 64 + c;   // i over nout * n columns
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    if (i < a.n * a.nout) {
         int z = zq;
-        for (; z + 12 < nz; z += 16) {
-            s0 += slices[(size_t)z * stride + i];
-            s1 += slices[(size_t)(z + 4) * stride + i];
-            s2 += slices[(size_t)(z + 8) * stride + i];
-            s3 += slices[(size_t)(z + 12) * stride + i];
+        for (; z + 28 < a.nz; z += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += a.slices[(size_t)(z + 4 * u) * a.stride + i];
         }
-        for (; z < nz; z += 4) s0 += slices[(size_t)z * stride + i];
+        for (; z < a.nz; z += 4) s[0] += a.slices[(size_t)z * a.stride + i];
     }
-    part[zq][c] = (s0 + s1) + (s2 + s3);
+    part[zq][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
-    if (zq == 0 && i < n) {
-        const float s = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
-        out[i] = accumulate ? out[i] + s : s;
+    if (zq == 0 && i < a.n * a.nout) {
+        const float t = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        float *o = a.out[i / a.n] + i % a.n;
+        *o = a.accumulate ? *o + t : t;
     }
+}
+
+hipError_t launch_reduce_slices3(const float *slices, float *out0, float *out1, float *out2, int n, int nout, int nz,
+                                 size_t stride, bool accumulate, hipStream_t st) {
+    ReduceArgs a{slices, {out0, out1, out2}, n, nout, nz, (int)accumulate, stride};
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n * nout + 63) / 64), dim3(256), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, size_t stride, bool accumulate,
                                 hipStream_t st) {
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 63) / 64), dim3(256), 0, st, slices, out, n, nz, stride, (int)accumulate);
-    return hipGetLastError();
+    return launch_reduce_slices3(slices, out, nullptr, nullptr, n, 1, nz, stride, accumulate, st);
 }
 
 // column sums of a row-major [rows][n] matrix (bias gradients): one slice per row chunk

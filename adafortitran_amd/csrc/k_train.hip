@@ -244,11 +244,7 @@ hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, co
     else
         return hipErrorInvalidValue;
     // slices[b][0..n) = dgamma partials, [n..2n) = dbeta partials, [2n..3n) = branch bias gradient
-    hipError_t e = launch_reduce_slices(slices, dgamma, n, nb, 3 * n, accumulate, st);
-    if (e != hipSuccess) return e;
-    e = launch_reduce_slices(slices + n, dbeta, n, nb, 3 * n, accumulate, st);
-    if (e != hipSuccess) return e;
-    return launch_reduce_slices(slices + 2 * n, dbias, n, nb, 3 * n, accumulate, st);
+    return launch_reduce_slices3(slices, dgamma, dbeta, dbias, n, 3, nb, (size_t)3 * n, accumulate, st);
 }
 
 hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dropout_p, uint32_t seed, hipStream_t st) {
