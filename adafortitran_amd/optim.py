@@ -58,12 +58,20 @@ class FlatParameters:
             off += n
 
 
-class ShardedFlatAdam:
+class ShardedFlatAdam(torch.optim.Optimizer):
     """Adam (torch.optim.Adam semantics, amsgrad off) over a FlatParameters, sharded across
-    ``process_group``.  ``step()`` = reduce-scatter grads (mean) -> update own shard -> all-gather params."""
+    ``process_group``.  ``step()`` = reduce-scatter grads (mean) -> optional global-norm clipping ->
+    update own shard -> all-gather params.  A ``torch.optim.Optimizer``, so the reference's
+    ``ExponentialLR(optimizer, gamma=0.995)`` (trainer.py:414) drives ``param_groups[0]["lr"]`` as usual.
+
+    ``max_grad_norm`` replaces the trainer's ``clip_grad_norm_`` call (trainer.py:222-223): with sharded
+    gradients the norm has to be taken after the reduction, on the averaged gradient."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 0.0, process_group: Optional[dist.ProcessGroup] = None) -> None:
+                 eps: float = 1e-8, weight_decay: float = 0.0, max_grad_norm: Optional[float] = None,
+                 process_group: Optional[dist.ProcessGroup] = None) -> None:
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
@@ -75,39 +83,61 @@ class ShardedFlatAdam:
             else self.flat.grad[lo:lo + self.shard]
         self.exp_avg = torch.zeros_like(self.p_shard)
         self.exp_avg_sq = torch.zeros_like(self.p_shard)
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
         self.steps = 0
-        # one ExponentialLR-style hook: the reference multiplies lr by 0.995 per epoch (trainer.py:414)
-        self.param_groups = [{"lr": lr}]
         if self.flat.data.device.type == "cuda":
             from . import training
             training.ACCUMULATE_INTO_GRAD = True   # the encoder backward adds into the flat grad views
 
-    def zero_grad(self, set_to_none: bool = False) -> None:
+    def zero_grad(self, set_to_none: bool = False) -> None:   # the views must stay attached to the flat buffer
         self.flat.zero_grad()
 
-    def step(self) -> None:
-        self.lr = self.param_groups[0]["lr"]
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         self.steps += 1
         if self.world > 1:
             dist.reduce_scatter_tensor(self.g_shard, self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
-        self._adam(1.0 / self.world)
+        scale = 1.0 / self.world
+        if self.max_grad_norm is not None:
+            sq = (self.g_shard.double() ** 2).sum() * scale * scale
+            if self.world > 1:
+                dist.all_reduce(sq, group=self.group)
+            norm = float(sq.sqrt())
+            scale *= min(1.0, self.max_grad_norm / (norm + 1e-6))   # clip_grad_norm_'s coefficient
+        self._adam(scale)
         if self.world > 1:
             dist.all_gather_into_tensor(self.flat.data, self.p_shard.clone(), group=self.group)
+        return loss
 
     def _adam(self, grad_scale: float) -> None:
-        b1, b2 = self.betas
+        g0 = self.param_groups[0]
+        lr, (b1, b2), eps, wd = g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"]
         if self.p_shard.device.type == "cuda":
             from . import _lib
             lib = _lib.load()
             _lib.check(lib.aft_adam_step_f32(self.p_shard.data_ptr(), self.g_shard.data_ptr(), self.exp_avg.data_ptr(),
-                                             self.exp_avg_sq.data_ptr(), self.shard, self.lr, b1, b2, self.eps,
-                                             self.weight_decay, grad_scale, self.steps,
-                                             _lib.current_stream_ptr(self.p_shard.device)))
+                                             self.exp_avg_sq.data_ptr(), self.shard, lr, b1, b2, eps, wd, grad_scale,
+                                             self.steps, _lib.current_stream_ptr(self.p_shard.device)))
             return
-        with torch.no_grad():
-            g = self.g_shard * grad_scale + self.weight_decay * self.p_shard
-            self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
-            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
-            bc1, bc2 = 1 - b1 ** self.steps, 1 - b2 ** self.steps
-            self.p_shard.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / bc2 ** 0.5 + self.eps, value=-self.lr / bc1)
+        g = self.g_shard * grad_scale + wd * self.p_shard
+        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** self.steps, 1 - b2 ** self.steps
+        self.p_shard.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / bc2 ** 0.5 + eps, value=-lr / bc1)
+
+    # checkpoints (reference trainer.py saves optimizer.state_dict()): this rank's shard of the moments
+    def state_dict(self):
+        return {"steps": self.steps, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "lr": self.param_groups[0]["lr"], "world": self.world, "rank": self.rank}
+
+    def load_state_dict(self, sd) -> None:
+        if sd["world"] != self.world or sd["rank"] != self.rank:
+            raise ValueError("optimizer shard was saved for a different world size / rank")
+        self.steps = int(sd["steps"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0]["lr"] = sd["lr"]

@@ -35,6 +35,32 @@ def test_flat_adam_matches_torch_adam():
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
 
 
+def test_scheduler_clipping_and_checkpoint():
+    """ExponentialLR drives the lr (reference trainer.py:414); max_grad_norm reproduces clip_grad_norm_ +
+    Adam; state_dict round-trips the moments."""
+    a, b = _net(), _net()
+    x, y = _data()
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2)
+    opt = ShardedFlatAdam(b.parameters(), lr=1e-2, max_grad_norm=0.05)
+    sa = torch.optim.lr_scheduler.ExponentialLR(ref, gamma=0.9)
+    sb = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+    for _ in range(4):
+        ref.zero_grad(); opt.zero_grad()
+        torch.nn.functional.mse_loss(a(x), y).backward()
+        torch.nn.utils.clip_grad_norm_(a.parameters(), 0.05)
+        ref.step(); sa.step()
+        torch.nn.functional.mse_loss(b(x), y).backward()
+        opt.step(); sb.step()
+    assert abs(opt.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) < 1e-12
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+    sd = opt.state_dict()
+    c = _net()
+    opt2 = ShardedFlatAdam(c.parameters(), lr=1.0)
+    opt2.load_state_dict(sd)
+    assert opt2.steps == 4 and torch.equal(opt2.exp_avg, opt.exp_avg) and opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
