@@ -164,7 +164,7 @@ class TransformerEncoderForChannels(nn.Module):
             return False
         layer0 = self.transformer.layers[0]
         d, heads, tokens = h.shape[2], layer0.self_attn.num_heads, h.shape[1]
-        return (d in (128, 256) and d // heads == 32 and tokens >= 32 and h.shape[0] % 2 == 0
+        return (d in (64, 128, 192, 256) and d // heads == 32 and tokens >= 32 and h.shape[0] % 2 == 0
                 and layer0.activation in (F.gelu, F.relu) and not layer0.norm_first
                 and layer0.linear1.out_features == 2 * d)
 

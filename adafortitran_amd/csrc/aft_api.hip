@@ -35,8 +35,8 @@ int check_config(const aft_config *c) {
         set_error("bad pilot grid or layer count (layers=%d, max %d)", c->num_layers, AFT_MAX_LAYERS);
         return AFT_ERR_SHAPE;
     }
-    if (c->model_dim != 128 && c->model_dim != 256) {
-        set_error("model_dim %d not covered by the gfx950 kernels (128 or 256)", c->model_dim);
+    if (c->model_dim != 64 && c->model_dim != 128 && c->model_dim != 192 && c->model_dim != 256) {
+        set_error("model_dim %d not covered by the gfx950 kernels (64, 128, 192 or 256)", c->model_dim);
         return AFT_ERR_SHAPE;
     }
     if (c->num_head <= 0 || c->model_dim % c->num_head || c->model_dim / c->num_head != kHeadDim) {

@@ -228,7 +228,7 @@ __device__ __forceinline__ f32x16 bias_acc(Srd bias, int f0, int h) {
 //   <true,true>  layer l's out-proj+LN1+FFN+LN2 and layer l+1's in-projection   (5 of 7 launches at L=6)
 //   <false,true> in-projection only (first layer)      <true,false> last layer, no in-projection
 template <int D, int ACT, bool MLP, bool QKV>
-__global__ __launch_bounds__(D * 2, D == 128 ? 3 : 2) void chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const ChainArgs a) {
     using S = ChainShape<D>;
     constexpr int W = S::WAVES;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -458,7 +458,7 @@ static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        resident = cus * (D == 128 ? 3 : 1);
+        resident = cus * (D <= 128 ? 3 : 1);
     }
     const int blocks = std::min((args.rows + 31) / 32, resident);
     const size_t lds = S::LDS_BYTES;
@@ -577,6 +577,10 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const f
     a.heads = c.num_head;
     const bool gelu = c.activation == AFT_ACT_GELU;
     const bool mlp = m != nullptr, qkv = qw != nullptr;
+    if (c.model_dim == 64)
+        return gelu ? launch_chain_t<64, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<64, AFT_ACT_RELU>(a, mlp, qkv, st);
+    if (c.model_dim == 192)
+        return gelu ? launch_chain_t<192, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<192, AFT_ACT_RELU>(a, mlp, qkv, st);
     if (c.model_dim == 128)
         return gelu ? launch_chain_t<128, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<128, AFT_ACT_RELU>(a, mlp, qkv, st);
     if (c.model_dim == 256)

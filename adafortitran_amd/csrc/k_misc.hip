@@ -124,8 +124,12 @@ hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *
         if (small) hipLaunchKernelGGL((embed_kernel<D_, A_, 6>), dim3(blocks), dim3(256), lds, st, a); \
         else hipLaunchKernelGGL((embed_kernel<D_, A_, kMaxPatchFeatures>), dim3(blocks), dim3(256), lds, st, a); \
     } while (0)
-    if (c.model_dim == 128 && c.adaptive) AFT_EMBED(128, true);
+    if (c.model_dim == 64 && c.adaptive) AFT_EMBED(64, true);
+    else if (c.model_dim == 64) AFT_EMBED(64, false);
+    else if (c.model_dim == 128 && c.adaptive) AFT_EMBED(128, true);
     else if (c.model_dim == 128) AFT_EMBED(128, false);
+    else if (c.model_dim == 192 && c.adaptive) AFT_EMBED(192, true);
+    else if (c.model_dim == 192) AFT_EMBED(192, false);
     else if (c.model_dim == 256 && c.adaptive) AFT_EMBED(256, true);
     else if (c.model_dim == 256) AFT_EMBED(256, false);
     else return hipErrorInvalidValue;

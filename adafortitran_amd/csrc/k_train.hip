@@ -152,10 +152,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
                                                       float *__restrict__ slices, int rows, int n, int rows_per_block,
                                                       uint32_t seed, uint32_t threshold, float keep_scale) {
     __shared__ f32x4 part[256];
-    const int groups = n >> 2, cg = threadIdx.x % groups, rsub = threadIdx.x / groups, rstep = 256 / groups;
+    const int groups = n >> 2, cg = threadIdx.x % groups, rsub = threadIdx.x / groups, rstep = 256 / groups;   // rsub >= rstep: idle
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int row = r0 + rsub; row < r1; row += rstep) {
+    for (int row = r0 + rsub; row < r1 && rsub < rstep; row += rstep) {
         const size_t i = ((size_t)row * n >> 2) + cg;
         const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i];
         f32x4 g = reinterpret_cast<f32x4 *>(dh)[i];
@@ -219,8 +219,12 @@ hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamm
     const dim3 grid((rows + 3) / 4), block(256);
     const uint32_t th = drop_threshold(dropout_p);
     const float ks = drop_keep(dropout_p);
-    if (n == 128)
+    if (n == 64)
+        hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else if (n == 128)
         hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else if (n == 192)
+        hipLaunchKernelGGL(add_ln_fwd_kernel<3>, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
     else if (n == 256)
         hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
     else
@@ -237,8 +241,12 @@ hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, co
     const int nb = ln_bwd_blocks(rows), rpb = (rows + nb - 1) / nb;
     const uint32_t th = drop_threshold(dropout_p);
     const float ks = drop_keep(dropout_p);
-    if (n == 128)
+    if (n == 64)
+        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else if (n == 128)
         hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else if (n == 192)
+        hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
     else if (n == 256)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
     else
@@ -260,7 +268,7 @@ hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dro
 // dbias (+)= column sums of da; `slices` holds ln_bwd_blocks(rows) * n floats; n = 256 or 512
 hipError_t launch_act_bwd(int act, const float *a, float *dh, float *dbias, float *slices, int rows, int n, float dropout_p,
                           uint32_t seed, bool accumulate, hipStream_t st) {
-    if (n % 4 || 256 % (n / 4)) return hipErrorInvalidValue;
+    if (n % 4 || n / 4 > 256) return hipErrorInvalidValue;
     const int nb = ln_bwd_blocks(rows), rpb = (rows + nb - 1) / nb;
     if (act)
         hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(nb), dim3(256), 0, st, a, dh, slices, rows, n, rpb, seed, drop_threshold(dropout_p), drop_keep(dropout_p));

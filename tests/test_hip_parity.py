@@ -151,6 +151,24 @@ def test_other_grid_geometries_match_oracle(oracle_lib, ofdm, pilot, patch, adap
     assert np.abs(out - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("d", [64, 192])
+def test_other_model_dims_match_oracle(oracle_lib, adaptive, d):
+    """d = 64 / 192 with head dim 32: two / six waves per chain workgroup."""
+    spec = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=3, model_dim=d, num_head=d // 32)
+    hid = (7, 42, 560) if adaptive else None
+    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=64)
+    cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(9, seed=65)
+    meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+    out = eng.forward(_t(inp["pilots"]), *meta)
+    assert torch.equal(torch.view_as_real(eng.forward(_t(inp["pilots"]), *meta)), torch.view_as_real(out))
+    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3))
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+
+
 def test_config5_persistent_tiles(oracle_lib):
     """BASELINE config 5 shapes (240x28 grid, 12 layers, d=256, 8 heads, 1120 tokens) at B=16:
     1120 row tiles over 256 resident workgroups, so every workgroup walks several tiles (the

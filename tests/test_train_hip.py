@@ -33,7 +33,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("d,heads,ofdm,planes,act", [(128, 4, (120, 14), 6, "gelu"), (128, 4, (24, 14), 2, "relu"),
-                                                     (256, 8, (48, 14), 4, "gelu")])
+                                                     (256, 8, (48, 14), 4, "gelu"), (64, 2, (48, 14), 4, "gelu"), (192, 6, (48, 14), 2, "relu")])
 def test_layer_forward_backward_matches_autograd(d, heads, ofdm, planes, act):
     from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
     cfg = _cfg(d, heads, ofdm, act)
