@@ -54,6 +54,8 @@ def build_reference(spec):
               num_head=spec["num_head"], activation=spec.get("activation", "gelu"),
               max_seq_len=spec.get("max_seq_len", 512),
               pos_encoding_type=spec.get("pos_encoding_type", "learnable"), device="cpu")
+    if "dropout" in spec:
+        kw["dropout"] = spec["dropout"]
     if spec.get("adaptive_hidden"):
         kw.update(channel_adaptivity_hidden_sizes=list(spec["adaptive_hidden"]), adaptive_token_length=6)
     mc = ModelConfig(**kw)
@@ -152,6 +154,42 @@ def run_set(name, spec, batch, keep):
     np.savez_compressed(path, **arrays)
     print(f"{name}: B={batch} |out|max={np.abs(arrays['out']).max():.4f} "
           f"2xMSE={2 * loss:.6f} params={meta_json['ref_params']} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+GRAD_SAMPLE_STRIDE, GRAD_SAMPLE_MAX = 7, 4096
+
+
+def run_grad(name, spec, batch):
+    """One training step of the reference, as TrainingLoop.train_epoch runs it (reference
+    src/main/trainer.py:195-233): model.train(), loss = MSELoss(cat(Re,Im)) of trainer._compute_loss
+    (:173-176 via utils.concat_complex_channel), loss.backward().  dropout = 0 so the step is
+    deterministic.  Kept per parameter: L2 norm, max |g| and every 7th element (<= 4096 of them)."""
+    model, sd = build_reference(spec)
+    model.train()
+    inp = synth.make_inputs(batch, ofdm=tuple(spec["ofdm"]), pilot=tuple(spec["pilot"]), seed=spec["seed"] + 1)
+    pil, tgt = torch.from_numpy(inp["pilots"]), torch.from_numpy(inp["target"])
+    meta = synth.meta_tuple(inp) if spec.get("adaptive_hidden") else None
+    out = model(pil, meta) if meta is not None else model(pil)
+    cat = lambda z: torch.cat((torch.real(z), torch.imag(z)), dim=1)  # noqa: E731
+    loss = torch.nn.MSELoss()(cat(out), cat(tgt))
+    loss.backward()
+    arrays = {"pilots": inp["pilots"], "target": inp["target"], "loss": np.float64(loss.item()),
+              "out": out.detach().numpy().astype(np.complex64)}
+    if spec.get("adaptive_hidden"):
+        arrays.update(snr=inp["snr"], ds=inp["ds"], dop=inp["dop"])
+    names = []
+    for n, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1).numpy()
+        names.append(n)
+        arrays[f"gnorm__{n}"] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        arrays[f"gmax__{n}"] = np.float64(np.abs(g).max())
+        arrays[f"gsample__{n}"] = g[::GRAD_SAMPLE_STRIDE][:GRAD_SAMPLE_MAX].astype(np.float32)
+    arrays["names"] = np.asarray(names)
+    meta_json = dict(spec=spec, batch=batch, torch=torch.__version__, weights_crc=synth.state_dict_checksum(sd))
+    arrays["meta_json"] = np.frombuffer(json.dumps(meta_json).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: B={batch} loss={loss.item():.6f} params={len(names)} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 def run_linear(name, batch, seed):
@@ -265,5 +303,9 @@ if __name__ == "__main__":
         run_linear("L_linear", 32, 31)
     if not only or "I_ingest" in only:
         run_ingest("I_ingest", 77)
+    if not only or "G_grad_ada" in only:
+        run_grad("G_grad_ada", dict(DEFAULT, num_layers=2, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=777), 3)
+    if not only or "G_grad_forti" in only:
+        run_grad("G_grad_forti", dict(DEFAULT, num_layers=2, dropout=0.0, activation="relu", seed=778), 2)
     leftovers = [os.path.join(r, f) for r, _d, fs in os.walk(REF) for f in fs if f.endswith(".pyc") and "cpython-310" in f]
     assert not leftovers, f"bytecode leaked into the reference mount: {leftovers}"
