@@ -224,3 +224,34 @@ def test_direct_gradient_accumulation_matches_autograd_accumulation():
     finally:
         training.ACCUMULATE_INTO_GRAD = False
     assert _rel(b, a) <= 1e-6
+
+
+def test_eval_after_training_uses_the_updated_flat_parameters():
+    """ShardedFlatAdam re-homes the parameters into one flat buffer; the inference engine must follow
+    (new pointers, in-place updates): HIP eval output == PyTorch composite on the same module."""
+    from adafortitran_amd import synth
+    from adafortitran_amd.optim import ShardedFlatAdam
+    torch.manual_seed(3)
+    model = _model("adafortitran", 0.1)
+    inp = synth.make_inputs(6, seed=11)
+    pil, tgt = torch.from_numpy(inp["pilots"]).cuda(), torch.from_numpy(inp["target"]).cuda()
+    meta = synth.meta_tuple(inp)
+    model.eval()
+    with torch.no_grad():
+        before = model(pil, meta).clone()          # builds the engine on the original parameter tensors
+    opt = ShardedFlatAdam(model.parameters(), lr=1e-3)
+    model.train()
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(torch.view_as_real(model(pil, meta)), torch.view_as_real(tgt)).backward()
+        opt.step()
+    model.eval()
+    with torch.no_grad():
+        hip = model(pil, meta)                     # HIP inference path
+    model.transformer_encoder.hip_training = False
+    try:
+        ref = model(pil, meta).detach()            # grad-enabled eval forward: pure PyTorch composite
+    finally:
+        model.transformer_encoder.hip_training = True
+    assert not torch.allclose(torch.view_as_real(hip), torch.view_as_real(before))
+    assert _rel(torch.view_as_real(hip), torch.view_as_real(ref)) <= 5e-5
