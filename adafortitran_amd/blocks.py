@@ -35,7 +35,17 @@ class ConvEnhancer(nn.Module):
                 layers.append(nn.ReLU())
         self.conv_block = nn.Sequential(*layers)
 
+    #: set to False to differentiate the stack through PyTorch-ROCm (MIOpen) instead (A/B tests)
+    hip_training = True
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (self.hip_training and x.device.type == "cuda" and torch.is_grad_enabled() and x.dtype == torch.float32
+                and x.dim() == 4 and x.shape[1] == 1):
+            # grad-enabled forward on the HIP device: the fused conv-stack kernel, its own backward
+            from .training import HipConvEnhancerFunction
+            convs = [self.conv_block[i] for i in (0, 2, 4, 6)]
+            args = [t for c in convs for t in (c.weight, c.bias)]
+            return HipConvEnhancerFunction.apply(x, *args)
         return self.conv_block(x)
 
 

@@ -101,6 +101,13 @@ hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dro
 hipError_t launch_act_bwd(int act, const float *a, float *dh, float *dbias, float *slices, int rows, int n, float dropout_p,
                           uint32_t seed, bool accumulate, hipStream_t st);
 hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t st);
+// ConvEnhancer training forward / backward-dgrad on plain planes (k_conv.hip) and its weight gradients (k_conv_train.hip)
+hipError_t launch_conv_train(const float *const w[4], const float *const b[4], const float *x, float *y, float *const save[3],
+                             const float *const mask[3], int planes, int S, int T, hipStream_t st);
+hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, const float *c3, const float *g1,
+                             const float *g2, const float *g3, const float *dy, float *const dw[4], float *const db[4],
+                             float *slices, int planes, int S, int T, bool accumulate, hipStream_t st);
+size_t conv_wgrad_slice_floats(int planes, int S, int T);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
                        float wd, float grad_scale, int step, hipStream_t st);
 

@@ -181,6 +181,49 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     return AFT_OK;
 }
 
+size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols) {
+    if (planes <= 0 || num_scs <= 0 || num_symbols <= 0) return 0;
+    return sizeof(float) * (al64((size_t)planes * 48 * num_scs * num_symbols) + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols)));
+}
+
+int aft_conv_enhancer_fwd_train_f32(const float *const weights[4], const float *const biases[4], const float *x, float *y,
+                                    float *c1, float *c2, float *c3, int planes, int num_scs, int num_symbols, void *stream) {
+    if (!weights || !biases || !x || !y || !c1 || !c2 || !c3 || planes <= 0 || num_scs <= 0 || num_symbols <= 0) {
+        set_error("bad ConvEnhancer argument");
+        return AFT_ERR_ARG;
+    }
+    float *const save[3] = {c1, c2, c3};
+    STEP("conv forward", launch_conv_train(weights, biases, x, y, save, nullptr, planes, num_scs, num_symbols,
+                                           static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
+int aft_conv_enhancer_bwd_f32(const float *const flipped_weights[4], const float *x, const float *c1, const float *c2,
+                              const float *c3, const float *dy, float *dx, float *const dweights[4], float *const dbiases[4],
+                              int accumulate, void *scratch, size_t scratch_bytes, int planes, int num_scs, int num_symbols,
+                              void *stream) {
+    if (!flipped_weights || !x || !c1 || !c2 || !c3 || !dy || !dx || !dweights || !dbiases || !scratch || planes <= 0) {
+        set_error("bad ConvEnhancer argument");
+        return AFT_ERR_ARG;
+    }
+    if (scratch_bytes < aft_conv_enhancer_scratch_bytes(planes, num_scs, num_symbols)) {
+        set_error("ConvEnhancer scratch too small");
+        return AFT_ERR_ARG;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t plane8 = (size_t)planes * 8 * num_scs * num_symbols;
+    float *g3 = static_cast<float *>(scratch), *g2 = g3 + plane8, *g1 = g2 + 4 * plane8;
+    float *slices = static_cast<float *>(scratch) + al64(6 * plane8);
+    // dgrad: the stack run on dy with conv4^T (1->8), conv3^T (8->32), conv2^T (32->8), conv1^T (8->1);
+    // stage outputs masked by the saved activations = g3, g2, g1
+    float *const save[3] = {g3, g2, g1};
+    const float *const mask[3] = {c3, c2, c1};
+    STEP("conv dgrad", launch_conv_train(flipped_weights, nullptr, dy, dx, save, mask, planes, num_scs, num_symbols, st));
+    STEP("conv wgrad", launch_conv_wgrad(x, c1, c2, c3, g1, g2, g3, dy, dweights, dbiases, slices, planes, num_scs, num_symbols,
+                                         accumulate != 0, st));
+    return AFT_OK;
+}
+
 int aft_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, float grad_scale, int step, void *stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) { set_error("bad Adam argument"); return AFT_ERR_ARG; }

@@ -32,7 +32,7 @@
 namespace aft {
 
 struct ConvArgs {
-    int mode;  // 0 = head (pilots -> conv_enhanced), 1 = tail (x, conv_enhanced -> complex out)
+    int mode;  // 0 = head (pilots -> conv_enhanced), 1 = tail (x, conv_enhanced -> complex out), 2 = plain (training)
     int S, T, SP, band_rows, nbands, ntiles, nseg, arena, extra;   // SP = LDS row-vector length (>= band_rows + 8)
     // head
     const float *pilots, *up_w, *up_b;
@@ -41,8 +41,12 @@ struct ConvArgs {
     const float *x, *lin2_w, *lin2_b, *resid;
     int d, tokens, p0, p1;
     const float *cw[4], *cb[4];
-    float *out_plane;    // head: [planes][S][T]
+    float *out_plane;    // head / plain: [planes][S][T]
     float *out_complex;  // tail: [B][S][T][2]
+    // training variant only (mode 2 = plain plane in, plain plane out):
+    const float *in_plane;   // [planes][S][T]
+    float *save[3];          // outputs of conv1 / conv2 / conv3 after their activation, [planes][C][T][S] (C = 8, 32, 8)
+    const float *mask[3];    // backward: activation of stage k = acc where mask[k] > 0 else 0 (instead of bias + ReLU)
 };
 
 constexpr int kConvThreads = 512;
@@ -56,6 +60,13 @@ __device__ __forceinline__ float lane_from_above(float v) {   // lane i <- lane 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
+// TRAIN = false is the inference kernel.  TRAIN = true adds what the training path needs:
+// a plain-plane input mode, the stage outputs written to HBM (forward: the activations the backward
+// needs; backward: the pre-activation gradients the weight-gradient kernels need), and a masked
+// activation (backward: the ReLU derivative taken from the saved forward activation).  The backward of
+// the stack IS this kernel run on the gradient with transposed, flipped weights: conv4^T is 1->8,
+// conv3^T 8->32, conv2^T 32->8, conv1^T 8->1.
+template <bool TRAIN>
 __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S = a.S, T = a.T, SP = a.SP, LR = a.band_rows + 8;
@@ -76,7 +87,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         smem[i] = a.cw[1][i];
         smem[2304 + i] = a.cw[2][i];
     }
-    if (a.mode == 0) {
+    if (TRAIN) {
+    } else if (a.mode == 0) {
         for (int i = tid; i < a.pf; i += kConvThreads) small[i] = a.pilots[((size_t)frame * a.pf + i) * 2 + part];
     } else {
         const int p = a.p0 * a.p1;
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     const int lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     float bias3[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias3[e] = a.cb[2][e + 4 * h];
+    for (int e = 0; e < 4; ++e) bias3[e] = (TRAIN && !a.cb[2]) ? 0.f : a.cb[2][e + 4 * h];
     __syncthreads();
     float wa2[36], wa3[48];
 #pragma unroll
@@ -112,11 +124,16 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         for (int i = tid; i < n4; i += kConvThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float *bias2 = small + a.extra;    // [2 halves][16]
-    if (tid < 32) bias2[tid] = a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
+    if (tid < 32) bias2[tid] = (TRAIN && !a.cb[1]) ? 0.f : a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
     __syncthreads();
 
     // ---- input plane ----
-    if (a.mode == 0) {   // pilot_upsampler row (gr*T + t): idx = sc*T + sym (view(B,1,S,T))
+    if (TRAIN && a.mode == 2) {
+        for (int i = tid; i < LR * T; i += kConvThreads) {
+            const int lr = i / T, t = i - lr * T, gr = gr0 + lr;
+            if (gr >= 0 && gr < S) in0[(t + 1) * col_stride + lr] = a.in_plane[((size_t)n * S + gr) * T + t];
+        }
+    } else if (a.mode == 0) {   // pilot_upsampler row (gr*T + t): idx = sc*T + sym (view(B,1,S,T))
         if (a.pf == 24) {   // default pilot grid: four pixels per pass, all 24 row loads in flight before the FMAs
             for (int i0 = tid; i0 < LR * T; i0 += 4 * kConvThreads) {
                 f32x4 wv[4][6];
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                 in0[(t + 1) * col_stride + lr] = v;
             }
         }
-    } else {
+    } else if (!TRAIN) {
         // linear_2 + inverse patch map + conv_enhanced residual.  One thread per token: its x row is read
         // once (d floats) and dotted with the p weight rows (LDS, wave-uniform address -> broadcast), in
         // groups of up to 8 features.  Feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1).
@@ -214,10 +231,16 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
             for (int kx = 0; kx < 3; ++kx) win[ky][kx] = in0[(t + kx) * col_stride + lr - 1 + ky];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            float acc = a.cb[0][o];
+            float acc = (TRAIN && !a.cb[0]) ? 0.f : a.cb[0][o];
 #pragma unroll
             for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[k9 / 3][k9 % 3], a.cw[0][o * 9 + k9], acc);
-            c1[o * plane + (t + 1) * col_stride + lr] = fmaxf(acc, 0.f);
+            float v = fmaxf(acc, 0.f);
+            if constexpr (TRAIN) {
+                const size_t gi = ((size_t)(n * 8 + o) * T + t) * S + gr;
+                if (a.mask[0]) v = a.mask[0][gi] > 0.f ? acc : 0.f;
+                if (a.save[0] && lr >= 4 && lr < 4 + a.band_rows) a.save[0][gi] = v;
+            }
+            c1[o * plane + (t + 1) * col_stride + lr] = v;
         }
     }
     __syncthreads();
@@ -240,13 +263,21 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
 
+        const bool own_row = r >= 4 && r < 4 + a.band_rows;   // rows this band is responsible for (no halo)
         auto store_col = [&](int tout, float v0, float v1, float v2, float v3) {
             if (tout >= ta && tout < tb && ok3) {
                 float *p = dst + (tout + 1) * col_stride;
-                p[0 * plane] = fmaxf(v0 + bias3[0], 0.f);
-                p[1 * plane] = fmaxf(v1 + bias3[1], 0.f);
-                p[2 * plane] = fmaxf(v2 + bias3[2], 0.f);
-                p[3 * plane] = fmaxf(v3 + bias3[3], 0.f);
+                float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float y = fmaxf(v[k] + bias3[k], 0.f);
+                    if constexpr (TRAIN) {
+                        const size_t gi = ((size_t)(n * 8 + 4 * h + k) * T + tout) * S + gr;
+                        if (a.mask[2]) y = a.mask[2][gi] > 0.f ? v[k] : 0.f;
+                        if (a.save[2] && own_row) a.save[2][gi] = y;
+                    }
+                    p[k * plane] = y;
+                }
             }
         };
         // B operand slot kb of conv2 column tcol: channel 4h + (kb&3), tap (kx, ky) = ((kb>>2)/3, (kb>>2)%3)
@@ -287,6 +318,17 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
             float x2[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);   // ReLU, or 0 outside the plane
+            if constexpr (TRAIN) {
+                if (a.mask[1] || a.save[1]) {
+                    const size_t g0 = ((size_t)(n * 32 + 4 * h) * T + tcol) * S + gr;   // channel (e&3) + 8(e>>2) + 4h
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const size_t gi = g0 + (size_t)((e & 3) + 8 * (e >> 2)) * T * S;
+                        if (a.mask[1]) x2[e] = (ok2 && a.mask[1][gi] > 0.f) ? acc2[e] : 0.f;
+                        if (a.save[1] && ok2 && own_row) a.save[1][gi] = x2[e];
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[16 + e], x2[e], acc3, 0, 0, 0);
 #pragma unroll
@@ -308,7 +350,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         if (gr >= S) continue;
         float acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = a.cb[3][0];
+        for (int q = 0; q < 4; ++q) acc[q] = (TRAIN && !a.cb[3]) ? 0.f : a.cb[3][0];
 #pragma unroll 2
         for (int ci = 0; ci < 8; ++ci) {
             float win[3][6];   // [ky][column t0-1 .. t0+4]; columns past T+1 are never used by a stored output
@@ -329,7 +371,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         for (int q = 0; q < 4; ++q) {
             const int t = t0 + q;
             if (t >= T) break;
-            if (a.mode == 0)
+            if (TRAIN || a.mode == 0)
                 a.out_plane[((size_t)n * S + gr) * T + t] = acc[q];
             else
                 a.out_complex[(((size_t)frame * S + gr) * T + t) * 2 + part] = acc[q];
@@ -364,18 +406,33 @@ static bool plan_bands(int S, int T, int extra_floats, ConvArgs *a, size_t *lds_
     return false;
 }
 
+template <bool TRAIN>
 static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStream_t st) {
     size_t lds = 0;
     if (!plan_bands(a.S, a.T, extra_floats, &a, &lds)) return hipErrorInvalidValue;
-    static bool attr_set = false;  // idempotent; a race only repeats the same call
+    static bool attr_set = false;  // per instantiation; idempotent, a race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stack_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stack_kernel<TRAIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_stack_kernel, dim3(planes * a.nbands), dim3(kConvThreads), lds, st, a);
+    hipLaunchKernelGGL(conv_stack_kernel<TRAIN>, dim3(planes * a.nbands), dim3(kConvThreads), lds, st, a);
     return hipGetLastError();
+}
+
+// Training path: ConvEnhancer on plain planes.  Forward: w/b = the module's tensors, save = {c1, c2, c3},
+// mask = {}.  Backward (dgrad): x = dL/dy, w = transposed + flipped weights of conv4..conv1, b = {},
+// mask = {c3, c2, c1}, save = the pre-activation gradients {g3, g2, g1}; y = dL/dx.
+hipError_t launch_conv_train(const float *const w[4], const float *const b[4], const float *x, float *y, float *const save[3],
+                             const float *const mask[3], int planes, int S, int T, hipStream_t st) {
+    ConvArgs a{};
+    a.mode = 2;
+    a.S = S; a.T = T;
+    a.in_plane = x; a.out_plane = y;
+    for (int i = 0; i < 4; ++i) { a.cw[i] = w[i]; a.cb[i] = b ? b[i] : nullptr; }
+    for (int i = 0; i < 3; ++i) { a.save[i] = save ? save[i] : nullptr; a.mask[i] = mask ? mask[i] : nullptr; }
+    return launch_conv<true>(a, planes, 0, st);
 }
 
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots, float *conv_enhanced,
@@ -387,7 +444,7 @@ hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const floa
     a.pf = c.pilot_scs * c.pilot_symbols;
     for (int i = 0; i < 4; ++i) { a.cw[i] = w.enh_w[i]; a.cb[i] = w.enh_b[i]; }
     a.out_plane = conv_enhanced;
-    return launch_conv(a, 2 * batch, a.pf, st);
+    return launch_conv<false>(a, 2 * batch, a.pf, st);
 }
 
 hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
@@ -401,7 +458,7 @@ hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x
     for (int i = 0; i < 4; ++i) { a.cw[i] = w.ref_w[i]; a.cb[i] = w.ref_b[i]; }
     a.out_complex = out;
     const int p = a.p0 * a.p1;
-    return launch_conv(a, 2 * batch, p * a.d + p, st);
+    return launch_conv<false>(a, 2 * batch, p * a.d + p, st);
 }
 
 }  // namespace aft

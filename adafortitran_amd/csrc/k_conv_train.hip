@@ -1,0 +1,212 @@
+// k_conv_train.hip -- weight and bias gradients of a ConvEnhancer.
+//
+// Reference semantics: four 3x3 cross-correlations with zero padding 1, channels 1->8->32->8->1, ReLU
+// after the first three (reference src/models/blocks/enhancers.py:12-20); PyTorch's backward gives, for
+// conv k with input a_{k-1}, pre-activation gradient g_k and weight [co][ci][ky][kx]:
+//     dW_k[co][ci][ky][kx] = sum_{n,s,t} g_k[n][co][s][t] * a_{k-1}[n][ci][s+ky-1][t+kx-1]
+//     db_k[co]             = sum_{n,s,t} g_k[n][co][s][t]
+// The forward (k_conv.hip, training variant) saves a_1..a_3 and its backward run saves g_1..g_3, all as
+// [plane][channel][symbol column][subcarrier row] (rows contiguous); a_0 (the stack's input) and g_4 (the
+// incoming gradient) are PyTorch planes [plane][row][column].
+//
+// conv2 and conv3 hold 2 x 2304 of the 2 x 2376 weights and nearly all the FLOPs.  Both are the same
+// product "32-channel tensor x 8-channel tensor shifted by the nine taps":
+//     conv2: dW2[a][b][tap] = sum A32=g2[a][p] * B8=a1[b][p + (tap-1)]
+//     conv3: dW3[b][a][tap] = sum A32=a2[a][p] * B8=g3[b][p - (tap-1)]
+// computed on v_mfma_f32_32x32x2_f32 with K = pixels: M = the 32 channels, N = (tap, b) = 72 of 96.
+// A wave takes chunks of 64 rows of one column of one plane, stages the A rows and the three B columns
+// (one halo row each side) coalesced into wave-private LDS, reads fragments from there (A: row stride
+// 65 floats, conflict-free), and keeps its 32 x 96 partial in registers across all its chunks; the four
+// waves of a workgroup are summed through LDS into one slice, slices by the shared fixed-order reduction.
+#include "aft_internal.h"
+
+namespace aft {
+
+constexpr int kWgA = 32 * 65, kWgBRow = 68, kWgB = 25 * kWgBRow;   // 24 (channel, column) rows + one zero row
+constexpr int kWgWave = kWgA + kWgB;                                // floats of LDS per wave (3780 >= 48*64 for the final sum)
+constexpr int kWgradSlices = 512;
+
+struct Wgrad32x8Args {
+    const float *A, *B;   // [planes][32][T][S], [planes][8][T][S]
+    float *slices;        // [gridDim.x][2304]
+    int planes, S, T, sign, sa, sb;   // out index = a * sa + b * sb + tap
+};
+
+__global__ __launch_bounds__(256) void wgrad32x8_kernel(const Wgrad32x8Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, kh = lane >> 5;
+    float *As = lds + wave * kWgWave, *Bs = As + kWgA;
+    const int S = a.S, T = a.T, schunks = (S + 63) / 64;
+    const int nchunks = a.planes * T * schunks;
+
+    // per-lane B fragment row for the three N tiles: column jn = 32 nt + i -> (tap = jn >> 3, b = jn & 7)
+    int boff[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int jn = 32 * nt + i, tap = jn >> 3, b = jn & 7, ky = tap / 3, kx = tap % 3;
+        boff[nt] = tap < 9 ? (b * 3 + kx) * kWgBRow + 1 + a.sign * (ky - 1) : 24 * kWgBRow + 1;
+    }
+    for (int q = lane; q < kWgBRow; q += 64) Bs[24 * kWgBRow + q] = 0.f;   // the zero row (padding taps)
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+    for (int c = blockIdx.x * 4 + wave; c < nchunks; c += gridDim.x * 4) {
+        const int sc = c % schunks, t = (c / schunks) % T, n = c / (schunks * T), s0 = sc * 64;
+        // ---- stage: A rows [32][64], B rows [8 channels][3 columns][66] ----
+        const float *ap = a.A + ((size_t)n * 32 * T + t) * S + s0;
+#pragma unroll 8
+        for (int ch = 0; ch < 32; ++ch) As[ch * 65 + lane] = s0 + lane < S ? ap[(size_t)ch * T * S + lane] : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tb = t + a.sign * (kx - 1);
+            const bool col_ok = tb >= 0 && tb < T;
+            const float *bp = a.B + ((size_t)n * 8 * T + (col_ok ? tb : 0)) * S;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float *row = bp + (size_t)b * T * S;
+                const int s = s0 - 1 + lane;
+                Bs[(b * 3 + kx) * kWgBRow + lane] = col_ok && s >= 0 && s < S ? row[s] : 0.f;
+                if (lane < 2) {
+                    const int s2 = s0 + 63 + lane;
+                    Bs[(b * 3 + kx) * kWgBRow + 64 + lane] = col_ok && s2 < S ? row[s2] : 0.f;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the staging writes of all lanes precede the fragment reads
+        __builtin_amdgcn_wave_barrier();
+        // ---- K = 64 pixels: 32 k-pairs x 3 N tiles ----
+        const float *af = As + i * 65 + kh;
+#pragma unroll 8
+        for (int kb = 0; kb < 32; ++kb) {
+            const float av = af[2 * kb];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bs[boff[nt] + 2 * kb + kh], acc[nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... and the reads precede the next chunk's writes
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- sum the four waves, write this workgroup's slice ----
+    __syncthreads();
+    float *mine = lds + wave * kWgWave;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[(nt * 16 + e) * 64 + lane] = acc[nt][e];
+    __syncthreads();
+    if (wave == 0) {
+        float *out = a.slices + (size_t)blockIdx.x * 2304;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int jn = 32 * nt + i, tap = jn >> 3, b = jn & 7;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int idx = (nt * 16 + e) * 64 + lane;
+                const float v = (lds[idx] + lds[kWgWave + idx]) + (lds[2 * kWgWave + idx] + lds[3 * kWgWave + idx]);
+                const int ach = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (tap < 9) out[ach * a.sa + b * a.sb + tap] = v;
+            }
+        }
+    }
+}
+
+// result[a][tap] = sum_p A8[a][p] * B1[p + sign * (tap - 1)],  A8 [planes][8][T][S], B1 [planes][S][T]
+// one thread per pixel (row fastest), 72 accumulators, one slice per workgroup
+__global__ __launch_bounds__(256) void wgrad8x1_kernel(const float *__restrict__ A8, const float *__restrict__ B1,
+                                                       float *__restrict__ slices, int planes, int S, int T, int sign) {
+    __shared__ float part[4][72];
+    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;   // p = t * S + s
+    float acc[72];
+#pragma unroll
+    for (int q = 0; q < 72; ++q) acc[q] = 0.f;
+    if (p < S * T) {
+        const int t = p / S, s = p - t * S;
+        float win[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ss = s + sign * (tap / 3 - 1), tt = t + sign * (tap % 3 - 1);
+            win[tap] = ss >= 0 && ss < S && tt >= 0 && tt < T ? B1[((size_t)n * S + ss) * T + tt] : 0.f;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const float av = A8[((size_t)(n * 8 + ch) * T + t) * S + s];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc[ch * 9 + tap] = av * win[tap];
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 72; ++q) {
+        float v = acc[q];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) part[wave][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 72)
+        slices[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 72 + threadIdx.x] =
+            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// per-channel sums of X [planes][C][npix] (bias gradients): one workgroup per (plane, channel),
+// slices[plane][C]
+__global__ __launch_bounds__(256) void chsum_kernel(const float *__restrict__ X, float *__restrict__ slices, int npix) {
+    __shared__ float part[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *x = X + (size_t)blockIdx.x * npix;   // blockIdx.x = plane * C + channel
+    float v = 0.f;
+    for (int p = threadIdx.x; p < npix; p += 256) v += x[p];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) slices[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+size_t conv_wgrad_slice_floats(int planes, int S, int T) {
+    return std::max<size_t>((size_t)kWgradSlices * 2304, (size_t)planes * ((S * T + 255) / 256) * 72);
+}
+
+hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, const float *c3, const float *g1,
+                             const float *g2, const float *g3, const float *dy, float *const dw[4], float *const db[4],
+                             float *slices, int planes, int S, int T, bool accumulate, hipStream_t st) {
+    const int npix = S * T, pblocks = (npix + 255) / 256;
+    static bool attr_set = false;
+    const size_t lds = sizeof(float) * 4 * kWgWave;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad32x8_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int chunks = planes * T * ((S + 63) / 64);
+    const int grid = std::max(1, std::min(kWgradSlices, (chunks + 3) / 4));
+    hipError_t e;
+    // conv2: dW2[co = a][ci = b][tap]          A32 = g2, B8 = a1, shift +
+    Wgrad32x8Args w2{g2, c1, slices, planes, S, T, +1, 72, 9};
+    hipLaunchKernelGGL(wgrad32x8_kernel, dim3(grid), dim3(256), lds, st, w2);
+    if ((e = launch_reduce_slices(slices, dw[1], 2304, grid, 2304, accumulate, st)) != hipSuccess) return e;
+    // conv3: dW3[co = b][ci = a][tap]          A32 = a2, B8 = g3, shift -
+    Wgrad32x8Args w3{c2, g3, slices, planes, S, T, -1, 9, 288};
+    hipLaunchKernelGGL(wgrad32x8_kernel, dim3(grid), dim3(256), lds, st, w3);
+    if ((e = launch_reduce_slices(slices, dw[2], 2304, grid, 2304, accumulate, st)) != hipSuccess) return e;
+    // conv1: dW1[co][tap] = sum g1[co][p] x[p + (tap-1)];  conv4: dW4[ci][tap] = sum a3[ci][p'] dy[p' - (tap-1)]
+    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, planes), dim3(256), 0, st, g1, x, slices, planes, S, T, +1);
+    if ((e = launch_reduce_slices(slices, dw[0], 72, planes * pblocks, 72, accumulate, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, planes), dim3(256), 0, st, c3, dy, slices, planes, S, T, -1);
+    if ((e = launch_reduce_slices(slices, dw[3], 72, planes * pblocks, 72, accumulate, st)) != hipSuccess) return e;
+    // biases: channel sums of the pre-activation gradients
+    const float *gs[4] = {g1, g2, g3, dy};
+    const int cs[4] = {8, 32, 8, 1};
+    for (int k = 0; k < 4; ++k) {
+        hipLaunchKernelGGL(chsum_kernel, dim3(planes * cs[k]), dim3(256), 0, st, gs[k], slices, npix);
+        if ((e = launch_reduce_slices(slices, db[k], cs[k], planes, cs[k], accumulate, st)) != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace aft

@@ -85,6 +85,58 @@ class HipEncoderLayerFunction(torch.autograd.Function):
         return (dx, None, None, None, *grads)
 
 
+def _ptr4(tensors):
+    arr = (C.c_void_p * 4)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class HipConvEnhancerFunction(torch.autograd.Function):
+    """ConvEnhancer (3x3 convs 1->8->32->8->1, ReLU after the first three; reference
+    ``blocks/enhancers.py:5-31``) on x [N,1,S,T]: forward = the fused conv-stack kernel in its training
+    variant (keeps the three hidden activations), backward = the same kernel run on the gradient with
+    transposed, flipped weights (data gradient) + the weight/bias-gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4):
+        lib = _lib.load()
+        x = x.contiguous()
+        n, _, S, T = x.shape
+        ws = [w.detach().contiguous() for w in (w1, w2, w3, w4)]
+        bs = [b.detach().contiguous() for b in (b1, b2, b3, b4)]
+        y = torch.empty_like(x)
+        c1 = torch.empty((n, 8, T, S), dtype=torch.float32, device=x.device)
+        c2 = torch.empty((n, 32, T, S), dtype=torch.float32, device=x.device)
+        c3 = torch.empty((n, 8, T, S), dtype=torch.float32, device=x.device)
+        _lib.check(lib.aft_conv_enhancer_fwd_train_f32(C.byref(_ptr4(ws)), C.byref(_ptr4(bs)), x.data_ptr(), y.data_ptr(),
+                                                       c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), n, S, T,
+                                                       _lib.current_stream_ptr(x.device)))
+        ctx.save_for_backward(x, c1, c2, c3, *ws)
+        ctx.param_objs = (w1, b1, w2, b2, w3, b3, w4, b4)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, c1, c2, c3, *ws = ctx.saved_tensors
+        n, _, S, T = x.shape
+        dy = dy.contiguous()
+        flipped = [w.transpose(0, 1).flip(2, 3).contiguous() for w in reversed(ws)]   # conv4^T .. conv1^T
+        objs = ctx.param_objs
+        direct = ACCUMULATE_INTO_GRAD and all(p.grad is not None and p.grad.is_contiguous() for p in objs)
+        grads = [p.grad for p in objs] if direct else [torch.empty_like(p) for p in objs]
+        dx = torch.empty_like(x)
+        scratch = torch.empty(lib.aft_conv_enhancer_scratch_bytes(n, S, T), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.aft_conv_enhancer_bwd_f32(C.byref(_ptr4(flipped)), x.data_ptr(), c1.data_ptr(), c2.data_ptr(),
+                                                 c3.data_ptr(), dy.data_ptr(), dx.data_ptr(), C.byref(_ptr4(grads[0::2])),
+                                                 C.byref(_ptr4(grads[1::2])), int(direct), scratch.data_ptr(), scratch.numel(),
+                                                 n, S, T, _lib.current_stream_ptr(x.device)))
+        if direct:
+            return (dx,) + (None,) * 8
+        return (dx, *grads)
+
+
 def layer_params(layer: torch.nn.Module):
     """The twelve parameter tensors of one nn.TransformerEncoderLayer, ABI order."""
     named = dict(layer.named_parameters())

@@ -155,6 +155,23 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
                               int accumulate, void *scratch, size_t scratch_bytes, int batch, float dropout_p,
                               uint64_t seed, void *stream);
 
+/* ConvEnhancer (reference src/models/blocks/enhancers.py:5-31: conv 1->8->32->8->1, ReLU after the
+ * first three) in train() mode on `planes` real planes x, y: f32 [planes, S, T].  weights[k] / biases[k]
+ * are conv_block.{0,2,4,6}.{weight,bias} in PyTorch layout.  c1, c2, c3 receive the activations the
+ * backward needs: f32 [planes, C, T, S] with C = 8, 32, 8 (an internal layout; treat as opaque). */
+int aft_conv_enhancer_fwd_train_f32(const float *const weights[4], const float *const biases[4], const float *x, float *y,
+                                    float *c1, float *c2, float *c3, int planes, int num_scs, int num_symbols, void *stream);
+
+/* Backward of that call: dy = dL/dy -> dx = dL/dx and the eight parameter gradients (PyTorch layouts;
+ * overwritten, or added to when accumulate != 0).  flipped_weights[k] must hold
+ * weights[3-k].transpose(0,1).flip(2,3) made contiguous ([8,1,3,3], [32,8,3,3], [8,32,3,3], [1,8,3,3]):
+ * the data gradient of the stack is the stack itself run on dy with those. */
+size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols);
+int aft_conv_enhancer_bwd_f32(const float *const flipped_weights[4], const float *x, const float *c1, const float *c2,
+                              const float *c3, const float *dy, float *dx, float *const dweights[4], float *const dbiases[4],
+                              int accumulate, void *scratch, size_t scratch_bytes, int planes, int num_scs, int num_symbols,
+                              void *stream);
+
 /* Replaces torch.optim.Adam.step (reference src/main/trainer.py:407-413; amsgrad off) on one flat
  * float32 shard of n elements: grad is first multiplied by grad_scale (1/world_size after a
  * sum-reduce-scatter), weight_decay is the L2 form Adam uses; `step` is the 1-based step count. */

@@ -53,6 +53,7 @@ def main():
         if a.only and a.only != mode:
             continue
         model.transformer_encoder.hip_training = mode == "hip"
+        model.initial_enhancer.hip_training = model.final_refiner.hip_training = mode == "hip"
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize()
