@@ -70,6 +70,10 @@ def load():
     lib.aft_conv_enhancer_fwd_train_f32.argtypes = [C.POINTER(p4), C.POINTER(p4), vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_conv_enhancer_bwd_f32.argtypes = [C.POINTER(p4), vp, vp, vp, vp, vp, vp, C.POINTER(p4), C.POINTER(p4), C.c_int, vp,
                                               C.c_size_t, C.c_int, C.c_int, C.c_int, vp]
+    lib.aft_dense_bwd_scratch_bytes.restype = C.c_size_t
+    lib.aft_dense_bwd_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.aft_dense_fwd_f32.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.aft_dense_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_adam_step_f32.argtypes = [vp, vp, vp, vp, C.c_size_t] + [C.c_float] * 6 + [C.c_int, vp]
     for name in _abi.EXPORTED_SYMBOLS:
         if name not in _abi.SIZE_SYMBOLS + ("aft_version", "aft_last_error"):

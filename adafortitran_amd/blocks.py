@@ -19,6 +19,8 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
+from .training import HipLinear   # nn.Linear whose grad-enabled forward on the HIP device runs the library's GEMMs
+
 
 class ConvEnhancer(nn.Module):
     """3x3 conv stack 1->8->32->8->1 (ReLU between) under the key ``conv_block.{0,2,4,6}``
@@ -89,7 +91,7 @@ class ChannelAdapter(nn.Module):
         h0, h1, h2 = hidden_sizes
 
         def mlp() -> nn.Sequential:
-            return nn.Sequential(nn.Linear(1, h0), nn.ReLU(), nn.Linear(h0, h1), nn.ReLU(), nn.Linear(h1, h2))
+            return nn.Sequential(HipLinear(1, h0), nn.ReLU(), HipLinear(h0, h1), nn.ReLU(), HipLinear(h1, h2))
 
         self.snr_encoder, self.ds_encoder, self.dop_encoder = mlp(), mlp(), mlp()
 
@@ -138,7 +140,7 @@ class TransformerEncoderForChannels(nn.Module):
                  activation: str = "gelu", dropout: float = 0.1, num_layers: int = 3, max_len: int = 512,
                  pos_encoding_type: str = "learnable") -> None:
         super().__init__()
-        self.linear_1 = nn.Linear(input_dim, model_dim)
+        self.linear_1 = HipLinear(input_dim, model_dim)
         if pos_encoding_type == "learnable":
             self.positional_encoding = LearnablePositionalEncoding(max_len, model_dim)
         elif pos_encoding_type == "sinusoidal":
@@ -148,7 +150,7 @@ class TransformerEncoderForChannels(nn.Module):
         layer = nn.TransformerEncoderLayer(d_model=model_dim, nhead=num_head, dim_feedforward=2 * model_dim,
                                            activation=activation, dropout=dropout, batch_first=True)
         self.transformer = nn.TransformerEncoder(layer, num_layers=num_layers)
-        self.linear_2 = nn.Linear(model_dim, output_dim)
+        self.linear_2 = HipLinear(model_dim, output_dim)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = self.positional_encoding(self.linear_1(x))

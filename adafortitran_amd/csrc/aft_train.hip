@@ -181,6 +181,44 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     return AFT_OK;
 }
 
+static size_t dense_slice_floats(int rows, int in_f, int out_f) {
+    const int tiles = ((in_f + 127) / 128) * ((out_f + 127) / 128);
+    return al64((size_t)gemm_split_slices(rows, tiles) * in_f * out_f) + al64((size_t)colsum_slices(rows) * out_f);
+}
+
+size_t aft_dense_bwd_scratch_bytes(int rows, int in_features, int out_features) {
+    if (rows <= 0 || in_features <= 0 || out_features <= 0) return 0;
+    return sizeof(float) * dense_slice_floats(rows, in_features, out_features);
+}
+
+int aft_dense_fwd_f32(const float *x, const float *weight, const float *bias, float *y, int rows, int in_features,
+                      int out_features, void *stream) {
+    if (!x || !weight || !y || rows <= 0 || in_features <= 0 || out_features <= 0) { set_error("bad dense argument"); return AFT_ERR_ARG; }
+    STEP("dense forward", launch_gemm(0, x, weight, y, bias, rows, out_features, in_features, in_features, in_features,
+                                      out_features, false, static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
+int aft_dense_bwd_f32(const float *x, const float *weight, const float *dy, float *dx, float *dweight, float *dbias,
+                      int accumulate, void *scratch, size_t scratch_bytes, int rows, int in_features, int out_features,
+                      void *stream) {
+    if (!x || !weight || !dy || !dweight || !scratch || rows <= 0 || in_features <= 0 || out_features <= 0) {
+        set_error("bad dense argument");
+        return AFT_ERR_ARG;
+    }
+    if (scratch_bytes < aft_dense_bwd_scratch_bytes(rows, in_features, out_features)) { set_error("dense scratch too small"); return AFT_ERR_ARG; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *sl = static_cast<float *>(scratch);
+    const int tiles = ((in_features + 127) / 128) * ((out_features + 127) / 128);
+    float *sl2 = sl + al64((size_t)gemm_split_slices(rows, tiles) * in_features * out_features);
+    if (dx) STEP("dense dgrad", launch_gemm(1, dy, weight, dx, nullptr, rows, in_features, out_features, out_features, in_features,
+                                            in_features, false, st));
+    STEP("dense wgrad", launch_gemm_tn(dy, x, dweight, sl, out_features, in_features, rows, out_features, in_features,
+                                       accumulate != 0, st));
+    if (dbias) STEP("dense bgrad", launch_colsum(dy, dbias, sl2, rows, out_features, out_features, accumulate != 0, st));
+    return AFT_OK;
+}
+
 size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols) {
     if (planes <= 0 || num_scs <= 0 || num_symbols <= 0) return 0;
     return sizeof(float) * (al64((size_t)planes * 48 * num_scs * num_symbols) + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols)));

@@ -24,12 +24,18 @@ constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
 // tile element (x, k), source contiguous in k:  src[(x0 + x) * ld + k0 + k]
 template <int NU>
 __device__ __forceinline__ void load_kc(const float *__restrict__ src, int ld, int x0, int xlim, int k0, int klim,
-                                        int tid, f32x4 (&v)[NU]) {
+                                        int tid, bool vec, f32x4 (&v)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u, x = e >> 2, kq = e & 3;
         const bool ok = x0 + x < xlim && k0 + 4 * kq < klim;
-        v[u] = ok ? *reinterpret_cast<const f32x4 *>(src + (size_t)(x0 + x) * ld + k0 + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *p = src + (size_t)(x0 + x) * ld + k0 + 4 * kq;
+        if (vec) {
+            v[u] = ok ? *reinterpret_cast<const f32x4 *>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {   // row length or leading dimension not a multiple of 4: element-wise, guarded
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[u][c] = ok && k0 + 4 * kq + c < klim ? p[c] : 0.f;
+        }
     }
 }
 template <int NU>
@@ -44,12 +50,18 @@ __device__ __forceinline__ void store_kc(float *__restrict__ lds, int tid, const
 // tile element (x, k), source contiguous in x:  src[(k0 + k) * ld + x0 + x]
 template <int NU>   // NU = 2: 128-wide tile (32 vec4 per k row); NU = 1: 64-wide tile (16 vec4 per k row)
 __device__ __forceinline__ void load_xc(const float *__restrict__ src, int ld, int x0, int xlim, int k0, int klim,
-                                        int tid, f32x4 (&v)[NU]) {
+                                        int tid, bool vec, f32x4 (&v)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u, k = e >> (3 + NU), xq = e & (16 * NU - 1);
         const bool ok = k0 + k < klim && x0 + 4 * xq < xlim;
-        v[u] = ok ? *reinterpret_cast<const f32x4 *>(src + (size_t)(k0 + k) * ld + x0 + 4 * xq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *p = src + (size_t)(k0 + k) * ld + x0 + 4 * xq;
+        if (vec) {
+            v[u] = ok ? *reinterpret_cast<const f32x4 *>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[u][c] = ok && x0 + 4 * xq + c < xlim ? p[c] : 0.f;
+        }
     }
 }
 template <int NU>
@@ -61,7 +73,7 @@ __device__ __forceinline__ void store_xc(float *__restrict__ lds, int tid, const
     }
 }
 
-// OP: 0 = NT, 1 = NN, 2 = TN (see header).  M, N multiples of 4; K multiple of 4 for NT/NN.
+// OP: 0 = NT, 1 = NN, 2 = TN (see header).  Any M, N, K (16-byte loads where the operand allows them).
 // BM = rows of C per workgroup: 128 (each wave 64x64) or 64 (each wave 32x64), the latter for launches
 // whose 128-row tiling would leave the 256 CUs with two workgroups each.
 template <int OP, int BM>
@@ -86,10 +98,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+    // 16-byte loads need 4-aligned leading dimensions, extents and base pointers; otherwise element-wise
+    const bool veca = !(lda & 3) && !((OP == 2 ? M : K) & 3) && !((size_t)A & 15);
+    const bool vecb = !(ldb & 3) && !((OP == 0 ? K : N) & 3) && !((size_t)B & 15);
     f32x4 ra[NUA], rb[2];
     auto fetch = [&](int k0) {
-        if constexpr (OP == 2) load_xc(A, lda, m0, M, k0, kend, tid, ra); else load_kc(A, lda, m0, M, k0, kend, tid, ra);
-        if constexpr (OP == 0) load_kc(B, ldb, n0, N, k0, kend, tid, rb); else load_xc(B, ldb, n0, N, k0, kend, tid, rb);
+        if constexpr (OP == 2) load_xc(A, lda, m0, M, k0, kend, tid, veca, ra); else load_kc(A, lda, m0, M, k0, kend, tid, veca, ra);
+        if constexpr (OP == 0) load_kc(B, ldb, n0, N, k0, kend, tid, vecb, rb); else load_xc(B, ldb, n0, N, k0, kend, tid, vecb, rb);
     };
     auto stage = [&](int buf) {
         if constexpr (OP == 2) store_xc(As[buf], tid, ra); else store_kc(As[buf], tid, ra);

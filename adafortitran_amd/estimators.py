@@ -26,6 +26,7 @@ from . import _abi
 from .blocks import (ChannelAdapter, ConvEnhancer, InversePatchEmbedding, PatchEmbedding,
                      TransformerEncoderForChannels)
 from .config import ModelConfig, SystemConfig, check_shape_coupling
+from .training import HipLinear
 
 
 class BaseFortiTranEstimator(nn.Module):
@@ -66,7 +67,7 @@ class BaseFortiTranEstimator(nn.Module):
 
     def _build_architecture(self) -> None:
         mc = self.model_config
-        self.pilot_upsampler = nn.Linear(self.pilot_features, self.ofdm_features)
+        self.pilot_upsampler = HipLinear(self.pilot_features, self.ofdm_features)
         self.initial_enhancer = ConvEnhancer()
         self.patch_embedder = PatchEmbedding(tuple(mc.patch_size))
         if self.use_channel_adaptation:

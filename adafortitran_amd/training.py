@@ -137,6 +137,63 @@ class HipConvEnhancerFunction(torch.autograd.Function):
         return (dx, *grads)
 
 
+class HipLinearFunction(torch.autograd.Function):
+    """y = x W^T + b on [..., in] float32 tensors: the row-major MFMA GEMM forward, dgrad, split-K wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w = weight.detach().contiguous()
+        b = None if bias is None else bias.detach().contiguous()
+        y = torch.empty((x2.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+        _lib.check(lib.aft_dense_fwd_f32(x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(),
+                                         x2.shape[0], w.shape[1], w.shape[0], _lib.current_stream_ptr(x.device)))
+        ctx.save_for_backward(x2, w)
+        ctx.param_objs = (weight, bias)
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, w = ctx.saved_tensors
+        weight, bias = ctx.param_objs
+        dy2 = dy.reshape(-1, w.shape[0]).contiguous()
+        rows, out_f, in_f = x2.shape[0], w.shape[0], w.shape[1]
+        direct = ACCUMULATE_INTO_GRAD and weight.grad is not None and weight.grad.is_contiguous() and (
+            bias is None or (bias.grad is not None and bias.grad.is_contiguous()))
+        dw = weight.grad if direct else torch.empty_like(w)
+        db = None if bias is None else (bias.grad if direct else torch.empty_like(bias))
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        scratch = torch.empty(lib.aft_dense_bwd_scratch_bytes(rows, in_f, out_f), dtype=torch.uint8, device=dy.device)
+        _lib.check(lib.aft_dense_bwd_f32(x2.data_ptr(), w.data_ptr(), dy2.data_ptr(), None if dx is None else dx.data_ptr(),
+                                         dw.data_ptr(), None if db is None else db.data_ptr(), int(direct), scratch.data_ptr(),
+                                         scratch.numel(), rows, in_f, out_f, _lib.current_stream_ptr(dy.device)))
+        gx = None if dx is None else dx.view(ctx.x_shape)
+        if direct:
+            return gx, None, None
+        return gx, dw, db
+
+
+class HipLinear(torch.nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) that CAN run its grad-enabled float32 forward and
+    backward on the library's GEMMs (HipLinearFunction).  Off by default: the model's own dense layers are
+    thin (6..24 columns on one side) and the 128-wide MFMA tile wastes most of its work on them, so
+    hipBLASLt's skinny kernels are faster there (measured: +0.6 ms per training step with this on).  Turn on
+    per module (``lin.hip_training = True``) or globally (``HipLinear.default_hip_training = True``)."""
+
+    default_hip_training = False
+    hip_training = None   # None = follow the class default
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        on = HipLinear.default_hip_training if self.hip_training is None else self.hip_training
+        if (on and x.device.type == "cuda" and torch.is_grad_enabled() and x.dtype == torch.float32
+                and self.weight.dtype == torch.float32):
+            return HipLinearFunction.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 def layer_params(layer: torch.nn.Module):
     """The twelve parameter tensors of one nn.TransformerEncoderLayer, ABI order."""
     named = dict(layer.named_parameters())

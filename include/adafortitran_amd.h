@@ -155,6 +155,17 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
                               int accumulate, void *scratch, size_t scratch_bytes, int batch, float dropout_p,
                               uint64_t seed, void *stream);
 
+/* nn.Linear in the training path (pilot_upsampler fortitran.py:86, linear_1 / linear_2 encoders.py:33,56,
+ * the adapter MLPs channel_adaptivity.py:35-39): y[rows,out] = x[rows,in] W[out,in]^T + b, and its
+ * backward dx = dy W (skipped when dx is NULL), dW (+)= dy^T x, db (+)= column sums of dy (NULL: none).
+ * Any sizes; the weight gradient's reduction over rows is split and summed in a fixed order. */
+int aft_dense_fwd_f32(const float *x, const float *weight, const float *bias, float *y, int rows, int in_features,
+                      int out_features, void *stream);
+size_t aft_dense_bwd_scratch_bytes(int rows, int in_features, int out_features);
+int aft_dense_bwd_f32(const float *x, const float *weight, const float *dy, float *dx, float *dweight, float *dbias,
+                      int accumulate, void *scratch, size_t scratch_bytes, int rows, int in_features, int out_features,
+                      void *stream);
+
 /* ConvEnhancer (reference src/models/blocks/enhancers.py:5-31: conv 1->8->32->8->1, ReLU after the
  * first three) in train() mode on `planes` real planes x, y: f32 [planes, S, T].  weights[k] / biases[k]
  * are conv_block.{0,2,4,6}.{weight,bias} in PyTorch layout.  c1, c2, c3 receive the activations the

@@ -147,7 +147,10 @@ def test_full_model_training_step_matches_pytorch_autograd(name):
     call = (lambda: model(pil, meta)) if meta is not None else (lambda: model(pil))
 
     def step(hip):
+        from adafortitran_amd import training
         model.transformer_encoder.hip_training = hip
+        model.initial_enhancer.hip_training = model.final_refiner.hip_training = hip
+        training.HipLinear.default_hip_training = hip
         model.zero_grad()
         out = call()
         loss = torch.nn.functional.mse_loss(torch.view_as_real(out), torch.view_as_real(tgt))
@@ -281,3 +284,27 @@ def test_conv_enhancer_forward_backward_matches_autograd(S, T, n):
     assert _rel(gx1, gx0) <= 1e-4
     for (name, _), a, b in zip(enh.named_parameters(), g1, g0):
         assert _rel(a, b) <= 2e-4, name
+
+
+@pytest.mark.parametrize("rows,in_f,out_f,bias", [(560, 12, 128, True), (561, 6, 128, True), (1120, 128, 6, True),
+                                                   (37, 1, 7, True), (128, 42, 560, False), (256, 24, 1680, True)])
+def test_dense_layer_forward_backward_matches_autograd(rows, in_f, out_f, bias):
+    """HipLinear on the layer shapes of the model (including row lengths that are not a multiple of 4)."""
+    from adafortitran_amd.training import HipLinear
+    torch.manual_seed(rows + in_f)
+    lin = HipLinear(in_f, out_f, bias=bias).cuda()
+    x = torch.randn(rows, in_f, device="cuda", requires_grad=True)
+    gy = torch.randn(rows, out_f, device="cuda")
+
+    def run(hip):
+        lin.hip_training = hip
+        lin.zero_grad(); x.grad = None
+        y = lin(x)
+        y.backward(gy)
+        return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in lin.parameters()]
+
+    y0, gx0, g0 = run(False)
+    y1, gx1, g1 = run(True)
+    assert _rel(y1, y0) <= 1e-5 and _rel(gx1, gx0) <= 1e-5
+    for a, b in zip(g1, g0):
+        assert _rel(a, b) <= 1e-4

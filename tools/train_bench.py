@@ -7,7 +7,7 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import adafortitran_amd as A
-from adafortitran_amd import synth
+from adafortitran_amd import synth, training
 
 
 def build(name, dropout):
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--model", default="adafortitran")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--only", default="", help="hip | torch")
+    ap.add_argument("--dense", default="blas", choices=["blas", "hip"], help="thin dense layers: hipBLASLt (default) or the library GEMM")
     ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"], help="flat = ShardedFlatAdam (fused kernel)")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -54,6 +55,7 @@ def main():
             continue
         model.transformer_encoder.hip_training = mode == "hip"
         model.initial_enhancer.hip_training = model.final_refiner.hip_training = mode == "hip"
+        training.HipLinear.default_hip_training = mode == "hip" and a.dense == "hip"
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize()
