@@ -53,6 +53,18 @@ constexpr int kConvThreads = 512;
 constexpr int kConvWaves = kConvThreads / 64;
 constexpr int kTileRows = 30;   // valid conv3 rows per 32-lane tile
 
+// 32-bit-offset buffer accesses for the training variant's saved tensors (each < 2 GB)
+using ConvSrd = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ ConvSrd conv_srd(const float *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float conv_ld(ConvSrd r, unsigned idx) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4u, 0, 0));
+}
+__device__ __forceinline__ void conv_st(ConvSrd r, unsigned idx, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, idx * 4u, 0, 0);
+}
+
 __device__ __forceinline__ float lane_from_below(float v) {   // lane i <- lane i-1 (DPP wave_shr:1)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
@@ -272,9 +284,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                 for (int k = 0; k < 4; ++k) {
                     float y = fmaxf(v[k] + bias3[k], 0.f);
                     if constexpr (TRAIN) {
-                        const size_t gi = ((size_t)(n * 8 + 4 * h + k) * T + tout) * S + gr;
-                        if (a.mask[2]) y = a.mask[2][gi] > 0.f ? v[k] : 0.f;
-                        if (a.save[2] && own_row) a.save[2][gi] = y;
+                        const unsigned gi = ((unsigned)(n * 8 + 4 * h + k) * T + tout) * S + gr;
+                        if (a.mask[2]) y = conv_ld(conv_srd(a.mask[2]), gi) > 0.f ? v[k] : 0.f;
+                        if (a.save[2] && own_row) conv_st(conv_srd(a.save[2]), gi, y);
                     }
                     p[k * plane] = y;
                 }
@@ -320,12 +332,18 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
             for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);   // ReLU, or 0 outside the plane
             if constexpr (TRAIN) {
                 if (a.mask[1] || a.save[1]) {
-                    const size_t g0 = ((size_t)(n * 32 + 4 * h) * T + tcol) * S + gr;   // channel (e&3) + 8(e>>2) + 4h
+                    const unsigned g0 = ((unsigned)(n * 32 + 4 * h) * T + tcol) * S + gr;   // channel (e&3) + 8(e>>2) + 4h
+                    const unsigned cstride = (unsigned)T * S;
+                    if (a.mask[1]) {
+                        const ConvSrd m = conv_srd(a.mask[1]);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const size_t gi = g0 + (size_t)((e & 3) + 8 * (e >> 2)) * T * S;
-                        if (a.mask[1]) x2[e] = (ok2 && a.mask[1][gi] > 0.f) ? acc2[e] : 0.f;
-                        if (a.save[1] && ok2 && own_row) a.save[1][gi] = x2[e];
+                        for (int e = 0; e < 16; ++e)
+                            x2[e] = (ok2 && conv_ld(m, g0 + ((e & 3) + 8 * (e >> 2)) * cstride) > 0.f) ? acc2[e] : 0.f;
+                    }
+                    if (a.save[1] && ok2 && own_row) {
+                        const ConvSrd sv = conv_srd(a.save[1]);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) conv_st(sv, g0 + ((e & 3) + 8 * (e >> 2)) * cstride, x2[e]);
                     }
                 }
             }
