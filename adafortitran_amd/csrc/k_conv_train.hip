@@ -54,30 +54,41 @@ __global__ __launch_bounds__(256) void wgrad32x8_kernel(const Wgrad32x8Args a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
 
-    for (int c = blockIdx.x * 4 + wave; c < nchunks; c += gridDim.x * 4) {
+    // chunk c = (plane n, column t, 64-row block): the 32 A rows, the 24 B rows (8 channels x 3 columns, 64
+    // values each) and their 2-value tails (lanes 0..47: row = lane / 2, one instruction for all 24) are
+    // fetched into registers one chunk ahead, so their latency hides under the previous chunk's MFMAs
+    float ra[32], rb[24], rt;
+    auto fetch = [&](int c) {
         const int sc = c % schunks, t = (c / schunks) % T, n = c / (schunks * T), s0 = sc * 64;
-        // ---- stage: A rows [32][64], B rows [8 channels][3 columns][66] ----
         const float *ap = a.A + ((size_t)n * 32 * T + t) * S + s0;
-#pragma unroll 8
-        for (int ch = 0; ch < 32; ++ch) As[ch * 65 + lane] = s0 + lane < S ? ap[(size_t)ch * T * S + lane] : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 32; ++ch) ra[ch] = s0 + lane < S ? ap[(size_t)ch * T * S + lane] : 0.f;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int tb = t + a.sign * (kx - 1);
             const bool col_ok = tb >= 0 && tb < T;
             const float *bp = a.B + ((size_t)n * 8 * T + (col_ok ? tb : 0)) * S;
+            const int s = s0 - 1 + lane;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const float *row = bp + (size_t)b * T * S;
-                const int s = s0 - 1 + lane;
-                Bs[(b * 3 + kx) * kWgBRow + lane] = col_ok && s >= 0 && s < S ? row[s] : 0.f;
-                if (lane < 2) {
-                    const int s2 = s0 + 63 + lane;
-                    Bs[(b * 3 + kx) * kWgBRow + 64 + lane] = col_ok && s2 < S ? row[s2] : 0.f;
-                }
-            }
+            for (int b = 0; b < 8; ++b) rb[b * 3 + kx] = col_ok && s >= 0 && s < S ? bp[(size_t)b * T * S + s] : 0.f;
         }
+        {
+            const int row = lane >> 1, b = row / 3, kx = row % 3, tb = t + a.sign * (kx - 1), s2 = s0 + 63 + (lane & 1);
+            rt = lane < 48 && tb >= 0 && tb < T && s2 < S ? a.B[((size_t)(n * 8 + b) * T + tb) * S + s2] : 0.f;
+        }
+    };
+    const int c0 = blockIdx.x * 4 + wave, cstep = gridDim.x * 4;
+    if (c0 < nchunks) fetch(c0);
+    for (int c = c0; c < nchunks; c += cstep) {
+        // ---- stage registers -> LDS: A rows [32][64], B rows [24][66] ----
+#pragma unroll
+        for (int ch = 0; ch < 32; ++ch) As[ch * 65 + lane] = ra[ch];
+#pragma unroll
+        for (int row = 0; row < 24; ++row) Bs[row * kWgBRow + lane] = rb[row];
+        if (lane < 48) Bs[(lane >> 1) * kWgBRow + 64 + (lane & 1)] = rt;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the staging writes of all lanes precede the fragment reads
         __builtin_amdgcn_wave_barrier();
+        if (c + cstep < nchunks) fetch(c + cstep);
         // ---- K = 64 pixels: 32 k-pairs x 3 N tiles ----
         const float *af = As + i * 65 + kh;
 #pragma unroll 8

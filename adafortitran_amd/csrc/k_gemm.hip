@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
 
 // enough slices to put two workgroups on every CU whatever the number of output tiles, never fewer than 128 rows each
 int gemm_split_slices(int rows, int tiles) {
-    return std::max(1, std::min(std::min(kGemmMaxSlices, (512 + tiles - 1) / tiles), rows / 128));
+    return std::max(1, std::min(std::min(kGemmMaxSlices, (512 + tiles - 1) / tiles), rows / 128));   // swept 192..1024: flat above 512
 }
 int colsum_slices(int rows) { return std::max(1, std::min(kColsumMaxSlices, rows / 64)); }
 
