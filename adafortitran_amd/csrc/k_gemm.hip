@@ -22,15 +22,15 @@ namespace aft {
 constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
 
 // tile element (x, k), source contiguous in k:  src[(x0 + x) * ld + k0 + k]
-template <int NU>
+template <int NU, bool VEC>
 __device__ __forceinline__ void load_kc(const float *__restrict__ src, int ld, int x0, int xlim, int k0, int klim,
-                                        int tid, bool vec, f32x4 (&v)[NU]) {
+                                        int tid, f32x4 (&v)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u, x = e >> 2, kq = e & 3;
         const bool ok = x0 + x < xlim && k0 + 4 * kq < klim;
         const float *p = src + (size_t)(x0 + x) * ld + k0 + 4 * kq;
-        if (vec) {
+        if constexpr (VEC) {
             v[u] = ok ? *reinterpret_cast<const f32x4 *>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {   // row length or leading dimension not a multiple of 4: element-wise, guarded
 #pragma unroll
@@ -48,15 +48,15 @@ __device__ __forceinline__ void store_kc(float *__restrict__ lds, int tid, const
     }
 }
 // tile element (x, k), source contiguous in x:  src[(k0 + k) * ld + x0 + x]
-template <int NU>   // NU = 2: 128-wide tile (32 vec4 per k row); NU = 1: 64-wide tile (16 vec4 per k row)
+template <int NU, bool VEC>   // NU = 2: 128-wide tile (32 vec4 per k row); NU = 1: 64-wide tile (16 vec4 per k row)
 __device__ __forceinline__ void load_xc(const float *__restrict__ src, int ld, int x0, int xlim, int k0, int klim,
-                                        int tid, bool vec, f32x4 (&v)[NU]) {
+                                        int tid, f32x4 (&v)[NU]) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u, k = e >> (3 + NU), xq = e & (16 * NU - 1);
         const bool ok = k0 + k < klim && x0 + 4 * xq < xlim;
         const float *p = src + (size_t)(k0 + k) * ld + x0 + 4 * xq;
-        if (vec) {
+        if constexpr (VEC) {
             v[u] = ok ? *reinterpret_cast<const f32x4 *>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
@@ -75,8 +75,11 @@ __device__ __forceinline__ void store_xc(float *__restrict__ lds, int tid, const
 
 // OP: 0 = NT, 1 = NN, 2 = TN (see header).  Any M, N, K (16-byte loads where the operand allows them).
 // BM = rows of C per workgroup: 128 (each wave 64x64) or 64 (each wave 32x64), the latter for launches
-// whose 128-row tiling would leave the 256 CUs with two workgroups each.
-template <int OP, int BM>
+// whose 128-row tiling would leave the 256 CUs with two workgroups each.  VEC = both operands allow
+// 16-byte loads (4-aligned leading dimensions, extents and base pointers); the element-wise variant is a
+// separate instantiation so that the fast path keeps its loads branch-free and back to back.  (16-byte
+// loads need 4-element-aligned leading dimensions and extents; the base address only dword alignment.)
+template <int OP, int BM, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                    float *__restrict__ C, const float *__restrict__ bias, int M, int N,
                                                    int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
@@ -98,13 +101,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    // 16-byte loads need 4-aligned leading dimensions, extents and base pointers; otherwise element-wise
-    const bool veca = !(lda & 3) && !((OP == 2 ? M : K) & 3) && !((size_t)A & 15);
-    const bool vecb = !(ldb & 3) && !((OP == 0 ? K : N) & 3) && !((size_t)B & 15);
     f32x4 ra[NUA], rb[2];
     auto fetch = [&](int k0) {
-        if constexpr (OP == 2) load_xc(A, lda, m0, M, k0, kend, tid, veca, ra); else load_kc(A, lda, m0, M, k0, kend, tid, veca, ra);
-        if constexpr (OP == 0) load_kc(B, ldb, n0, N, k0, kend, tid, vecb, rb); else load_xc(B, ldb, n0, N, k0, kend, tid, vecb, rb);
+        if constexpr (OP == 2) load_xc<NUA, VEC>(A, lda, m0, M, k0, kend, tid, ra); else load_kc<NUA, VEC>(A, lda, m0, M, k0, kend, tid, ra);
+        if constexpr (OP == 0) load_kc<2, VEC>(B, ldb, n0, N, k0, kend, tid, rb); else load_xc<2, VEC>(B, ldb, n0, N, k0, kend, tid, rb);
     };
     auto stage = [&](int buf) {
         if constexpr (OP == 2) store_xc(As[buf], tid, ra); else store_kc(As[buf], tid, ra);
@@ -228,12 +228,25 @@ int gemm_split_slices(int rows, int tiles) {
 }
 int colsum_slices(int rows) { return std::max(1, std::min(kColsumMaxSlices, rows / 64)); }
 
+static bool gemm_vec_ok(int op, const float *A, const float *B, int M, int N, int K, int lda, int ldb) {
+    // gfx950 global loads of 16 bytes only need dword alignment of the address; what matters is that the
+    // four elements are consecutive in-bounds elements of one row
+    (void)A; (void)B;
+    const bool a = !(lda & 3) && !((op == 2 ? M : K) & 3);
+    const bool b = !(ldb & 3) && !((op == 0 ? K : N) & 3);
+    return a && b;
+}
+
 template <int OP, int BM>
 static void gemm_go(const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda, int ldb,
                     int ldc, bool accumulate, hipStream_t st) {
     const dim3 grid((N + GBN - 1) / GBN, (M + BM - 1) / BM, 1);
-    hipLaunchKernelGGL((gemm_kernel<OP, BM>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
-                       (int)accumulate);
+    if (gemm_vec_ok(OP, A, B, M, N, K, lda, ldb))
+        hipLaunchKernelGGL((gemm_kernel<OP, BM, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
+                           (int)accumulate);
+    else
+        hipLaunchKernelGGL((gemm_kernel<OP, BM, false>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
+                           (int)accumulate);
 }
 
 hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,
@@ -258,8 +271,12 @@ hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slice
     const int nz = gemm_split_slices(R, tiles);
     const int chunk = ((R + nz - 1) / nz + GBK - 1) / GBK * GBK;
     const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, nz);
-    hipLaunchKernelGGL((gemm_kernel<2, 128>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb, N,
-                       chunk, (size_t)M * N, 0);
+    if (gemm_vec_ok(2, A, B, M, N, R, lda, ldb))
+        hipLaunchKernelGGL((gemm_kernel<2, 128, true>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb, N,
+                           chunk, (size_t)M * N, 0);
+    else
+        hipLaunchKernelGGL((gemm_kernel<2, 128, false>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb,
+                           N, chunk, (size_t)M * N, 0);
     return launch_reduce_slices(slices, C, M * N, nz, (size_t)M * N, accumulate, st);
 }
 

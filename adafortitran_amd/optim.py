@@ -35,27 +35,28 @@ class FlatParameters:
         dev, dt = self.params[0].device, self.params[0].dtype
         if dt != torch.float32 or any(p.dtype != dt or p.device != dev for p in self.params):
             raise ValueError("FlatParameters needs float32 parameters on one device")
-        self.numel = sum(p.numel() for p in self.params)
+        # every tensor starts on a 64-byte boundary of the flat buffers (vector loads of the kernels)
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 15) // 16 * 16
+        self.numel = off
         self.padded = (self.numel + pad_to - 1) // pad_to * pad_to
         self.data = torch.zeros(self.padded, dtype=dt, device=dev)
         self.grad = torch.zeros(self.padded, dtype=dt, device=dev)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             self.data[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.data[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
-            off += n
 
     def zero_grad(self) -> None:
         """Keep the grad views alive (set_to_none would detach them from the flat buffer)."""
         self.grad.zero_()
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad[off:off + n].data_ptr():
                 p.grad = self.grad[off:off + n].view(p.shape)
-            off += n
 
 
 class ShardedFlatAdam(torch.optim.Optimizer):
