@@ -177,13 +177,13 @@ class HipLinearFunction(torch.autograd.Function):
 
 
 class HipLinear(torch.nn.Linear):
-    """nn.Linear (same parameters, same state_dict keys) that CAN run its grad-enabled float32 forward and
-    backward on the library's GEMMs (HipLinearFunction).  Off by default: the model's own dense layers are
-    thin (6..24 columns on one side) and the 128-wide MFMA tile wastes most of its work on them, so
-    hipBLASLt's skinny kernels are faster there (measured: +0.6 ms per training step with this on).  Turn on
-    per module (``lin.hip_training = True``) or globally (``HipLinear.default_hip_training = True``)."""
+    """nn.Linear (same parameters, same state_dict keys) whose grad-enabled float32 forward and backward on the
+    HIP device run the library's GEMMs (HipLinearFunction).  The model's dense layers are thin (6..24 columns
+    on one side), so they are memory-bound either way; measured 0.2-0.3 ms per training step faster than
+    hipBLASLt's choices for these shapes.  ``lin.hip_training = False`` (or
+    ``HipLinear.default_hip_training = False``) hands a layer back to PyTorch-ROCm."""
 
-    default_hip_training = False
+    default_hip_training = True
     hip_training = None   # None = follow the class default
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

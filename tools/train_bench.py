@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--model", default="adafortitran")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--only", default="", help="hip | torch")
-    ap.add_argument("--dense", default="blas", choices=["blas", "hip"], help="thin dense layers: hipBLASLt (default) or the library GEMM")
+    ap.add_argument("--dense", default="hip", choices=["blas", "hip"], help="thin dense layers: the library GEMM (default) or hipBLASLt")
     ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"], help="flat = ShardedFlatAdam (fused kernel)")
     a = ap.parse_args()
     torch.manual_seed(0)
