@@ -66,42 +66,84 @@ struct EmbedArgs {
     int S, T, p0, p1, tokens, d, din, planes;
 };
 
-// PMAX = unroll bound of the patch features: 6 (the default 3x2 patch and smaller) or 16
+// PMAX = unroll bound of the patch features: 6 (the default 3x2 patch and smaller) or 16.
+// Half a wave (32 lanes) owns one token at a time and walks tokens with a grid stride; lane l produces the
+// D/32 consecutive outputs l*D/32.. of its token.  The lane's slice of W1 ((p + 6) x D/32 values) and of
+// the bias stays in registers for all its tokens, so per token there are only the 6..12 broadcast input
+// loads, one 16-byte positional load and one 16-byte store: the kernel is bound by writing x.
 template <int D, bool ADAPTIVE, int PMAX>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
-    extern __shared__ float sm[];  // W1 transposed [din][D]
-    const int tid = threadIdx.x;
-    for (int i = tid; i < a.din * D; i += 256) sm[(i % a.din) * D + i / a.din] = a.w1[i];
-    constexpr int PER = D / 32;
-    const int tl = tid >> 5, lane32 = tid & 31;
-    const long row = (long)blockIdx.x * 8 + tl;
-    const bool live = row < (long)a.planes * a.tokens;
-    const int n = live ? (int)(row / a.tokens) : 0, t = live ? (int)(row % a.tokens) : 0;
+    constexpr int PER = D / 32, NF = ADAPTIVE ? PMAX + 6 : PMAX;
+    const int tid = threadIdx.x, hw = tid >> 5, lane32 = tid & 31;
     const int tw = a.T / a.p1, p = a.p0 * a.p1;
-    // all inputs of this token first (independent loads in flight together), then the FMAs
-    float vin[PMAX + 6];
-    const float *ce = a.conv_enhanced + ((size_t)n * a.S + (t / tw) * a.p0) * a.T + (t % tw) * a.p1;
-#pragma unroll
-    for (int f = 0; f < PMAX; ++f) vin[f] = f < p ? ce[(f / a.p1) * a.T + f % a.p1] : 0.f;
-    if constexpr (ADAPTIVE) {
-        const float *tk = a.tokens6 + ((size_t)(n >> 1) * a.tokens + t) * 6;
-#pragma unroll
-        for (int f = 0; f < 6; ++f) vin[PMAX + f] = tk[f];
-    }
-    float acc[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) acc[i] = a.b1[lane32 * PER + i] + a.pos[(size_t)t * D + lane32 * PER + i];
+    extern __shared__ float sm[];   // W1 transposed to [din][D]: staged once per workgroup with coalesced loads
+    for (int i = tid; i < a.din * D; i += 256) sm[(i % a.din) * D + i / a.din] = a.w1[i];
     __syncthreads();
-    if (!live) return;
+    float w[NF][PER], b1[PER];
 #pragma unroll
-    for (int f = 0; f < (ADAPTIVE ? PMAX + 6 : PMAX); ++f) {
-        if (f < PMAX && f >= p) continue;
-        const int frow = f < PMAX ? f : p + (f - PMAX);   // row of W1^T: patch features then adapter features
+    for (int f = 0; f < NF; ++f) {
+        const int frow = f < PMAX ? f : p + (f - PMAX);   // column of W1 [D][din]: patch features then adapter features
 #pragma unroll
-        for (int i = 0; i < PER; ++i) acc[i] = fmaf(sm[frow * D + lane32 * PER + i], vin[f], acc[i]);
+        for (int i = 0; i < PER; ++i) w[f][i] = (f < PMAX && f >= p) ? 0.f : sm[frow * D + lane32 * PER + i];
     }
 #pragma unroll
-    for (int i = 0; i < PER; ++i) a.x[row * D + lane32 * PER + i] = acc[i];
+    for (int i = 0; i < PER; ++i) b1[i] = a.b1[lane32 * PER + i];
+    // 32-bit token bookkeeping (the forward's size guard keeps rows * D below 2^31); the patch-element
+    // offsets are fixed per thread, (plane, token) advance incrementally: no division by a run-time value
+    // per element -- those were most of this kernel's instructions
+    const unsigned rows = (unsigned)a.planes * a.tokens, rstep = gridDim.x * 8u, tokens = a.tokens;
+    const unsigned dn = rstep / tokens, dt = rstep % tokens;
+    int poff[PMAX];
+#pragma unroll
+    for (int f = 0; f < PMAX; ++f) poff[f] = (f / a.p1) * a.T + f % a.p1;
+    struct Tok { unsigned row, n, t; };
+    auto advance = [&](Tok k) {
+        k.row += rstep; k.n += dn; k.t += dt;
+        if (k.t >= tokens) { k.t -= tokens; ++k.n; }
+        return k;
+    };
+    // inputs of a token (its patch elements, adapter features and positional slice); fetched one token
+    // ahead so that their latency hides under the previous token's FMAs and store
+    auto fetch = [&](const Tok &k, float (&vin)[NF], float (&ps)[PER]) {
+        const unsigned tq = k.t / (unsigned)tw, tr = k.t - tq * tw;
+        const float *ce = a.conv_enhanced + ((size_t)k.n * a.S + tq * a.p0) * a.T + tr * a.p1;
+#pragma unroll
+        for (int f = 0; f < PMAX; ++f) vin[f] = f < p ? ce[poff[f]] : 0.f;
+        if constexpr (ADAPTIVE) {
+            const float *tk = a.tokens6 + ((size_t)(k.n >> 1) * tokens + k.t) * 6;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) vin[PMAX + f] = tk[f];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) ps[i] = a.pos[k.t * D + lane32 * PER + i];
+    };
+    auto emit = [&](const Tok &k, const float (&vin)[NF], const float (&ps)[PER]) {
+        float acc[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) acc[i] = b1[i] + ps[i];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) acc[i] = fmaf(w[f][i], vin[f], acc[i]);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) a.x[(size_t)k.row * D + lane32 * PER + i] = acc[i];
+    };
+    float va[NF], pa[PER], vb[NF], pb[PER];
+    Tok k0;
+    k0.row = blockIdx.x * 8u + hw;
+    k0.n = k0.row / tokens;
+    k0.t = k0.row - k0.n * tokens;
+    if (k0.row < rows) fetch(k0, va, pa);
+    while (k0.row < rows) {
+        const Tok k1 = advance(k0), k2 = advance(k1);
+        if (k1.row < rows) fetch(k1, vb, pb);
+        emit(k0, va, pa);
+        if (k1.row < rows) {
+            if (k2.row < rows) fetch(k2, va, pa);
+            emit(k1, vb, pb);
+        }
+        k0 = k2;
+    }
 }
 
 hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced, const float *tokens6,
@@ -115,7 +157,7 @@ hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *
     a.din = a.p0 * a.p1 + (c.adaptive ? 6 : 0);
     a.planes = 2 * batch;
     const long rows = (long)a.planes * a.tokens;
-    const int blocks = (int)((rows + 7) / 8);
+    const int blocks = (int)std::min<long>((rows + 7) / 8, 1024);   // swept 256..4096 at B = 128: 4 waves per SIMD, ~9 tokens per half wave
     const size_t lds = sizeof(float) * a.din * a.d;
     const bool small = a.p0 * a.p1 <= 6;
     if (a.p0 * a.p1 > kMaxPatchFeatures) return hipErrorInvalidValue;   // check_config rejects these
