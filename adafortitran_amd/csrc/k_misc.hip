@@ -247,7 +247,7 @@ hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long l
     const long long n_floats = 2 * n_complex;
     long long blocks = (n_floats / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 128) blocks = 128;   // one float64 atomic per workgroup on ONE address: few, fat workgroups
     hipLaunchKernelGGL(mse_kernel, dim3((int)blocks), dim3(256), 0, st, est, ref, sum_sq, n_floats);
     return hipGetLastError();
 }
