@@ -31,10 +31,24 @@ __global__ __launch_bounds__(256) void adapter_kernel(const AdapterArgs a) {
         a1[i] = fmaxf(acc, 0.f);
     }
     __syncthreads();
+    // last layer: a row of h1 weights per output.  The kernel is latency-bound (three dependent layers, a
+    // few outputs per thread), so the row loads must all be in flight together: fully unrolled for the
+    // reference's default h1 = 42 (21 8-byte loads), a rolled loop otherwise.
     for (int i = tid; i < a.h2; i += 256) {
         float acc = a.b[e][2][i];
         const float *wr = a.w[e][2] + (size_t)i * a.h1;
-        for (int k = 0; k < a.h1; ++k) acc = fmaf(wr[k], a1[k], acc);
+        if (a.h1 == 42) {
+            f32x2 wv[21];
+#pragma unroll
+            for (int k = 0; k < 21; ++k) wv[k] = *reinterpret_cast<const f32x2 *>(wr + 2 * k);
+#pragma unroll
+            for (int k = 0; k < 21; ++k) {
+                acc = fmaf(wv[k][0], a1[2 * k], acc);
+                acc = fmaf(wv[k][1], a1[2 * k + 1], acc);
+            }
+        } else {
+            for (int k = 0; k < a.h1; ++k) acc = fmaf(wr[k], a1[k], acc);
+        }
         a.tokens6[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)] = acc;
     }
 }
