@@ -74,8 +74,7 @@ __device__ __forceinline__ void store_xc(float *__restrict__ lds, int tid, const
 }
 
 // OP: 0 = NT, 1 = NN, 2 = TN (see header).  Any M, N, K (16-byte loads where the operand allows them).
-// BM = rows of C per workgroup: 128 (each wave 64x64) or 64 (each wave 32x64), the latter for launches
-// whose 128-row tiling would leave the 256 CUs with two workgroups each.  VEC = both operands allow
+// BM = rows of C per workgroup: 128 (each wave 64x64; the split-K TN product) or 64 (each wave 32x64; NT / NN).  VEC = both operands allow
 // 16-byte loads (4-aligned leading dimensions, extents and base pointers); the element-wise variant is a
 // separate instantiation so that the fast path keeps its loads branch-free and back to back.  (16-byte
 // loads need 4-element-aligned leading dimensions and extents; the base address only dword alignment.)
@@ -89,20 +88,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     constexpr int TI = BM / 64, NUA = BM / 64;   // MFMA row tiles per wave; A-tile vec4 per thread
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GBN;
-    const int kbeg = blockIdx.z * k_chunk, kend = min(K, kbeg + k_chunk);
-    C += (size_t)blockIdx.z * c_slice;
-
-    f32x16 acc[TI][2];
-#pragma unroll
-    for (int a = 0; a < TI; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // Work items.  TN: one (tile, row slice) per workgroup (grid = n tiles x m tiles x slices).  NT / NN: the
+    // grid is a few workgroups per CU and each WALKS tiles (n tile fastest: neighbours share their A rows in
+    // L2), fetching the first k-step of its next tile during the last step of the current one.  Without
+    // that, all workgroups of a launch run their (8-step) K loops in lock-step rounds and the first fetch and
+    // the epilogue of every round are exposed chip-wide.
+    const int ntn = (N + GBN - 1) / GBN, ntm = (M + BM - 1) / BM;
+    const int ntiles = OP == 2 ? 1 : ntn * ntm, tstep = OP == 2 ? 1 : (int)gridDim.x;
+    const int kbeg = OP == 2 ? blockIdx.z * k_chunk : 0, kend = OP == 2 ? min(K, kbeg + k_chunk) : K;
+    if constexpr (OP == 2) C += (size_t)blockIdx.z * c_slice;
+    const int nsteps = (kend - kbeg + GBK - 1) / GBK;
 
     f32x4 ra[NUA], rb[2];
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int m0, int n0, int k0) {
         if constexpr (OP == 2) load_xc<NUA, VEC>(A, lda, m0, M, k0, kend, tid, ra); else load_kc<NUA, VEC>(A, lda, m0, M, k0, kend, tid, ra);
         if constexpr (OP == 0) load_kc<2, VEC>(B, ldb, n0, N, k0, kend, tid, rb); else load_xc<2, VEC>(B, ldb, n0, N, k0, kend, tid, rb);
     };
@@ -110,49 +108,77 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
         if constexpr (OP == 2) store_xc(As[buf], tid, ra); else store_kc(As[buf], tid, ra);
         if constexpr (OP == 0) store_kc(Bs[buf], tid, rb); else store_xc(Bs[buf], tid, rb);
     };
-
-    const int nsteps = (kend - kbeg + GBK - 1) / GBK;
-    if (nsteps > 0) {
-        fetch(kbeg);
-        stage(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < nsteps; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nsteps) fetch(kbeg + (it + 1) * GBK);
-        const float *as = As[buf] + h * GLD + wm * (BM / 2) + j;
-        const float *bs = Bs[buf] + h * GLD + wn * 64 + j;
-#pragma unroll
-        for (int kb = 0; kb < GBK / 2; ++kb) {
-            const float b0 = bs[2 * kb * GLD], b1 = bs[2 * kb * GLD + 32];
-#pragma unroll
-            for (int ti = 0; ti < TI; ++ti) {
-                const float av = as[2 * kb * GLD + 32 * ti];
-                acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[ti][0], 0, 0, 0);
-                acc[ti][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[ti][1], 0, 0, 0);
-            }
+    auto origin = [&](int tile, int &m0, int &n0) {
+        if constexpr (OP == 2) {
+            m0 = blockIdx.y * BM;
+            n0 = blockIdx.x * GBN;
+        } else {
+            m0 = (tile / ntn) * BM;
+            n0 = (tile % ntn) * GBN;
         }
-        if (it + 1 < nsteps) stage(buf ^ 1);
+    };
+
+    int tile = OP == 2 ? 0 : (int)blockIdx.x, m0 = 0, n0 = 0;
+    if (tile < ntiles) {
+        origin(tile, m0, n0);
+        if (nsteps > 0) fetch(m0, n0, kbeg);
+    }
+    while (tile < ntiles) {
+        f32x16 acc[TI][2];
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        const int next = tile + tstep;
+        int m1 = 0, n1 = 0;
+        if (next < ntiles) origin(next, m1, n1);
+        if (nsteps > 0) stage(0);
         __syncthreads();
-    }
-
+        for (int it = 0; it < nsteps; ++it) {
+            const int buf = it & 1;
+            if (it + 1 < nsteps) fetch(m0, n0, kbeg + (it + 1) * GBK);
+            else if (next < ntiles) fetch(m1, n1, kbeg);   // the next tile's first k-step rides under this one's last
+            const float *as = As[buf] + h * GLD + wm * (BM / 2) + j;
+            const float *bs = Bs[buf] + h * GLD + wn * 64 + j;
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
+            for (int kb = 0; kb < GBK / 2; ++kb) {
+                const float b0 = bs[2 * kb * GLD], b1 = bs[2 * kb * GLD + 32];
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-            const int col = n0 + wn * 64 + tj * 32 + j;
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / 2) + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= M) continue;
-                float *p = C + (size_t)row * ldc + col;
-                float v = acc[ti][tj][e] + bv;
-                if (accumulate) v += *p;
-                *p = v;
+                for (int ti = 0; ti < TI; ++ti) {
+                    const float av = as[2 * kb * GLD + 32 * ti];
+                    acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[ti][0], 0, 0, 0);
+                    acc[ti][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[ti][1], 0, 0, 0);
+                }
+            }
+            if (it + 1 < nsteps) {
+                stage(buf ^ 1);
+                __syncthreads();
             }
         }
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int col = n0 + wn * 64 + tj * 32 + j;
+                if (col >= N) continue;
+                const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + wm * (BM / 2) + ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (row >= M) continue;
+                    float *p = C + (size_t)row * ldc + col;
+                    float v = acc[ti][tj][e] + bv;
+                    if (accumulate) v += *p;
+                    *p = v;
+                }
+            }
+        __syncthreads();   // every wave is done with the LDS buffers before the next tile restages buffer 0
+        tile = next;
+        m0 = m1;
+        n0 = n1;
+    }
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_z slices[z * stride + i].  64 columns per workgroup, the
@@ -240,7 +266,15 @@ static bool gemm_vec_ok(int op, const float *A, const float *B, int M, int N, in
 template <int OP, int BM>
 static void gemm_go(const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda, int ldb,
                     int ldc, bool accumulate, hipStream_t st) {
-    const dim3 grid((N + GBN - 1) / GBN, (M + BM - 1) / BM, 1);
+    const int ntiles = ((N + GBN - 1) / GBN) * ((M + BM - 1) / BM);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const dim3 grid(std::min(ntiles, cus * (BM == 128 ? 2 : 4)), 1, 1);   // resident workgroups per CU (VGPR bound: 192 / 120); swept 2..8
     if (gemm_vec_ok(OP, A, B, M, N, K, lda, ldb))
         hipLaunchKernelGGL((gemm_kernel<OP, BM, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
                            (int)accumulate);
@@ -251,13 +285,12 @@ static void gemm_go(const float *A, const float *B, float *C, const float *bias,
 
 hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,
                        int ldb, int ldc, bool accumulate, hipStream_t st) {
-    const bool small = (long long)((M + 127) / 128) * ((N + GBN - 1) / GBN) < 1024;   // < 4 workgroups per CU
+    // 64-row tiles: the tile-walking kernel then needs 120 VGPRs (4 workgroups per CU) instead of 192 (2), which
+    // measures faster on every shape of the training step than 128-row tiles
     if (op == 0) {
-        if (small) gemm_go<0, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
-        else gemm_go<0, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
+        gemm_go<0, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
     } else if (op == 1) {
-        if (small) gemm_go<1, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
-        else gemm_go<1, 128>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
+        gemm_go<1, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
     } else {
         return hipErrorInvalidValue;
     }
