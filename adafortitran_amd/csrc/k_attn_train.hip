@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const AttnTrainArgs 
 }
 
 // ---- dK, dV: own = key tile, walks the query tiles (staged: Q, dO, lse, D) ----
-__global__ __launch_bounds__(kAtThreads) void attn_bwd_kv_kernel(const AttnTrainArgs a) {
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kv_kernel(const AttnTrainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
@@ -259,33 +259,46 @@ __global__ __launch_bounds__(kAtThreads) void attn_bwd_kv_kernel(const AttnTrain
     __syncthreads();
     for (int qt = 0; qt < a.ntiles; ++qt) {
         const float *buf = lds[qt & 1];
-        if (qt + 1 < a.ntiles) stage_fetch(sr, qb, ld, dob, a.d, lse, dsum, qt + 1, a.tokens, tid);
         if (active) {
-            float qf[16], dof[16], ls[16], dsm[16];
-            lds_rowfrag(buf, j, h, qf);                                    // A operands: lane <-> query
-            lds_rowfrag(buf + kAtTileFloats, j, h, dof);
-            lds_rowscalars(buf + 2 * kAtTileFloats, h, ls);
-            lds_rowscalars(buf + 2 * kAtTileFloats + 32, h, dsm);
-            const f32x16 s = mma16(qf, kf, zero16());                      // [row = query][col = key]
-            const f32x16 dp = mma16(dof, vf, zero16());
+            // operands are read from LDS right before their product so that at most two 16-register
+            // fragments are live next to the accumulators (3 waves per SIMD need <= 168 VGPRs)
+            f32x16 s, dp;
+            {
+                float qf[16];
+                lds_rowfrag(buf, j, h, qf);                                // A operand: lane <-> query
+                s = mma16(qf, kf, zero16());                               // [row = query][col = key]
+            }
+            {
+                float dof[16];
+                lds_rowfrag(buf + kAtTileFloats, j, h, dof);
+                dp = mma16(dof, vf, zero16());
+            }
             float pd[16], ds[16];
+            {
+                float ls[16], dsm[16];
+                lds_rowscalars(buf + 2 * kAtTileFloats, h, ls);
+                lds_rowscalars(buf + 2 * kAtTileFloats + 32, h, dsm);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int query = qt * 32 + rowmap(r, h);
-                const bool ok = key_ok && query < a.tokens;
-                const float p = ok ? __builtin_amdgcn_exp2f(s[r] - ls[r]) : 0.f;
-                const float f = a.threshold ? drop_factor(a.seed, ((uint32_t)ph * a.tokens + min(query, a.tokens - 1)) * a.tokens + keyc,
-                                                          a.threshold, a.keep_scale) : 1.f;
-                pd[r] = p * f;
-                ds[r] = p * (dp[r] * f - dsm[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int query = qt * 32 + rowmap(r, h);
+                    const bool ok = key_ok && query < a.tokens;
+                    const float p = ok ? __builtin_amdgcn_exp2f(s[r] - ls[r]) : 0.f;
+                    const float f = a.threshold ? drop_factor(a.seed, ((uint32_t)ph * a.tokens + min(query, a.tokens - 1)) * a.tokens + keyc,
+                                                              a.threshold, a.keep_scale) : 1.f;
+                    pd[r] = p * f;
+                    ds[r] = p * (dp[r] * f - dsm[r]);
+                }
             }
             float qT[16], doT[16];
-            lds_colfrag(buf, j, h, qT);                                    // A operands: lane <-> feature
-            lds_colfrag(buf + kAtTileFloats, j, h, doT);
+            lds_colfrag(buf + kAtTileFloats, j, h, doT);                   // A operands: lane <-> feature
             dv = mma16(doT, pd, dv);                                       // [row = feature][col = key]
+            lds_colfrag(buf, j, h, qT);
             dk = mma16(qT, ds, dk);
         }
-        if (qt + 1 < a.ntiles) stage_store(sr, lds[(qt + 1) & 1], tid);
+        if (qt + 1 < a.ntiles) {   // fetched after the products: the 18 staging registers are not live across them
+            stage_fetch(sr, qb, ld, dob, a.d, lse, dsum, qt + 1, a.tokens, tid);
+            stage_store(sr, lds[(qt + 1) & 1], tid);
+        }
         __syncthreads();
     }
     if (!active) return;
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(kAtThreads) void attn_bwd_kv_kernel(const AttnTrain
 }
 
 // ---- dQ: own = query tile, walks the key tiles (staged: K, V) ----
-__global__ __launch_bounds__(kAtThreads) void attn_bwd_q_kernel(const AttnTrainArgs a) {
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_q_kernel(const AttnTrainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
