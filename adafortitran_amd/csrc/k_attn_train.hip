@@ -158,7 +158,7 @@ __device__ __forceinline__ void lds_rowscalars(const float *__restrict__ s, int 
 }
 
 // ---- forward: own = query tile, walks the key tiles (staged: K, V) ----
-__global__ __launch_bounds__(kAtThreads) void attn_train_fwd_kernel(const AttnTrainArgs a) {
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_train_fwd_kernel(const AttnTrainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
