@@ -16,10 +16,10 @@ namespace {
 size_t al64(size_t floats) { return (floats + 63) / 64 * 64; }
 
 struct Tape {   // offsets in floats
-    size_t qkv, attn, lse, s1, st1, x1, a, s2, st2, total;
+    size_t qkv, attn, lse, s1, st1, x1, a, hd, s2, st2, total;
 };
 struct Scratch {
-    size_t g1, g2, gff, hd, dqkv, dsum, slices, total;
+    size_t g1, g2, gff, dqkv, dsum, slices, total;
 };
 
 int tokens_of_cfg(const aft_config &c) { return (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols); }
@@ -35,6 +35,7 @@ Tape plan_tape(const aft_config &c, int batch) {
     t.st1 = off;  off += al64(rows * 2);
     t.x1 = off;   off += al64(rows * d);
     t.a = off;    off += al64(rows * ff);
+    t.hd = off;   off += al64(rows * ff);   // drop(act(a)): kept so the backward does not recompute it (24 us per layer)
     t.s2 = off;   off += al64(rows * d);
     t.st2 = off;  off += al64(rows * 2);
     t.total = off;
@@ -48,7 +49,6 @@ Scratch plan_scratch(const aft_config &c, int batch) {
     s.g1 = off;     off += al64(rows * d);
     s.g2 = off;     off += al64(rows * d);
     s.gff = off;    off += al64(rows * ff);
-    s.hd = off;     off += al64(rows * ff);
     s.dqkv = off;   off += al64(rows * 3 * d);
     s.dsum = off;   off += al64(rows * c.num_head);
     s.slices = off; off += al64(std::max((size_t)(512 + 6) * 128 * 128, (size_t)kColsumMaxSlices * 3 * 2 * d));   // wgrad: tiles * slices <= 512 + tiles
@@ -131,8 +131,8 @@ int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weigh
     STEP("norm1", launch_add_ln_fwd(x_in, o, w->norm1_w, w->norm1_b, tp + t.s1, tp + t.st1, tp + t.x1, rows, d, 1e-5f,
                                     dropout_p, site_seed(seed, 1), st));
     STEP("linear1", launch_gemm(0, tp + t.x1, w->lin1_w, tp + t.a, w->lin1_b, rows, ff, d, d, d, ff, false, st));
-    STEP("activation", launch_act_fwd(cfg->activation, tp + t.a, sc + s.hd, (size_t)rows * ff, dropout_p, site_seed(seed, 2), st));
-    STEP("linear2", launch_gemm(0, sc + s.hd, w->lin2_w, o, w->lin2_b, rows, d, ff, ff, ff, d, false, st));
+    STEP("activation", launch_act_fwd(cfg->activation, tp + t.a, tp + t.hd, (size_t)rows * ff, dropout_p, site_seed(seed, 2), st));
+    STEP("linear2", launch_gemm(0, tp + t.hd, w->lin2_w, o, w->lin2_b, rows, d, ff, ff, ff, d, false, st));
     STEP("norm2", launch_add_ln_fwd(tp + t.x1, o, w->norm2_w, w->norm2_b, tp + t.s2, tp + t.st2, x_out, rows, d, 1e-5f,
                                     dropout_p, site_seed(seed, 3), st));
     return AFT_OK;
@@ -156,12 +156,12 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     float *sc = static_cast<float *>(scratch);
     const int tokens = tokens_of_cfg(*cfg), planes = 2 * batch, rows = planes * tokens, d = cfg->model_dim, ff = 2 * d;
     const bool acc = accumulate != 0;
-    float *g1 = sc + s.g1, *g2 = sc + s.g2, *gff = sc + s.gff, *hd = sc + s.hd, *dqkv = sc + s.dqkv, *sl = sc + s.slices;
+    float *g1 = sc + s.g1, *g2 = sc + s.g2, *gff = sc + s.gff, *dqkv = sc + s.dqkv, *sl = sc + s.slices;
+    const float *hd = tp + t.hd;
 
     // LN2: g1 = d(x1) through the residual, g2 = d(linear2 output) (dropout 3 applied)
     STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, g->lin2_b, sl,
                                     rows, d, dropout_p, site_seed(seed, 3), acc, st));
-    STEP("activation (recompute)", launch_act_fwd(cfg->activation, tp + t.a, hd, (size_t)rows * ff, dropout_p, site_seed(seed, 2), st));
     STEP("linear2 wgrad", launch_gemm_tn(g2, hd, g->lin2_w, sl, d, ff, rows, d, ff, acc, st));
     STEP("linear2 dgrad", launch_gemm(1, g2, w->lin2_w, gff, nullptr, rows, ff, d, d, ff, ff, false, st));
     STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, g->lin1_b, sl, rows, ff, dropout_p, site_seed(seed, 2),

@@ -108,13 +108,11 @@ def test_dropout_keep_rate():
     _lib.check(lib.aft_encoder_layer_fwd_train_f32(C.byref(cfg), C.byref(w), x.data_ptr(), out.data_ptr(), tape.data_ptr(),
                                                    tape.numel(), scratch.data_ptr(), scratch.numel(), 1, p, 7, None))
     torch.cuda.synchronize()
-    # s2 sits after qkv, attn, lse, s1, st1, x1, a in the tape; recover it from the scratch-free
-    # identity instead: norm2's input has the same value in all d columns of a row -> LN output 0,
-    # so check the hidden activations directly (scratch.hd = third block of the scratch)
+    # the hidden activation after dropout is the 8th block of the tape: qkv, attn, lse, s1, st1, x1, a, hd
     rows, ff = planes * cfg.tokens, 2 * d
     al = lambda n: (n + 63) // 64 * 64
-    hd_off = 2 * al(rows * d) + al(rows * ff)
-    hd = scratch.view(torch.float32)[hd_off:hd_off + rows * ff]
+    hd_off = al(rows * 3 * d) + al(rows * d) + al(rows * heads) + al(rows * d) + al(rows * 2) + al(rows * d) + al(rows * ff)
+    hd = tape.view(torch.float32)[hd_off:hd_off + rows * ff]
     kept = float((hd != 0).double().mean())
     assert abs(kept - (1 - p)) < 0.01
     vals = hd[hd != 0]
