@@ -306,3 +306,59 @@ def test_dense_layer_forward_backward_matches_autograd(rows, in_f, out_f, bias):
     assert _rel(y1, y0) <= 1e-5 and _rel(gx1, gx0) <= 1e-5
     for a, b in zip(g1, g0):
         assert _rel(a, b) <= 1e-4
+
+
+def _random_train_specs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        p0, p1 = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        gs, gt = int(rng.integers(4, 20)), int(rng.integers(2, 8))
+        if gs * gt < 32 or gs * gt > 300 or gs * p0 > 120:
+            continue
+        d = int(rng.choice([64, 128, 192, 256]))
+        out.append(dict(ofdm=(gs * p0, gt * p1), pilot=(int(rng.integers(2, 9)), int(rng.integers(1, 3))), patch=(p0, p1),
+                        d=d, act=str(rng.choice(["gelu", "relu"])), adaptive=bool(rng.integers(0, 2)), batch=int(rng.integers(1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("spec", _random_train_specs(8, 77),
+                         ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['d']}{'a' if s['adaptive'] else 'f'}")
+def test_random_configurations_training_step_matches_autograd(spec):
+    """Whole-model loss.backward() on random valid configurations: HIP training kernels (encoder, conv stacks,
+    dense layers) against PyTorch-ROCm autograd on the same module, dropout 0."""
+    import adafortitran_amd as A
+    from adafortitran_amd import synth, training
+    tokens = (spec["ofdm"][0] // spec["patch"][0]) * (spec["ofdm"][1] // spec["patch"][1])
+    sc = A.SystemConfig(ofdm=dict(num_scs=spec["ofdm"][0], num_symbols=spec["ofdm"][1]),
+                        pilot=dict(num_scs=spec["pilot"][0], num_symbols=spec["pilot"][1]))
+    kw = dict(model_type="adafortitran" if spec["adaptive"] else "fortitran", patch_size=spec["patch"], num_layers=2,
+              model_dim=spec["d"], num_head=spec["d"] // 32, activation=spec["act"], max_seq_len=512,
+              pos_encoding_type="learnable", device="cuda", dropout=0.0)
+    if spec["adaptive"]:
+        kw.update(channel_adaptivity_hidden_sizes=[5, 9, 2 * tokens], adaptive_token_length=6)
+    torch.manual_seed(0)
+    model = (A.AdaFortiTranEstimator if spec["adaptive"] else A.FortiTranEstimator)(sc, A.ModelConfig(**kw)).train()
+    B = spec["batch"]
+    inp = synth.make_inputs(B, ofdm=spec["ofdm"], pilot=spec["pilot"], seed=9)
+    pil, tgt = torch.from_numpy(inp["pilots"]).cuda(), torch.from_numpy(inp["target"]).cuda()
+    meta = synth.meta_tuple(inp) if spec["adaptive"] else None
+
+    def step(hip):
+        model.transformer_encoder.hip_training = hip
+        model.initial_enhancer.hip_training = model.final_refiner.hip_training = hip
+        training.HipLinear.default_hip_training = hip
+        model.zero_grad()
+        out = model(pil, meta) if meta is not None else model(pil)
+        loss = torch.nn.functional.mse_loss(torch.view_as_real(out), torch.view_as_real(tgt))
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    try:
+        l0, g0 = step(False)
+        l1, g1 = step(True)
+    finally:
+        training.HipLinear.default_hip_training = True
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    for n in g0:
+        assert _rel(g1[n], g0[n]) <= 2e-3, n
