@@ -76,6 +76,19 @@ constexpr int kGemmMaxSlices = 256;   // split of the token-row reduction in wei
 constexpr int kColsumMaxSlices = 1024; // ... in bias / LayerNorm-parameter gradients (one slice per workgroup)
 int colsum_slices(int rows);
 int gemm_split_slices(int rows, int tiles);
+size_t gemm_tn_slice_floats(int M, int N, int R);   // slice storage launch_gemm_tn needs
+// While a ReduceBatchScope is alive on this thread, launch_reduce_slices* only queue their job (each producer must
+// then own its slice storage until flush()); flush() runs all queued reductions in one launch.
+constexpr int kMaxReduceJobs = 12;
+struct ReduceJobs;
+struct ReduceBatchScope {
+    ReduceJobs *jobs;
+    ReduceBatchScope();
+    ~ReduceBatchScope();
+    hipError_t flush(hipStream_t st);
+    ReduceBatchScope(const ReduceBatchScope &) = delete;
+    ReduceBatchScope &operator=(const ReduceBatchScope &) = delete;
+};
 int ln_bwd_blocks(int rows);
 // op 0: C = A[M][K] B[N][K]^T + bias;  op 1: C = A[M][K] B[K][N]   (accumulate: C += ...)
 hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,

@@ -51,7 +51,12 @@ Scratch plan_scratch(const aft_config &c, int batch) {
     s.gff = off;    off += al64(rows * ff);
     s.dqkv = off;   off += al64(rows * 3 * d);
     s.dsum = off;   off += al64(rows * c.num_head);
-    s.slices = off; off += al64(std::max((size_t)(512 + 6) * 128 * 128, (size_t)kColsumMaxSlices * 3 * 2 * d));   // wgrad: tiles * slices <= 512 + tiles
+    // every gradient kernel of the layer keeps its partial slices until the single reduction launch at the end
+    const int r = (int)rows;
+    s.slices = off;
+    off += al64(gemm_tn_slice_floats(d, ff, r)) + al64(gemm_tn_slice_floats(ff, d, r)) + al64(gemm_tn_slice_floats(d, d, r)) +
+           al64(gemm_tn_slice_floats(3 * d, d, r)) + 2 * al64((size_t)ln_bwd_blocks(r) * 3 * d) +
+           al64((size_t)ln_bwd_blocks(r) * ff) + al64((size_t)colsum_slices(r) * 3 * d);
     s.total = off;
     return s;
 }
@@ -159,25 +164,36 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     float *g1 = sc + s.g1, *g2 = sc + s.g2, *gff = sc + s.gff, *dqkv = sc + s.dqkv, *sl = sc + s.slices;
     const float *hd = tp + t.hd;
 
+    // slice storage per producer (bump-allocated from the scratch's slice region), one reduction launch at the end
+    float *sl_ln2 = sl;
+    float *sl_w2 = sl_ln2 + al64((size_t)ln_bwd_blocks(rows) * 3 * d);
+    float *sl_act = sl_w2 + al64(gemm_tn_slice_floats(d, ff, rows));
+    float *sl_w1 = sl_act + al64((size_t)ln_bwd_blocks(rows) * ff);
+    float *sl_ln1 = sl_w1 + al64(gemm_tn_slice_floats(ff, d, rows));
+    float *sl_wo = sl_ln1 + al64((size_t)ln_bwd_blocks(rows) * 3 * d);
+    float *sl_wq = sl_wo + al64(gemm_tn_slice_floats(d, d, rows));
+    float *sl_bq = sl_wq + al64(gemm_tn_slice_floats(3 * d, d, rows));
+    ReduceBatchScope reductions;
     // LN2: g1 = d(x1) through the residual, g2 = d(linear2 output) (dropout 3 applied)
-    STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, g->lin2_b, sl,
+    STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, g->lin2_b, sl_ln2,
                                     rows, d, dropout_p, site_seed(seed, 3), acc, st));
-    STEP("linear2 wgrad", launch_gemm_tn(g2, hd, g->lin2_w, sl, d, ff, rows, d, ff, acc, st));
+    STEP("linear2 wgrad", launch_gemm_tn(g2, hd, g->lin2_w, sl_w2, d, ff, rows, d, ff, acc, st));
     STEP("linear2 dgrad", launch_gemm(1, g2, w->lin2_w, gff, nullptr, rows, ff, d, d, ff, ff, false, st));
-    STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, g->lin1_b, sl, rows, ff, dropout_p, site_seed(seed, 2),
+    STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, g->lin1_b, sl_act, rows, ff, dropout_p, site_seed(seed, 2),
                                           acc, st));
-    STEP("linear1 wgrad", launch_gemm_tn(gff, tp + t.x1, g->lin1_w, sl, ff, d, rows, ff, d, acc, st));
+    STEP("linear1 wgrad", launch_gemm_tn(gff, tp + t.x1, g->lin1_w, sl_w1, ff, d, rows, ff, d, acc, st));
     STEP("linear1 dgrad", launch_gemm(1, gff, w->lin1_w, g1, nullptr, rows, d, ff, ff, d, d, true, st));
     // LN1: dx_in = d(x_in) through the residual, g2 = d(out_proj output) (dropout 1 applied)
-    STEP("norm1 bwd", launch_ln_bwd(g1, tp + t.s1, tp + t.st1, w->norm1_w, dx_in, g2, g->norm1_w, g->norm1_b, g->out_proj_b, sl,
+    STEP("norm1 bwd", launch_ln_bwd(g1, tp + t.s1, tp + t.st1, w->norm1_w, dx_in, g2, g->norm1_w, g->norm1_b, g->out_proj_b, sl_ln1,
                                     rows, d, dropout_p, site_seed(seed, 1), acc, st));
-    STEP("out_proj wgrad", launch_gemm_tn(g2, tp + t.attn, g->out_proj_w, sl, d, d, rows, d, d, acc, st));
+    STEP("out_proj wgrad", launch_gemm_tn(g2, tp + t.attn, g->out_proj_w, sl_wo, d, d, rows, d, d, acc, st));
     STEP("out_proj dgrad", launch_gemm(1, g2, w->out_proj_w, g1, nullptr, rows, d, d, d, d, d, false, st));
     STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,
                                                 dropout_p, site_seed(seed, 0), st));
-    STEP("in_proj wgrad", launch_gemm_tn(dqkv, x_in, g->in_proj_w, sl, 3 * d, d, rows, 3 * d, d, acc, st));
-    STEP("in_proj bgrad", launch_colsum(dqkv, g->in_proj_b, sl, rows, 3 * d, 3 * d, acc, st));
+    STEP("in_proj wgrad", launch_gemm_tn(dqkv, x_in, g->in_proj_w, sl_wq, 3 * d, d, rows, 3 * d, d, acc, st));
+    STEP("in_proj bgrad", launch_colsum(dqkv, g->in_proj_b, sl_bq, rows, 3 * d, 3 * d, acc, st));
     STEP("in_proj dgrad", launch_gemm(1, dqkv, w->in_proj_w, dx_in, nullptr, rows, d, 3 * d, 3 * d, d, d, true, st));
+    STEP("gradient reductions", reductions.flush(st));
     return AFT_OK;
 }
 
@@ -211,11 +227,13 @@ int aft_dense_bwd_f32(const float *x, const float *weight, const float *dy, floa
     float *sl = static_cast<float *>(scratch);
     const int tiles = ((in_features + 127) / 128) * ((out_features + 127) / 128);
     float *sl2 = sl + al64((size_t)gemm_split_slices(rows, tiles) * in_features * out_features);
+    ReduceBatchScope reductions;
     if (dx) STEP("dense dgrad", launch_gemm(1, dy, weight, dx, nullptr, rows, in_features, out_features, out_features, in_features,
                                             in_features, false, st));
     STEP("dense wgrad", launch_gemm_tn(dy, x, dweight, sl, out_features, in_features, rows, out_features, in_features,
                                        accumulate != 0, st));
     if (dbias) STEP("dense bgrad", launch_colsum(dy, dbias, sl2, rows, out_features, out_features, accumulate != 0, st));
+    STEP("gradient reductions", reductions.flush(st));
     return AFT_OK;
 }
 

@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void chsum_kernel(const float *__restrict__ X,
     if (threadIdx.x == 0) slices[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-size_t conv_wgrad_slice_floats(int planes, int S, int T) {
-    return std::max<size_t>((size_t)kWgradSlices * 2304, (size_t)planes * ((S * T + 255) / 256) * 72);
+size_t conv_wgrad_slice_floats(int planes, int S, int T) {   // all eight reductions keep their slices until one launch
+    return 2 * (size_t)kWgradSlices * 2304 + 2 * (size_t)planes * ((S * T + 255) / 256) * 72 + (size_t)planes * 64;
 }
 
 hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, const float *c3, const float *g1,
@@ -197,26 +197,31 @@ hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, c
     const int chunks = planes * T * ((S + 63) / 64);
     const int grid = std::max(1, std::min(kWgradSlices, (chunks + 3) / 4));
     hipError_t e;
+    ReduceBatchScope reductions;
+    float *sl2 = slices, *sl3 = sl2 + (size_t)kWgradSlices * 2304, *sl1 = sl3 + (size_t)kWgradSlices * 2304;
+    float *sl4 = sl1 + (size_t)planes * pblocks * 72, *slb = sl4 + (size_t)planes * pblocks * 72;
     // conv2: dW2[co = a][ci = b][tap]          A32 = g2, B8 = a1, shift +
-    Wgrad32x8Args w2{g2, c1, slices, planes, S, T, +1, 72, 9};
+    Wgrad32x8Args w2{g2, c1, sl2, planes, S, T, +1, 72, 9};
     hipLaunchKernelGGL(wgrad32x8_kernel, dim3(grid), dim3(256), lds, st, w2);
-    if ((e = launch_reduce_slices(slices, dw[1], 2304, grid, 2304, accumulate, st)) != hipSuccess) return e;
+    if ((e = launch_reduce_slices(sl2, dw[1], 2304, grid, 2304, accumulate, st)) != hipSuccess) return e;
     // conv3: dW3[co = b][ci = a][tap]          A32 = a2, B8 = g3, shift -
-    Wgrad32x8Args w3{c2, g3, slices, planes, S, T, -1, 9, 288};
+    Wgrad32x8Args w3{c2, g3, sl3, planes, S, T, -1, 9, 288};
     hipLaunchKernelGGL(wgrad32x8_kernel, dim3(grid), dim3(256), lds, st, w3);
-    if ((e = launch_reduce_slices(slices, dw[2], 2304, grid, 2304, accumulate, st)) != hipSuccess) return e;
+    if ((e = launch_reduce_slices(sl3, dw[2], 2304, grid, 2304, accumulate, st)) != hipSuccess) return e;
     // conv1: dW1[co][tap] = sum g1[co][p] x[p + (tap-1)];  conv4: dW4[ci][tap] = sum a3[ci][p'] dy[p' - (tap-1)]
-    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, planes), dim3(256), 0, st, g1, x, slices, planes, S, T, +1);
-    if ((e = launch_reduce_slices(slices, dw[0], 72, planes * pblocks, 72, accumulate, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, planes), dim3(256), 0, st, c3, dy, slices, planes, S, T, -1);
-    if ((e = launch_reduce_slices(slices, dw[3], 72, planes * pblocks, 72, accumulate, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, planes), dim3(256), 0, st, g1, x, sl1, planes, S, T, +1);
+    if ((e = launch_reduce_slices(sl1, dw[0], 72, planes * pblocks, 72, accumulate, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, planes), dim3(256), 0, st, c3, dy, sl4, planes, S, T, -1);
+    if ((e = launch_reduce_slices(sl4, dw[3], 72, planes * pblocks, 72, accumulate, st)) != hipSuccess) return e;
     // biases: channel sums of the pre-activation gradients
     const float *gs[4] = {g1, g2, g3, dy};
     const int cs[4] = {8, 32, 8, 1};
     for (int k = 0; k < 4; ++k) {
-        hipLaunchKernelGGL(chsum_kernel, dim3(planes * cs[k]), dim3(256), 0, st, gs[k], slices, npix);
-        if ((e = launch_reduce_slices(slices, db[k], cs[k], planes, cs[k], accumulate, st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(chsum_kernel, dim3(planes * cs[k]), dim3(256), 0, st, gs[k], slb, npix);
+        if ((e = launch_reduce_slices(slb, db[k], cs[k], planes, cs[k], accumulate, st)) != hipSuccess) return e;
+        slb += (size_t)planes * cs[k];
     }
+    if ((e = reductions.flush(st)) != hipSuccess) return e;
     return hipGetLastError();
 }
 

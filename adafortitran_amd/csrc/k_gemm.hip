@@ -214,9 +214,69 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const ReduceArgs a) 
     }
 }
 
+// Several reductions in ONE launch: the gradient kernels of a layer each leave their partial slices in their
+// own scratch region and queue a job here; the layer's backward ends with a single flush (the reductions are
+// a few microseconds each, i.e. mostly launch latency when issued one by one).
+struct ReduceJobs {
+    ReduceArgs job[kMaxReduceJobs];
+    int first_block[kMaxReduceJobs + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobs q) {
+    __shared__ float part[4][64];
+    int jb = 0;
+    while (jb + 1 < q.njobs && (int)blockIdx.x >= q.first_block[jb + 1]) ++jb;
+    const ReduceArgs &a = q.job[jb];
+    const int c = threadIdx.x & 63, zq = threadIdx.x >> 6, i = (blockIdx.x - q.first_block[jb]) * 64 + c;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    if (i < a.n * a.nout) {
+        int z = zq;
+        for (; z + 28 < a.nz; z += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += a.slices[(size_t)(z + 4 * u) * a.stride + i];
+        }
+        for (; z < a.nz; z += 4) s[0] += a.slices[(size_t)z * a.stride + i];
+    }
+    part[zq][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (zq == 0 && i < a.n * a.nout) {
+        const float t = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        float *o = a.out[i / a.n] + i % a.n;
+        *o = a.accumulate ? *o + t : t;
+    }
+}
+
+static thread_local ReduceJobs *g_batch = nullptr;
+
+ReduceBatchScope::ReduceBatchScope() : jobs(new ReduceJobs()) {
+    jobs->njobs = 0;
+    jobs->first_block[0] = 0;
+    g_batch = jobs;
+}
+ReduceBatchScope::~ReduceBatchScope() {
+    g_batch = nullptr;
+    delete jobs;
+}
+hipError_t ReduceBatchScope::flush(hipStream_t st) {
+    g_batch = nullptr;   // whatever follows launches directly again
+    if (jobs->njobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(jobs->first_block[jobs->njobs]), dim3(256), 0, st, *jobs);
+    jobs->njobs = 0;
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce_slices3(const float *slices, float *out0, float *out1, float *out2, int n, int nout, int nz,
                                  size_t stride, bool accumulate, hipStream_t st) {
     ReduceArgs a{slices, {out0, out1, out2}, n, nout, nz, (int)accumulate, stride};
+    if (g_batch && g_batch->njobs < kMaxReduceJobs) {   // deferred: the caller keeps `slices` untouched until the flush
+        ReduceJobs &q = *g_batch;
+        q.job[q.njobs] = a;
+        q.first_block[q.njobs + 1] = q.first_block[q.njobs] + (n * nout + 63) / 64;
+        ++q.njobs;
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(reduce_slices_kernel, dim3((n * nout + 63) / 64), dim3(256), 0, st, a);
     return hipGetLastError();
 }
@@ -251,6 +311,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
 // enough slices to put two workgroups on every CU whatever the number of output tiles, never fewer than 128 rows each
 int gemm_split_slices(int rows, int tiles) {
     return std::max(1, std::min(std::min(kGemmMaxSlices, (512 + tiles - 1) / tiles), rows / 128));   // swept 192..1024: flat above 512
+}
+size_t gemm_tn_slice_floats(int M, int N, int R) {
+    const int tiles = ((N + GBN - 1) / GBN) * ((M + GBM - 1) / GBM);
+    return (size_t)gemm_split_slices(R, tiles) * M * N;
 }
 int colsum_slices(int rows) { return std::max(1, std::min(kColsumMaxSlices, rows / 64)); }
 
