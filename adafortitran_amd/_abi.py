@@ -137,6 +137,7 @@ EXPORTED_SYMBOLS = (
     "aft_encoder_layer_fwd_train_f32", "aft_encoder_layer_bwd_f32", "aft_adam_step_f32",
     "aft_conv_enhancer_fwd_train_f32", "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_bwd_f32",
     "aft_dense_fwd_f32", "aft_dense_bwd_scratch_bytes", "aft_dense_bwd_f32",
+    "aft_adapter_fwd_train_f32", "aft_adapter_bwd_f32",
 )
 #: size queries (return size_t, not a status code)
 SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",

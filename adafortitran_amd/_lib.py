@@ -74,6 +74,10 @@ def load():
     lib.aft_dense_bwd_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.aft_dense_fwd_f32.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_dense_bwd_f32.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp]
+    p3, p9, i3 = C.c_void_p * 3, C.c_void_p * 9, C.c_int32 * 3
+    lib.aft_adapter_fwd_train_f32.argtypes = [C.POINTER(p3), C.POINTER(p9), C.POINTER(p9), C.POINTER(i3), C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.aft_adapter_bwd_f32.argtypes = [C.POINTER(p3), C.POINTER(p9), C.POINTER(p9), C.POINTER(i3), C.c_int, C.c_int, vp, vp, vp,
+                                        vp, vp, C.POINTER(p9), C.POINTER(p9), C.c_int, vp]
     lib.aft_adam_step_f32.argtypes = [vp, vp, vp, vp, C.c_size_t] + [C.c_float] * 6 + [C.c_int, vp]
     for name in _abi.EXPORTED_SYMBOLS:
         if name not in _abi.SIZE_SYMBOLS + ("aft_version", "aft_last_error"):

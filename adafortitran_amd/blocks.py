@@ -95,7 +95,21 @@ class ChannelAdapter(nn.Module):
 
         self.snr_encoder, self.ds_encoder, self.dop_encoder = mlp(), mlp(), mlp()
 
+    #: set to False to differentiate the three MLPs layer by layer (HipLinear / PyTorch-ROCm) instead
+    hip_training = True
+
+    def _hip_train_eligible(self, x: torch.Tensor) -> bool:
+        first, second = self.snr_encoder[0], self.snr_encoder[2]
+        return (self.hip_training and x.device.type == "cuda" and torch.is_grad_enabled()
+                and first.weight.dtype == torch.float32 and first.out_features <= 256 and second.out_features <= 64)
+
     def forward(self, snr: torch.Tensor, delay_spread: torch.Tensor, doppler_shift: torch.Tensor) -> torch.Tensor:
+        if self._hip_train_eligible(snr):
+            # grad-enabled forward on the HIP device: one forward and two backward kernels for all three MLPs
+            from .training import HipChannelAdapterFunction
+            params = [t for enc in (self.snr_encoder, self.ds_encoder, self.dop_encoder) for i in (0, 2, 4)
+                      for t in (enc[i].weight, enc[i].bias)]
+            return HipChannelAdapterFunction.apply(snr, delay_spread, doppler_shift, *params)
         B = snr.shape[0]
         parts = [enc(v).reshape(B, -1, 2) for enc, v in ((self.snr_encoder, snr), (self.ds_encoder, delay_spread),
                                                         (self.dop_encoder, doppler_shift))]

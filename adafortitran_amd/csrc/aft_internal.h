@@ -121,6 +121,13 @@ hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, c
                              const float *g2, const float *g3, const float *dy, float *const dw[4], float *const db[4],
                              float *slices, int planes, int S, int T, bool accumulate, hipStream_t st);
 size_t conv_wgrad_slice_floats(int planes, int S, int T);
+hipError_t launch_adapter_train_fwd(const float *const cond[3], const float *const w[9], const float *const b[9],
+                                    const int hidden[3], int tokens, int frames, float *tokens6, float *a0, float *a1,
+                                    hipStream_t st);
+hipError_t launch_adapter_train_bwd(const float *const cond[3], const float *const w[9], const float *const b[9],
+                                    const int hidden[3], int tokens, int frames, const float *a0, const float *a1,
+                                    const float *dtok, float *da0, float *da1, float *const dw[9], float *const db[9],
+                                    bool accumulate, hipStream_t st);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
                        float wd, float grad_scale, int step, hipStream_t st);
 

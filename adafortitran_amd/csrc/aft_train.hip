@@ -280,6 +280,40 @@ int aft_conv_enhancer_bwd_f32(const float *const flipped_weights[4], const float
     return AFT_OK;
 }
 
+int aft_adapter_fwd_train_f32(const float *const conditions[3], const float *const weights[9], const float *const biases[9],
+                              const int32_t hidden[3], int tokens, int frames, float *tokens6, float *hidden0, float *hidden1,
+                              void *stream) {
+    if (!conditions || !weights || !biases || !hidden || !tokens6 || !hidden0 || !hidden1 || frames <= 0 || tokens <= 0 ||
+        hidden[2] != 2 * tokens) {
+        set_error("bad ChannelAdapter argument");
+        return AFT_ERR_ARG;
+    }
+    const int h[3] = {hidden[0], hidden[1], hidden[2]};
+    STEP("adapter forward", launch_adapter_train_fwd(conditions, weights, biases, h, tokens, frames, tokens6, hidden0, hidden1,
+                                                     static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
+int aft_adapter_bwd_f32(const float *const conditions[3], const float *const weights[9], const float *const biases[9],
+                        const int32_t hidden[3], int tokens, int frames, const float *hidden0, const float *hidden1,
+                        const float *dtokens6, float *dhidden0, float *dhidden1, float *const dweights[9],
+                        float *const dbiases[9], int accumulate, void *stream) {
+    if (!conditions || !weights || !biases || !hidden || !hidden0 || !hidden1 || !dtokens6 || !dhidden0 || !dhidden1 ||
+        !dweights || !dbiases || frames <= 0 || tokens <= 0 || hidden[2] != 2 * tokens) {
+        set_error("bad ChannelAdapter argument");
+        return AFT_ERR_ARG;
+    }
+    if (hidden[1] > 64 || hidden[0] > 256) {
+        set_error("ChannelAdapter hidden sizes [%d, %d] not covered by the fused backward (<= 256, <= 64)", hidden[0], hidden[1]);
+        return AFT_ERR_SHAPE;
+    }
+    const int h[3] = {hidden[0], hidden[1], hidden[2]};
+    STEP("adapter backward", launch_adapter_train_bwd(conditions, weights, biases, h, tokens, frames, hidden0, hidden1, dtokens6,
+                                                      dhidden0, dhidden1, dweights, dbiases, accumulate != 0,
+                                                      static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
 int aft_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, float grad_scale, int step, void *stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) { set_error("bad Adam argument"); return AFT_ERR_ARG; }

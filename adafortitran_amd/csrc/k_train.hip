@@ -210,6 +210,164 @@ hipError_t launch_adam(float *p, const float *g, float *m, float *v, size_t n, f
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// ChannelAdapter in the training path (reference src/models/blocks/channel_adaptivity.py:24-40,59-63): three
+// MLPs Linear(1,h0)-ReLU-Linear(h0,h1)-ReLU-Linear(h1,h2) on raw scalars, output element i of encoder e ->
+// token i/2, feature 2e + i%2.  0.07 MFLOP per frame: as separate dense layers its forward + backward is
+// ~45 launches of pure latency, so it is three kernels here: forward (keeps the hidden activations), data
+// gradients per (frame, encoder), and one kernel for all 18 parameter gradients (a thread per element loops
+// over the frames in a fixed order: deterministic, no atomics).
+// ---------------------------------------------------------------------------------------------
+struct AdapterTrainArgs {
+    const float *cond[3];
+    const float *w[3][3], *b[3][3];
+    float *tokens6;            // forward out [frames][tokens][6]
+    float *a0, *a1;            // hidden activations (post-ReLU) [frames][3][h0], [frames][3][h1]
+    const float *dtok;         // backward in [frames][tokens][6]
+    float *da0, *da1;          // [frames][3][h0], [frames][3][h1]
+    float *dw[3][3], *db[3][3];
+    int h0, h1, h2, tokens, frames, accumulate;
+};
+
+__global__ __launch_bounds__(256) void adapter_train_fwd_kernel(const AdapterTrainArgs a) {
+    extern __shared__ float sm[];
+    float *a0 = sm, *a1 = sm + a.h0;
+    const int b = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+    const float x = a.cond[e][b];
+    for (int i = tid; i < a.h0; i += 256) {
+        const float v = fmaxf(fmaf(a.w[e][0][i], x, a.b[e][0][i]), 0.f);
+        a0[i] = v;
+        a.a0[((size_t)b * 3 + e) * a.h0 + i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.h1; i += 256) {
+        float acc = a.b[e][1][i];
+        for (int k = 0; k < a.h0; ++k) acc = fmaf(a.w[e][1][i * a.h0 + k], a0[k], acc);
+        const float v = fmaxf(acc, 0.f);
+        a1[i] = v;
+        a.a1[((size_t)b * 3 + e) * a.h1 + i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.h2; i += 256) {
+        float acc = a.b[e][2][i];
+        const float *wr = a.w[e][2] + (size_t)i * a.h1;
+        for (int k = 0; k < a.h1; ++k) acc = fmaf(wr[k], a1[k], acc);
+        a.tokens6[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)] = acc;
+    }
+}
+
+// da1[k] = relu'(a1[k]) sum_i dout[i] W3[i][k];  da0[m] = relu'(a0[m]) sum_k da1[k] W2[k][m]   per (frame, encoder)
+constexpr int kAdaH1Max = 64;
+__global__ __launch_bounds__(256) void adapter_train_dgrad_kernel(const AdapterTrainArgs a) {
+    __shared__ float part[4][kAdaH1Max];
+    __shared__ float d1[kAdaH1Max];
+    const int b = blockIdx.x, e = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float acc[kAdaH1Max];
+#pragma unroll
+    for (int k = 0; k < kAdaH1Max; ++k) acc[k] = 0.f;
+    for (int i = tid; i < a.h2; i += 256) {
+        const float g = a.dtok[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)];
+        const float *wr = a.w[e][2] + (size_t)i * a.h1;
+#pragma unroll
+        for (int k = 0; k < kAdaH1Max; ++k)
+            if (k < a.h1) acc[k] = fmaf(g, wr[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kAdaH1Max; ++k) {
+        if (k >= a.h1) break;
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) part[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < a.h1) {
+        const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        const float r = a.a1[((size_t)b * 3 + e) * a.h1 + tid] > 0.f ? v : 0.f;
+        d1[tid] = r;
+        a.da1[((size_t)b * 3 + e) * a.h1 + tid] = r;
+    }
+    __syncthreads();
+    if (tid < a.h0) {
+        float v = 0.f;
+        for (int k = 0; k < a.h1; ++k) v = fmaf(d1[k], a.w[e][1][k * a.h0 + tid], v);
+        a.da0[((size_t)b * 3 + e) * a.h0 + tid] = a.a0[((size_t)b * 3 + e) * a.h0 + tid] > 0.f ? v : 0.f;
+    }
+}
+
+// all parameter gradients: element index -> (encoder, tensor, position); sum over the frames in order
+__global__ __launch_bounds__(256) void adapter_train_wgrad_kernel(const AdapterTrainArgs a) {
+    const int per = a.h2 * a.h1 + a.h2 + a.h1 * a.h0 + a.h1 + a.h0 + a.h0;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * per) return;
+    const int e = idx / per;
+    int r = idx - e * per;
+    double s = 0.0;   // float64 sums: the raw conditions (up to 1400) make these reductions ill-conditioned in fp32
+    float *out;
+    if (r < a.h2 * a.h1) {                       // dW3[i][k] = sum_b dout[b][i] a1[b][k]
+        const int i = r / a.h1, k = r - i * a.h1;
+        for (int b = 0; b < a.frames; ++b)
+            s += (double)a.dtok[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)] * (double)a.a1[((size_t)b * 3 + e) * a.h1 + k];
+        out = a.dw[e][2] + r;
+    } else if ((r -= a.h2 * a.h1) < a.h2) {      // db3[i]
+        for (int b = 0; b < a.frames; ++b) s += a.dtok[((size_t)b * a.tokens + (r >> 1)) * 6 + 2 * e + (r & 1)];
+        out = a.db[e][2] + r;
+    } else if ((r -= a.h2) < a.h1 * a.h0) {      // dW2[k][m] = sum_b da1[b][k] a0[b][m]
+        const int k = r / a.h0, m = r - k * a.h0;
+        for (int b = 0; b < a.frames; ++b) s += (double)a.da1[((size_t)b * 3 + e) * a.h1 + k] * (double)a.a0[((size_t)b * 3 + e) * a.h0 + m];
+        out = a.dw[e][1] + r;
+    } else if ((r -= a.h1 * a.h0) < a.h1) {      // db2[k]
+        for (int b = 0; b < a.frames; ++b) s += a.da1[((size_t)b * 3 + e) * a.h1 + r];
+        out = a.db[e][1] + r;
+    } else if ((r -= a.h1) < a.h0) {             // dW1[m] = sum_b da0[b][m] x[b]
+        for (int b = 0; b < a.frames; ++b) s += (double)a.da0[((size_t)b * 3 + e) * a.h0 + r] * (double)a.cond[e][b];
+        out = a.dw[e][0] + r;
+    } else {                                     // db1[m]
+        r -= a.h0;
+        for (int b = 0; b < a.frames; ++b) s += a.da0[((size_t)b * 3 + e) * a.h0 + r];
+        out = a.db[e][0] + r;
+    }
+    *out = a.accumulate ? *out + (float)s : (float)s;
+}
+
+static void fill_adapter(AdapterTrainArgs &a, const float *const cond[3], const float *const w[9], const float *const b[9],
+                         const int hidden[3], int tokens, int frames) {
+    for (int e = 0; e < 3; ++e) {
+        a.cond[e] = cond[e];
+        for (int j = 0; j < 3; ++j) {
+            a.w[e][j] = w[3 * e + j];
+            a.b[e][j] = b[3 * e + j];
+        }
+    }
+    a.h0 = hidden[0]; a.h1 = hidden[1]; a.h2 = hidden[2];
+    a.tokens = tokens; a.frames = frames;
+}
+
+hipError_t launch_adapter_train_fwd(const float *const cond[3], const float *const w[9], const float *const b[9],
+                                    const int hidden[3], int tokens, int frames, float *tokens6, float *a0, float *a1,
+                                    hipStream_t st) {
+    AdapterTrainArgs a{};
+    fill_adapter(a, cond, w, b, hidden, tokens, frames);
+    a.tokens6 = tokens6; a.a0 = a0; a.a1 = a1;
+    hipLaunchKernelGGL(adapter_train_fwd_kernel, dim3(frames, 3), dim3(256), sizeof(float) * (a.h0 + a.h1), st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_adapter_train_bwd(const float *const cond[3], const float *const w[9], const float *const b[9],
+                                    const int hidden[3], int tokens, int frames, const float *a0, const float *a1,
+                                    const float *dtok, float *da0, float *da1, float *const dw[9], float *const db[9],
+                                    bool accumulate, hipStream_t st) {
+    if (hidden[1] > kAdaH1Max || hidden[0] > 256) return hipErrorInvalidValue;
+    AdapterTrainArgs a{};
+    fill_adapter(a, cond, w, b, hidden, tokens, frames);
+    a.a0 = const_cast<float *>(a0); a.a1 = const_cast<float *>(a1);
+    a.dtok = dtok; a.da0 = da0; a.da1 = da1; a.accumulate = accumulate;
+    for (int e = 0; e < 3; ++e)
+        for (int j = 0; j < 3; ++j) { a.dw[e][j] = dw[3 * e + j]; a.db[e][j] = db[3 * e + j]; }
+    hipLaunchKernelGGL(adapter_train_dgrad_kernel, dim3(frames, 3), dim3(256), 0, st, a);
+    const int per = a.h2 * a.h1 + a.h2 + a.h1 * a.h0 + a.h1 + a.h0 + a.h0;
+    hipLaunchKernelGGL(adapter_train_wgrad_kernel, dim3((3 * per + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 static inline uint32_t drop_threshold(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
 static inline float drop_keep(float p) { return p > 0.f ? 1.f / (1.f - p) : 1.f; }
 

@@ -137,6 +137,60 @@ class HipConvEnhancerFunction(torch.autograd.Function):
         return (dx, *grads)
 
 
+def _ptrs(tensors, n):
+    arr = (C.c_void_p * n)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class HipChannelAdapterFunction(torch.autograd.Function):
+    """ChannelAdapter (three MLPs 1 -> h0 -> h1 -> h2 on snr / delay spread / doppler, reference
+    ``blocks/channel_adaptivity.py:24-63``) -> tokens [frames, h2/2, 6]; forward, data-gradient and parameter-
+    gradient kernels of the library (``aft_adapter_fwd_train_f32`` / ``aft_adapter_bwd_f32``).  ``params`` are the
+    18 tensors in the order {snr, ds, dop}_encoder.{0,2,4}.{weight, bias}."""
+
+    @staticmethod
+    def forward(ctx, snr, ds, dop, *params):
+        lib = _lib.load()
+        conds = [c.detach().reshape(-1).to(torch.float32).contiguous() for c in (snr, ds, dop)]
+        ws = [p.detach().contiguous() for p in params[0::2]]
+        bs = [p.detach().contiguous() for p in params[1::2]]
+        frames, dev = conds[0].numel(), conds[0].device
+        h0, h1, h2 = ws[0].shape[0], ws[1].shape[0], ws[2].shape[0]
+        tokens = h2 // 2
+        out = torch.empty((frames, tokens, 6), dtype=torch.float32, device=dev)
+        a0 = torch.empty((frames, 3, h0), dtype=torch.float32, device=dev)
+        a1 = torch.empty((frames, 3, h1), dtype=torch.float32, device=dev)
+        hid = (C.c_int32 * 3)(h0, h1, h2)
+        _lib.check(lib.aft_adapter_fwd_train_f32(C.byref(_ptrs(conds, 3)), C.byref(_ptrs(ws, 9)), C.byref(_ptrs(bs, 9)),
+                                                 C.byref(hid), tokens, frames, out.data_ptr(), a0.data_ptr(), a1.data_ptr(),
+                                                 _lib.current_stream_ptr(dev)))
+        ctx.save_for_backward(a0, a1, *conds, *ws, *bs)
+        ctx.param_objs = params
+        return out
+
+    @staticmethod
+    def backward(ctx, dtok):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        a0, a1, conds, ws, bs = saved[0], saved[1], saved[2:5], saved[5:14], saved[14:23]
+        frames, h0, h1, h2 = a0.shape[0], a0.shape[2], a1.shape[2], ws[2].shape[0]
+        dtok = dtok.contiguous()
+        objs = ctx.param_objs
+        direct = ACCUMULATE_INTO_GRAD and all(p.grad is not None and p.grad.is_contiguous() for p in objs)
+        grads = [p.grad for p in objs] if direct else [torch.empty_like(p) for p in objs]
+        da0, da1 = torch.empty_like(a0), torch.empty_like(a1)
+        hid = (C.c_int32 * 3)(h0, h1, h2)
+        _lib.check(lib.aft_adapter_bwd_f32(C.byref(_ptrs(conds, 3)), C.byref(_ptrs(ws, 9)), C.byref(_ptrs(bs, 9)), C.byref(hid),
+                                           h2 // 2, frames, a0.data_ptr(), a1.data_ptr(), dtok.data_ptr(), da0.data_ptr(),
+                                           da1.data_ptr(), C.byref(_ptrs(grads[0::2], 9)), C.byref(_ptrs(grads[1::2], 9)),
+                                           int(direct), _lib.current_stream_ptr(dtok.device)))
+        if direct:
+            return (None,) * (3 + len(objs))
+        return (None, None, None, *grads)
+
+
 class HipLinearFunction(torch.autograd.Function):
     """y = x W^T + b on [..., in] float32 tensors: the row-major MFMA GEMM forward, dgrad, split-K wgrad."""
 

@@ -183,6 +183,19 @@ int aft_conv_enhancer_bwd_f32(const float *const flipped_weights[4], const float
                               int accumulate, void *scratch, size_t scratch_bytes, int planes, int num_scs, int num_symbols,
                               void *stream);
 
+/* ChannelAdapter (reference src/models/blocks/channel_adaptivity.py:24-63) in train() mode: conditions[e] f32
+ * [frames] (snr, delay spread, doppler), weights / biases in the order {snr,ds,dop}_encoder.{0,2,4}; tokens6 f32
+ * [frames, tokens, 6]; hidden0 / hidden1 receive the post-ReLU activations [frames,3,h0] / [frames,3,h1] the
+ * backward needs.  The backward turns dL/dtokens6 into the 18 parameter gradients (inputs carry no gradient);
+ * dhidden0 / dhidden1 are scratch of the same shapes. */
+int aft_adapter_fwd_train_f32(const float *const conditions[3], const float *const weights[9], const float *const biases[9],
+                              const int32_t hidden[3], int tokens, int frames, float *tokens6, float *hidden0, float *hidden1,
+                              void *stream);
+int aft_adapter_bwd_f32(const float *const conditions[3], const float *const weights[9], const float *const biases[9],
+                        const int32_t hidden[3], int tokens, int frames, const float *hidden0, const float *hidden1,
+                        const float *dtokens6, float *dhidden0, float *dhidden1, float *const dweights[9],
+                        float *const dbiases[9], int accumulate, void *stream);
+
 /* Replaces torch.optim.Adam.step (reference src/main/trainer.py:407-413; amsgrad off) on one flat
  * float32 shard of n elements: grad is first multiplied by grad_scale (1/world_size after a
  * sum-reduce-scatter), weight_decay is the L2 form Adam uses; `step` is the 1-based step count. */

@@ -149,6 +149,8 @@ def test_full_model_training_step_matches_pytorch_autograd(name):
         model.transformer_encoder.hip_training = hip
         model.initial_enhancer.hip_training = model.final_refiner.hip_training = hip
         training.HipLinear.default_hip_training = hip
+        if hasattr(model, "channel_adapter"):
+            model.channel_adapter.hip_training = hip
         model.zero_grad()
         out = call()
         loss = torch.nn.functional.mse_loss(torch.view_as_real(out), torch.view_as_real(tgt))
@@ -348,6 +350,8 @@ def test_random_configurations_training_step_matches_autograd(spec):
         model.transformer_encoder.hip_training = hip
         model.initial_enhancer.hip_training = model.final_refiner.hip_training = hip
         training.HipLinear.default_hip_training = hip
+        if hasattr(model, "channel_adapter"):
+            model.channel_adapter.hip_training = hip
         model.zero_grad()
         out = model(pil, meta) if meta is not None else model(pil)
         loss = torch.nn.functional.mse_loss(torch.view_as_real(out), torch.view_as_real(tgt))
@@ -361,4 +365,35 @@ def test_random_configurations_training_step_matches_autograd(spec):
         training.HipLinear.default_hip_training = True
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     for n in g0:
-        assert _rel(g1[n], g0[n]) <= 2e-3, n
+        # the adapter's gradients are ill-conditioned fp32 sums of raw channel conditions (values up to 1400): two
+        # PyTorch runs with different reduction orders differ by ~1e-3 of |g|max on them (see test_train_golden.py)
+        assert _rel(g1[n], g0[n]) <= (2e-2 if n.startswith("channel_adapter") else 2e-3), n
+
+
+@pytest.mark.parametrize("hidden,frames", [((7, 42, 560), 12), ((5, 9, 80), 3), ((16, 64, 256), 7)])
+def test_channel_adapter_forward_backward_matches_autograd(hidden, frames):
+    import adafortitran_amd.blocks as blocks
+    from adafortitran_amd import training
+    torch.manual_seed(hidden[1])
+    ad = blocks.ChannelAdapter(hidden).cuda()
+    snr = torch.randint(0, 7, (frames, 1), device="cuda").float() * 5
+    ds = torch.randint(1, 8, (frames, 1), device="cuda").float() * 50
+    dop = torch.randint(1, 8, (frames, 1), device="cuda").float() * 200
+    gy = torch.randn(frames, hidden[2] // 2, 6, device="cuda")
+
+    def run(hip):
+        ad.hip_training = hip
+        training.HipLinear.default_hip_training = False      # reference path: plain PyTorch-ROCm autograd
+        ad.zero_grad()
+        y = ad(snr, ds, dop)
+        y.backward(gy)
+        return y.detach().clone(), [p.grad.clone() for p in ad.parameters()]
+
+    try:
+        y0, g0 = run(False)
+        y1, g1 = run(True)
+    finally:
+        training.HipLinear.default_hip_training = True
+    assert _rel(y1, y0) <= 1e-5
+    for (name, _), a, b in zip(ad.named_parameters(), g1, g0):
+        assert _rel(a, b) <= 1e-4, name

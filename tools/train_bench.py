@@ -56,6 +56,8 @@ def main():
         model.transformer_encoder.hip_training = mode == "hip"
         model.initial_enhancer.hip_training = model.final_refiner.hip_training = mode == "hip"
         training.HipLinear.default_hip_training = mode == "hip" and a.dense == "hip"
+        if hasattr(model, "channel_adapter"):
+            model.channel_adapter.hip_training = mode == "hip"
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize()
