@@ -268,9 +268,19 @@ __global__ __launch_bounds__(256) void adapter_train_dgrad_kernel(const AdapterT
     for (int i = tid; i < a.h2; i += 256) {
         const float g = a.dtok[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)];
         const float *wr = a.w[e][2] + (size_t)i * a.h1;
+        if ((a.h1 & 1) == 0) {   // rows of an even length start 8-byte aligned: half as many, wider loads
 #pragma unroll
-        for (int k = 0; k < kAdaH1Max; ++k)
-            if (k < a.h1) acc[k] = fmaf(g, wr[k], acc[k]);
+            for (int k = 0; k < kAdaH1Max; k += 2)
+                if (k < a.h1) {
+                    const f32x2 wv = *reinterpret_cast<const f32x2 *>(wr + k);
+                    acc[k] = fmaf(g, wv[0], acc[k]);
+                    acc[k + 1] = fmaf(g, wv[1], acc[k + 1]);
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kAdaH1Max; ++k)
+                if (k < a.h1) acc[k] = fmaf(g, wr[k], acc[k]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < kAdaH1Max; ++k) {
@@ -300,32 +310,52 @@ __global__ __launch_bounds__(256) void adapter_train_wgrad_kernel(const AdapterT
     if (idx >= 3 * per) return;
     const int e = idx / per;
     int r = idx - e * per;
-    double s = 0.0;   // float64 sums: the raw conditions (up to 1400) make these reductions ill-conditioned in fp32
+    // every gradient is sum_b u[b] * v[b] (or sum_b u[b]) with strided u, v: describe the two streams, then one
+    // loop with four independent float64 partial sums (the raw conditions, up to 1400, make these reductions
+    // ill-conditioned in fp32; four chains keep enough loads in flight)
+    const float *u, *v = nullptr;
+    size_t us, vs = 0;
     float *out;
+    const size_t tstride = (size_t)a.tokens * 6;
     if (r < a.h2 * a.h1) {                       // dW3[i][k] = sum_b dout[b][i] a1[b][k]
         const int i = r / a.h1, k = r - i * a.h1;
-        for (int b = 0; b < a.frames; ++b)
-            s += (double)a.dtok[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)] * (double)a.a1[((size_t)b * 3 + e) * a.h1 + k];
+        u = a.dtok + (size_t)(i >> 1) * 6 + 2 * e + (i & 1); us = tstride;
+        v = a.a1 + (size_t)e * a.h1 + k; vs = (size_t)3 * a.h1;
         out = a.dw[e][2] + r;
     } else if ((r -= a.h2 * a.h1) < a.h2) {      // db3[i]
-        for (int b = 0; b < a.frames; ++b) s += a.dtok[((size_t)b * a.tokens + (r >> 1)) * 6 + 2 * e + (r & 1)];
+        u = a.dtok + (size_t)(r >> 1) * 6 + 2 * e + (r & 1); us = tstride;
         out = a.db[e][2] + r;
     } else if ((r -= a.h2) < a.h1 * a.h0) {      // dW2[k][m] = sum_b da1[b][k] a0[b][m]
         const int k = r / a.h0, m = r - k * a.h0;
-        for (int b = 0; b < a.frames; ++b) s += (double)a.da1[((size_t)b * 3 + e) * a.h1 + k] * (double)a.a0[((size_t)b * 3 + e) * a.h0 + m];
+        u = a.da1 + (size_t)e * a.h1 + k; us = (size_t)3 * a.h1;
+        v = a.a0 + (size_t)e * a.h0 + m; vs = (size_t)3 * a.h0;
         out = a.dw[e][1] + r;
     } else if ((r -= a.h1 * a.h0) < a.h1) {      // db2[k]
-        for (int b = 0; b < a.frames; ++b) s += a.da1[((size_t)b * 3 + e) * a.h1 + r];
+        u = a.da1 + (size_t)e * a.h1 + r; us = (size_t)3 * a.h1;
         out = a.db[e][1] + r;
     } else if ((r -= a.h1) < a.h0) {             // dW1[m] = sum_b da0[b][m] x[b]
-        for (int b = 0; b < a.frames; ++b) s += (double)a.da0[((size_t)b * 3 + e) * a.h0 + r] * (double)a.cond[e][b];
+        u = a.da0 + (size_t)e * a.h0 + r; us = (size_t)3 * a.h0;
+        v = a.cond[e]; vs = 1;
         out = a.dw[e][0] + r;
     } else {                                     // db1[m]
         r -= a.h0;
-        for (int b = 0; b < a.frames; ++b) s += a.da0[((size_t)b * 3 + e) * a.h0 + r];
+        u = a.da0 + (size_t)e * a.h0 + r; us = (size_t)3 * a.h0;
         out = a.db[e][0] + r;
     }
-    *out = a.accumulate ? *out + (float)s : (float)s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 3 < a.frames; b += 4) {
+        const float u0 = u[(size_t)b * us], u1 = u[(size_t)(b + 1) * us], u2 = u[(size_t)(b + 2) * us], u3 = u[(size_t)(b + 3) * us];
+        const float v0 = v ? v[(size_t)b * vs] : 1.f, v1 = v ? v[(size_t)(b + 1) * vs] : 1.f;
+        const float v2 = v ? v[(size_t)(b + 2) * vs] : 1.f, v3 = v ? v[(size_t)(b + 3) * vs] : 1.f;
+        s0 += (double)u0 * (double)v0;
+        s1 += (double)u1 * (double)v1;
+        s2 += (double)u2 * (double)v2;
+        s3 += (double)u3 * (double)v3;
+    }
+    for (; b < a.frames; ++b) s0 += (double)u[(size_t)b * us] * (double)(v ? v[(size_t)b * vs] : 1.f);
+    const float t = (float)((s0 + s1) + (s2 + s3));
+    *out = a.accumulate ? *out + t : t;
 }
 
 static void fill_adapter(AdapterTrainArgs &a, const float *const cond[3], const float *const w[9], const float *const b[9],
