@@ -218,12 +218,18 @@ def main() -> None:
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
+    marks = [ev0]                      # one event per step boundary: per-step device times (median, p10/p90)
     for _ in range(args.steps):
         step()
+        m = torch.cuda.Event(enable_timing=True)
+        m.record()
+        marks.append(m)
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]   # noqa: E731
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -253,6 +259,7 @@ def main() -> None:
                                    f"batch {B} frames per GPU, forward + device MSE partial, inputs resident in HBM",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded over {world} rank(s)"},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
+            "device_step_ms": {"p10": round(pct(0.10), 4), "p50": round(pct(0.50), 4), "p90": round(pct(0.90), 4)},
             "mse_db_vs_random_target": round(10 * np.log10(mse), 4),
             "roofline": {"kernel": "chain_kernel<128,GELU,MLP=true,QKV=true> (out-proj+LN1+FFN+LN2 + next layer's QKV)",
                          "bound": "mfma",
