@@ -397,3 +397,46 @@ def test_channel_adapter_forward_backward_matches_autograd(hidden, frames):
     assert _rel(y1, y0) <= 1e-5
     for (name, _), a, b in zip(ad.named_parameters(), g1, g0):
         assert _rel(a, b) <= 1e-4, name
+
+
+def test_grad_scaler_branch_of_the_reference_trainer():
+    """The reference's mixed-precision branch (trainer.py:207-217): forward outside autocast, loss under autocast,
+    scaler.scale(loss).backward(), unscale_, clip, scaler.step, scaler.update -- on the HIP training kernels, with the
+    flat optimizer; same parameters afterwards as the plain fp32 step on PyTorch-ROCm autograd."""
+    from adafortitran_amd import synth, training
+    from adafortitran_amd.optim import ShardedFlatAdam
+    inp = synth.make_inputs(4, seed=21)
+    pil, tgt = torch.from_numpy(inp["pilots"]).cuda(), torch.from_numpy(inp["target"]).cuda()
+    cat = lambda z: torch.cat((torch.real(z), torch.imag(z)), dim=1)  # noqa: E731
+
+    def run(hip):
+        torch.manual_seed(5)
+        model = _model("fortitran", 0.0).train()
+        model.transformer_encoder.hip_training = hip
+        model.initial_enhancer.hip_training = model.final_refiner.hip_training = hip
+        training.HipLinear.default_hip_training = hip
+        opt = ShardedFlatAdam(model.parameters(), lr=1e-3) if hip else torch.optim.Adam(model.parameters(), lr=1e-3)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        for _ in range(3):
+            opt.zero_grad()
+            out = model(pil)
+            with torch.autocast("cuda"):
+                loss = torch.nn.MSELoss()(cat(out), cat(tgt))
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            scaler.step(opt)
+            scaler.update()
+        return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+
+    try:
+        ref = run(False)
+        got = run(True)
+    finally:
+        training.HipLinear.default_hip_training = True
+        training.ACCUMULATE_INTO_GRAD = False
+    assert torch.isfinite(got).all()
+    diff = (got - ref).abs()
+    # Adam divides by sqrt(v): an element whose gradient is ~0 can step +-lr on fp32 noise, so the bound on any single
+    # element is steps * lr; the bulk must agree closely
+    assert float(diff.max()) <= 3.1e-3 and float(diff.median()) <= 1e-6 and float((diff > 1e-4).float().mean()) <= 0.01
