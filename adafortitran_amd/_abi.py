@@ -129,7 +129,7 @@ def pos_key_of(state: Dict[str, object]) -> str:
 
 #: every symbol include/adafortitran_amd.h declares (tests check the .so exports them all)
 EXPORTED_SYMBOLS = (
-    "aft_version", "aft_last_error", "aft_workspace_bytes", "aft_forward_f32",
+    "aft_version", "aft_last_error", "aft_check_config", "aft_workspace_bytes", "aft_forward_f32",
     "aft_linear_forward_f32", "aft_mse_partial_f32", "aft_stage_upsample_f32",
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",
     "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",

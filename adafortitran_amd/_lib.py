@@ -45,6 +45,7 @@ def load():
     lib.aft_workspace_bytes.restype = C.c_size_t
     lib.aft_workspace_bytes.argtypes = [C.POINTER(_abi.AftConfig), C.c_int]
     vp, cfgp, wp = C.c_void_p, C.POINTER(_abi.AftConfig), C.POINTER(_abi.AftWeights)
+    lib.aft_check_config.argtypes = [cfgp]
     lib.aft_forward_f32.argtypes = [cfgp, wp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
     lib.aft_linear_forward_f32.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_mse_partial_f32.argtypes = [vp, vp, vp, C.c_longlong, vp]

@@ -1,11 +1,13 @@
-"""Parameter containers + autograd (training) math of the estimator's building blocks.
+"""Parameter containers + the differentiable (training) forward of the estimator's building blocks.
 
 These nn.Modules exist for two reasons: (1) they own the parameters under exactly the
 reference's ``state_dict`` names, so checkpoints move both ways;
-(2) their ``forward`` is the differentiable PyTorch-ROCm path used under ``train()`` /
-autograd, where the forward-only HIP kernels do not apply (SURVEY.md 8b "Grad / mode").
+(2) their ``forward`` is the differentiable path used under autograd: on the HIP device the encoder
+layers, the conv stacks, the dense layers and the adapter MLPs call the library's hand-written
+forward/backward kernels through ``torch.autograd.Function`` (training.py); on CPU
+they are the plain ``torch.nn`` modules the reference is made of.
 In ``eval()`` + ``no_grad()`` on a HIP device the estimator bypasses these forwards and
-calls the C ABI on the parameters' device pointers.
+calls the C ABI (``aft_forward_f32``) on the parameters' device pointers.
 
 Behavioural spec: reference src/models/blocks/{enhancers,patch_processors,
 channel_adaptivity,encoders,positional_encodings}.py.
@@ -39,10 +41,19 @@ class ConvEnhancer(nn.Module):
 
     #: set to False to differentiate the stack through PyTorch-ROCm (MIOpen) instead (A/B tests)
     hip_training = True
+    _covered = {}   # (S, T) -> the fused kernel has an LDS band plan for that grid
+
+    @classmethod
+    def _grid_covered(cls, S: int, T: int) -> bool:
+        key = (int(S), int(T))
+        if key not in cls._covered:
+            from .hip_ops import conv_enhancer_covered
+            cls._covered[key] = conv_enhancer_covered(*key)
+        return cls._covered[key]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if (self.hip_training and x.device.type == "cuda" and torch.is_grad_enabled() and x.dtype == torch.float32
-                and x.dim() == 4 and x.shape[1] == 1):
+                and x.dim() == 4 and x.shape[1] == 1 and self._grid_covered(x.shape[2], x.shape[3])):
             # grad-enabled forward on the HIP device: the fused conv-stack kernel, its own backward
             from .training import HipConvEnhancerFunction
             convs = [self.conv_block[i] for i in (0, 2, 4, 6)]

@@ -1,6 +1,7 @@
 // aft_api.hip -- the C ABI of include/adafortitran_amd.h: argument checking, workspace plan and
-// the launch sequence of one forward.  No allocation, no synchronisation, no global mutable state
-// besides a thread-local error string (hipGraph-capturable, re-entrant per stream).
+// the launch sequence of one forward.  No allocation, no synchronisation, no per-call state: besides a
+// thread-local error string the only things cached are per-device facts (CU count, LDS function
+// attribute) in tables indexed by device ordinal (hipGraph-capturable, re-entrant per stream).
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +17,31 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+
+int current_device_cus() {
+    static int cus[kMaxDevices];   // 0 = not asked yet; per device, idempotent
+    const int dev = current_device();
+    int c = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        __atomic_store_n(&cus[dev], c, __ATOMIC_RELAXED);
+    }
+    return c;
+}
+
+hipError_t ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, size_t bytes) {
+    const int dev = current_device();
+    if (!once.needed(dev)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) once.mark(dev);
+    return e;
 }
 
 static int tokens_of(const aft_config &c) { return (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols); }
@@ -54,6 +80,15 @@ int check_config(const aft_config *c) {
     if (c->activation != AFT_ACT_RELU && c->activation != AFT_ACT_GELU) {
         set_error("unknown activation %d", c->activation);
         return AFT_ERR_ARG;
+    }
+    {
+        const int p = c->patch_scs * c->patch_symbols;
+        if (!conv_plan_ok(c->num_scs, c->num_symbols, c->pilot_scs * c->pilot_symbols) ||
+            !conv_plan_ok(c->num_scs, c->num_symbols, p * c->model_dim + p)) {
+            set_error("OFDM grid %dx%d: no LDS band plan for the fused conv stack (too many symbols per row band)",
+                      c->num_scs, c->num_symbols);
+            return AFT_ERR_SHAPE;
+        }
     }
     if (c->adaptive && (c->hidden[0] <= 0 || c->hidden[1] <= 0 || c->hidden[2] != 2 * tokens_of(*c))) {
         set_error("channel_adaptivity_hidden_sizes [%d,%d,%d]: last must be 2 x tokens (%d)", c->hidden[0],
@@ -124,6 +159,8 @@ extern "C" {
 int aft_version(void) { return AFT_ABI_VERSION; }
 
 const char *aft_last_error(void) { return g_err; }
+
+int aft_check_config(const aft_config *cfg) { return check_config(cfg); }
 
 size_t aft_workspace_bytes(const aft_config *cfg, int batch) {
     if (check_config(cfg) != AFT_OK || batch <= 0) return 0;

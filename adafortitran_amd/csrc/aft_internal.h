@@ -41,6 +41,22 @@ Workspace plan_workspace(const aft_config &c, int batch);
 void set_error(const char *fmt, ...);
 int check_config(const aft_config *c);
 
+// Per-DEVICE facts (aft_api.hip).  The library keeps no state that describes a call, but two things
+// are properties of a device, not of a call: its CU count (persistent grids are sized to it) and the
+// "this kernel may use N bytes of dynamic LDS" function attribute, which HIP keeps per device.  Both
+// live in tables indexed by the current device ordinal, so a process that drives several GPUs through
+// this ABI gets each of them configured; entries are idempotent (a race repeats the same call).
+constexpr int kMaxDevices = 64;
+int current_device();        // hipGetDevice, clamped to [0, kMaxDevices)
+int current_device_cus();    // multiprocessor count of the current device (cached per device)
+struct PerDeviceOnce {       // one flag per device; `static PerDeviceOnce x;` inside a launcher
+    unsigned long long done = 0;
+    bool needed(int dev) const { return !((__atomic_load_n(&done, __ATOMIC_RELAXED) >> dev) & 1ull); }
+    void mark(int dev) { __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELAXED); }
+};
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device)
+hipError_t ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, size_t bytes);
+
 // ---- kernel launchers (each enqueues on `st`, returns hipError_t of the launch) ----
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots,
                            float *conv_enhanced, int batch, hipStream_t st);
@@ -61,6 +77,8 @@ hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float 
 // qbias = the layer's in_proj_bias (first d entries are the query bias, applied at fragment load).
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
                             float *attn, int planes, int tokens, int tokpad, hipStream_t st);
+// true when the fused conv-stack kernel has an LDS band plan for an S x T grid with `extra_floats` of side data
+bool conv_plan_ok(int S, int T, int extra_floats);
 hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
                        float *out, int batch, hipStream_t st);
 hipError_t launch_linear(const float *weight, const float *bias, const float *pilots, float *out, int batch,

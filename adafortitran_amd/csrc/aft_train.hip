@@ -238,7 +238,7 @@ int aft_dense_bwd_f32(const float *x, const float *weight, const float *dy, floa
 }
 
 size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols) {
-    if (planes <= 0 || num_scs <= 0 || num_symbols <= 0) return 0;
+    if (planes <= 0 || num_scs <= 0 || num_symbols <= 0 || !conv_plan_ok(num_scs, num_symbols, 0)) return 0;
     return sizeof(float) * (al64((size_t)planes * 48 * num_scs * num_symbols) + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols)));
 }
 

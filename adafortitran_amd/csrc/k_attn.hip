@@ -228,13 +228,7 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
                             float *attn, int planes, int tokens, int tokpad, hipStream_t st) {
     const int ntasks = planes * c.num_head * (tokpad / kTile);
-    static int resident_blocks = 0;   // 256 CUs x 3 workgroups (launch bound: 3 waves / SIMD)
-    if (resident_blocks == 0) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        resident_blocks = AFT_ATTN_WAVES * cus;
-    }
+    const int resident_blocks = AFT_ATTN_WAVES * current_device_cus();   // CUs x 3 workgroups (launch bound: 3 waves / SIMD)
     const int blocks = std::min((ntasks + 3) / 4, resident_blocks);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)kHeadDim);
 #ifdef AFT_DIAG_STAMPS

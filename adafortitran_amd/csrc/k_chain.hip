@@ -446,20 +446,11 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
 template <int D, int ACT, bool MLP, bool QKV>
 static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
     using S = ChainShape<D>;
-    static bool attr_set = false;  // idempotent; races only repeat the same call
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<D, ACT, MLP, QKV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static int resident = 0;   // co-resident workgroups: CUs x (3 at d=128 | 1 at d=256), see __launch_bounds__ / LDS
-    if (resident == 0) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        resident = cus * (D <= 128 ? 3 : 1);
-    }
+    static PerDeviceOnce lds_attr;   // per instantiation x device
+    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_kernel<D, ACT, MLP, QKV>), S::LDS_BYTES);
+    if (ea != hipSuccess) return ea;
+    // co-resident workgroups: CUs x (3 at d<=128 | 1 at d=256), see __launch_bounds__ / LDS
+    const int resident = current_device_cus() * (D <= 128 ? 3 : 1);
     const int blocks = std::min((args.rows + 31) / 32, resident);
     const size_t lds = S::LDS_BYTES;
 #ifdef AFT_DIAG_STAMPS

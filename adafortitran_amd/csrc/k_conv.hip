@@ -424,17 +424,19 @@ static bool plan_bands(int S, int T, int extra_floats, ConvArgs *a, size_t *lds_
     return false;
 }
 
+bool conv_plan_ok(int S, int T, int extra_floats) {
+    ConvArgs a{};
+    size_t lds = 0;
+    return S > 0 && T > 0 && plan_bands(S, T, extra_floats, &a, &lds);
+}
+
 template <bool TRAIN>
 static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStream_t st) {
     size_t lds = 0;
     if (!plan_bands(a.S, a.T, extra_floats, &a, &lds)) return hipErrorInvalidValue;
-    static bool attr_set = false;  // per instantiation; idempotent, a race only repeats the same call
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stack_kernel<TRAIN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static PerDeviceOnce lds_attr;   // per instantiation x device
+    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(conv_stack_kernel<TRAIN>), 160 * 1024);
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL(conv_stack_kernel<TRAIN>, dim3(planes * a.nbands), dim3(kConvThreads), lds, st, a);
     return hipGetLastError();
 }

@@ -186,14 +186,10 @@ hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, c
                              const float *g2, const float *g3, const float *dy, float *const dw[4], float *const db[4],
                              float *slices, int planes, int S, int T, bool accumulate, hipStream_t st) {
     const int npix = S * T, pblocks = (npix + 255) / 256;
-    static bool attr_set = false;
+    static PerDeviceOnce lds_attr;
     const size_t lds = sizeof(float) * 4 * kWgWave;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad32x8_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(wgrad32x8_kernel), lds);
+    if (ea != hipSuccess) return ea;
     const int chunks = planes * T * ((S + 63) / 64);
     const int grid = std::max(1, std::min(kWgradSlices, (chunks + 3) / 4));
     hipError_t e;

@@ -331,13 +331,7 @@ template <int OP, int BM>
 static void gemm_go(const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda, int ldb,
                     int ldc, bool accumulate, hipStream_t st) {
     const int ntiles = ((N + GBN - 1) / GBN) * ((M + BM - 1) / BM);
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+    const int cus = current_device_cus();
     const dim3 grid(std::min(ntiles, cus * (BM == 128 ? 2 : 4)), 1, 1);   // resident workgroups per CU (VGPR bound: 192 / 120); swept 2..8
     if (gemm_vec_ok(OP, A, B, M, N, K, lda, ldb))
         hipLaunchKernelGGL((gemm_kernel<OP, BM, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,

@@ -10,13 +10,23 @@ Execution paths of ``forward``:
   * HIP device, ``eval()`` and autograd off, float32 parameters  ->  ONE call into
     ``aft_forward_f32`` (hand-written HIP).  A missing/failed extension RAISES here; there
     is no silent PyTorch fallback for this case.
-  * ``train()`` or autograd on (the reference trainer's ``train_epoch``), CPU device, or
-    non-fp32 parameters -> the differentiable PyTorch composite in blocks.py.  This is the
-    autograd path, not a fallback: the HIP kernels are forward-only.
+  * HIP device with autograd on (the reference trainer's ``train_epoch``) -> the differentiable
+    composite in blocks.py, whose encoder layers, conv stacks, dense layers and adapter MLPs run the
+    library's hand-written forward/backward kernels behind ``torch.autograd.Function`` (training.py,
+    SURVEY.md 8f-1); only reshapes, concatenations and the loss are PyTorch ops.
+  * ``device: cpu`` -> the same composite on ATen's CPU kernels (what the reference itself runs).
+
+Coverage is ONE predicate, asked once at construction (``aft_check_config``): a configuration the
+reference accepts but the gfx950 kernels do not cover (model_dim outside {64,128,192,256}, head dim
+!= 32, < 32 tokens, patch > 16 elements, a grid with no LDS band plan) is refused with a ``ValueError``
+when the model is built on a HIP device -- before any training -- instead of training through
+per-block PyTorch fallbacks and failing in the first ``eval()`` forward.  ``AFT_ALLOW_COMPOSITE=1`` in
+the environment opts into running such a model entirely on the PyTorch-ROCm composite (logged).
 """
 from __future__ import annotations
 
 import logging
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -27,6 +37,54 @@ from .blocks import (ChannelAdapter, ConvEnhancer, InversePatchEmbedding, PatchE
                      TransformerEncoderForChannels)
 from .config import ModelConfig, SystemConfig, check_shape_coupling
 from .training import HipLinear
+
+
+class _InputStager:
+    """The model-owned H2D copy of ``forward`` (reference fortitran.py:167-173) for the HIP inference path:
+    pilots + the three condition vectors of a batch (25 KB at B=128) are packed into ONE pinned host
+    buffer and moved with ONE asynchronous copy on the caller's stream, instead of four pageable
+    ``.to(device)`` copies that each end in a stream synchronisation -- the host keeps running ahead of
+    the device exactly as it does when the inputs are already resident.  A small ring of pinned buffers,
+    each guarded by an event, makes re-use safe; the device side is stream-ordered."""
+
+    SLOTS = 4
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.nbytes = 0
+        self.host, self.events, self.dev = [], [], None
+        self.turn = 0
+
+    def _resize(self, nbytes: int) -> None:
+        self.nbytes = max(nbytes, 4096)
+        self.host = [torch.empty(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        self.events = [None] * self.SLOTS
+        self.dev = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
+
+    def stage(self, pilots: torch.Tensor, conds: Optional[List[torch.Tensor]]):
+        B = pilots.shape[0]
+        pil_bytes = pilots.numel() * 8
+        total = (pil_bytes + 15) // 16 * 16 + (3 * B * 4 if conds is not None else 0)
+        if total > self.nbytes:
+            self._resize(total)
+        slot = self.turn
+        self.turn = (slot + 1) % self.SLOTS
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()          # the copy that last read this pinned buffer has finished
+        host = self.host[slot]
+        host[:pil_bytes].view(torch.complex64).view(pilots.shape).copy_(pilots)
+        off = (pil_bytes + 15) // 16 * 16
+        if conds is not None:
+            for i, c in enumerate(conds):
+                host[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32).copy_(c.reshape(-1))
+        self.dev[:total].copy_(host[:total], non_blocking=True)
+        ev = self.events[slot] or torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
+        pil_dev = self.dev[:pil_bytes].view(torch.complex64).view(pilots.shape)
+        if conds is None:
+            return pil_dev, None
+        return pil_dev, [self.dev[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32) for i in range(3)]
 
 
 class BaseFortiTranEstimator(nn.Module):
@@ -41,9 +99,13 @@ class BaseFortiTranEstimator(nn.Module):
         self.device = torch.device(model_config.device)
         self.logger = logging.getLogger(self.__class__.__name__)
         self._engine = None
+        self._engine_entries = ()      # (owner dict, key, tensor, data_ptr) per state_dict tensor of the engine
+        self._stager = None            # pinned-ring H2D staging of CPU inputs on the HIP inference path
+        self._hip_covered = False
         self._setup_dimensions()
         self._build_architecture()
         self.to(self.device)
+        self._check_hip_coverage()
         self._log_initialization_info()
 
     # ---- construction (fortitran.py:52-126) -------------------------------------------------
@@ -86,32 +148,73 @@ class BaseFortiTranEstimator(nn.Module):
                          info["pilot_size"], info["patch_size"], info["model_dim"], info["num_layers"],
                          info["device"], f"{info['total_parameters']:,}", f"{info['trainable_parameters']:,}")
 
-    # ---- engine management ------------------------------------------------------------------
+    # ---- coverage + engine management ---------------------------------------------------------
+    def _check_hip_coverage(self) -> None:
+        """The single coverage predicate (module docstring): on a HIP device ask the library whether its
+        kernels cover this configuration; refuse at construction if not."""
+        self._hip_covered = False
+        if self.pilot_upsampler.weight.device.type != "cuda":
+            return
+        from .hip_ops import config_coverage   # loads the extension: a missing .so raises here, loudly
+        cfg = _abi.config_from_pydantic(self.system_config, self.model_config, self.use_channel_adaptation)
+        reason = config_coverage(cfg)
+        if reason is None:
+            self._hip_covered = True
+            return
+        if os.environ.get("AFT_ALLOW_COMPOSITE") == "1":
+            self.logger.warning("configuration not covered by the gfx950 kernels (%s): AFT_ALLOW_COMPOSITE=1, "
+                                "running the PyTorch-ROCm composite for training AND evaluation", reason)
+            return
+        raise ValueError(f"configuration not covered by the gfx950 kernels: {reason}. Build the model with "
+                         "device='cpu', or set AFT_ALLOW_COMPOSITE=1 to run the PyTorch-ROCm composite instead.")
+
     def _apply(self, fn, *args, **kwargs):  # .to()/.cuda()/.float() re-allocate parameters
         self._engine = None
-        return super()._apply(fn, *args, **kwargs)
+        out = super()._apply(fn, *args, **kwargs)
+        if hasattr(self, "pilot_upsampler") and self._hip_covered != (self.pilot_upsampler.weight.device.type == "cuda"):
+            self._check_hip_coverage()    # moved between CPU and the HIP device after construction
+        return out
 
     def load_state_dict(self, *args, **kwargs):
         self._engine = None
         return super().load_state_dict(*args, **kwargs)
 
     def _hip_eligible(self) -> bool:
-        if self.training or torch.is_grad_enabled():
-            return False
-        p = self.pilot_upsampler.weight
-        return p.device.type == "cuda" and all(q.dtype == torch.float32 for q in self.parameters())
+        return self._hip_covered and not self.training and not torch.is_grad_enabled()
 
     def _hip_engine(self):
+        """The cached engine, or None when the parameters are not float32 (then the composite runs, as
+        for any dtype the reference would run).  The per-call check is O(number of tensors) pointer /
+        identity compares (~10 us): an engine stays valid until a tensor object is replaced in its
+        module or re-homed (``p.data = ...``, e.g. by optim.FlatParameters); in-place updates by an
+        optimizer keep it valid because the ABI reads the parameters' own storage."""
+        eng = self._engine
+        if eng is not None:
+            for owner, key, tensor, ptr in self._engine_entries:
+                cur = owner.get(key)
+                if cur is not tensor or cur.data_ptr() != ptr:
+                    eng = None
+                    break
+            if eng is not None:
+                return eng
         from .hip_ops import HipEngine  # raises loudly if the extension is missing
-        tensors = {k: v for k, v in self.state_dict(keep_vars=True).items()}
+        entries, tensors = [], {}
+        for prefix, mod in self.named_modules():
+            for owner in (mod._parameters, mod._buffers):
+                for key, t in owner.items():
+                    if t is None or (owner is mod._buffers and key in mod._non_persistent_buffers_set):
+                        continue
+                    tensors[f"{prefix}.{key}" if prefix else key] = t
+                    entries.append((owner, key, t, t.data_ptr()))
+        if any(t.is_floating_point() and t.dtype != torch.float32 for t in tensors.values()):
+            self._engine, self._engine_entries = None, ()
+            return None
         for k, v in tensors.items():
             if not v.is_contiguous():
                 raise ValueError(f"parameter {k} is not contiguous")
-        eng = self._engine
-        if eng is None or eng.signature() != tuple(v.data_ptr() for v in tensors.values() if v.is_floating_point()):
-            cfg = _abi.config_from_pydantic(self.system_config, self.model_config, self.use_channel_adaptation)
-            eng = HipEngine(cfg, {k: v.detach() for k, v in tensors.items()})
-            self._engine = eng
+        cfg = _abi.config_from_pydantic(self.system_config, self.model_config, self.use_channel_adaptation)
+        eng = HipEngine(cfg, {k: v.detach() for k, v in tensors.items()})
+        self._engine, self._engine_entries = eng, tuple(entries)
         return eng
 
     # ---- forward (fortitran.py:145-233) -----------------------------------------------------
@@ -123,14 +226,28 @@ class BaseFortiTranEstimator(nn.Module):
         conditions: Optional[List[torch.Tensor]] = None
         if self.use_channel_adaptation:
             _, snr, delay_spread, max_dop_shift, _, _ = meta_data
-            conditions = [t.to(self.device) for t in (snr, delay_spread, max_dop_shift)]
-        pilot_symbols = pilot_symbols.to(self.device)  # the model owns the H2D copy (fortitran.py:173)
+            conditions = [snr, delay_spread, max_dop_shift]
 
-        if self._hip_eligible():
-            eng = self._hip_engine()
+        eng = self._hip_engine() if self._hip_eligible() else None
+        if eng is not None:
+            # the model owns the H2D copy (fortitran.py:167-173): CPU inputs as the DataLoader yields them go
+            # through the pinned staging ring in one asynchronous copy; device-resident inputs pass through
+            if (pilot_symbols.device.type == "cpu" and pilot_symbols.dtype == torch.complex64 and pilot_symbols.dim() == 3
+                    and (conditions is None or all(c.device.type == "cpu" and c.dtype == torch.float32
+                                                   and c.numel() == pilot_symbols.shape[0] for c in conditions))):
+                if self._stager is None or self._stager.device != self.pilot_upsampler.weight.device:
+                    self._stager = _InputStager(self.pilot_upsampler.weight.device)
+                pilot_symbols, conditions = self._stager.stage(pilot_symbols, conditions)
+            else:
+                pilot_symbols = pilot_symbols.to(self.device)
+                if conditions is not None:
+                    conditions = [t.to(self.device) for t in conditions]
             if conditions is None:
                 return eng.forward(pilot_symbols)
             return eng.forward(pilot_symbols, *conditions)
+        if conditions is not None:
+            conditions = [t.to(self.device) for t in conditions]
+        pilot_symbols = pilot_symbols.to(self.device)  # the model owns the H2D copy (fortitran.py:173)
 
         if pilot_symbols.device.type == "cuda" and torch.is_grad_enabled():
             # training on the HIP device: the Re and Im planes go through the network as ONE batch of

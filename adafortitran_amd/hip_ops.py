@@ -21,6 +21,19 @@ def _dev_f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def config_coverage(cfg: _abi.AftConfig) -> Optional[str]:
+    """None when the gfx950 kernels cover ``cfg``, else the library's reason (``aft_check_config``)."""
+    lib = _lib.load()
+    if lib.aft_check_config(C.byref(cfg)) == _abi.AFT_OK:
+        return None
+    return lib.aft_last_error().decode(errors="replace")
+
+
+def conv_enhancer_covered(num_scs: int, num_symbols: int) -> bool:
+    """True when the fused conv-stack kernel has an LDS band plan for this grid (training path)."""
+    return _lib.load().aft_conv_enhancer_scratch_bytes(1, int(num_scs), int(num_symbols)) > 0
+
+
 class HipEngine:
     """Owns an ``aft_config``, the weight pointer table and a workspace for one model.
 

@@ -47,7 +47,7 @@ class MseAccumulator:
         every rank; equals the reference's sample-weighted mean up to summation order)."""
         pair = self.local_pair()
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized():   # world_size 1 included: same code path on every launch
             gathered = [torch.empty_like(pair) for _ in range(dist.get_world_size(group))]
             dist.all_gather(gathered, pair, group=group)
             pair = torch.stack(gathered).sum(dim=0)

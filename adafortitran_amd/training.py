@@ -6,8 +6,8 @@ library's ``aft_encoder_layer_fwd_train_f32`` / ``aft_encoder_layer_bwd_f32``: o
 ``train()`` mode, with the activation tape owned by autograd.  ``encoder_stack_train`` chains it
 over the layers of ``nn.TransformerEncoder`` so that ``loss.backward()`` in the reference's
 ``TrainingLoop.train_epoch`` (``src/main/trainer.py:195-233``) runs hand-written kernels for the
-encoder (95 % of the FLOPs).  The conv stacks, the embedding and the adapter MLPs still
-differentiate through PyTorch-ROCm autograd.
+encoder (95 % of the FLOPs); ``HipConvEnhancerFunction``, ``HipLinearFunction`` and
+``HipChannelAdapterFunction`` do the same for the conv stacks, the dense layers and the adapter MLPs.
 
 Dropout uses a counter-based generator keyed by a per-call seed (drawn from torch's default
 generator, so ``torch.manual_seed`` makes runs repeatable); the masks differ from PyTorch's Philox
@@ -23,11 +23,23 @@ import torch
 from . import _abi, _lib
 
 
-#: When True (set by optim.ShardedFlatAdam, whose .grad tensors are views into one flat buffer), the
-#: backward adds the parameter gradients straight into the existing ``.grad`` tensors and reports
-#: "no gradient" to autograd, which saves autograd's own 12 accumulate kernels per layer.  Leave it
-#: False with optimizers / wrappers that rely on autograd's AccumulateGrad hooks (torch DDP).
-ACCUMULATE_INTO_GRAD = False
+def direct_grad_ok(params) -> bool:
+    """True when EVERY tensor in ``params`` is owned by a live ``optim.FlatParameters`` that asked for direct
+    accumulation and its ``.grad`` still is that owner's float32 view.  Then the backward adds the parameter
+    gradients straight into those views and reports "no gradient" to autograd, which saves autograd's own
+    accumulate kernel per parameter.  The behaviour is scoped to the tagged parameters of that optimizer (the
+    tag holds a weak reference and dies with the FlatParameters): models driven by any other optimizer, with
+    ``zero_grad(set_to_none=True)``, or whose ``.grad`` was re-pointed, get ordinary autograd gradients.
+    ``FlatParameters(direct_accumulation=False)`` keeps autograd's AccumulateGrad path (needed for
+    ``torch.autograd.grad``, ``backward(inputs=...)``, gradient hooks, torch DDP)."""
+    for p in params:
+        if p is None:
+            continue
+        ref = getattr(p, "_aft_flat_owner", None)
+        owner = ref() if ref is not None else None
+        if owner is None or not owner.direct_accumulation or not owner.owns_grad(p):
+            return False
+    return True
 
 
 def _layer_struct(cls, tensors: Sequence[torch.Tensor]):
@@ -69,8 +81,7 @@ class HipEncoderLayerFunction(torch.autograd.Function):
         x, tape, *params = ctx.saved_tensors
         cfg = ctx.cfg
         grad_out = grad_out.contiguous()
-        direct = ACCUMULATE_INTO_GRAD and all(
-            p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for p in ctx.param_objs)
+        direct = direct_grad_ok(ctx.param_objs)
         grads = [p.grad for p in ctx.param_objs] if direct else [torch.empty_like(p) for p in params]
         dx = torch.empty_like(x)
         scratch = torch.empty(lib.aft_encoder_train_scratch_bytes(C.byref(cfg), ctx.batch), dtype=torch.uint8, device=x.device)
@@ -124,7 +135,7 @@ class HipConvEnhancerFunction(torch.autograd.Function):
         dy = dy.contiguous()
         flipped = [w.transpose(0, 1).flip(2, 3).contiguous() for w in reversed(ws)]   # conv4^T .. conv1^T
         objs = ctx.param_objs
-        direct = ACCUMULATE_INTO_GRAD and all(p.grad is not None and p.grad.is_contiguous() for p in objs)
+        direct = direct_grad_ok(objs)
         grads = [p.grad for p in objs] if direct else [torch.empty_like(p) for p in objs]
         dx = torch.empty_like(x)
         scratch = torch.empty(lib.aft_conv_enhancer_scratch_bytes(n, S, T), dtype=torch.uint8, device=x.device)
@@ -178,7 +189,7 @@ class HipChannelAdapterFunction(torch.autograd.Function):
         frames, h0, h1, h2 = a0.shape[0], a0.shape[2], a1.shape[2], ws[2].shape[0]
         dtok = dtok.contiguous()
         objs = ctx.param_objs
-        direct = ACCUMULATE_INTO_GRAD and all(p.grad is not None and p.grad.is_contiguous() for p in objs)
+        direct = direct_grad_ok(objs)
         grads = [p.grad for p in objs] if direct else [torch.empty_like(p) for p in objs]
         da0, da1 = torch.empty_like(a0), torch.empty_like(a1)
         hid = (C.c_int32 * 3)(h0, h1, h2)
@@ -215,8 +226,7 @@ class HipLinearFunction(torch.autograd.Function):
         weight, bias = ctx.param_objs
         dy2 = dy.reshape(-1, w.shape[0]).contiguous()
         rows, out_f, in_f = x2.shape[0], w.shape[0], w.shape[1]
-        direct = ACCUMULATE_INTO_GRAD and weight.grad is not None and weight.grad.is_contiguous() and (
-            bias is None or (bias.grad is not None and bias.grad.is_contiguous()))
+        direct = direct_grad_ok((weight, bias))
         dw = weight.grad if direct else torch.empty_like(w)
         db = None if bias is None else (bias.grad if direct else torch.empty_like(bias))
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None

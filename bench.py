@@ -1,29 +1,43 @@
 #!/usr/bin/env python3
 """bench.py -- OFDM frames/s of the AdaFortiTran forward path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model adafortitran|fortitran] [--batch 128]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+``--gpus N`` with N > 1 and no torchrun environment: this process touches no GPU, starts
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` on
+itself, relays rank 0's JSON line and exits with the children's status (fewer than N visible
+devices => non-zero exit).  Under torchrun (WORLD_SIZE set) it is one rank: one process per GPU.
 
 A *step* is one pass of the hot path over one batch of synthetic input on every rank: one
-``aft_forward_f32`` (B=128 complex 120x14 frames, inputs already resident in HBM) plus the
-device-side channel-MSE partial sum.  One process per GPU; frames shard across ranks with no
-data-path collective (weak scaling: 128 frames per GPU); a single RCCL all-gather of the
-per-rank (sum|e|^2, n) pair closes the sweep.  Rank 0 prints ONE JSON line.
+``aft_forward_f32`` (config 3: AdaFortiTran default, B=128 complex 120x14 frames, inputs already
+resident in HBM) plus the device-side channel-MSE partial sum.  Frames shard across ranks with no
+data-path collective (weak scaling: 128 frames per GPU); ONE RCCL all-gather of the per-rank
+(sum|e|^2, n) pair closes the sweep.  Rank 0 prints ONE JSON line.
 
-Besides the contract fields the line carries
-  roofline      -- dominant kernel (chain: out-proj+LN1+FFN+LN2+QKV) vs the fp32-MFMA roof,
-                   duration measured live with events on the launch stream;
-  kernels       -- the same measurement for every kernel class of the forward;
-  cpu_baseline  -- the reference-equivalent CPU path (same torch.nn modules => same ATen /
-                   oneDNN / MKL kernels as the reference) timed on this box's host cores on a
-                   bounded sample, rank 0, N=1 only; the C oracle's rate rides along.
+Besides the contract fields the line carries (rank 0; the legs marked N=1 run only when one GPU is used)
+  roofline        dominant kernel (chain: out-proj+LN1+FFN+LN2+QKV) vs the fp32-MFMA roof; its duration is
+                  measured live: K whole forwards are bracketed by ONE event pair on the launch stream, and
+                  that time is apportioned to the kernel classes by their shares of a per-launch-event pass
+                  of the same flow (per-launch event pairs alone inflate each kernel by ~3 us);
+  kernels         the same for every kernel class of the forward;
+  module_surface  (N=1) the metric as SURVEY.md 8(d) defines it: AdaFortiTranEstimator.forward called as the
+                  reference trainer calls it -- CPU complex64 pilots + CPU meta 6-tuple, eval()+no_grad(),
+                  H2D inside forward (reference trainer.py:280-288,332-337; fortitran.py:167-173);
+  configs         (N=1) sub-records for BASELINE.json's configs: C1 linear B=32, C2 FortiTran B=128,
+                  C3 (= the headline), C5 (240x28 grid, 12 layers, d=256, 8 heads) at 64 frames per GPU;
+  parity          (N=1) channel-estimation MSE vs the oracle on a bounded sample of the same inputs:
+                  max|h_hip - h_oracle|, mean|h_hip - h_oracle|^2, |MSE_hip - MSE_oracle| / MSE_oracle;
+  cpu_baseline    (N=1) the reference-equivalent CPU path (same torch.nn modules => same ATen / oneDNN /
+                  MKL kernels as the reference) on this box's host cores, bounded sample; CPU model,
+                  physical core count and the threads used are stated; the C oracle's rate rides along.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,85 +45,358 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense, = fp32 vector peak
+SEED = 20251114
 
-SPEC = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=6, model_dim=128, num_head=4)
-HIDDEN = (7, 42, 560)
-PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, = fp32 vector peak
-PEAK_HBM_GBS = 8000.0
+C3 = dict(name="C3", model="adafortitran", ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=6, model_dim=128,
+          num_head=4, hidden=(7, 42, 560), max_seq_len=512, batch=128,
+          label="AdaFortiTran default config (6 layers, d=128, 4 heads, adaptive tokens), 120x14 grid, pilots 12x2")
+C2 = dict(C3, name="C2", model="fortitran", hidden=None,
+          label="FortiTran default config (6 layers, d=128, 4 heads), 120x14 grid, pilots 12x2")
+C5 = dict(name="C5", model="adafortitran", ofdm=(240, 28), pilot=(24, 4), patch=(3, 2), num_layers=12, model_dim=256,
+          num_head=8, hidden=(7, 42, 2240), max_seq_len=1120, batch=64,
+          label="AdaFortiTran 12 layers / d=256 / 8 heads, 240x28 grid, patch [3,2], pilots 24x4, 64 frames per GPU "
+                "(batch 512 over 8 GPUs)")
 
 
-def algorithmic_flops(spec, tokens, planes):
-    """FLOPs per launch (MAC = 2) of each kernel class -- SURVEY.md 2.2 / 8(d) per-plane figures
-    x the planes one launch processes (DESIGN.md 'roofline accounting')."""
-    d, L = spec["model_dim"], spec["num_layers"]
+def _spec(c):
+    return dict(ofdm=c["ofdm"], pilot=c["pilot"], patch=c["patch"], num_layers=c["num_layers"], model_dim=c["model_dim"],
+                num_head=c["num_head"])
+
+
+def algorithmic_flops(c, batch):
+    """FLOPs per launch (MAC = 2) of each kernel class: SURVEY.md 2.2 / 8(d) per-plane figures x the planes one
+    launch processes (DESIGN.md 'roofline accounting')."""
+    (S, T), (Ps, Pt), (p0, p1) = c["ofdm"], c["pilot"], c["patch"]
+    d, L, planes = c["model_dim"], c["num_layers"], 2 * batch
+    tokens = (S // p0) * (T // p1)
     rows = planes * tokens
     qkv = 2 * rows * d * 3 * d
     proj = 2 * rows * d * d
     ffn = 2 * rows * d * 2 * d * 2
-    attn = 2 * 2 * planes * tokens * tokens * d      # QK^T + PV over all heads
-    conv = planes * 15_966_720                        # 4 convs, SURVEY.md 2.2 K2 (120x14 grid)
-    up = planes * 80_640
-    return {"qkv": qkv, "chain": proj + ffn + qkv, "chain_last": proj + ffn, "attention": attn, "upsample": conv + up,
-            "tail": conv + 2 * planes * tokens * d * 6, "embed": 2 * rows * d * 12,
-            "encoder_total": L * (qkv + proj + ffn + attn)}
+    attn = 2 * 2 * planes * tokens * tokens * d          # QK^T + PV over all heads
+    conv = planes * S * T * 2 * 9 * (1 * 8 + 8 * 32 + 32 * 8 + 8 * 1)
+    up = planes * 2 * Ps * Pt * S * T
+    pin = p0 * p1 + (6 if c["hidden"] else 0)
+    fl = {"qkv": qkv, "chain": proj + ffn + qkv, "chain_last": proj + ffn, "attention": attn, "upsample": conv + up,
+          "tail": conv + 2 * rows * d * p0 * p1, "embed": 2 * rows * d * pin,
+          "encoder_total": L * (qkv + proj + ffn + attn)}
+    fl["forward_total"] = fl["upsample"] + fl["embed"] + fl["encoder_total"] + fl["tail"]
+    return fl
 
 
-def time_kernels_in_flow(eng, batch, reps, pil, out, layers):
-    """Average duration (ms) of every kernel class, launched in the order of a real forward (conv head,
-    embed, QKV, [attention, chain] x (L-1), attention, last chain, conv tail) with one event pair around
-    each launch, recorded on the stream the library launches on (torch's current stream).  Measuring
-    the dominant kernel between its real neighbours keeps it at the clocks and cache state it has inside
-    the timed region (a loop of the same kernel alone runs 6-8 % slower: sustained fp32-MFMA power)."""
+def host_cpu_info():
+    """CPU model, sockets, physical cores, logical CPUs ('print CPU model, physical core count')."""
+    model, pairs, sockets = "unknown", set(), set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                    sockets.add(phys)
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return {"cpu_model": model, "sockets": max(1, len(sockets)), "physical_cores": len(pairs) or logical,
+            "logical_cpus": logical}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch (N > 1 without torchrun): nothing above or inside touches the GPU
+# ------------------------------------------------------------------------------------------------------------------
+def self_launch(args, argv) -> int:
+    import torch   # device_count() does not initialise the GPU on this image
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {n} device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if proc.returncode != 0 or line is None:
+        sys.stdout.write(proc.stdout)
+        print(f"bench.py: the {args.gpus}-rank launch failed (exit {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 3
+    print(line)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# measurement helpers (one rank)
+# ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """Engine + synthetic inputs of one config, resident on `device`."""
+
+    def __init__(self, c, device, rank=0, batch=None):
+        import torch
+        from adafortitran_amd import _abi, synth
+        from adafortitran_amd.hip_ops import engine_from_numpy
+        self.c, self.device = c, device
+        self.B = batch or c["batch"]
+        self.adaptive = c["hidden"] is not None
+        self.sd = synth.make_state_dict(**_spec(c), adaptive_hidden=c["hidden"], max_seq_len=c["max_seq_len"], seed=SEED)
+        self.cfg = _abi.make_config(**_spec(c), adaptive_hidden=c["hidden"])
+        self.eng = engine_from_numpy(self.cfg, self.sd, device)
+        self.inp = synth.make_inputs(self.B, ofdm=c["ofdm"], pilot=c["pilot"], seed=SEED + 1000 * rank)
+        self.pil = torch.from_numpy(self.inp["pilots"]).to(device)
+        self.tgt = torch.from_numpy(self.inp["target"]).to(device)
+        self.meta = [torch.from_numpy(self.inp[k]).to(device) for k in ("snr", "ds", "dop")] if self.adaptive else [None] * 3
+        self.out = torch.empty((self.B, *c["ofdm"]), dtype=torch.complex64, device=device)
+
+    def forward(self):
+        return self.eng.forward(self.pil, *self.meta, out=self.out)
+
+
+def timed_steps(step, steps, warmup, fence):
+    """W untimed + exactly K timed steps between fences; returns (wall s, device ms, per-step device ms sorted)."""
+    import torch
+    for _ in range(warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    marks = [ev0]
+    for _ in range(steps):
+        step()
+        m = torch.cuda.Event(enable_timing=True)
+        m.record()
+        marks.append(m)
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+    return wall, ev0.elapsed_time(ev1), per_step
+
+
+def kernel_times(wl, reps):
+    """Average duration (ms) of every kernel class inside a real forward.
+
+    Pass 1: `reps` whole flows (conv head, embed, QKV, [attention, chain] x (L-1), attention, last chain, conv
+    tail -- the launch order of aft_forward_f32, same kernels / grids / arguments through
+    aft_profile_kernel_f32) enqueued back to back between ONE event pair: T_flow, free of per-launch event
+    overhead.  Pass 2: the same flows with an event pair around every launch give each class's SHARE
+    (each pair inflates its kernel by ~3 us, which cancels in the ratio to first order).  Class time =
+    share x T_flow / launches.  Events are recorded on torch's current stream = the stream the library
+    launches on."""
+    import torch
     from adafortitran_amd.hip_ops import profile_kernel
-    flow = [("upsample", pil), ("embed", None), ("qkv", None)]
-    for _ in range(layers - 1):
+    L = wl.c["num_layers"]
+    flow = [("upsample", wl.pil), ("embed", None), ("qkv", None)]
+    for _ in range(L - 1):
         flow += [("attention", None), ("chain", None)]
-    flow += [("attention", None), ("chain_last", None), ("tail", out)]
-    for which, io in flow:
-        profile_kernel(eng, which, batch, 1, io)
+    flow += [("attention", None), ("chain_last", None), ("tail", wl.out)]
+    launches = {}
+    for which, _ in flow:
+        launches[which] = launches.get(which, 0) + 1
+
+    def run_flow():
+        for which, io in flow:
+            profile_kernel(wl.eng, which, wl.B, 1, io)
+
+    wl.forward()            # fills the workspace the profile hook replays on
+    run_flow()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run_flow()
+    e1.record()
+    torch.cuda.synchronize()
+    t_flow = e0.elapsed_time(e1) / reps
     pairs = []
     for _ in range(reps):
         for which, io in flow:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            profile_kernel(eng, which, batch, 1, io)
-            e1.record()
-            pairs.append((which, e0, e1))
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            profile_kernel(wl.eng, which, wl.B, 1, io)
+            b.record()
+            pairs.append((which, a, b))
     torch.cuda.synchronize()
-    tot, cnt = {}, {}
-    for which, e0, e1 in pairs:
-        tot[which] = tot.get(which, 0.0) + e0.elapsed_time(e1)
-        cnt[which] = cnt.get(which, 0) + 1
-    return {k: tot[k] / cnt[k] for k in tot}
+    tot = {}
+    for which, a, b in pairs:
+        tot[which] = tot.get(which, 0.0) + a.elapsed_time(b)
+    total = sum(tot.values())
+    ms = {k: tot[k] / total * t_flow / launches[k] for k in tot}
+    raw = {k: tot[k] / reps / launches[k] for k in tot}
+    return ms, raw, t_flow
 
 
-def cpu_baseline(model_name, batch, sd, inp):
-    """Reference-equivalent CPU path: this package's estimator on device='cpu' is assembled from
-    the same torch.nn modules as the reference (nn.Linear / Conv2d / TransformerEncoder fast path),
-    validated against reference outputs in tests/test_estimators_cpu.py."""
+def kernel_report(wl, reps):
+    c, B = wl.c, wl.B
+    fl = algorithmic_flops(c, B)
+    ms, raw, t_flow = kernel_times(wl, reps)
+    L = c["num_layers"]
+    kernels = {k: {"ms": round(v, 4), "tflops": round(fl[k] / v / 1e9, 2), "ms_with_event_pair": round(raw[k], 4)}
+               for k, v in ms.items()}
+    enc_ms = ms["qkv"] + L * ms["attention"] + (L - 1) * ms["chain"] + ms["chain_last"]
+    dom = max(("chain", "attention"), key=lambda k: ms[k] * ((L - 1) if k == "chain" else L))
+    names = {"chain": f"chain_kernel<{c['model_dim']},GELU,MLP=true,QKV=true> (out-proj+LN1+FFN+LN2 + next layer's QKV)",
+             "attention": "attn_kernel (softmax(QK^T/sqrt(32)) V per (plane, head))"}
+    achieved = fl[dom] / ms[dom] / 1e9
+    roof = {"kernel": names[dom], "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "flops_per_launch": fl[dom],
+            "ms_per_launch": round(ms[dom], 4), "launches_per_forward": (L - 1) if dom == "chain" else L,
+            "instruction_class": "v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (exact fp32)",
+            "timing": "one event pair around whole forwards on the launch stream, apportioned by per-launch shares"}
+    return kernels, roof, round(fl["encoder_total"] / enc_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4), round(t_flow, 4), fl
+
+
+def parity_vs_oracle(wl, sample):
+    """HIP path vs the CPU oracle on the first `sample` frames of the workload's own inputs (oracle = checker only)."""
+    import numpy as np
+    from oracle import oracle
+    t0 = time.perf_counter()
+    idx = slice(0, sample)
+    args = [wl.inp[k][idx] for k in ("snr", "ds", "dop")] if wl.adaptive else [None] * 3
+    ref = oracle.Oracle(wl.cfg, wl.sd).forward(wl.inp["pilots"][idx], *args)
+    secs = time.perf_counter() - t0
+    got = wl.forward()[idx].cpu().numpy()
+    tgt = wl.inp["target"][idx]
+    mse_hip = float(np.mean(np.abs(got - tgt) ** 2, dtype=np.float64))
+    mse_ref = float(np.mean(np.abs(ref - tgt) ** 2, dtype=np.float64))
+    return {"sample": f"first {sample} frame(s) of the timed batch, oracle/aft_oracle.c on {oracle.num_threads()} thread(s), {secs:.1f} s",
+            "max_abs_vs_oracle": float(np.abs(got - ref).max()), "ymax": float(np.abs(ref).max()),
+            "mean_sq_vs_oracle": float(np.mean(np.abs(got - ref) ** 2, dtype=np.float64)),
+            "mse_hip": mse_hip, "mse_oracle": mse_ref, "rel_dMSE": abs(mse_hip - mse_ref) / mse_ref,
+            "tolerance": {"max_abs": "5e-5*ymax", "rel_dMSE": 1e-4}}
+
+
+def make_module(c, device_str, sd):
+    import torch
     import adafortitran_amd as A
-    from adafortitran_amd import synth
-    adaptive = model_name == "adafortitran"
-    sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
-    kw = dict(model_type=model_name, patch_size=(3, 2), num_layers=6, model_dim=128, num_head=4, device="cpu")
+    adaptive = c["hidden"] is not None
+    sc = A.SystemConfig(ofdm=dict(num_scs=c["ofdm"][0], num_symbols=c["ofdm"][1]),
+                        pilot=dict(num_scs=c["pilot"][0], num_symbols=c["pilot"][1]))
+    kw = dict(model_type=c["model"], patch_size=tuple(c["patch"]), num_layers=c["num_layers"], model_dim=c["model_dim"],
+              num_head=c["num_head"], max_seq_len=c["max_seq_len"], device=device_str)
     if adaptive:
-        kw.update(channel_adaptivity_hidden_sizes=list(HIDDEN), adaptive_token_length=6)
+        kw.update(channel_adaptivity_hidden_sizes=list(c["hidden"]), adaptive_token_length=6)
     model = (A.AdaFortiTranEstimator if adaptive else A.FortiTranEstimator)(sc, A.ModelConfig(**kw)).eval()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    pil = torch.from_numpy(inp["pilots"])
-    meta = synth.meta_tuple(inp) if adaptive else None
-    call = (lambda: model(pil, meta)) if adaptive else (lambda: model(pil))
-    host_cores = os.cpu_count() or 1
-    default_threads = torch.get_num_threads()
+    return model
+
+
+def module_surface(wl, steps, warmup, engine_fps):
+    """SURVEY.md 8(d) metric form: model(pilots_cpu, meta_cpu) as the reference's evaluator calls it
+    (trainer.py:332-337), H2D of pilots + meta inside the timed region, output left on the device."""
+    import torch
+    from adafortitran_amd import synth
+    from adafortitran_amd.metrics import MseAccumulator
+    model = make_module(wl.c, "cuda", wl.sd)
+    pil_cpu = torch.from_numpy(wl.inp["pilots"])
+    meta_cpu = synth.meta_tuple(wl.inp) if wl.adaptive else None
+    acc = MseAccumulator(wl.device)
+
+    def step():
+        with torch.no_grad():
+            est = model(pil_cpu, meta_cpu) if wl.adaptive else model(pil_cpu)
+        acc.update(est, wl.tgt)
+
+    wall, dev_ms, per = timed_steps(step, steps, warmup, torch.cuda.synchronize)
     with torch.no_grad():
-        # intra-op thread count that serves the reference best on this host (oversubscribing a
-        # 280-token problem with every hardware thread is slower than a moderate count)
+        est = model(pil_cpu, meta_cpu) if wl.adaptive else model(pil_cpu)
+    same = bool(torch.equal(torch.view_as_real(est), torch.view_as_real(wl.forward())))
+    fps = wl.B * steps / wall
+    return {"value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(wall / steps * 1e3, 4),
+            "device_ms_per_step": round(dev_ms / steps, 4), "steps": steps,
+            "ratio_to_resident_inputs": round(fps / engine_fps, 4), "bit_identical_to_engine_call": same,
+            "call": "AdaFortiTranEstimator(device='cuda').eval(); torch.no_grad(); model(pilots_cpu complex64, meta 6-tuple "
+                    "of CPU tensors) + device MSE partial; H2D of pilots+meta inside forward (one pinned async copy)"}
+
+
+def config_record(c, device, steps, warmup, oracle_sample, kernel_reps):
+    import torch
+    from adafortitran_amd.metrics import MseAccumulator
+    wl = Workload(c, device)
+    acc = MseAccumulator(device)
+
+    def step():
+        wl.forward()
+        acc.update(wl.out, wl.tgt)
+
+    wall, dev_ms, per = timed_steps(step, steps, warmup, torch.cuda.synchronize)
+    kernels, roof, enc_util, t_flow, fl = kernel_report(wl, kernel_reps)
+    fps = wl.B * steps / wall
+    rec = {"workload": f"{c['label']}, batch {wl.B} per GPU, forward + device MSE partial, inputs resident in HBM",
+           "value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(wall / steps * 1e3, 4), "steps": steps,
+           "whole_path_tflops": round(fl["forward_total"] * steps / wall / 1e12 , 2),
+           "encoder_mfma_util": enc_util, "dominant_kernel": roof, "kernels": kernels}
+    if oracle_sample:
+        rec["parity"] = parity_vs_oracle(wl, oracle_sample)
+    del wl
+    torch.cuda.empty_cache()
+    return rec
+
+
+def linear_record(device, steps, warmup):
+    """BASELINE config 1: LinearEstimator, 120x14 grid, batch 32 -- plumbing only.  Module surface (CPU complex64 pilots in),
+    plane-wise; checked against the oracle's linear restatement."""
+    import numpy as np
+    import torch
+    import adafortitran_amd as A
+    from adafortitran_amd import synth
+    from oracle import oracle
+    B = 32
+    sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
+    mc = A.ModelConfig(model_type="linear", patch_size=(3, 2), num_layers=1, model_dim=32, num_head=1, device="cuda")
+    model = A.LinearEstimator(sc, mc).eval()
+    w = synth.uniform_pm(SEED, "linear.weight", (1680, 24), 1 / np.sqrt(24))
+    b = synth.uniform_pm(SEED, "linear.bias", (1680,), 1 / np.sqrt(24))
+    model.load_state_dict({"linear.weight": torch.from_numpy(w), "linear.bias": torch.from_numpy(b)})
+    inp = synth.make_inputs(B, seed=SEED)
+    pil_cpu = torch.from_numpy(inp["pilots"])
+
+    def step():
+        with torch.no_grad():
+            model(pil_cpu)
+
+    wall, dev_ms, per = timed_steps(step, steps, warmup, torch.cuda.synchronize)
+    with torch.no_grad():
+        got = model(pil_cpu).cpu().numpy()
+    ref = oracle.linear_forward(w, b, inp["pilots"], (120, 14))
+    return {"workload": "Linear estimator (src/models/linear.py), 120x14 grid, batch 32, plane-wise on complex pilots -- plumbing only",
+            "value": round(B * steps / wall, 1), "unit": "frames/s", "ms_per_step": round(wall / steps * 1e3, 4), "steps": steps,
+            "bound": "launch latency (one 2.7 MFLOP kernel + one H2D copy per step)",
+            "parity": {"max_abs_vs_oracle": float(np.abs(got - ref).max()), "ymax": float(np.abs(ref).max())}}
+
+
+def cpu_baseline(wl):
+    """Reference-equivalent CPU path: this package's estimator on device='cpu' is assembled from the same torch.nn
+    modules as the reference (nn.Linear / Conv2d / TransformerEncoder fast path), validated against reference
+    outputs in tests/test_estimators_cpu.py.  Bounded: a thread sweep + <= 10 forwards of the same B=128 batch."""
+    import numpy as np
+    import torch
+    from adafortitran_amd import synth
+    model = make_module(wl.c, "cpu", wl.sd)
+    pil = torch.from_numpy(wl.inp["pilots"])
+    meta = synth.meta_tuple(wl.inp) if wl.adaptive else None
+    call = (lambda: model(pil, meta)) if wl.adaptive else (lambda: model(pil))
+    info = host_cpu_info()
+    logical, default_threads = info["logical_cpus"], torch.get_num_threads()
+    with torch.no_grad():
+        # intra-op thread count that serves the reference best on this host (oversubscribing a 280-token
+        # problem with every hardware thread is slower than a moderate count)
         best_t, best_dt = default_threads, float("inf")
-        for cand in sorted({8, 16, 32, 64, max(1, host_cores // 2), host_cores, default_threads}):
-            if cand > host_cores:
+        for cand in sorted({8, 16, 32, 64, info["physical_cores"], max(1, logical // 2), logical, default_threads}):
+            if cand > logical:
                 continue
             torch.set_num_threads(cand)
             call()
@@ -119,7 +406,6 @@ def cpu_baseline(model_name, batch, sd, inp):
             if dt < best_dt:
                 best_t, best_dt = cand, dt
         torch.set_num_threads(best_t)
-        threads = best_t
         times = []
         t_end = time.perf_counter() + 10.0
         while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 10):
@@ -128,39 +414,38 @@ def cpu_baseline(model_name, batch, sd, inp):
             times.append(time.perf_counter() - t0)
         torch.set_num_threads(default_threads)
     med = float(np.median(times))
-    out = {"value": batch / med, "unit": "frames/s", "cores": threads, "kind": "port",
-           "sample": f"{len(times)} forwards of B={batch} (same workload), median {med * 1e3:.0f} ms, best of a "
-                     f"thread sweep on {host_cores} logical CPUs; torch {torch.__version__} nn-module composite = "
-                     f"the reference's own ATen/oneDNN/MKL CPU kernels, eval()+no_grad(), fp32"}
-    # the C oracle (oracle/aft_oracle.c) on a smaller bounded sample, for the record
-    try:
-        from adafortitran_amd import _abi
+    out = {"value": round(wl.B / med, 2), "unit": "frames/s", "cores": best_t, "kind": "port", **info,
+           "sample": f"{len(times)} forwards of B={wl.B} (the same workload), median {med * 1e3:.0f} ms, best of a thread sweep; "
+                     f"torch {torch.__version__} nn-module composite = the reference's own ATen/oneDNN/MKL CPU kernels, "
+                     f"eval()+no_grad(), fp32"}
+    try:    # the C oracle (oracle/aft_oracle.c) on a smaller bounded sample, for the record
         from oracle import oracle
-        cfg = _abi.make_config(**SPEC, adaptive_hidden=HIDDEN if adaptive else None)
-        orc = oracle.Oracle(cfg, sd)
+        orc = oracle.Oracle(wl.cfg, wl.sd)
         nb = 8
-        args = [inp[k][:nb] for k in ("snr", "ds", "dop")] if adaptive else [None] * 3
+        args = [wl.inp[k][:nb] for k in ("snr", "ds", "dop")] if wl.adaptive else [None] * 3
         t0 = time.perf_counter()
-        orc.forward(inp["pilots"][:nb], *args)
+        orc.forward(wl.inp["pilots"][:nb], *args)
         dt = time.perf_counter() - t0
-        out["oracle_c"] = {"value": nb / dt, "unit": "frames/s", "cores": oracle.num_threads(),
-                           "sample": f"1 forward of B={nb}, OpenMP, double accumulation"}
+        out["oracle_c"] = {"value": round(nb / dt, 2), "unit": "frames/s", "cores": oracle.num_threads(),
+                           "sample": f"1 forward of B={nb}, OpenMP over planes, double accumulation"}
     except Exception as exc:  # the oracle is optional test infrastructure
         out["oracle_c"] = {"error": str(exc)[:120]}
     return out
 
 
 def load_pmc_traffic():
-    """HBM bytes per chain-kernel launch from the committed rocprofv3 --pmc summary, if present."""
+    """HBM bytes per chain-kernel launch from the committed rocprofv3 --pmc summary (a constant of the committed
+    profile, not something this run observed)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get("chain_bytes_per_launch")
+            return json.load(fh).get("chain_bytes_per_launch"), "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass: " \
+                "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
     except Exception:
-        return None
+        return None, None
 
 
-def main() -> None:
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -168,15 +453,29 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
     ap.add_argument("--model", default="adafortitran", choices=["adafortitran", "fortitran"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the N=1 legs (module surface, configs, parity, CPU)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args, sys.argv[1:])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+
+    import numpy as np
+    import torch
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        print("bench.py needs an MI355X: the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} has no device {local_rank}", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -185,25 +484,16 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
-    from adafortitran_amd import _abi, synth
-    from adafortitran_amd.hip_ops import engine_from_numpy
     from adafortitran_amd.metrics import MseAccumulator
 
-    adaptive = args.model == "adafortitran"
-    B = args.batch
-    sd = synth.make_state_dict(**SPEC, adaptive_hidden=HIDDEN if adaptive else None, seed=20251114)
-    cfg = _abi.make_config(**SPEC, adaptive_hidden=HIDDEN if adaptive else None)
-    eng = engine_from_numpy(cfg, sd, device)
-    inp = synth.make_inputs(B, seed=20251114 + 1000 * rank)   # a different shard of frames per rank
-    pil = torch.from_numpy(inp["pilots"]).to(device)
-    tgt = torch.from_numpy(inp["target"]).to(device)
-    meta = [torch.from_numpy(inp[k]).to(device) for k in ("snr", "ds", "dop")] if adaptive else [None] * 3
-    out = torch.empty((B, 120, 14), dtype=torch.complex64, device=device)
+    head = dict(C3 if args.model == "adafortitran" else C2)
+    wl = Workload(head, device, rank=rank, batch=args.batch)   # a different shard of frames per rank
+    B = wl.B
     acc = MseAccumulator(device)
 
     def step():
-        eng.forward(pil, *meta, out=out)
-        acc.update(out, tgt)          # device-side partial sum, no host sync
+        wl.forward()
+        acc.update(wl.out, wl.tgt)          # device-side partial sum, no host sync
 
     def fence():
         torch.cuda.synchronize()
@@ -213,22 +503,9 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
-    acc = MseAccumulator(device)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    marks = [ev0]                      # one event per step boundary: per-step device times (median, p10/p90)
-    for _ in range(args.steps):
-        step()
-        m = torch.cuda.Event(enable_timing=True)
-        m.record()
-        marks.append(m)
-    ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+    acc.sum_sq.zero_()
+    acc.n_elements = 0
+    elapsed, dev_ms, per_step = timed_steps(step, args.steps, 0, fence)
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]   # noqa: E731
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -240,45 +517,46 @@ def main() -> None:
 
     if rank == 0:
         frames = B * world * args.steps
-        planes, tokens = 2 * B, cfg.tokens
-        fl = algorithmic_flops(SPEC, tokens, planes)
-        kms = time_kernels_in_flow(eng, B, 20, pil, out, SPEC["num_layers"])
-        kernels = {name: {"ms": round(ms, 4), "tflops": round(fl[name] / ms / 1e9, 2)} for name, ms in kms.items()}
-        chain_ms = kernels["chain"]["ms"]
-        achieved = fl["chain"] / chain_ms / 1e9
-        L = SPEC["num_layers"]
-        enc_ms = (kernels["qkv"]["ms"] + L * kernels["attention"]["ms"] + (L - 1) * chain_ms
-                  + kernels["chain_last"]["ms"])
+        kernels, roof, enc_util, t_flow, fl = kernel_report(wl, 20)
+        traffic, traffic_source = load_pmc_traffic()
+        roof["traffic"], roof["traffic_source"] = traffic, traffic_source
+        fps = frames / elapsed
         result = {
             "metric": "OFDM frames/sec (120x14 grid, batch 128) + channel-estimation MSE vs reference",
-            "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{'AdaFortiTran' if adaptive else 'FortiTran'} default config (6 layers, d=128, 4 heads"
-                                   f"{', adaptive tokens' if adaptive else ''}), 120x14 grid, pilots 12x2, "
-                                   f"batch {B} frames per GPU, forward + device MSE partial, inputs resident in HBM",
+            "config": {"workload": f"{head['label']}, batch {B} frames per GPU, forward + device MSE partial, inputs resident in HBM",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded over {world} rank(s)"},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "device_step_ms": {"p10": round(pct(0.10), 4), "p50": round(pct(0.50), 4), "p90": round(pct(0.90), 4)},
             "mse_db_vs_random_target": round(10 * np.log10(mse), 4),
-            "roofline": {"kernel": "chain_kernel<128,GELU,MLP=true,QKV=true> (out-proj+LN1+FFN+LN2 + next layer's QKV)",
-                         "bound": "mfma",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": load_pmc_traffic(),
-                         "flops_per_launch": fl["chain"], "ms_per_launch": chain_ms,
-                         "instruction_class": "v_mfma_f32_32x32x2_f32 (exact fp32)"},
-            "kernels": kernels,
-            "encoder_mfma_util": round(fl["encoder_total"] / enc_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "whole_path_tflops": round((1_429_387_932 if adaptive else 1_428_241_920) * frames / elapsed / 1e12, 2),
+            "roofline": roof, "kernels": kernels, "kernel_flow_ms": t_flow, "encoder_mfma_util": enc_util,
+            "whole_path_tflops": round(fl["forward_total"] * world * args.steps / elapsed / 1e12, 2),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.model, B, sd, inp)
-            result["speedup_vs_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+        if world == 1 and not args.headline_only:
+            result["parity"] = parity_vs_oracle(wl, 8)
+            result["module_surface"] = module_surface(wl, args.steps, args.warmup, fps / world)
+            cfgs = {}
+            cfgs["C1"] = linear_record(device, 200, 20)
+            other = C2 if head["name"] == "C3" else C3
+            cfgs[other["name"]] = config_record(other, device, 100, 10, 8, 10)
+            cfgs[head["name"]] = {"see": "top-level fields of this line (headline)", "value": result["value"],
+                                  "ms_per_step": result["ms_per_step"], "dominant_kernel_frac": roof["frac"],
+                                  "encoder_mfma_util": enc_util, "parity_rel_dMSE": result["parity"]["rel_dMSE"]}
+            cfgs["C4"] = {"see": "this command with --gpus 8: 128 frames per GPU, the headline workload per rank + one "
+                                 "RCCL all-gather of the (sum|e|^2, n) pairs"}
+            cfgs["C5@64/GPU"] = config_record(C5, device, 20, 3, 1, 3)
+            result["configs"] = cfgs
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(wl)
+                result["speedup_vs_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -11,9 +11,13 @@
  *   - plain C symbols, no C++/torch types; all tensors are raw DEVICE pointers owned
  *     by the caller (PyTorch allocates inputs, outputs, weights and the workspace);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*, NULL =
- *     default stream), never synchronises, allocates nothing, keeps no global state
- *     (hipGraph-capturable); the caller's loss.item() is the sync point, as in
- *     reference src/main/trainer.py:229,253,344;
+ *     default stream), never synchronises, allocates nothing and keeps no state that
+ *     describes a call (hipGraph-capturable, also as the very first call of a process);
+ *     what the library caches is per DEVICE and idempotent -- the CU count and the
+ *     "kernel may use N bytes of dynamic LDS" attribute, in tables indexed by the
+ *     current device ordinal -- so one process may drive several GPUs through this ABI;
+ *     the caller's loss.item() is the sync point, as in reference
+ *     src/main/trainer.py:229,253,344;
  *   - complex64 tensors are passed as float* to interleaved (re,im) pairs, i.e. the
  *     memory of torch.view_as_real(x);
  *   - return 0 on success; AFT_ERR_ARG / AFT_ERR_SHAPE -> the Python side raises
@@ -82,6 +86,11 @@ typedef struct aft_weights {
 
 int aft_version(void);
 const char *aft_last_error(void);
+
+/* AFT_OK when the gfx950 kernels cover `cfg`; else AFT_ERR_SHAPE / AFT_ERR_ARG with the reason in
+ * aft_last_error().  The estimator calls it at construction (the reference validates its config in
+ * __init__, fortitran.py:52-81), so an uncovered shape is refused before any training starts. */
+int aft_check_config(const aft_config *cfg);
 
 /* Bytes of scratch aft_forward_f32 needs for `batch` frames (0 on a bad config). */
 size_t aft_workspace_bytes(const aft_config *cfg, int batch);
@@ -176,7 +185,8 @@ int aft_conv_enhancer_fwd_train_f32(const float *const weights[4], const float *
 /* Backward of that call: dy = dL/dy -> dx = dL/dx and the eight parameter gradients (PyTorch layouts;
  * overwritten, or added to when accumulate != 0).  flipped_weights[k] must hold
  * weights[3-k].transpose(0,1).flip(2,3) made contiguous ([8,1,3,3], [32,8,3,3], [8,32,3,3], [1,8,3,3]):
- * the data gradient of the stack is the stack itself run on dy with those. */
+ * the data gradient of the stack is the stack itself run on dy with those.
+ * aft_conv_enhancer_scratch_bytes returns 0 for a grid the fused kernel has no LDS band plan for. */
 size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols);
 int aft_conv_enhancer_bwd_f32(const float *const flipped_weights[4], const float *x, const float *c1, const float *c2,
                               const float *c3, const float *dy, float *dx, float *const dweights[4], float *const dbiases[4],

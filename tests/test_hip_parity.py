@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): the hand-written HIP path, called through
 the C ABI, against (a) golden vectors produced by the reference itself and (b) the CPU oracle on
 the same seeded inputs.  Tolerances are the stated fp32 ones of SURVEY.md 8(d)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -192,6 +194,29 @@ def test_config5_persistent_tiles(oracle_lib):
     assert np.abs(got - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
 
 
+def test_config5_at_stated_size_per_gpu(oracle_lib):
+    """BASELINE config 5 at its stated per-GPU size: 64 frames (512 over 8 GPUs) of the 240x28 grid
+    = 143 360 token rows, 4480 row tiles, 9216 (plane, head) attention problems of 1120 keys.
+    Size-independent properties (determinism, chunk independence bit for bit) + an oracle sample."""
+    g = Golden("C5_ada_large")
+    cfg, sd = g.abi_config(), g.state_dict()
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    B = 64
+    inp = synth.make_inputs(B, ofdm=(240, 28), pilot=(24, 4), seed=516)
+    meta = [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    pil = _t(inp["pilots"])
+    full = eng.forward(pil, *meta).clone()
+    again = eng.forward(pil, *meta)
+    assert torch.equal(torch.view_as_real(again), torch.view_as_real(full))
+    part = eng.forward(pil[40:43], *[m[40:43] for m in meta])
+    assert torch.equal(torch.view_as_real(part), torch.view_as_real(full[40:43]))
+    idx = [63]
+    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"][idx], inp["snr"][idx], inp["ds"][idx], inp["dop"][idx])
+    got = full[idx].cpu().numpy()
+    assert np.abs(got - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("name", ["D_forti", "A_ada"])
 def test_module_surface_on_gpu(name):
     """The drop-in nn.Module: CPU inputs in, device output out, HIP path under eval+no_grad,
@@ -218,9 +243,60 @@ def test_module_surface_on_gpu(name):
             model(pil)
 
 
+def test_module_engine_cache_and_invalidation():
+    """The module's per-call engine lookup is pointer/identity compares only: the same engine object
+    serves consecutive forwards, in-place parameter updates are seen without a rebuild (the ABI reads
+    the parameters' own storage), and a re-homed or replaced tensor rebuilds it."""
+    from test_estimators_cpu import _configs
+    g = Golden("D_forti")
+    sc, mc = _configs(g.spec, device="cuda")
+    model = A.FortiTranEstimator(sc, mc)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()})
+    model.eval()
+    pil = torch.from_numpy(g["pilots"])
+    with torch.no_grad():
+        out0 = model(pil).clone()
+        eng = model._engine
+        model(pil)
+        assert model._engine is eng                                    # O(1) path: no rebuild
+        w = model.final_refiner.conv_block[6].bias
+        w.add_(0.25)                                                    # in-place update (what an optimizer does)
+        out1 = model(pil)
+        assert model._engine is eng
+        assert np.allclose((out1 - out0).cpu().numpy(), 0.25 + 0.25j, atol=1e-6)
+        w.data = w.data.clone() - 0.25                                 # re-homed storage -> new pointer
+        out2 = model(pil)
+        assert model._engine is not eng
+        assert torch.equal(torch.view_as_real(out2), torch.view_as_real(out0))
+        eng2 = model._engine
+        model.final_refiner.conv_block[6].bias = torch.nn.Parameter(w.data.clone() + 0.5)   # replaced object
+        out3 = model(pil)
+        assert model._engine is not eng2
+        assert np.allclose((out3 - out0).cpu().numpy(), 0.5 + 0.5j, atol=1e-6)
+
+
+def test_uncovered_configuration_is_refused_at_construction(monkeypatch):
+    """One coverage predicate, asked at construction on the HIP device: a shape the reference accepts but
+    the kernels do not cover raises a ValueError before any training, unless the caller opts
+    into the PyTorch-ROCm composite."""
+    # head dim 16: accepted by the reference's schema, not by the kernels
+    sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
+    kw = dict(model_type="fortitran", patch_size=(3, 2), num_layers=2, model_dim=128, num_head=8)
+    assert A.FortiTranEstimator(sc, A.ModelConfig(device="cpu", **kw)) is not None      # CPU: the reference's own path
+    monkeypatch.delenv("AFT_ALLOW_COMPOSITE", raising=False)
+    with pytest.raises(ValueError, match="not covered by the gfx950 kernels"):
+        A.FortiTranEstimator(sc, A.ModelConfig(device="cuda", **kw))
+    monkeypatch.setenv("AFT_ALLOW_COMPOSITE", "1")
+    model = A.FortiTranEstimator(sc, A.ModelConfig(device="cuda", **kw)).eval()
+    pil = torch.from_numpy(synth.make_inputs(2, seed=3)["pilots"])
+    with torch.no_grad():
+        out = model(pil)
+    assert out.shape == (2, 120, 14) and model._engine is None          # composite ran, no C-ABI engine
+
+
 def test_stream_and_graph_semantics():
     """The ABI is asynchronous on the caller's stream and allocation-free: it runs on a side
-    stream and inside a captured hipGraph (after one warm call that sets kernel attributes)."""
+    stream and inside a captured hipGraph (test_graph_capture_as_first_call covers the cold start)."""
     g = Golden("A_ada")
     eng = _engine(g)
     pil, meta = _t(g["pilots"]), _meta(g)
@@ -245,6 +321,18 @@ def test_stream_and_graph_semantics():
     torch.cuda.synchronize()
     want = eng.forward(pil2, *meta)
     assert torch.equal(torch.view_as_real(static_out), torch.view_as_real(want))
+
+
+def test_graph_capture_as_first_call():
+    """No call-describing state in the library: in a fresh process the FIRST call may already be a
+    hipGraph capture (kernel attributes / CU count are set per device on demand, nothing needs a warm
+    call).  Runs tests/graph_first_call.py as a child process."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_first_call.py")
+    res = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "graph-first-call" in res.stdout
 
 
 def test_abi_error_codes():

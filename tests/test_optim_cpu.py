@@ -61,6 +61,33 @@ def test_scheduler_clipping_and_checkpoint():
     assert opt2.steps == 4 and torch.equal(opt2.exp_avg, opt.exp_avg) and opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
 
 
+def test_state_dict_is_exchangeable_with_torch_adam():
+    """The checkpoint is torch.optim.Adam's format: a ShardedFlatAdam state loads into torch.optim.Adam over
+    the same parameters and the two continue identically; and the other way round."""
+    a, b = _net(), _net()
+    x, y = _data()
+    opt = ShardedFlatAdam(a.parameters(), lr=1e-2)
+    ref = torch.optim.Adam(b.parameters(), lr=1e-2)
+    for _ in range(3):
+        for net, o in ((a, opt), (b, ref)):
+            o.zero_grad()
+            torch.nn.functional.mse_loss(net(x), y).backward()
+            o.step()
+    c, d = _net(), _net()
+    c.load_state_dict(a.state_dict()); d.load_state_dict(b.state_dict())
+    into_torch = torch.optim.Adam(c.parameters(), lr=1.0)
+    into_torch.load_state_dict(opt.state_dict())               # ours -> torch
+    into_flat = ShardedFlatAdam(d.parameters(), lr=1.0)
+    into_flat.load_state_dict(ref.state_dict())                # torch -> ours
+    assert into_flat.steps == 3 and into_torch.param_groups[0]["lr"] == 1e-2
+    for net, o in ((c, into_torch), (d, into_flat), (a, opt)):
+        o.zero_grad()
+        torch.nn.functional.mse_loss(net(x), y).backward()
+        o.step()
+    for p, q, r in zip(a.parameters(), c.parameters(), d.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7) and torch.allclose(p, r, rtol=1e-5, atol=1e-7)
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,6 +101,59 @@ def _worker(rank, world, port, out):
         opt.step()
     out[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
     dist.destroy_process_group()
+
+
+def _scaler_worker(rank, world, port, out):
+    """The reference's GradScaler branch on two ranks with an inf injected into ONE rank's gradients: with
+    reduce_gradients() both ranks see the inf, both skip, nobody hangs, parameters stay identical; without it the
+    optimizer refuses instead of desynchronising the collectives."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _net()
+    x, y = _data()
+    lo, hi = rank * len(x) // world, (rank + 1) * len(x) // world
+    opt = ShardedFlatAdam(net.parameters(), lr=1e-2)
+    scaler = torch.amp.GradScaler("cpu", init_scale=4.0, growth_interval=1000)
+    before = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    log = []
+    for it in range(3):
+        opt.zero_grad()
+        scaler.scale(torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi])).backward()
+        if it == 1 and rank == 1:
+            next(net.parameters()).grad.view(-1)[0] = float("inf")      # only rank 1 overflows
+        if it == 0:
+            try:
+                scaler.step(opt)                                         # unreduced grads on 2 ranks: refused
+                log.append("stepped")
+            except RuntimeError as exc:
+                log.append("refused" if "reduce_gradients" in str(exc) else "other")
+            scaler = torch.amp.GradScaler("cpu", init_scale=4.0, growth_interval=1000)
+            continue
+        opt.reduce_gradients()
+        scaler.unscale_(opt)
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+        scaler.step(opt)
+        scaler.update()
+        log.append((opt.steps, float(scaler.get_scale())))
+    after = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    out[rank] = (log, after.numpy(), bool(torch.equal(before, after)))
+    dist.destroy_process_group()
+
+
+def test_grad_scaler_with_injected_inf_on_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_scaler_worker, args=(2, port, out), nprocs=2, join=True)
+    (log0, p0, same0), (log1, p1, same1) = out[0], out[1]
+    assert log0[0] == "refused" and log1[0] == "refused"
+    # iteration 1: inf on rank 1 only -> BOTH ranks skip (steps stays 0) and both back the scale off 4 -> 2
+    assert log0[1] == (0, 2.0) and log1[1] == (0, 2.0)
+    # iteration 2: clean -> both step once
+    assert log0[2][0] == 1 and log1[2][0] == 1
+    assert np.array_equal(p0, p1) and not same0 and np.isfinite(p0).all()
 
 
 def test_sharded_step_world_size_2_matches_single_process():

@@ -216,17 +216,32 @@ def test_direct_gradient_accumulation_matches_autograd_accumulation():
     tgt = torch.from_numpy(synth.make_inputs(4, seed=9)["target"]).cuda()
 
     def grads(direct):
-        training.ACCUMULATE_INTO_GRAD = direct
+        flat.direct_accumulation = direct
         flat.zero_grad()
         torch.nn.functional.mse_loss(torch.view_as_real(model(pil)), torch.view_as_real(tgt)).backward()
         return flat.grad.clone()
 
     flat = FlatParameters(model.parameters())
-    try:
-        a, b = grads(False), grads(True)
-    finally:
-        training.ACCUMULATE_INTO_GRAD = False
+    assert not training.direct_grad_ok(model.parameters())             # off unless the owner asks for it
+    a, b = grads(False), grads(True)
+    assert training.direct_grad_ok(model.parameters())
     assert _rel(b, a) <= 1e-6
+    # scoped to the tagged parameters of a LIVE owner: another model, a re-pointed .grad or a released owner
+    # all get ordinary autograd gradients
+    other = _model("fortitran", 0.0).train()
+    assert not training.direct_grad_ok(other.parameters())
+    w = model.pilot_upsampler.weight
+    keep = w.grad
+    w.grad = torch.zeros_like(w)
+    assert not training.direct_grad_ok([w])
+    w.grad = keep
+    flat.release()
+    assert not training.direct_grad_ok(model.parameters())
+    model.zero_grad(set_to_none=True)
+    torch.nn.functional.mse_loss(torch.view_as_real(model(pil)), torch.view_as_real(tgt)).backward()
+    got = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    want = torch.cat([a[o:o + p.numel()] for p, o in zip(flat.params, flat.offsets)])
+    assert _rel(got, want) <= 1e-6
 
 
 def test_eval_after_training_uses_the_updated_flat_parameters():
@@ -434,7 +449,6 @@ def test_grad_scaler_branch_of_the_reference_trainer():
         got = run(True)
     finally:
         training.HipLinear.default_hip_training = True
-        training.ACCUMULATE_INTO_GRAD = False
     assert torch.isfinite(got).all()
     diff = (got - ref).abs()
     # Adam divides by sqrt(v): an element whose gradient is ~0 can step +-lr on fp32 noise, so the bound on any single
