@@ -30,16 +30,22 @@ def lib_path() -> str:
 def load():
     """Load the library once and type its entry points."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_LIB_PATH):
+    if _lib is None:
+        _lib = load_path(_LIB_PATH)
+    return _lib
+
+
+def load_path(path: str):
+    """Load and type one build of the library (the product uses exactly one, `load()`; tools/ab_kernels.py loads
+    several variants side by side to time them in one process)."""
+    if not os.path.exists(path):
         raise AftError(
-            f"{_LIB_PATH} is missing: build it with `python -m adafortitran_amd.build` "
+            f"{path} is missing: build it with `python -m adafortitran_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the HIP path.")
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
     for name in _abi.EXPORTED_SYMBOLS:
         if not hasattr(lib, name):
-            raise AftError(f"{_LIB_PATH} does not export {name}")
+            raise AftError(f"{path} does not export {name}")
     lib.aft_version.restype = C.c_int
     lib.aft_last_error.restype = C.c_char_p
     lib.aft_workspace_bytes.restype = C.c_size_t
@@ -85,7 +91,6 @@ def load():
             getattr(lib, name).restype = C.c_int
     if lib.aft_version() != _abi.AFT_ABI_VERSION:
         raise AftError(f"ABI mismatch: library {lib.aft_version()} vs binding {_abi.AFT_ABI_VERSION}")
-    _lib = lib
     return lib
 
 

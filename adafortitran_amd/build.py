@@ -29,26 +29,36 @@ def _deps(src: str):
 DIAG = False  # --diag: -DAFT_DIAG_STAMPS (in-kernel phase stamps; never for the product build)
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+def _compile(src: str, force: bool, objdir: str, extra) -> str:
+    obj = os.path.join(objdir, src.replace(".hip", ".o"))
     if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src)):
         return obj
-    flags = FLAGS + (["-DAFT_DIAG_STAMPS"] if DIAG else [])
+    flags = FLAGS + (["-DAFT_DIAG_STAMPS"] if DIAG else []) + list(extra)
     subprocess.run([HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj], check=True)
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+    """The product library (variant ""), or an A/B variant `libaft_hip_<variant>.so` compiled with extra -D flags
+    (tools/ab_kernels.py loads several of them in one process; variants always rebuild from scratch)."""
+    objdir, lib = CSRC, LIB
+    if variant:
+        objdir = os.path.join(CSRC, "build_" + variant)
+        os.makedirs(objdir, exist_ok=True)
+        lib = os.path.join(CSRC, f"libaft_hip_{variant}.so")
+        force = True
     with ThreadPoolExecutor(max_workers=4) as pool:
-        objs = list(pool.map(lambda s: _compile(s, force), SOURCES))
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
+        objs = list(pool.map(lambda s: _compile(s, force, objdir, extra_flags), SOURCES))
+    if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs,
                         "-Wl,-rpath,/opt/rocm/lib"], check=True)
         if verbose:
-            print("built", LIB)
-    return LIB
+            print("built", lib)
+    return lib
 
 
 if __name__ == "__main__":
+    # python -m adafortitran_amd.build [--force] [--diag] [--variant NAME -DX=1 -DY=2 ...]
     DIAG = "--diag" in sys.argv
-    build(force="--force" in sys.argv or DIAG, verbose=True)
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    build(force="--force" in sys.argv or DIAG, verbose=True, variant=var, extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")])

@@ -41,8 +41,8 @@ class HipEngine:
     tensors; the engine keeps references so the device pointers stay valid.
     """
 
-    def __init__(self, cfg: _abi.AftConfig, tensors: Dict[str, torch.Tensor]):
-        self.lib = _lib.load()
+    def __init__(self, cfg: _abi.AftConfig, tensors: Dict[str, torch.Tensor], lib=None):
+        self.lib = lib if lib is not None else _lib.load()
         self.cfg = cfg
         self.device = next(iter(tensors.values())).device
         if self.device.type != "cuda":
@@ -156,11 +156,11 @@ def profile_kernel(eng: HipEngine, which: str, batch: int, reps: int, io: Option
                                               ws.data_ptr(), ws.numel(), batch, reps, eng._stream()))
 
 
-def engine_from_numpy(cfg: _abi.AftConfig, state: Dict[str, np.ndarray], device="cuda:0") -> HipEngine:
+def engine_from_numpy(cfg: _abi.AftConfig, state: Dict[str, np.ndarray], device="cuda:0", lib=None) -> HipEngine:
     """Upload a numpy state_dict (e.g. from ``synth.make_state_dict``) and build an engine."""
     dev = torch.device(device)
     tensors = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in state.items()}
-    return HipEngine(cfg, tensors)
+    return HipEngine(cfg, tensors, lib=lib)
 
 
 def linear_forward(weight: torch.Tensor, bias: Optional[torch.Tensor], pilots: torch.Tensor, ofdm_size) -> torch.Tensor:
