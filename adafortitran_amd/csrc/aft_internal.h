@@ -17,9 +17,26 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kWave = 64;       // CDNA4 wavefront
 constexpr int kHeadDim = 32;    // model_dim / num_head for every config the kernels cover
 constexpr int kTile = 32;       // v_mfma_f32_32x32x2_f32 tile edge
-constexpr int kMaxPatchFeatures = 16;   // patch_scs * patch_symbols the embedding kernel unrolls
+constexpr int kMaxPatchFeatures = 16;
+constexpr int kSchedSlots = 2048;       // (xcc id, se id, sh id, cu id) -> one ticket counter per CU   // patch_scs * patch_symbols the embedding kernel unrolls
 
 inline __host__ __device__ int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Wave priority from the work a persistent wave has LEFT (`left` of `total` equal steps; both wave-uniform).
+// Why: at equal priority the oldest wave of a SIMD wins every fp32-MFMA issue conflict, so co-resident waves (or
+// workgroups) that run the same program advance almost one after the other and the youngest ones finish alone --
+// measured with the AFT_STAMPS build: identical attention tasks of one round ended after 20 .. 65 us, 2.4 of 3
+// wave slots busy on average.  A wave that gets ahead drops its priority, so the laggards catch up at every band
+// edge; the bands shrink geometrically towards the end (1/2, 1/4, 1/8 of the work), which bounds the stagger of the
+// finish times to the last eighth.  Priority only arbitrates issue; results do not depend on it.
+__device__ __forceinline__ void set_progress_priority(int left, int total) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AFT_NO_PROGRESS_PRIORITY)
+    if (2 * left > total) __builtin_amdgcn_s_setprio(3);
+    else if (4 * left > total) __builtin_amdgcn_s_setprio(2);
+    else if (8 * left > total) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 
 // Device-resident scratch of one forward call; all offsets in floats, 256-B aligned.
 // Layout in HBM (DESIGN.md "data layout"):

@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
@@ -51,101 +52,68 @@ __device__ __forceinline__ void srd_store(Srd r, unsigned byte_off, f32x4 v) {
 #define AFT_ATTN_WAVES 3   // waves per SIMD the register budget is capped for (and the persistent grid sized to)
 #endif
 
-struct AttnState {
-    float m_run, l_run;
-    f32x16 oacc;
-};
+// Growth of a row's maximum (in log2 units) over the reference that is tolerated before the accumulators are rescaled:
+// the probabilities are exp2(s - m_ref) with a STALE reference m_ref, so they may reach 2^kRescaleThreshold instead
+// of 1.  In fp32 that costs no precision (only the exponent moves); 2^64 x 1120 keys x |v| is far from overflow.
+constexpr float kRescaleThreshold = 64.0f;
+// |row maximum| of the first key tile below which a wave keeps the reference at ZERO for all its rows (no subtraction
+// at all); trained encoders live here (|logit| of a few units)
+constexpr float kZeroRefThreshold = 32.0f;
 
-// One chunk of CH key tiles: S^T tiles -> online-softmax update -> O^T += V^T P^T.
-// TAIL = false: all CH tiles exist and are full (no masks, no bounds checks: the steady state);
-// TAIL = true : the final chunk -- tiles >= nkt are skipped, the ragged last tile is masked.
-template <int CH, bool TAIL>
-__device__ __forceinline__ void attn_chunk(AttnState &st, const f32x4 (&qreg)[4], Srd ks, Srd vs, unsigned kb,
-                                           unsigned vb, int c0, int nkt, int tokens, int h) {
-    f32x16 sacc[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int kt = c0 + c;
-        sacc[c] = f32x16{0};
-        if (!TAIL || kt < nkt) {
-            f32x4 kreg[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) kreg[s] = srd_load(ks, kb + (unsigned)(kt * 1024 + s * 256) * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    sacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s][j], qreg[s][j], sacc[c], 0, 0, 0);
-            if (TAIL && kt * kTile + kTile > tokens) {  // ragged last tile: pad keys -> -inf
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = kt * kTile + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (key >= tokens) sacc[c][e] = -INFINITY;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[c][e] = -INFINITY;
-        }
-    }
-    // running max over this chunk (lane-local over registers, then the other key half)
-    float cmax = sacc[0][0];
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, sacc[c][e]);
-    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-    const float m_new = fmaxf(st.m_run, cmax);  // finite: every chunk holds >= 1 real key
-    const float alpha = __builtin_amdgcn_exp2f(st.m_run - m_new);
-    // exponentials: the shift and the row sum run on register PAIRS (v_pk_add_f32: two floats per
-    // lane per issue) -- VALU issue comes straight out of fp32-MFMA time on this path
-    const f32x2 m2 = {m_new, m_new};
-    f32x2 psum2 = {0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            f32x2 t = f32x2{sacc[c][e], sacc[c][e + 1]} - m2;
-            t[0] = __builtin_amdgcn_exp2f(t[0]);
-            t[1] = __builtin_amdgcn_exp2f(t[1]);
-            sacc[c][e] = t[0];
-            sacc[c][e + 1] = t[1];
-            psum2 += t;
-        }
-    float psum = psum2[0] + psum2[1];
-    psum += __shfl_xor(psum, 32);
-    st.l_run = st.l_run * alpha + psum;
-    st.m_run = m_new;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) st.oacc[e] *= alpha;
-    // O^T += V^T P^T
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int kt = c0 + c;
-        if (!TAIL || kt < nkt) {
-            const bool ragged = TAIL && kt * kTile + kTile > tokens;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (ragged && kt * kTile + 8 * g >= tokens) continue;   // both halves of this k group are padding
-                const int key0 = kt * kTile + 8 * g + 4 * h;
-                f32x4 v = srd_load(vs, vb + (unsigned)(kt * 1024 + g * 256) * 4);
-                if (ragged) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (key0 + j >= tokens) v[j] = 0.f;  // workspace pad is never trusted
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    st.oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], sacc[c][4 * g + j], st.oacc, 0, 0, 0);
-            }
-        }
-    }
+__device__ __forceinline__ float other_half(float x) {   // value held by lane (l ^ 32): v_permlane32_swap
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
+
+__device__ __forceinline__ float max16(const f32x16 &v) {   // 8 x v_max3_f32
+    float m = __builtin_fmaxf(v[0], v[1]);
+#pragma unroll
+    for (int e = 2; e < 16; e += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, v[e]), v[e + 1]);
+    return m;
+}
+
+// S^T tile = K tile . Q^T - m_ref: 16 MFMAs on one accumulator that starts from the inline constant 0.  A non-zero
+// reference enters as ONE more MFMA of the same chain (A = 1 on the k = 0 half, B = -m_ref of the lane's query), so
+// no register tuple of initial values and no copies are needed; `zero_ref` (wave-uniform) skips it.
+__device__ __forceinline__ f32x16 qk_tile(const f32x4 (&kreg)[4], const f32x4 (&qreg)[4], bool zero_ref, float a_one,
+                                          float neg_m) {
+    f32x16 c;
+    if (zero_ref) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[0][0], qreg[0][0], f32x16{0}, 0, 0, 0);
+    } else {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_one, neg_m, f32x16{0}, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[0][0], qreg[0][0], c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 1; i < 16; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i >> 2][i & 3], qreg[i >> 2][i & 3], c, 0, 0, 0);
+    return c;
+}
+
+struct AttnRow {          // per-lane softmax state of the lane's query row
+    float m_ref;          // reference maximum (log2 units); logits are produced as s - m_ref
+    f32x2 lsum2;          // partial row sums of this lane's 16 keys per tile (two interleaved chains)
+    f32x16 oacc;          // O^T accumulator
+    bool zero_ref;        // wave-uniform: m_ref == 0 in every lane
+};
 
 // launch bound (256, 3): <= 168 registers keeps accumulators in VGPRs (the MFMA's VGPR form) --
 // with the default 512-register budget hipcc parks them in AGPRs and pays ~2.5 v_accvgpr moves
 // per MFMA around the softmax, which on the fp32 matrix path comes straight out of MFMA time.
-template <int CH>
+//
+// Softmax with a stale reference maximum (round 2).  A VALU instruction costs 2.6-4.3 cycles of fp32-MFMA time
+// and v_exp_f32 8 (tools/micro/valu_cost.hip) and both kernels of the encoder are ALU-bound (MFMA + VALU cycles
+// fill ~95 % of the SIMD time), so the per-tile VALU work is cut to what the arithmetic needs:
+//   * m_ref = row maximum of the FIRST key tile (or 0 for the whole wave when all those maxima are small).  Every
+//     later tile comes out of its MFMA chain as S - m_ref, is exponentiated with a bare v_exp_f32 and summed in
+//     per-lane partial sums; no running-max update, no alpha, no O rescale, no register copies per tile.
+//   * one wave-uniform test per tile (8 x v_max3 + compare): only when some row's tile maximum exceeds m_ref by
+//     more than kRescaleThreshold are m_ref, O, the partial sums and the pending logits rescaled (exact: every
+//     factor is exp2 of the change of reference).  Rows that did not grow get a factor of 1.
+//   * QK^T of tile t+1 is issued before the exponentials of tile t; two named accumulators alternate roles
+//     (the loop is unrolled by two) so neither is ever copied.
+//   * the next task's Q / K tile 0 / V tile 0 are requested during the last key tile of the current one.
+template <int UNUSED>
 __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                       const float *__restrict__ vt, const float *__restrict__ qbias,
                                                       float *__restrict__ out, int heads, int tokens, int tokpad,
@@ -153,62 +121,168 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *
                                                       float scale_log2e, int ntasks, unsigned long long *stamps) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // persistent waves with a static, balanced schedule: the grid is sized to the co-resident wave
-    // count and wave w takes tasks w, w + W, w + 2W ... (B=128: 9216 tasks over 3072 waves = exactly
-    // 3 each), so every SIMD finishes together -- a 40-us task has no tail to wait for.
     const Srd qs = make_srd(q), ks = make_srd(k), vs = make_srd(vt), os = make_srd(out);
     const int total_waves = gridDim.x * 4;
     const int nkt = tokpad / kTile;
     const int r = lane & 31, h = lane >> 5;
+    const bool ragged = (tokens & (kTile - 1)) != 0;   // last key tile holds padded keys
+    const float a_one = h == 0 ? 1.0f : 0.0f;           // A operand of the reference MFMA: 1 on the k = 0 half
+    // XCD-aware task order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b and b+8 share an
+    // L2.  Give each XCD a CONTIGUOUS range of tasks: the 9 query tiles of one (plane, head) then read their K / V^T
+    // (72 KB) through ONE L2 instead of two or three.  A pure speed choice; any mapping is correct.
+    int vblock = blockIdx.x;
+    if ((gridDim.x & 7) == 0) vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 #ifdef AFT_DIAG_STAMPS
 #define ASTAMP(i) do { if (stamps && lane == 0) stamps[(size_t)task * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ASTAMP(i) do { } while (0)
 #endif
-  for (int task = blockIdx.x * 4 + wave; task < ntasks; task += total_waves) {
+    // q, k, vt arrive in MFMA-fragment order from k_chain.hip: [ph][tile][s or g][lane][4] -> every
+    // operand load below is one fully coalesced 1-KB buffer_load_dwordx4 per wave
+    auto head_base = [&](int task) { return ((unsigned)(task / nkt) * tokpad * kHeadDim + lane * 4) * 4; };
+    auto load_tile = [&](Srd src, int kt, f32x4 (&dst)[4], unsigned base) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dst[s] = srd_load(src, base + (unsigned)(kt * 1024 + s * 256) * 4);
+    };
+    // padded keys of the ragged last tile: logits -> -inf (probability 0), V^T columns -> 0 (the workspace pad is
+    // never trusted: 0 x NaN would poison the row)
+    auto mask_logits = [&](f32x16 &sv, int kt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (kt * kTile + (e & 3) + 8 * (e >> 2) + 4 * h >= tokens) sv[e] = -INFINITY;
+    };
+    auto mask_values = [&](f32x4 (&vv)[4], int kt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (kt * kTile + 8 * g + 4 * h + j >= tokens) vv[g][j] = 0.f;
+    };
+
+  // wave priority by work left (set_progress_priority, aft_internal.h): keeps the waves of a SIMD abreast
+  const int rounds = (ntasks + total_waves - 1) / total_waves;
+  int round = 0;
+  int task = vblock * 4 + wave;
+  f32x4 qreg[4], kcur[4], vcur[4];
+  if (task < ntasks) {       // operands of the first task; later ones are requested during the previous task's last tile
+      const unsigned hb0 = head_base(task);
+      load_tile(qs, task % nkt, qreg, hb0);
+      load_tile(ks, 0, kcur, hb0);
+      load_tile(vs, 0, vcur, hb0);
+  }
+  for (; task < ntasks; task += total_waves, ++round) {
     ASTAMP(0);
 #ifdef AFT_DIAG_STAMPS
     if (stamps && lane == 0) stamps[(size_t)task * 8 + 6] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int qt = task % nkt;
     const int ph = task / nkt;  // plane * heads + head
-
-    // q, k, vt arrive in MFMA-fragment order from k_chain.hip: [ph][tile][s or g][lane][4] -> every
-    // operand load below is one fully coalesced 1-KB global_load_dwordx4 per wave
-    const unsigned hb = ((unsigned)ph * tokpad * kHeadDim + lane * 4) * 4;   // byte offset of this (plane, head)
-    const unsigned kb = hb, vb = hb;
+    const unsigned hb = head_base(task);   // byte offset of this (plane, head)
+    const int next_task = task + total_waves;
+    const bool has_next = next_task < ntasks;
 
     // B operand of S^T = K Q^T : lane (q = r, h) holds Q[q][8s + 4h + j]; the query bias of the
     // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
     // a row constant to the logits, which softmax cancels), then everything is pre-scaled
-    f32x4 qreg[4];
     const float *bq = qbias + (ph % heads) * kHeadDim + 4 * h;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qreg[s] = srd_load(qs, hb + (unsigned)(qt * 1024 + s * 256) * 4);
-        qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
+    for (int s = 0; s < 4; ++s) qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
+
+    // ---- key tile 0: plain logits, reference maximum ----
+    AttnRow st;
+    f32x16 sA = qk_tile(kcur, qreg, true, a_one, 0.f), sB;
+    if (nkt > 1) load_tile(ks, 1, kcur, hb);
+    if (ragged && nkt == 1) { mask_logits(sA, 0); mask_values(vcur, 0); }
+    {
+        float m0 = max16(sA);
+        m0 = fmaxf(m0, other_half(m0));                  // finite: tile 0 holds >= 1 real key
+        st.zero_ref = !__any(fabsf(m0) > kZeroRefThreshold);
+        st.m_ref = st.zero_ref ? 0.f : m0;
+        if (!st.zero_ref) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sA[e] -= m0;
+        }
     }
-
-    AttnState st;
-    st.m_run = -INFINITY;
-    st.l_run = 0.f;
     st.oacc = f32x16{0};
-
-    int c0 = 0;
-    const int full_tiles = tokens / kTile;   // tiles with no padded key
+    st.lsum2 = f32x2{0.f, 0.f};
     ASTAMP(1);
-    for (; c0 + CH <= full_tiles; c0 += CH) attn_chunk<CH, false>(st, qreg, ks, vs, kb, vb, c0, nkt, tokens, h);
+
+    // one key tile: `cur` holds S_kt - m_ref (its chain finished an iteration ago), `nxt` receives S_{kt+1} - m_ref.
+    // FAST (compile time) = the steady state: tiles kt+1 and kt+2 exist and are full, so there is no mask, no bounds
+    // test and no task hand-over in the body; the last two or three tiles of a task run the general form.
+    auto step = [&](auto fast, f32x16 &cur, f32x16 &nxt, int kt) {
+        constexpr bool FAST = decltype(fast)::value;
+        set_progress_priority((rounds - 1 - round) * nkt + (nkt - 1 - kt), rounds * nkt);
+        const bool more = FAST || kt + 1 < nkt;
+        if (more) {
+            nxt = qk_tile(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
+            if (FAST || kt + 2 < nkt) load_tile(ks, kt + 2, kcur, hb);
+        } else if (has_next) {      // last tile: Q and K are idle -> request the next task's
+            const unsigned hbn = head_base(next_task);
+            load_tile(qs, next_task % nkt, qreg, hbn);
+            load_tile(ks, 0, kcur, hbn);
+        }
+        // stale-reference test for THIS tile
+        const float tmax = max16(cur);
+        if (__builtin_expect(__any(tmax > kRescaleThreshold), 0)) {
+            const float tm = fmaxf(tmax, other_half(tmax));
+            const float grow = fmaxf(tm, 0.f);           // new reference = m_ref + grow  (0 for rows that stay)
+            const float f = __builtin_amdgcn_exp2f(-grow);
+            st.m_ref += grow;
+            st.zero_ref = false;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                cur[e] -= grow;
+                if (more) nxt[e] -= grow;                 // the pending tile was started from the old reference
+                st.oacc[e] *= f;
+            }
+            st.lsum2 *= f;
+        }
+        if (!FAST && ragged && more && kt + 2 == nkt) mask_logits(nxt, kt + 1);
+        // probabilities (bare v_exp_f32: logits are pre-scaled by log2 e) and per-lane partial row sums
+        f32x16 p;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            p[e] = __builtin_amdgcn_exp2f(cur[e]);
+            p[e + 1] = __builtin_amdgcn_exp2f(cur[e + 1]);
+            st.lsum2 += f32x2{p[e], p[e + 1]};
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                st.oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[g][j], p[4 * g + j], st.oacc, 0, 0, 0);
+        if (more) {
+            load_tile(vs, kt + 1, vcur, hb);
+            if (!FAST && ragged && kt + 2 == nkt) mask_values(vcur, kt + 1);
+        } else if (has_next) {
+            load_tile(vs, 0, vcur, head_base(next_task));
+        }
+    };
+    using Fast = std::integral_constant<bool, true>;
+    using General = std::integral_constant<bool, false>;
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 3 < nkt; kt += 2) {       // both steps see tiles kt+1 .. kt+3 in range
+        step(Fast{}, sA, sB, kt);
+        step(Fast{}, sB, sA, kt + 1);
+    }
+    step(General{}, sA, sB, kt);           // the last two or three tiles (nkt - kt is 2 or 3; 1 when nkt == 1)
+    if (kt + 1 < nkt) step(General{}, sB, sA, kt + 1);
+    if (kt + 2 < nkt) step(General{}, sA, sB, kt + 2);
     ASTAMP(2);
-    for (; c0 < nkt; c0 += CH) attn_chunk<CH, true>(st, qreg, ks, vs, kb, vb, c0, nkt, tokens, h);
     ASTAMP(3);
 
     // O^T accumulator: lane = query r, register e = feature d = (e&3) + 8*(e>>2) + 4h -- i.e. registers
     // 4s..4s+3 are the operand-fragment element (s, h) of this head's feature block.  Stored in the
     // fragment order k_chain.hip consumes: [global 32-row tile][head][s][lane = row%32 + 32h][4]
     // (global rows = plane*tokens + q; a query tile straddles two row tiles when 32 does not divide tokens).
+    float l_run = st.lsum2[0] + st.lsum2[1];
+    l_run += other_half(l_run);
     const int qrow = qt * kTile + r;
     if (qrow < tokens) {
-        const float inv = 1.0f / st.l_run;
+        const float inv = 1.0f / l_run;
         const int plane = ph / heads, head = ph % heads;
         const unsigned grow = (unsigned)plane * tokens + qrow;
         const unsigned dst = (((grow >> 5) * (unsigned)(model_dim / kHeadDim) + head) * 1024 + ((grow & 31) + 32 * h) * 4) * 4;
@@ -251,8 +325,27 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
             for (int t = 0; t < n; ++t)
                 clk += (double)(hbuf[t * 8 + 4] - hbuf[t * 8 + 0]) / (double)(hbuf[t * 8 + 5] - hbuf[t * 8 + 6]) * 100e6;
             printf("in-kernel shader clock: %.3f GHz\n", clk / n / 1e9);
-            printf("attn stamps: mean per task: prologue=%.0f steady=%.0f tail=%.0f store=%.0f (cycles); MFMA ideal %d\n",
-                   sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, 288 * 64);
+            printf("attn stamps: mean per task: prologue=%.0f loop=%.0f store=%.0f (cycles); MFMA ideal %d\n",
+                   sum[1] / n, sum[2] / n, sum[4] / n, 32 * (tokpad / kTile) * 64);
+            // schedule: when do the tasks of each persistent round start / end (memrealtime = 100 MHz ticks)
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int t = 0; t < n; ++t) { t0 = std::min(t0, hbuf[t * 8 + 6]); t1 = std::max(t1, hbuf[t * 8 + 5]); }
+            const int per_round = blocks * 4;
+            double busy = 0;
+            for (int t = 0; t < n; ++t) busy += (double)(hbuf[t * 8 + 5] - hbuf[t * 8 + 6]);
+            printf("  span %.1f us, %d tasks in rounds of %d; mean concurrent waves per SIMD %.2f\n", (t1 - t0) / 100.0, n, per_round,
+                   busy / (double)(t1 - t0) / 1024.0);
+            for (int r0 = 0; r0 < n; r0 += per_round) {
+                double smin = 1e30, smax = 0, ssum = 0, emin = 1e30, emax = 0, esum = 0;
+                const int r1 = std::min(n, r0 + per_round);
+                for (int t = r0; t < r1; ++t) {
+                    const double st = (hbuf[t * 8 + 6] - t0) / 100.0, en = (hbuf[t * 8 + 5] - t0) / 100.0;
+                    smin = std::min(smin, st); smax = std::max(smax, st); ssum += st;
+                    emin = std::min(emin, en); emax = std::max(emax, en); esum += en;
+                }
+                printf("  round %d: start %.1f / %.1f / %.1f us (min/mean/max), end %.1f / %.1f / %.1f us\n", r0 / per_round, smin,
+                       ssum / (r1 - r0), smax, emin, esum / (r1 - r0), emax);
+            }
         }
         return hipGetLastError();
     }

@@ -263,8 +263,22 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
     // row tiles with stride gridDim.x (no dispatch gaps, no launch tail; LDS buffers need no extra
     // barrier between tiles: every re-write sits >= 1 barrier after the last read of the old data)
     const int ntiles = (a.rows + 31) / 32;
+    // Wave priority by ROUNDS LEFT (3, 2, 1, 0 for the last round).  Measured (AFT_STAMPS build): at equal priority the
+    // workgroups of one round finish up to 2x apart and the late ones run alone at the end of the launch; a workgroup
+    // that gets a round ahead drops its priority so the laggards catch up (chain_last 103 -> 100 us, forward -1.2 %).
+    // Tried and rejected: priority bands by quarter tiles (slower), per-CU arrival tickets + rotating priority (the
+    // ticket atomic costs 4 us per launch and the finish-time spread did not shrink).
+    const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int round = 0;
 #pragma unroll 1
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++round) {
+    {
+        const int left = rounds - 1 - round;
+        if (left >= 3) __builtin_amdgcn_s_setprio(3);
+        else if (left == 2) __builtin_amdgcn_s_setprio(2);
+        else if (left == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
     const int row0 = tile * 32;
     const int grow = min(row0 + r, a.rows - 1);               // clamped: ragged last tile computes, never stores
     const bool row_ok = row0 + r < a.rows;
@@ -495,6 +509,41 @@ static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
             for (size_t i = 0; i < busy.size(); ++i) if (cnt[i]) { ++ncu; tot += busy[i]; mn = std::min(mn, cnt[i]); mx = std::max(mx, cnt[i]); }
             printf("  span %.1f us; %d distinct CUs; tiles/CU min %d max %d; mean concurrent workgroups per CU %.2f; mean tile time %.1f us\n",
                    (t1 - t0) / 100.0, ncu, mn, mx, tot / ncu / (double)(t1 - t0), tot / nblk / 100.0);
+            {   // is the spread of finish times WITHIN a CU (arbitration between its workgroups) or ACROSS CUs / XCDs?
+                std::vector<double> first(8 * 4096, 1e30), last(8 * 4096, 0.0);
+                double xlast[8] = {0}; int xn[8] = {0};
+                for (int b = 0; b < nblk; ++b) {
+                    const unsigned long long id = h[b * 16 + 14];
+                    const unsigned hw = (unsigned)(id >> 32), xcc = (unsigned)id & 7;
+                    const unsigned cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (((hw >> 12) & 1) << 7);
+                    const double en = (h[b * 16 + 13] - t0) / 100.0;
+                    if (b + blocks >= nblk || b + 2 * blocks >= nblk) {   // a workgroup's last tile
+                        if (b + blocks >= nblk) { first[xcc * 4096 + cu] = std::min(first[xcc * 4096 + cu], en); last[xcc * 4096 + cu] = std::max(last[xcc * 4096 + cu], en); }
+                    }
+                }
+                double fmin = 1e30, fmax = 0, fsum = 0, lmin = 1e30, lmax = 0, lsum = 0; int n = 0;
+                for (size_t i = 0; i < last.size(); ++i) if (last[i] > 0) {
+                    ++n; fmin = std::min(fmin, first[i]); fmax = std::max(fmax, first[i]); fsum += first[i];
+                    lmin = std::min(lmin, last[i]); lmax = std::max(lmax, last[i]); lsum += last[i];
+                    xlast[i / 4096] += last[i]; xn[i / 4096]++;
+                }
+                printf("  per CU, last-round tiles: first workgroup done %.1f / %.1f / %.1f us, last workgroup done %.1f / %.1f / %.1f us (min/mean/max over %d CUs)\n",
+                       fmin, fsum / n, fmax, lmin, lsum / n, lmax, n);
+                printf("  mean finish per XCD:");
+                for (int x = 0; x < 8; ++x) printf(" %.1f", xn[x] ? xlast[x] / xn[x] : 0.0);
+                printf("\n");
+            }
+            for (int r0 = 0; r0 < nblk; r0 += blocks) {   // persistent rounds: when do their tiles start / end
+                double smin = 1e30, smax = 0, ssum = 0, emin = 1e30, emax = 0, esum = 0;
+                const int r1 = std::min(nblk, r0 + blocks);
+                for (int b = r0; b < r1; ++b) {
+                    const double st = (h[b * 16 + 12] - t0) / 100.0, en = (h[b * 16 + 13] - t0) / 100.0;
+                    smin = std::min(smin, st); smax = std::max(smax, st); ssum += st;
+                    emin = std::min(emin, en); emax = std::max(emax, en); esum += en;
+                }
+                printf("  round %d (%d tiles): start %.1f / %.1f / %.1f us (min/mean/max), end %.1f / %.1f / %.1f us\n", r0 / blocks, r1 - r0,
+                       smin, ssum / (r1 - r0), smax, emin, esum / (r1 - r0), emax);
+            }
         }
         return hipGetLastError();
     }

@@ -32,7 +32,7 @@ __device__ __forceinline__ void filler(float (&r)[8], f32x2 (&p)[4], f32x4 &ld, 
 template <int SHAPE, int KIND, int N>
 __global__ __launch_bounds__(256) void loop(float *out, int iters, float a0) {
     __shared__ float lds[4096];
-    f32x16 acc = {0};
+    f32x16 acc = {0}, accb = {0};
     f32x4 acc4[4] = {{0}, {0}, {0}, {0}};
     float r[8];
     f32x2 p[4];
@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256) void loop(float *out, int iters, float a0) {
         for (int u = 0; u < 16; ++u) {
             if constexpr (SHAPE == 32) {
                 asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+            } else if constexpr (SHAPE == 322) {   // two independent 32x32x2 chains, alternating
+                if (u & 1) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accb) : "v"(a), "v"(b));
+                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
             } else {
                 asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc4[(2 * u) & 3]) : "v"(a), "v"(b));
                 asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc4[(2 * u + 1) & 3]) : "v"(a), "v"(b));
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void loop(float *out, int iters, float a0) {
     float s = ld[0] + ld[3];
     for (int i = 0; i < 8; ++i) s += r[i];
     for (int i = 0; i < 4; ++i) s += p[i][0] + p[i][1];
-    for (int e = 0; e < 16; ++e) s += acc[e];
+    for (int e = 0; e < 16; ++e) s += acc[e] + accb[e];
     for (int i = 0; i < 4; ++i) s += acc4[i][0] + acc4[i][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
@@ -117,8 +120,17 @@ void table() {
     row<SHAPE, SNOP, 4>("s_nop 0", b1, b3);
 }
 
-int main() {
+int main(int argc, char **argv) {
     hipMalloc(&dbuf, 4 * 1024 * 1024 * 4);
+    if (argc > 1) {   // short form: the two-chain question only
+        const double a1 = run<32, NONE, 0>(1), a3 = run<32, NONE, 0>(3), b1 = run<322, NONE, 0>(1), b3 = run<322, NONE, 0>(3);
+        printf("bare 32x32x2: one chain %.1f / %.1f TF (1 / 3 waves per SIMD); two alternating chains %.1f / %.1f TF\n", a1, a3, b1, b3);
+        row<322, FMA, 2>("v_fma_f32 (2 chains)", b1, b3);
+        row<322, FMA, 4>("v_fma_f32 (2 chains)", b1, b3);
+        row<322, EXP, 2>("v_exp_f32 (2 chains)", b1, b3);
+        row<322, DSREAD128, 1>("ds_read_b128 (2 chains)", b1, b3);
+        return 0;
+    }
     table<32>();
     table<16>();
     return 0;
