@@ -116,6 +116,7 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     ws.k = off;             off += align64(per_head);
     ws.vt = off;            off += align64(per_head);
     ws.wpack = off;         off += align64(packed_layer_floats(c.model_dim) * c.num_layers);
+    ws.out6 = off;          off += align64(rows * out6_stride(c));
     ws.total_floats = off;
     return ws;
 }
@@ -125,8 +126,10 @@ static int hip_fail(const char *what, hipError_t e) {
     return AFT_ERR_HIP;
 }
 
+// `fused` (whole forward only): the first launch computes x0 from conv_enhanced / tokens6 itself (no embed kernel) and
+// the last one leaves linear_2's output in the q buffer instead of storing x (the conv tail reads it from there).
 static int run_encoder(const aft_config &c, const aft_weights &w, const Workspace &ws, float *base, int first_layer,
-                       int last_layer, hipStream_t st) {
+                       int last_layer, hipStream_t st, bool fused = false) {
     float *x = base + ws.x, *attn = base + ws.attn, *q = base + ws.q, *k = base + ws.k, *vt = base + ws.vt;
     const int rows = ws.planes * ws.tokens;
     const size_t pl = packed_layer_floats(c.model_dim);
@@ -136,15 +139,23 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
     e = launch_pack_weights(c, w, wp + first_layer * pl, first_layer, last_layer - first_layer + 1, st);
     if (e != hipSuccess) return hip_fail("pack_weights", e);
     // in-projection of the first layer (QKV-only pass of the chain kernel)
+    ChainFusion first{}, last{};
+    if (fused) {
+        first.conv_enhanced = base + ws.conv_enhanced;
+        first.tokens6 = c.adaptive ? base + ws.tokens6 : nullptr;
+        first.lin1_w = w.lin1_w; first.lin1_b = w.lin1_b; first.pos = w.pos;
+        last.lin2_w = w.lin2_w; last.lin2_b = w.lin2_b; last.out6 = base + ws.out6;
+    }
     e = launch_chain(c, nullptr, nullptr, &w.layers[first_layer], wp + first_layer * pl, nullptr, x, q, k, vt, rows,
-                     ws.tokens, ws.tokpad, st);
+                     ws.tokens, ws.tokpad, st, fused ? &first : nullptr);
     if (e != hipSuccess) return hip_fail("chain(qkv)", e);
     for (int l = first_layer; l <= last_layer; ++l) {
         e = launch_attention(c, q, k, vt, w.layers[l].in_proj_b, attn, ws.planes, ws.tokens, ws.tokpad, st);
         if (e != hipSuccess) return hip_fail("attention", e);
         const bool more = l < last_layer;
         e = launch_chain(c, &w.layers[l], wp + l * pl, more ? &w.layers[l + 1] : nullptr,
-                         more ? wp + (l + 1) * pl : nullptr, attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st);
+                         more ? wp + (l + 1) * pl : nullptr, attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st,
+                         fused && !more ? &last : nullptr);
         if (e != hipSuccess) return hip_fail("chain(mlp)", e);
     }
     return AFT_OK;
@@ -197,12 +208,10 @@ int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pi
         e = launch_adapter(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, st);
         if (e != hipSuccess) return hip_fail("adapter", e);
     }
-    e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, base + ws.x,
-                     batch, st);
-    if (e != hipSuccess) return hip_fail("embed", e);
-    rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st);
+    // patch embedding + linear_1 + positions run inside the first chain launch, linear_2 inside the last one
+    rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st, true);
     if (rc != AFT_OK) return rc;
-    e = launch_tail(*cfg, *w, base + ws.x, base + ws.conv_enhanced, out, batch, st);
+    e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6);
     if (e != hipSuccess) return hip_fail("tail", e);
     return AFT_OK;
 }
@@ -327,10 +336,15 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
             case AFT_KERNEL_EMBED:
                 e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, x, batch, st);
                 break;
-            case AFT_KERNEL_QKV:
+            case AFT_KERNEL_QKV: {   // as in the forward: embedding fused in front of the in-projection
+                ChainFusion f{};
+                f.conv_enhanced = base + ws.conv_enhanced;
+                f.tokens6 = cfg->adaptive ? base + ws.tokens6 : nullptr;
+                f.lin1_w = w->lin1_w; f.lin1_b = w->lin1_b; f.pos = w->pos;
                 e = launch_chain(*cfg, nullptr, nullptr, &w->layers[0], base + ws.wpack, nullptr, x, q, k, vt, rows,
-                                 ws.tokens, ws.tokpad, st);
+                                 ws.tokens, ws.tokpad, st, &f);
                 break;
+            }
             case AFT_KERNEL_ATTENTION:
                 e = launch_attention(*cfg, q, k, vt, w->layers[0].in_proj_b, attn, ws.planes, ws.tokens, ws.tokpad, st);
                 break;
@@ -339,13 +353,16 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                                  base + ws.wpack + packed_layer_floats(cfg->model_dim), attn, x, q, k, vt, rows,
                                  ws.tokens, ws.tokpad, st);
                 break;
-            case AFT_KERNEL_CHAIN_LAST:
+            case AFT_KERNEL_CHAIN_LAST: {   // as in the forward: linear_2 fused behind LN2, x not stored
+                ChainFusion f{};
+                f.lin2_w = w->lin2_w; f.lin2_b = w->lin2_b; f.out6 = base + ws.out6;
                 e = launch_chain(*cfg, &w->layers[0], base + ws.wpack, nullptr, nullptr, attn, x, q, k, vt, rows,
-                                 ws.tokens, ws.tokpad, st);
+                                 ws.tokens, ws.tokpad, st, &f);
                 break;
+            }
             case AFT_KERNEL_TAIL:
                 AFT_REQUIRE(out != nullptr, "tail profile needs an output buffer");
-                e = launch_tail(*cfg, *w, x, base + ws.conv_enhanced, out, batch, st);
+                e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6);
                 break;
             default:
                 set_error("unknown kernel id %d", which);

@@ -22,6 +22,19 @@ constexpr int kSchedSlots = 2048;       // (xcc id, se id, sh id, cu id) -> one 
 
 inline __host__ __device__ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// fp32 MFMA with one scalar instruction behind it.  Measured (tools/micro/valu_cost.hip short): a v_mfma_f32_32x32x2_f32
+// that directly follows another one in the instruction stream issues ~6 cycles late (143 TFLOP/s for back-to-back
+// chains, one or two accumulators, 1 or 3 waves per SIMD alike); ONE scalar instruction between them (s_nop 0, s_mov)
+// removes the bubble: 156 TFLOP/s = 99 % of the 157.3 TFLOP/s roof.  VALU or LDS instructions in the gap do the same,
+// so the s_nop only matters where MFMAs would otherwise be adjacent -- which is every GEMM inner loop here.
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AFT_NO_MFMA_SPACER)
+    asm volatile("s_nop 0" : "+v"(c));   // tied to the accumulator so that it stays between this MFMA and the next of the chain
+#endif
+    return c;
+}
+
 // Wave priority from the work a persistent wave has LEFT (`left` of `total` equal steps; both wave-uniform).
 // Why: at equal priority the oldest wave of a SIMD wins every fp32-MFMA issue conflict, so co-resident waves (or
 // workgroups) that run the same program advance almost one after the other and the youngest ones finish alone --
@@ -47,8 +60,9 @@ __device__ __forceinline__ void set_progress_priority(int left, int total) {
 //   q, k          [2B][H][tokpad/32][4 s][64 lanes][4]  f32  MFMA-fragment order: (key%32 + 32hh, d = 8s+4hh+j)
 //   vt            [2B][H][tokpad/32][4 g][64 lanes][4]  f32  fragment order: (d + 32hh, key = 32kt+8g+4hh+j)
 //   wpack         [L][8*d*d]            f32  encoder GEMM weights in MFMA-fragment order (rebuilt per call)
+//   out6          [2B*tokens][8 | 16]   f32  linear_2 output of the last chain launch (input of the conv tail)
 struct Workspace {
-    size_t conv_enhanced, tokens6, x, attn, q, k, vt, wpack, total_floats;
+    size_t conv_enhanced, tokens6, x, attn, q, k, vt, wpack, out6, total_floats;
     int tokens, tokpad, planes;
 };
 
@@ -84,9 +98,19 @@ hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *
 // Row-local chain on [rows, d]: (mlp) x <- LN2(x1 + FFN(x1)), x1 = LN1(x + attn Wo^T + bo);
 // (qkv) q,k,vt <- split(x Wqkv^T + b).  `mlp_w` may be NULL (QKV only), `qkv_w` may be NULL.
 // `*_packed` = that layer's block of the fragment-packed weight image (launch_pack_weights).
+// Optional work fused into the first / last chain launch of a forward (k_chain.hip, ChainArgs):
+//   first (QKV only)  : x0 = embed(conv_enhanced, tokens6) computed in the kernel and written to x   (set conv_enhanced)
+//   last (no QKV)     : out6 = linear_2(x2) written instead of x                                     (set out6)
+struct ChainFusion {
+    const float *conv_enhanced = nullptr, *tokens6 = nullptr, *lin1_w = nullptr, *lin1_b = nullptr, *pos = nullptr;
+    const float *lin2_w = nullptr, *lin2_b = nullptr;
+    float *out6 = nullptr;
+};
+inline int out6_stride(const aft_config &c) { return c.patch_scs * c.patch_symbols <= 8 ? 8 : 16; }
 hipError_t launch_chain(const aft_config &c, const aft_layer_weights *mlp_w, const float *mlp_packed,
                         const aft_layer_weights *qkv_w, const float *qkv_packed, const float *attn, float *x,
-                        float *q, float *k, float *vt, int rows, int tokens, int tokpad, hipStream_t st);
+                        float *q, float *k, float *vt, int rows, int tokens, int tokpad, hipStream_t st,
+                        const ChainFusion *fuse = nullptr);
 size_t packed_layer_floats(int d);
 // Re-lay the encoder GEMM weights of layers [first, first+count) into MFMA-fragment order.
 hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float *packed, int first_layer, int count,
@@ -96,8 +120,9 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
                             float *attn, int planes, int tokens, int tokpad, hipStream_t st);
 // true when the fused conv-stack kernel has an LDS band plan for an S x T grid with `extra_floats` of side data
 bool conv_plan_ok(int S, int T, int extra_floats);
+// x = encoder output [rows][d] (linear_2 applied here), or NULL with out6 = linear_2 output [rows][out6_stride(c)]
 hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
-                       float *out, int batch, hipStream_t st);
+                       float *out, int batch, hipStream_t st, const float *out6 = nullptr);
 hipError_t launch_linear(const float *weight, const float *bias, const float *pilots, float *out, int batch,
                          int in_features, int out_features, hipStream_t st);
 hipError_t launch_pilot_gather(const float *hzero_ls, float *pilots, int *counts, int batch, int grid_elems,

@@ -80,13 +80,13 @@ __device__ __forceinline__ f32x16 qk_tile(const f32x4 (&kreg)[4], const f32x4 (&
                                           float neg_m) {
     f32x16 c;
     if (zero_ref) {
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[0][0], qreg[0][0], f32x16{0}, 0, 0, 0);
+        c = mfma_f32(kreg[0][0], qreg[0][0], f32x16{0});
     } else {
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a_one, neg_m, f32x16{0}, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[0][0], qreg[0][0], c, 0, 0, 0);
+        c = mfma_f32(a_one, neg_m, f32x16{0});
+        c = mfma_f32(kreg[0][0], qreg[0][0], c);
     }
 #pragma unroll
-    for (int i = 1; i < 16; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[i >> 2][i & 3], qreg[i >> 2][i & 3], c, 0, 0, 0);
+    for (int i = 1; i < 16; ++i) c = mfma_f32(kreg[i >> 2][i & 3], qreg[i >> 2][i & 3], c);
     return c;
 }
 
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                st.oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[g][j], p[4 * g + j], st.oacc, 0, 0, 0);
+                st.oacc = mfma_f32(vcur[g][j], p[4 * g + j], st.oacc);
         if (more) {
             load_tile(vs, kt + 1, vcur, hb);
             if (!FAST && ragged && kt + 2 == nkt) mask_values(vcur, kt + 1);

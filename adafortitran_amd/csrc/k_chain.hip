@@ -63,6 +63,16 @@ struct ChainArgs {
     const float *bv;                                   // in_proj_bias + 2D (value bias)
     float *q, *k, *vt;
     int rows, tokens, tokpad, heads;
+    // <MLP,!QKV> only, optional: transformer_encoder.linear_2 (reference blocks/encoders.py:56,70) fused behind LN2.
+    // out6 [rows][out6_stride] receives x2 W2^T + b2 and x is NOT stored (the conv tail reads out6); NULL = store x.
+    const float *lin2_w, *lin2_b;   // torch [P][D], [P]
+    float *out6;
+    int out6_features, out6_stride;
+    // <!MLP,QKV> only, optional: patch embedding + adapter concat + linear_1 + positional table (reference
+    // blocks/patch_processors.py:22,34-35, fortitran.py:217, encoders.py:67-68) fused in front of the in-projection:
+    // x0 is computed from conv_enhanced / tokens6 instead of being read, and written to x.  NULL conv = read x.
+    const float *emb_conv, *emb_tok6, *emb_w1, *emb_b1, *emb_pos;   // [planes][S][T], [frames][tokens][6] or NULL, [D][K], [D], [>=tokens][D]
+    int emb_S, emb_T, emb_p0, emb_p1, emb_K;                          // K = p0*p1 (+6 with adapter tokens)
     unsigned long long *stamps;  // diagnostic build only (AFT_DIAG_STAMPS), else NULL
 };
 
@@ -125,6 +135,7 @@ __device__ __forceinline__ void gemm_run(WRing<NT, PF> &ring, Srd w, unsigned w_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float wv = ring.b[kb % (PF + 1)][t][s][j];
+                    // (the s_nop spacer of aft_internal.h::mfma_f32 measured 1.5 % slower here, unlike in k_attn.hip)
                     acc[t] = (NORMAL >> t) & 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wv, acc[t], 0, 0, 0)
                                                : __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[j], acc[t], 0, 0, 0);
                 }
@@ -259,6 +270,21 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         }
         __syncthreads();
     }
+    // fused embedding (<!MLP,QKV> with emb_conv set): linear_1's weights [D][K] and the K input-feature offsets are
+    // staged once per workgroup in the upper half of the hidden buffer (idle in this variant: `xq` below alternates
+    // between xb and hb's lower half), so nothing tile-invariant is held in registers across the in-projection GEMM.
+    constexpr int kEmbSteps = (kMaxPatchFeatures + 6 + 1) / 2;
+    float *emb_w = hb + S::XB;                                   // [D][K]
+    int *emb_offs = reinterpret_cast<int *>(emb_w + D * (kMaxPatchFeatures + 6));   // [K]: offset into the row's patch block, or ~index into tokens6
+    if constexpr (!MLP) {
+        if (a.emb_conv != nullptr) {
+            const int pk = a.emb_p0 * a.emb_p1;
+            for (int i = tid; i < D * a.emb_K; i += S::THREADS) emb_w[i] = a.emb_w1[i];
+            for (int k = tid; k < a.emb_K; k += S::THREADS)
+                emb_offs[k] = k < pk ? (k / a.emb_p1) * a.emb_T + k % a.emb_p1 : ~(k - pk);
+            __syncthreads();
+        }
+    }
     // persistent workgroups: the grid is sized to the co-resident count and each workgroup walks the
     // row tiles with stride gridDim.x (no dispatch gaps, no launch tail; LDS buffers need no extra
     // barrier between tiles: every re-write sits >= 1 barrier after the last read of the old data)
@@ -270,8 +296,34 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
     // ticket atomic costs 4 us per launch and the finish-time spread did not shrink).
     const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     int round = 0;
+    // linear_2 partials of the previous tile (fused variant of <MLP,!QKV>): sum the W per-wave partials in wave order, add
+    // the bias, store [row][out6_stride].  Called by ONE wave per tile, after the barrier that ended that tile.
+    int pending_row0 = -1;
+    auto reduce_out6 = [&]() {
+        const int P = a.out6_features;
+        if (pending_row0 + r < a.rows) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {      // features 4h + {0..3} (half 0), 8 + 4h + {0..3} (half 1)
+                const int f0 = 8 * half + 4 * h;
+                if (f0 < P) {
+                    f32x4 sum = *reinterpret_cast<const f32x4 *>(hb + lane * 8 + 4 * half);
+#pragma unroll
+                    for (int u = 1; u < W; ++u) {
+                        const f32x4 t = *reinterpret_cast<const f32x4 *>(hb + (u * 64 + lane) * 8 + 4 * half);
+                        sum += t;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum[j] += f0 + j < P ? a.lin2_b[f0 + j] : 0.f;   // padding columns hold 0
+                    *reinterpret_cast<f32x4 *>(a.out6 + (size_t)(pending_row0 + r) * a.out6_stride + f0) = sum;
+                }
+            }
+        }
+    };
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++round) {
+    if constexpr (MLP && !QKV) {
+        if (pending_row0 >= 0 && w == (round & (W - 1 < 3 ? W - 1 : 3))) reduce_out6();
+    }
     {
         const int left = rounds - 1 - round;
         if (left >= 3) __builtin_amdgcn_s_setprio(3);
@@ -360,18 +412,82 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         STAMP(7);
         layernorm_rows<D>(cur, stats, par + 2 * D + fb, par + 3 * D + fb, w, r, h);   // -> x2
         STAMP(8);
-        if (row_ok) {
+        bool store_x = true;
+        if constexpr (!QKV) {
+            if (a.out6 != nullptr) {
+                // linear_2 as one more transposed product: A = W2 rows (lane = output feature p < P, zero above),
+                // B = x2 of this wave's 32-feature block (registers, operand layout) -> this wave's partial of
+                // out6^T [p][row]; the W partials meet in the idle hidden buffer and are summed in wave order.
+                store_x = false;
+                const int P = a.out6_features;
+                f32x16 acc6 = f32x16{0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+                    if (r < P) wv = *reinterpret_cast<const f32x4 *>(a.lin2_w + (size_t)r * D + fb + 8 * s + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc6 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j], cur[4 * s + j], acc6, 0, 0, 0);
+                }
+                // accumulator: lane = row r, register e = output feature (e&3) + 8(e>>2) + 4h; P <= 16 -> registers 0..7.
+                // The partials are summed one tile LATER (reduce_out6 at the top of the loop / after it), behind the
+                // barrier that ends this tile anyway: no extra barrier, and the waves take turns as the reducer.
+                float *part = hb + (w * 64 + lane) * 8;
+                *reinterpret_cast<f32x4 *>(part) = f32x4{acc6[0], acc6[1], acc6[2], acc6[3]};
+                *reinterpret_cast<f32x4 *>(part + 4) = f32x4{acc6[4], acc6[5], acc6[6], acc6[7]};
+                pending_row0 = row0;
+            }
+        }
+        if (store_x && row_ok) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 srd_store(srd_x, xrow + 32 * s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
         }
     } else {
         gemm_preload<W, 3, 1, W>(ring_qkv, srd_wq, wq_lane);
+        if (a.emb_conv == nullptr) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const f32x4 t = srd_load(srd_x, xrow + 32 * s);
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 t = srd_load(srd_x, xrow + 32 * s);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cur[4 * s + j] = t[j];
+                for (int j = 0; j < 4; ++j) cur[4 * s + j] = t[j];
+            }
+        } else {
+            // x0 = [patch features | adapter features] W1^T + b1 + pos[token]: ceil(K/2) MFMAs of the same transposed
+            // form (A = W1 rows of this wave's feature block, B = the row's input features), the accumulator starting
+            // from b1 + pos -- it comes out in operand layout like any other `cur`.
+            const int plane = grow / a.tokens, tok = grow - plane * a.tokens;
+            const int tpr = a.emb_T / a.emb_p1, g = tok / tpr, tc = tok - g * tpr;
+            const float *cplane = a.emb_conv + ((size_t)plane * a.emb_S + g * a.emb_p0) * a.emb_T + tc * a.emb_p1;
+            const float *t6 = a.emb_tok6 ? a.emb_tok6 + ((size_t)(plane >> 1) * a.tokens + tok) * 6 : nullptr;
+            f32x16 acc0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(a.emb_b1 + fb + 8 * s + 4 * h);
+                const f32x4 ps = *reinterpret_cast<const f32x4 *>(a.emb_pos + (size_t)tok * D + fb + 8 * s + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc0[4 * s + j] = b[j] + ps[j];
+            }
+            float av[kEmbSteps], bv[kEmbSteps];   // all operand loads in flight before the first MFMA
+#pragma unroll
+            for (int st = 0; st < kEmbSteps; ++st) {
+                const int k = 2 * st + h;      // this lane half's k index of step st
+                av[st] = 0.f;
+                bv[st] = 0.f;
+                if (k < a.emb_K) {
+                    const int off = emb_offs[k];
+                    av[st] = emb_w[(fb + r) * a.emb_K + k];
+                    bv[st] = off >= 0 ? cplane[off] : t6[~off];
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < kEmbSteps; ++st)
+                if (2 * st < a.emb_K) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv[st], acc0, 0, 0, 0);
+            cur = acc0;
+            if (row_ok) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    srd_store(srd_x, xrow + 32 * s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
+            }
         }
     }
 
@@ -455,6 +571,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
     // barrier in front of the next tile's LN1 partials: one more barrier.
     if constexpr (MLP && !QKV) __syncthreads();
   }
+    if constexpr (MLP && !QKV) {
+        if (pending_row0 >= 0 && w == 0) reduce_out6();   // the last tile's partials (behind the loop's closing barrier)
+    }
 }
 
 template <int D, int ACT, bool MLP, bool QKV>
@@ -596,9 +715,20 @@ static hipError_t launch_chain_t(const ChainArgs &args, bool mlp, bool qkv, hipS
 hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const float *m_packed,
                         const aft_layer_weights *qw, const float *q_packed,
                         const float *attn, float *x, float *q, float *k, float *vt, int rows, int tokens,
-                        int tokpad, hipStream_t st) {
+                        int tokpad, hipStream_t st, const ChainFusion *fuse) {
     const size_t dd = (size_t)c.model_dim * c.model_dim;
     ChainArgs a{};
+    if (fuse != nullptr && fuse->out6 != nullptr && m != nullptr && qw == nullptr) {
+        a.lin2_w = fuse->lin2_w; a.lin2_b = fuse->lin2_b; a.out6 = fuse->out6;
+        a.out6_features = c.patch_scs * c.patch_symbols;
+        a.out6_stride = out6_stride(c);
+    }
+    if (fuse != nullptr && fuse->conv_enhanced != nullptr && m == nullptr) {
+        a.emb_conv = fuse->conv_enhanced; a.emb_tok6 = fuse->tokens6; a.emb_w1 = fuse->lin1_w; a.emb_b1 = fuse->lin1_b;
+        a.emb_pos = fuse->pos;
+        a.emb_S = c.num_scs; a.emb_T = c.num_symbols; a.emb_p0 = c.patch_scs; a.emb_p1 = c.patch_symbols;
+        a.emb_K = c.patch_scs * c.patch_symbols + (fuse->tokens6 ? 6 : 0);
+    }
     a.attn = attn;
     a.x = x;
     if (m != nullptr) {

@@ -39,6 +39,8 @@ struct ConvArgs {
     int pf;
     // tail
     const float *x, *lin2_w, *lin2_b, *resid;
+    const float *lin2_out;   // tail: linear_2 already applied by the last chain launch, [rows][lin2_stride]; NULL = apply it here
+    int lin2_stride;
     int d, tokens, p0, p1;
     const float *cw[4], *cb[4];
     float *out_plane;    // head / plain: [planes][S][T]
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     if (TRAIN) {
     } else if (a.mode == 0) {
         for (int i = tid; i < a.pf; i += kConvThreads) small[i] = a.pilots[((size_t)frame * a.pf + i) * 2 + part];
-    } else {
+    } else if (a.lin2_out == nullptr) {
         const int p = a.p0 * a.p1;
         for (int i = tid; i < p * a.d; i += kConvThreads) small[i] = a.lin2_w[i];
         for (int i = tid; i < p; i += kConvThreads) small[p * a.d + i] = a.lin2_b[i];
@@ -186,6 +188,17 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                 for (int kk = 0; kk < a.pf; ++kk) v = fmaf(wr[kk], small[kk], v);
                 in0[(t + 1) * col_stride + lr] = v;
             }
+        }
+    } else if (!TRAIN && a.lin2_out != nullptr) {
+        // inverse patch map + conv_enhanced residual on the linear_2 output of the last chain launch: feature f of
+        // token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1); one thread per pixel of the band
+        const int p0 = a.p0, p1 = a.p1, tpr = T / p1;
+        for (int i = tid; i < LR * T; i += kConvThreads) {
+            const int lr = i / T, t = i - lr * T, gr = gr0 + lr;
+            if (gr < 0 || gr >= S) continue;
+            const int g = gr / p0, tc = t / p1, f = (gr - g * p0) * p1 + (t - tc * p1);
+            in0[(t + 1) * col_stride + lr] = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] +
+                                             a.resid[((size_t)n * S + gr) * T + t];
         }
     } else if (!TRAIN) {
         // linear_2 + inverse patch map + conv_enhanced residual.  One thread per token: its x row is read
@@ -468,9 +481,11 @@ hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const floa
 }
 
 hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
-                       float *out, int batch, hipStream_t st) {
+                       float *out, int batch, hipStream_t st, const float *out6) {
     ConvArgs a{};
     a.mode = 1;
+    a.lin2_out = out6;
+    a.lin2_stride = out6_stride(c);
     a.S = c.num_scs; a.T = c.num_symbols;
     a.x = x; a.lin2_w = w.lin2_w; a.lin2_b = w.lin2_b; a.resid = conv_enhanced;
     a.d = c.model_dim; a.p0 = c.patch_scs; a.p1 = c.patch_symbols;

@@ -78,10 +78,11 @@ def algorithmic_flops(c, batch):
     conv = planes * S * T * 2 * 9 * (1 * 8 + 8 * 32 + 32 * 8 + 8 * 1)
     up = planes * 2 * Ps * Pt * S * T
     pin = p0 * p1 + (6 if c["hidden"] else 0)
-    fl = {"qkv": qkv, "chain": proj + ffn + qkv, "chain_last": proj + ffn, "attention": attn, "upsample": conv + up,
-          "tail": conv + 2 * rows * d * p0 * p1, "embed": 2 * rows * d * pin,
-          "encoder_total": L * (qkv + proj + ffn + attn)}
-    fl["forward_total"] = fl["upsample"] + fl["embed"] + fl["encoder_total"] + fl["tail"]
+    emb, lin2 = 2 * rows * d * pin, 2 * rows * d * p0 * p1
+    # the first chain launch also does patch embedding + linear_1, the last one linear_2 (fused since round 2)
+    fl = {"qkv": qkv + emb, "chain": proj + ffn + qkv, "chain_last": proj + ffn + lin2, "attention": attn, "upsample": conv + up,
+          "tail": conv, "encoder_total": L * (qkv + proj + ffn + attn)}
+    fl["forward_total"] = fl["upsample"] + emb + fl["encoder_total"] + lin2 + fl["tail"]
     return fl
 
 
@@ -189,8 +190,8 @@ def timed_steps(step, steps, warmup, fence):
 def kernel_times(wl, reps):
     """Average duration (ms) of every kernel class inside a real forward.
 
-    Pass 1: `reps` whole flows (conv head, embed, QKV, [attention, chain] x (L-1), attention, last chain, conv
-    tail -- the launch order of aft_forward_f32, same kernels / grids / arguments through
+    Pass 1: `reps` whole flows (conv head, embed+QKV, [attention, chain] x (L-1), attention, last chain + linear_2,
+    conv tail -- the launch order of aft_forward_f32, same kernels / grids / arguments through
     aft_profile_kernel_f32) enqueued back to back between ONE event pair: T_flow, free of per-launch event
     overhead.  Pass 2: the same flows with an event pair around every launch give each class's SHARE
     (each pair inflates its kernel by ~3 us, which cancels in the ratio to first order).  Class time =
@@ -199,7 +200,7 @@ def kernel_times(wl, reps):
     import torch
     from adafortitran_amd.hip_ops import profile_kernel
     L = wl.c["num_layers"]
-    flow = [("upsample", wl.pil), ("embed", None), ("qkv", None)]
+    flow = [("upsample", wl.pil), ("qkv", None)]
     for _ in range(L - 1):
         flow += [("attention", None), ("chain", None)]
     flow += [("attention", None), ("chain_last", None), ("tail", wl.out)]

@@ -239,12 +239,13 @@ int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float 
  * aft_forward_f32 of the same (cfg, batch) left in `workspace`, so the caller can bracket it with
  * events on that stream.  Same kernels, grids and arguments as inside aft_forward_f32. */
 #define AFT_KERNEL_UPSAMPLE 0   /* fused pilot-linear + initial ConvEnhancer                 */
-#define AFT_KERNEL_EMBED 1      /* patch gather + adapter concat + linear_1 + pos            */
-#define AFT_KERNEL_QKV 2        /* chain kernel, in-projection only (layer 0)                */
+#define AFT_KERNEL_EMBED 1      /* patch gather + adapter concat + linear_1 + pos as its own kernel (the stage entry
+                                   point's; aft_forward_f32 runs it inside AFT_KERNEL_QKV)                     */
+#define AFT_KERNEL_QKV 2        /* chain kernel: embedding + in-projection of layer 0        */
 #define AFT_KERNEL_ATTENTION 3  /* MFMA attention                                            */
 #define AFT_KERNEL_CHAIN 4      /* chain kernel: out-proj+LN1+FFN+LN2 (layer 0) + QKV (layer 1) */
-#define AFT_KERNEL_TAIL 5       /* linear_2 + fold + residual + final ConvEnhancer           */
-#define AFT_KERNEL_CHAIN_LAST 6 /* chain kernel of the last layer (no in-projection behind it) */
+#define AFT_KERNEL_TAIL 5       /* fold + residual + final ConvEnhancer (linear_2 done by AFT_KERNEL_CHAIN_LAST) */
+#define AFT_KERNEL_CHAIN_LAST 6 /* chain kernel of the last layer: out-proj+LN1+FFN+LN2 + linear_2             */
 int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int which, float *out,
                            void *workspace, size_t workspace_bytes, int batch, int reps, void *stream);
 

@@ -38,8 +38,9 @@ def test_loader_checks_version_and_host_only_calls():
     # conv_enhanced + tokens6 + x + attn + q + k + vt at B=128 (DESIGN.md data layout)
     planes, tokens, tokpad, d = 256, 280, 288, 128
     # conv_enhanced + tokens6 + x + attn + q + k + vt + fragment-packed encoder weights (6 layers x 8 d^2)
+    # + linear_2 output of the last chain launch (rows x 8)
     expect = 4 * (planes * 1680 + 128 * tokens * 6 + 2 * planes * tokens * d + 3 * planes * 4 * tokpad * 32
-                  + 6 * 8 * d * d)
+                  + 6 * 8 * d * d + planes * tokens * 8)
     assert expect <= nbytes <= expect + 8 * 256
     bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3))
     assert lib.aft_workspace_bytes(ctypes.byref(bad), 8) == 0

@@ -8,7 +8,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-enum Kind { NONE, FMA, PKFMA, EXP, MOV, ADDU, CNDMASK, DSREAD128, DSREAD32, SNOP, PKMUL, MAXF, DPP };
+enum Kind { NONE, FMA, PKFMA, EXP, MOV, ADDU, CNDMASK, DSREAD128, DSREAD32, SNOP, PKMUL, MAXF, DPP, SNOP3, SNOP7, SMOV };
 
 template <int KIND>
 __device__ __forceinline__ void filler(float (&r)[8], f32x2 (&p)[4], f32x4 &ld, unsigned lds_addr, int i) {
@@ -25,6 +25,9 @@ __device__ __forceinline__ void filler(float (&r)[8], f32x2 (&p)[4], f32x4 &ld, 
     if constexpr (KIND == DSREAD128) asm volatile("ds_read_b128 %0, %1" : "=v"(ld) : "v"(lds_addr));
     if constexpr (KIND == DSREAD32) asm volatile("ds_read_b32 %0, %1" : "=v"(x) : "v"(lds_addr));
     if constexpr (KIND == SNOP) asm volatile("s_nop 0");
+    if constexpr (KIND == SNOP3) asm volatile("s_nop 3");
+    if constexpr (KIND == SNOP7) asm volatile("s_nop 7");
+    if constexpr (KIND == SMOV) asm volatile("s_mov_b32 s40, 0" ::: "s40");
 }
 
 // SHAPE 32: one 32x32x2 accumulator chain.  SHAPE 16: four 16x16x4 accumulators round-robin (equal FLOPs per "slot":
@@ -129,6 +132,15 @@ int main(int argc, char **argv) {
         row<322, FMA, 4>("v_fma_f32 (2 chains)", b1, b3);
         row<322, EXP, 2>("v_exp_f32 (2 chains)", b1, b3);
         row<322, DSREAD128, 1>("ds_read_b128 (2 chains)", b1, b3);
+        row<32, SNOP, 1>("s_nop 0", a1, a3);
+        row<32, SNOP, 2>("s_nop 0", a1, a3);
+        row<32, SNOP3, 1>("s_nop 3", a1, a3);
+        row<32, SNOP7, 1>("s_nop 7", a1, a3);
+        row<32, SNOP7, 2>("s_nop 7", a1, a3);
+        row<32, SMOV, 1>("s_mov_b32", a1, a3);
+        row<32, SMOV, 4>("s_mov_b32", a1, a3);
+        row<322, SNOP, 1>("s_nop 0 (2 chains)", b1, b3);
+        row<322, SNOP, 4>("s_nop 0 (2 chains)", b1, b3);
         return 0;
     }
     table<32>();
