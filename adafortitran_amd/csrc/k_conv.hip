@@ -275,7 +275,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     for (int task = wave; task < a.ntiles * a.nseg; task += kConvWaves) {
         const int tile = task / a.nseg, seg = task - tile * a.nseg;
         const int ta = seg * T / a.nseg, tb = (seg + 1) * T / a.nseg;   // output columns [ta, tb)
-        const int tlo = max(ta - 1, 0), thi = min(tb, T - 1);           // conv2 columns needed
+        // Inference: every conv2 column is computed ONCE.  A wave sweeps exactly its own columns [ta, tb); the two
+        // output columns next to a segment seam then lack one kx tap each: the owner stores its raw partial sum in place
+        // (c3), the neighbour stores the missing tap's contribution in the exchange planes (the dead input plane), and a
+        // small fix-up pass behind the barrier adds them and applies bias + ReLU.  14 column sweeps for 14 columns
+        // instead of 16 (the training instantiation keeps the overlapping sweep: its stage outputs are masked / saved
+        // in store_col).
+        // (needs 16 exchange planes of SP floats = the input plane of a grid with >= 14 symbols)
+        const bool EXACT = !TRAIN && a.nseg == 2 && T + 2 >= 16;
+        const int tlo = EXACT ? ta : max(ta - 1, 0), thi = EXACT ? tb - 1 : min(tb, T - 1);   // conv2 columns swept
         const int r = r3lo + kTileRows * tile - 1 + j;                   // this lane's local row
         const int gr = gr0 + r;
         const bool ok2 = gr >= 0 && gr < S;                              // conv2 output inside the plane (else zero padding)
@@ -290,6 +298,19 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 
         const bool own_row = r >= 4 && r < 4 + a.band_rows;   // rows this band is responsible for (no halo)
         auto store_col = [&](int tout, float v0, float v1, float v2, float v3) {
+            if (EXACT) {
+                if (!ok3 || tout < 0 || tout >= T) return;
+                const bool mine = tout >= ta && tout < tb;
+                const bool seam = (tout == ta && ta > 0) || (tout == tb - 1 && tb < T);   // own column next to a seam
+                if (!mine || seam) {
+                    if (!mine && !(tout == ta - 1 || tout == tb)) return;
+                    // raw sums: own seam column -> c3 in place, neighbour's seam column -> exchange plane (tout & 1)
+                    float *p = mine ? dst + (tout + 1) * col_stride : in0 + ((tout & 1) * 8 + 4 * h) * SP + r;
+                    const int cs = mine ? plane : SP;
+                    p[0] = v0; p[cs] = v1; p[2 * cs] = v2; p[3 * cs] = v3;
+                    return;
+                }
+            }
             if (tout >= ta && tout < tb && ok3) {
                 float *p = dst + (tout + 1) * col_stride;
                 float v[4] = {v0, v1, v2, v3};
@@ -370,9 +391,24 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                 acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[32 + e], lane_from_above(x2[e]), acc3, 0, 0, 0);
         }
         store_col(thi - 1, acc3[8], acc3[9], acc3[10], acc3[11]);
-        store_col(thi, acc3[4], acc3[5], acc3[6], acc3[7]);   // only stored when thi == T-1 (column T is zero padding)
+        store_col(thi, acc3[4], acc3[5], acc3[6], acc3[7]);   // overlapping sweep: only stored when thi == T-1 (column T is zero padding)
+        if (EXACT) store_col(thi + 1, acc3[0], acc3[1], acc3[2], acc3[3]);   // the kx = 0 tap of column thi for the right neighbour
     }
     __syncthreads();
+    if constexpr (!TRAIN) {
+        // seam fix-up: c3[ch][t][row] = ReLU(own partial + neighbour's tap + bias) for the two columns at each seam
+        const int nseam = (a.nseg == 2 && T + 2 >= 16) ? 1 : 0;
+        if (nseam > 0) {
+            for (int i = tid; i < nseam * 2 * 8 * (LR - 6); i += kConvThreads) {
+                const int lr = 3 + i % (LR - 6), q = i / (LR - 6), ch = q & 7, side = (q >> 3) & 1, sm = q >> 4;
+                const int t = (sm + 1) * T / a.nseg - 1 + side;   // tb - 1 of the left segment, ta of the right one
+                float *pc = c3 + ch * plane + (t + 1) * col_stride + lr;
+                const int gr = gr0 + lr;
+                if (gr >= 0 && gr < S) *pc = fmaxf(*pc + in0[((t & 1) * 8 + ch) * SP + lr] + a.cb[2][ch], 0.f);
+            }
+            __syncthreads();
+        }
+    }
 
     // ---- conv4: 8 -> 1, no activation, rows of this band only; one thread = one row x 4 columns ----
     const int tstrips = (T + 3) >> 2;
