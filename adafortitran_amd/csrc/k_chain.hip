@@ -80,9 +80,9 @@ struct ChainArgs {
 // Packed layout (pack_weights_kernel): [tile][k-block][s][lane][4] so ONE global_load_dwordx4 of a
 // wave reads 1 KB contiguous (16 x 64-B TA accesses instead of 64 scattered ones; with the torch
 // [out,in] layout GRBM_TA_BUSY was 92 % and the matrix pipe starved).
-template <int NT, int PF>
-struct WRing {
-    f32x4 b[PF + 1][NT][4];
+template <int NT, int PFS>
+struct WRing {   // PFS + 1 k-STEPS (8 deep: one 16-byte fragment element per tile) of NT tiles
+    f32x4 b[PFS + 1][NT];
 };
 
 // All hot loads go through a buffer resource (SRD + 32-bit byte offset), not global_load with 64-bit
@@ -100,46 +100,47 @@ __device__ __forceinline__ void srd_store(Srd r, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, byte_off, 0, 0);
 }
 
-template <int NKB, int NT, int PF, int TS>
-__device__ __forceinline__ void ring_load(WRing<NT, PF> &ring, Srd w, unsigned w_lane, int kb) {
+// Weight fragments are streamed with k-STEP granularity (one 16-byte element of each of the NT tiles = NT x 4 MFMAs):
+// the ring holds the PFS steps in flight plus the one being consumed.  Round 1 prefetched whole 32-deep k-blocks
+// (96 registers for the in-projection's ring); steps keep the same lead in cycles (PFS x NT x 256) at a third to a half
+// of the registers -- the kernel no longer spills (a scratch reload is a VMEM load: its wait drains vmcnt, i.e. it waited
+// for the stores and loads in flight at the tile seams).
+template <int NKB, int NT, int PFS, int TS>
+__device__ __forceinline__ void ring_load(WRing<NT, PFS> &ring, Srd w, unsigned w_lane, int step) {
+    const int kb = step >> 2, s = step & 3;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            ring.b[kb % (PF + 1)][t][s] = srd_load(w, w_lane + (unsigned)((t * TS * NKB + kb) * 1024 + s * 256) * 4);
+        ring.b[step % (PFS + 1)][t] = srd_load(w, w_lane + (unsigned)((t * TS * NKB + kb) * 1024 + s * 256) * 4);
 }
 
-// Issue the first PF k-blocks of a GEMM's weights -- called BEFORE the previous phase's epilogue /
+// Issue the first PFS k-steps of a GEMM's weights -- called BEFORE the previous phase's epilogue /
 // barrier so their L2 latency hides under that work.
-template <int NKB, int NT, int PF, int TS>
-__device__ __forceinline__ void gemm_preload(WRing<NT, PF> &ring, Srd w, unsigned w_lane) {
+template <int NKB, int NT, int PFS, int TS>
+__device__ __forceinline__ void gemm_preload(WRing<NT, PFS> &ring, Srd w, unsigned w_lane) {
 #pragma unroll
-    for (int p = 0; p < PF && p < NKB; ++p) ring_load<NKB, NT, PF, TS>(ring, w, w_lane, p);
+    for (int p = 0; p < PFS && p < 4 * NKB; ++p) ring_load<NKB, NT, PFS, TS>(ring, w, w_lane, p);
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc[t] += W_tile[t] (32 features x 32*NKB) . act (32*NKB x 32 rows): transposed product, lane =
 // token row.  `act(kb, s)` yields this lane's activation fragment (registers or LDS).  Bit t of
 // NORMAL swaps the operands of tile t back (lane = feature), used for the V tile.
-template <int NKB, int NT, int PF, int TS, unsigned NORMAL, class Act>
-__device__ __forceinline__ void gemm_run(WRing<NT, PF> &ring, Srd w, unsigned w_lane, f32x16 (&acc)[NT], Act act) {
+template <int NKB, int NT, int PFS, int TS, unsigned NORMAL, class Act>
+__device__ __forceinline__ void gemm_run(WRing<NT, PFS> &ring, Srd w, unsigned w_lane, f32x16 (&acc)[NT], Act act) {
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        if (kb + PF < NKB) ring_load<NKB, NT, PF, TS>(ring, w, w_lane, kb + PF);
+    for (int step = 0; step < 4 * NKB; ++step) {
+        if (step + PFS < 4 * NKB) ring_load<NKB, NT, PFS, TS>(ring, w, w_lane, step + PFS);
         __builtin_amdgcn_sched_barrier(0);
+        const f32x4 a = act(step >> 2, step & 3);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const f32x4 a = act(kb, s);
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float wv = ring.b[kb % (PF + 1)][t][s][j];
-                    // (the s_nop spacer of aft_internal.h::mfma_f32 measured 1.5 % slower here, unlike in k_attn.hip)
-                    acc[t] = (NORMAL >> t) & 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wv, acc[t], 0, 0, 0)
-                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[j], acc[t], 0, 0, 0);
-                }
-        }
+            for (int j = 0; j < 4; ++j) {
+                const float wv = ring.b[step % (PFS + 1)][t][j];
+                // (the s_nop spacer of aft_internal.h::mfma_f32 measured 1.5 % slower here, unlike in k_attn.hip)
+                acc[t] = (NORMAL >> t) & 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wv, acc[t], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[j], acc[t], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
     const unsigned wo_off = (unsigned)w * W * 1024 + lane * 4, w1_off = (unsigned)(2 * w) * W * 1024 + lane * 4;
     const unsigned w2_off = (unsigned)w * (2 * W) * 1024 + lane * 4;
     const unsigned wq_off = (unsigned)w * W * 1024 + lane * 4;   // tiles w, W+w, 2W+w (stride W tiles)
+    const Srd srd_bv = make_srd(a.bv);
 
     if constexpr (MLP) {
         for (int i = tid; i < D; i += S::THREADS) {   // LayerNorm affine vectors -> LDS, once per workgroup
@@ -351,13 +353,17 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
                                            __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_ID, XCC_ID
     }
 #endif
-    WRing<1, 2> ring_d;    // out-proj / FFN-down fragments   (declared per tile: nothing is live across tiles)
-    WRing<2, 1> ring_ff;   // FFN-up fragments
-    WRing<3, 1> ring_qkv;  // in-projection fragments (q, k, v tiles of head w)
+#ifndef AFT_CHAIN_PFS
+#define AFT_CHAIN_PFS 4   // lead of the weight stream in units of 4 MFMAs (256 cycles); 3..8 measured within 1.5 %
+#endif
+    constexpr int PFD = AFT_CHAIN_PFS, PFF = (AFT_CHAIN_PFS + 1) / 2, PFQ = (AFT_CHAIN_PFS + 2) / 3;
+    WRing<1, PFD> ring_d;    // out-proj / FFN-down fragments   (declared per tile: nothing is live across tiles)
+    WRing<2, PFF> ring_ff;   // FFN-up fragments
+    WRing<3, PFQ> ring_qkv;  // in-projection fragments (q, k, v tiles of head w)
     f32x16 cur;   // this lane's 16 features of the current activation (operand layout)
     if constexpr (MLP) {
         f32x16 acc_o[1] = {bias_acc(srd_bo, fb, h)};
-        gemm_preload<W, 1, 2, 1>(ring_d, srd_wo, wo_lane);
+        gemm_preload<W, 1, PFD, 1>(ring_d, srd_wo, wo_lane);
         // attention output of this row tile, all W feature blocks, straight into operand registers
         f32x4 of[W][4];
         const unsigned ap = ((unsigned)tile * W * 1024 + lane * 4) * 4;
@@ -370,9 +376,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         for (int s = 0; s < 4; ++s) xres[s] = srd_load(srd_x, xrow + 32 * s);
         STAMP(1);
         // ---- out-projection (transposed) + bias + residual ----
-        gemm_run<W, 1, 2, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
+        gemm_run<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
         f32x16 acc_h[2] = {bias_acc(srd_b1, 2 * fb, h), bias_acc(srd_b1, 2 * fb + 32, h)};
-        gemm_preload<W, 2, 1, 1>(ring_ff, srd_w1, w1_lane);
+        gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w1, w1_lane);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -386,11 +392,11 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         __syncthreads();
         STAMP(4);
         // ---- FFN up-projection + activation -> hidden blocks 2w, 2w+1 ----
-        gemm_run<W, 2, 1, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
+        gemm_run<W, 2, PFF, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
         });
         f32x16 acc_d[1] = {bias_acc(srd_b2, fb, h)};
-        gemm_preload<2 * W, 1, 2, 1>(ring_d, srd_w2, w2_lane);
+        gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w2, w2_lane);
         STAMP(5);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -403,10 +409,10 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         __syncthreads();
         STAMP(6);
         // ---- FFN down-projection (transposed) + bias + residual(x1, registers) ----
-        gemm_run<2 * W, 1, 2, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
+        gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
         });
-        if constexpr (QKV) gemm_preload<W, 3, 1, W>(ring_qkv, srd_wq, wq_lane);
+        if constexpr (QKV) gemm_preload<W, 3, PFQ, W>(ring_qkv, srd_wq, wq_lane);
 #pragma unroll
         for (int e = 0; e < 16; ++e) cur[e] += acc_d[0][e];
         STAMP(7);
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
                 srd_store(srd_x, xrow + 32 * s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
         }
     } else {
-        gemm_preload<W, 3, 1, W>(ring_qkv, srd_wq, wq_lane);
+        gemm_preload<W, 3, PFQ, W>(ring_qkv, srd_wq, wq_lane);
         if (a.emb_conv == nullptr) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -492,7 +498,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
     }
 
     if constexpr (QKV) {
-        const float bias_v = a.bv[fb + r];   // V tile: lane = feature (fetched before the barrier wait)
+        // V tile: lane = feature (fetched before the barrier wait; through an SRD: a 64-bit per-lane pointer here was one
+        // of the values the register allocator spilled, and a scratch reload drains vmcnt -- i.e. waited for the x stores)
+        const float bias_v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_bv, (unsigned)(fb + r) * 4, 0, 0));
         // publish x2 (or x0) for the in-projection.  x1 readers are all past the hidden-exchange barrier.
         // The QKV-only variant has one barrier per tile, so it alternates between two exchange buffers
         // (xb / the idle hidden buffer): a re-write then sits two barriers behind the last read.
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
 #pragma unroll
         for (int e = 0; e < 16; ++e) vinit[e] = bias_v;
         f32x16 acc[3] = {f32x16{0}, f32x16{0}, vinit};
-        gemm_run<W, 3, 1, W, 0x4>(ring_qkv, srd_wq, wq_lane, acc, [&](int kb, int s) {
+        gemm_run<W, 3, PFQ, W, 0x4>(ring_qkv, srd_wq, wq_lane, acc, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(xq + (kb * 4 + s) * 256 + lane * 4);
         });
         STAMP(10);
