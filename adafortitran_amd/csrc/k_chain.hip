@@ -96,6 +96,11 @@ __device__ __forceinline__ Srd make_srd(const float *p) {
 __device__ __forceinline__ f32x4 srd_load(Srd r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+// byte_off + CONST with a compile-time CONST: the part above the 12-bit instruction offset rides in the scalar
+// offset operand (a literal), so no v_add_u32 per load is needed to form the address (128 weight loads per tile)
+__device__ __forceinline__ f32x4 srd_load_c(Srd r, unsigned byte_off, unsigned const_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + (const_off & 0xfffu), const_off & ~0xfffu, 0));
+}
 __device__ __forceinline__ void srd_store(Srd r, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, byte_off, 0, 0);
 }
@@ -110,7 +115,7 @@ __device__ __forceinline__ void ring_load(WRing<NT, PFS> &ring, Srd w, unsigned 
     const int kb = step >> 2, s = step & 3;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-        ring.b[step % (PFS + 1)][t] = srd_load(w, w_lane + (unsigned)((t * TS * NKB + kb) * 1024 + s * 256) * 4);
+        ring.b[step % (PFS + 1)][t] = srd_load_c(w, w_lane, (unsigned)((t * TS * NKB + kb) * 1024 + s * 256) * 4);
 }
 
 // Issue the first PFS k-steps of a GEMM's weights -- called BEFORE the previous phase's epilogue /
@@ -125,7 +130,9 @@ __device__ __forceinline__ void gemm_preload(WRing<NT, PFS> &ring, Srd w, unsign
 // acc[t] += W_tile[t] (32 features x 32*NKB) . act (32*NKB x 32 rows): transposed product, lane =
 // token row.  `act(kb, s)` yields this lane's activation fragment (registers or LDS).  Bit t of
 // NORMAL swaps the operands of tile t back (lane = feature), used for the V tile.
-template <int NKB, int NT, int PFS, int TS, unsigned NORMAL, class Act>
+// Bit t of ZERO: tile t's accumulator starts from 0 -- its first MFMA then takes the inline constant as C and acc[t]
+// needs no initialisation at all (16 v_mov per tile otherwise).
+template <int NKB, int NT, int PFS, int TS, unsigned NORMAL, class Act, unsigned ZERO = 0>
 __device__ __forceinline__ void gemm_run(WRing<NT, PFS> &ring, Srd w, unsigned w_lane, f32x16 (&acc)[NT], Act act) {
 #pragma unroll
     for (int step = 0; step < 4 * NKB; ++step) {
@@ -138,8 +145,12 @@ __device__ __forceinline__ void gemm_run(WRing<NT, PFS> &ring, Srd w, unsigned w
             for (int j = 0; j < 4; ++j) {
                 const float wv = ring.b[step % (PFS + 1)][t][j];
                 // (the s_nop spacer of aft_internal.h::mfma_f32 measured 1.5 % slower here, unlike in k_attn.hip)
-                acc[t] = (NORMAL >> t) & 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wv, acc[t], 0, 0, 0)
-                                           : __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[j], acc[t], 0, 0, 0);
+                if (((ZERO >> t) & 1) && step == 0 && j == 0)
+                    acc[t] = (NORMAL >> t) & 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wv, f32x16{0}, 0, 0, 0)
+                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[j], f32x16{0}, 0, 0, 0);
+                else
+                    acc[t] = (NORMAL >> t) & 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wv, acc[t], 0, 0, 0)
+                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[j], acc[t], 0, 0, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -298,6 +309,34 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
     // ticket atomic costs 4 us per launch and the finish-time spread did not shrink).
     const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     int round = 0;
+    // Operands a tile starts from -- the first AFT_CHAIN_PFK feature blocks of the attention output of its 32 rows
+    // (straight into operand registers) and the residual rows of x -- are requested one tile AHEAD, just before the
+    // previous tile's store epilogue: their latency hides behind those stores, and (vmcnt counts loads and stores in
+    // issue order) the first out-projection MFMA does not wait for the previous tile's stores to drain.
+#ifndef AFT_CHAIN_PFK
+#define AFT_CHAIN_PFK 0
+#endif
+    constexpr int PFK = MLP ? (AFT_CHAIN_PFK < W ? AFT_CHAIN_PFK : W) : 0;
+    constexpr bool AHEAD = AFT_CHAIN_PFK > 0;
+    f32x4 of[MLP ? W : 1][4], xres[4];
+    auto request_attn = [&](int t, int kb0, int kb1) {
+        const unsigned ap = ((unsigned)t * W * 1024 + lane * 4) * 4;
+#pragma unroll
+        for (int kb = 0; kb < W; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (kb >= kb0 && kb < kb1) of[kb][s] = srd_load_c(srd_attn, ap, (unsigned)(kb * 1024 + s * 256) * 4);
+    };
+    auto request_x = [&](int t) {
+        const unsigned xr = ((unsigned)min(t * 32 + r, a.rows - 1) * D + fb + 4 * h) * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xres[s] = srd_load(srd_x, xr + 32 * s);
+    };
+    auto request_tile = [&](int t) {
+        if constexpr (MLP) request_attn(t, 0, PFK);
+        if (MLP || a.emb_conv == nullptr) request_x(t);
+    };
+    if (AHEAD && (int)blockIdx.x < ntiles) request_tile(blockIdx.x);
     // linear_2 partials of the previous tile (fused variant of <MLP,!QKV>): sum the W per-wave partials in wave order, add
     // the bias, store [row][out6_stride].  Called by ONE wave per tile, after the barrier that ended that tile.
     int pending_row0 = -1;
@@ -365,15 +404,8 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         f32x16 acc_o[1] = {bias_acc(srd_bo, fb, h)};
         gemm_preload<W, 1, PFD, 1>(ring_d, srd_wo, wo_lane);
         // attention output of this row tile, all W feature blocks, straight into operand registers
-        f32x4 of[W][4];
-        const unsigned ap = ((unsigned)tile * W * 1024 + lane * 4) * 4;
-#pragma unroll
-        for (int kb = 0; kb < W; ++kb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) of[kb][s] = srd_load(srd_attn, ap + (kb * 1024 + s * 256) * 4);
-        f32x4 xres[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) xres[s] = srd_load(srd_x, xrow + 32 * s);
+        request_attn(tile, AHEAD ? PFK : 0, W);
+        if (!AHEAD) request_x(tile);
         STAMP(1);
         // ---- out-projection (transposed) + bias + residual ----
         gemm_run<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
@@ -418,6 +450,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         STAMP(7);
         layernorm_rows<D>(cur, stats, par + 2 * D + fb, par + 3 * D + fb, w, r, h);   // -> x2
         STAMP(8);
+        if constexpr (!QKV) {
+            if (AHEAD && tile + (int)gridDim.x < ntiles) request_tile(tile + (int)gridDim.x);
+        }
         bool store_x = true;
         if constexpr (!QKV) {
             if (a.out6 != nullptr) {
@@ -451,12 +486,11 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
     } else {
         gemm_preload<W, 3, PFQ, W>(ring_qkv, srd_wq, wq_lane);
         if (a.emb_conv == nullptr) {
+            if (!AHEAD) request_x(tile);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x4 t = srd_load(srd_x, xrow + 32 * s);
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cur[4 * s + j] = t[j];
-            }
+                for (int j = 0; j < 4; ++j) cur[4 * s + j] = xres[s][j];
         } else {
             // x0 = [patch features | adapter features] W1^T + b1 + pos[token]: ceil(K/2) MFMAs of the same transposed
             // form (A = W1 rows of this wave's feature block, B = the row's input features), the accumulator starting
@@ -514,11 +548,12 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         f32x16 vinit;
 #pragma unroll
         for (int e = 0; e < 16; ++e) vinit[e] = bias_v;
-        f32x16 acc[3] = {f32x16{0}, f32x16{0}, vinit};
-        gemm_run<W, 3, PFQ, W, 0x4>(ring_qkv, srd_wq, wq_lane, acc, [&](int kb, int s) {
-            return *reinterpret_cast<const f32x4 *>(xq + (kb * 4 + s) * 256 + lane * 4);
-        });
+        f32x16 acc[3];
+        acc[2] = vinit;
+        auto xq_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xq + (kb * 4 + s) * 256 + lane * 4); };
+        gemm_run<W, 3, PFQ, W, 0x4, decltype(xq_frag), 0x3>(ring_qkv, srd_wq, wq_lane, acc, xq_frag);   // q, k start from 0
         STAMP(10);
+        if (AHEAD && tile + (int)gridDim.x < ntiles) request_tile(tile + (int)gridDim.x);   // before this tile's stores
         // ---- epilogue: q, k, v of head w for 32 token rows, written in MFMA-FRAGMENT order so that
         // k_attn.hip reads every operand with fully coalesced 1-KB loads:
         //   q, k : [plane*H + head][key tile][s][lane = key%32 + 32*hh][4]   value (key, d = 8s + 4hh + j)
@@ -529,6 +564,26 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         const unsigned head_stride = (unsigned)a.tokpad * kHeadDim;             // floats per (plane, head)
         const unsigned ph0 = (unsigned)(plane0 * a.heads + w);
         const bool full = row0 + 32 <= a.rows;
+        if (full && tok0 + 32 <= a.tokens && (a.tokens & 7) == 0) {
+            // the common case -- the tile lies inside one plane and 8 divides the token count (tok0 is then a multiple of
+            // 8): every V^T group of four tokens is one whole fragment element at lane-linear offset, and all the block
+            // indices are wave-uniform (scalar offset operand); only the q / k row index needs per-lane arithmetic
+            const int tok = tok0 + r;
+            const unsigned ph_base = ph0 * head_stride;
+            const unsigned lane_off = (ph_base + (unsigned)(tok >> 5) * 1024 + ((tok & 31) + 32 * h) * 4) * 4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                srd_store(srd_q, lane_off + s * 1024, f32x4{acc[0][4 * s], acc[0][4 * s + 1], acc[0][4 * s + 2], acc[0][4 * s + 3]});
+                srd_store(srd_k, lane_off + s * 1024, f32x4{acc[1][4 * s], acc[1][4 * s + 1], acc[1][4 * s + 2], acc[1][4 * s + 3]});
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const unsigned kb8 = (unsigned)(tok0 >> 3) + gq;     // 8-key group of tokens tok0 + 8 gq + 4h + {0..3}
+                const f32x4 v = {acc[2][4 * gq], acc[2][4 * gq + 1], acc[2][4 * gq + 2], acc[2][4 * gq + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(srd_vt, 0, 0, 0)), v),
+                                                       srd_vt, lane * 16, (ph_base + (kb8 >> 2) * 1024 + (kb8 & 3) * 256) * 4, 0);
+            }
+        } else {
         {
             int tok = tok0 + r;
             unsigned ph = ph0;
@@ -568,6 +623,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
                 }
             }
         }
+        }   // general epilogue
     }
     STAMP(11);
 #ifdef AFT_DIAG_STAMPS
