@@ -7,7 +7,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 for name in ("kernel_stats.csv", "kernel_trace_summary.txt", "pmc_summary.txt", "bench_under_rocprof.json",
@@ -36,5 +36,18 @@ out = {
     "algorithmic_bytes_per_launch": alg, "algorithmic_total": sum(alg.values()),
     "mfma_busy_frac": vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (vals.get("GRBM_GUI_ACTIVE", 1) / 8 * 1024),
 }
+# attention: K / V^T re-read check: algorithmic reads = q + k + vt once, writes = attn once
+avals = {}
+for block in re.split(r"\n  (?=\S)", text):
+    if block.startswith("attn_kernel<"):
+        for m in re.finditer(r"(\w+)\s+mean=\s*([\d.]+)", block):
+            avals.setdefault(m.group(1), float(m.group(2)))
+if "FETCH_SIZE" in avals:
+    alg_read = 3 * planes * heads * tokpad * 32 * 4
+    out["attention"] = {"kernel": "attn_kernel, B=128 frames (1024 (plane, head) problems, 9 query tiles each)",
+                        "FETCH_SIZE_KB_mean": avals["FETCH_SIZE"], "WRITE_SIZE_KB_mean": avals.get("WRITE_SIZE"),
+                        "read_bytes_per_launch_corrected": int(2 * avals["FETCH_SIZE"] * 1024),
+                        "algorithmic_read_bytes": alg_read,
+                        "read_ratio": round(2 * avals["FETCH_SIZE"] * 1024 / alg_read, 3)}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
