@@ -365,6 +365,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
     if constexpr (MLP && !QKV) {
         if (pending_row0 >= 0 && w == (round & (W - 1 < 3 ? W - 1 : 3))) reduce_out6();
     }
+#ifndef AFT_NO_PROGRESS_PRIORITY
     {
         const int left = rounds - 1 - round;
         if (left >= 3) __builtin_amdgcn_s_setprio(3);
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
         else if (left == 1) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
     }
+#endif
     const int row0 = tile * 32;
     const int grow = min(row0 + r, a.rows - 1);               // clamped: ragged last tile computes, never stores
     const bool row_ok = row0 + r < a.rows;

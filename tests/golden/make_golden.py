@@ -159,7 +159,7 @@ def run_set(name, spec, batch, keep):
 GRAD_SAMPLE_STRIDE, GRAD_SAMPLE_MAX = 7, 4096
 
 
-def run_grad(name, spec, batch):
+def run_grad(name, spec, batch, store_inputs=True):
     """One training step of the reference, as TrainingLoop.train_epoch runs it (reference
     src/main/trainer.py:195-233): model.train(), loss = MSELoss(cat(Re,Im)) of trainer._compute_loss
     (:173-176 via utils.concat_complex_channel), loss.backward().  dropout = 0 so the step is
@@ -173,10 +173,13 @@ def run_grad(name, spec, batch):
     cat = lambda z: torch.cat((torch.real(z), torch.imag(z)), dim=1)  # noqa: E731
     loss = torch.nn.MSELoss()(cat(out), cat(tgt))
     loss.backward()
-    arrays = {"pilots": inp["pilots"], "target": inp["target"], "loss": np.float64(loss.item()),
-              "out": out.detach().numpy().astype(np.complex64)}
-    if spec.get("adaptive_hidden"):
-        arrays.update(snr=inp["snr"], ds=inp["ds"], dop=inp["dop"])
+    arrays = {"loss": np.float64(loss.item())}
+    if store_inputs:
+        arrays.update(pilots=inp["pilots"], target=inp["target"], out=out.detach().numpy().astype(np.complex64))
+        if spec.get("adaptive_hidden"):
+            arrays.update(snr=inp["snr"], ds=inp["ds"], dop=inp["dop"])
+    else:   # full-size sets: the inputs are regenerated bit-exactly by synth.make_inputs(batch, seed = spec.seed + 1)
+        arrays["out_sample"] = out.detach().numpy().astype(np.complex64).reshape(-1)[::997]
     names = []
     for n, p in model.named_parameters():
         g = p.grad.detach().reshape(-1).numpy()
@@ -307,5 +310,10 @@ if __name__ == "__main__":
         run_grad("G_grad_ada", dict(DEFAULT, num_layers=2, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=777), 3)
     if not only or "G_grad_forti" in only:
         run_grad("G_grad_forti", dict(DEFAULT, num_layers=2, dropout=0.0, activation="relu", seed=778), 2)
+    # full depth at the benchmark's batch: 6 layers, B = 128, inputs regenerated from the seed
+    if not only or "G_grad_forti_full" in only:
+        run_grad("G_grad_forti_full", dict(DEFAULT, dropout=0.0, seed=779), 128, store_inputs=False)
+    if not only or "G_grad_ada_full" in only:
+        run_grad("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128, store_inputs=False)
     leftovers = [os.path.join(r, f) for r, _d, fs in os.walk(REF) for f in fs if f.endswith(".pyc") and "cpython-310" in f]
     assert not leftovers, f"bytecode leaked into the reference mount: {leftovers}"

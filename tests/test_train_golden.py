@@ -18,7 +18,14 @@ STRIDE, MAXN = 7, 4096
 # adaptive model feeds raw channel conditions (Doppler up to 1400 Hz, delay spread up to 350 ns) through
 # the adapter MLPs; its fp32 gradients carry ~1e-4 of rounding noise (two CPU runs of the reference with
 # different thread counts differ by that much), so that set is compared at 2e-3.
-TOL = {"G_grad_forti": (2e-5, 5e-4), "G_grad_ada": (2e-3, 2e-3)}
+TOL = {"G_grad_forti": (2e-5, 5e-4), "G_grad_ada": (2e-3, 2e-3),
+       # full depth at the benchmark's batch (6 layers, B = 128; inputs regenerated bit-exactly from the fixture's seed).
+       # Gradients are sums over 71 680 token rows: fp32 summation order alone moves them by ~1e-4 relative.
+       "G_grad_forti_full": (2e-4, 3e-3), "G_grad_ada_full": (4e-3, 1.5e-2)}
+# ... and of each tensor's L2 norm (defaults to the element tolerance).  At full depth the gradients of the first layers
+# (pilot_upsampler: |g|max 3e-7) are sums over 71 680 rows of values that passed six layers backwards: single elements
+# carry ~1e-3 of fp32 noise on the HIP path (other summation orders) while the norms agree to 4e-5 / 7e-4.
+NORM_TOL = {"G_grad_forti_full": 2e-4, "G_grad_ada_full": 2e-3}
 
 
 def _step(name, device):
@@ -35,8 +42,14 @@ def _step(name, device):
     model = (A.AdaFortiTranEstimator if g.adaptive else A.FortiTranEstimator)(sc, A.ModelConfig(**kw))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()}, strict=True)
     model.train()
-    pil, tgt = torch.from_numpy(g["pilots"]), torch.from_numpy(g["target"]).to(device)
-    meta = synth.meta_tuple({k: g[k] for k in ("snr", "ds", "dop")}) if g.adaptive else None
+    if "pilots" in g:
+        inp = {k: g[k] for k in ("pilots", "target")}
+        if g.adaptive:
+            inp.update({k: g[k] for k in ("snr", "ds", "dop")})
+    else:   # full-size sets keep no inputs: synth regenerates them bit-exactly (make_golden.py::run_grad)
+        inp = synth.make_inputs(g.meta["batch"], ofdm=tuple(s["ofdm"]), pilot=tuple(s["pilot"]), seed=s["seed"] + 1)
+    pil, tgt = torch.from_numpy(inp["pilots"]), torch.from_numpy(inp["target"]).to(device)
+    meta = synth.meta_tuple(inp) if g.adaptive else None
     out = model(pil, meta) if meta is not None else model(pil)
     cat = lambda z: torch.cat((torch.real(z), torch.imag(z)), dim=1)  # noqa: E731
     loss = torch.nn.MSELoss()(cat(out), cat(tgt))      # reference trainer._compute_loss
@@ -44,8 +57,9 @@ def _step(name, device):
     return g, model, float(loss.detach())
 
 
-def _check(g, model, loss, tol):
-    assert abs(loss - float(g["loss"])) <= 1e-6 * abs(float(g["loss"])) + 1e-9
+def _check(g, model, loss, tol, norm_tol=None):
+    norm_tol = tol if norm_tol is None else norm_tol
+    assert abs(loss - float(g["loss"])) <= 2e-6 * abs(float(g["loss"])) + 1e-9
     names = [str(n) for n in g["names"]]
     params = dict(model.named_parameters())
     assert sorted(names) == sorted(params)              # same parameter set as the reference module
@@ -54,7 +68,22 @@ def _check(g, model, loss, tol):
         gmax = float(g[f"gmax__{n}"])
         assert np.abs(got[::STRIDE][:MAXN] - g[f"gsample__{n}"]).max() <= tol * gmax + 1e-12, n
         norm = float(np.sqrt((got.astype(np.float64) ** 2).sum()))
-        assert abs(norm - float(g[f"gnorm__{n}"])) <= tol * float(g[f"gnorm__{n}"]) + 1e-12, n
+        assert abs(norm - float(g[f"gnorm__{n}"])) <= norm_tol * float(g[f"gnorm__{n}"]) + 1e-12, n
+
+
+def test_full_depth_composite_matches_reference_gradients_cpu():
+    """6 layers at the benchmark's batch of 128 on the CPU composite (one forward + backward, ~10 s)."""
+    g, model, loss = _step("G_grad_forti_full", "cpu")
+    _check(g, model, loss, TOL["G_grad_forti_full"][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["G_grad_forti_full", "G_grad_ada_full"])
+def test_hip_full_depth_training_step_matches_reference_gradients(name):
+    """The whole training step of the default models (6 layers, B = 128 = 71 680 token rows through every training
+    kernel at its benchmark size) against gradients computed by the reference itself."""
+    g, model, loss = _step(name, "cuda")
+    _check(g, model, loss, TOL[name][1], NORM_TOL[name])
 
 
 @pytest.mark.parametrize("name", ["G_grad_ada", "G_grad_forti"])
