@@ -479,7 +479,7 @@ def main() -> int:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:   # under torchrun the RCCL path runs for every world size, 1 included
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
