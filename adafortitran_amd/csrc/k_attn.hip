@@ -247,12 +247,14 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *
             p[e + 1] = __builtin_amdgcn_exp2f(cur[e + 1]);
             st.lsum2 += f32x2{p[e], p[e + 1]};
         }
-        // O^T += V^T P^T
+        // O^T += V^T P^T  (k-groups of 8 keys that are all padding -- only in the ragged last tile -- are skipped)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
+            if (!FAST && ragged && kt * kTile + 8 * g >= tokens) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 st.oacc = mfma_f32(vcur[g][j], p[4 * g + j], st.oacc);
+        }
         if (more) {
             load_tile(vs, kt + 1, vcur, hb);
             if (!FAST && ragged && kt + 2 == nkt) mask_values(vcur, kt + 1);
