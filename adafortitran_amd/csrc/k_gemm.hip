@@ -181,6 +181,172 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
     }
 }
 
+// ---- the aligned fast path -------------------------------------------------------------------------------------
+// Same tiling, LDS layout and tile walk as gemm_kernel, for shapes whose leading dimensions, N and k extent allow
+// 16-byte accesses everywhere (every GEMM of the encoder's training step).  What differs is everything beside the
+// MFMAs -- a PMC pass over the training step showed 4.8-5.1 VALU instructions per MFMA in gemm_kernel, and VALU
+// issued beside fp32 MFMAs costs matrix time:
+//   * operand loads go through buffer resources: the per-lane byte offset is computed ONCE per kernel, the tile
+//     origin and the k position ride in the scalar offset, rows outside the matrix get an out-of-range offset
+//     (the hardware returns zeros), so the k loop carries no address arithmetic and no guards;
+//   * the k loop is unrolled over the two LDS buffers, the buffer choice folds into the LDS immediates;
+//   * the product is accumulated TRANSPOSED (the MFMA's A operand is the B-matrix fragment): a lane then owns one
+//     row of C and its registers run along the columns, so the epilogue is eight 16-byte stores per 32x64 wave tile
+//     straight from the accumulators, and the bias is the accumulators' initial value (16-byte loads).
+using GemmSrd = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kGemmOutOfRange = 0x7ffffff0u;   // >= any num_records used here: the load returns zeros
+__device__ __forceinline__ GemmSrd gemm_srd(const float *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 gemm_ld(GemmSrd r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int OP, int BM>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                        float *__restrict__ C, const float *__restrict__ bias, int M, int N,
+                                                        int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
+                                                        int accumulate) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int TI = BM / 64, NUA = BM / 64;
+    constexpr bool A_KC = OP != 2, B_KC = OP == 0;   // operand rows contiguous in k (else contiguous in m / n)
+    const int ntn = (N + GBN - 1) / GBN, ntm = (M + BM - 1) / BM;
+    const int ntiles = OP == 2 ? 1 : ntn * ntm, tstep = OP == 2 ? 1 : (int)gridDim.x;
+    const int kbeg = OP == 2 ? blockIdx.z * k_chunk : 0, kend = OP == 2 ? min(K, kbeg + k_chunk) : K;
+    if constexpr (OP == 2) C += (size_t)blockIdx.z * c_slice;
+    const int nsteps = (kend - kbeg) / GBK;   // the k extent is a multiple of GBK (launch-side condition)
+
+    const GemmSrd sa = gemm_srd(A, (unsigned)((OP == 2 ? K : M) * lda) * 4u);
+    const GemmSrd sb = gemm_srd(B, (unsigned)((OP == 0 ? N : K) * ldb) * 4u);
+    const GemmSrd sbias = gemm_srd(bias, bias ? (unsigned)N * 4u : 0u);
+    // tile-invariant lane offsets (bytes) and the lane's extent coordinate for the per-tile range check
+    unsigned va[NUA], vb[2];
+    int xa[NUA], xb[2];
+#pragma unroll
+    for (int u = 0; u < NUA; ++u) {
+        const int e = tid + 256 * u;
+        if constexpr (A_KC) { xa[u] = e >> 2; va[u] = (unsigned)((e >> 2) * lda + 4 * (e & 3)) * 4u; }
+        else { xa[u] = 4 * (e & (16 * NUA - 1)); va[u] = (unsigned)((e >> (3 + NUA)) * lda + xa[u]) * 4u; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u;
+        if constexpr (B_KC) { xb[u] = e >> 2; vb[u] = (unsigned)((e >> 2) * ldb + 4 * (e & 3)) * 4u; }
+        else { xb[u] = 4 * (e & 31); vb[u] = (unsigned)((e >> 5) * ldb + xb[u]) * 4u; }
+    }
+    const unsigned ka = (A_KC ? GBK : GBK * lda) * 4u, kb_ = (B_KC ? GBK : GBK * ldb) * 4u;   // scalar offset per k-step
+
+    f32x4 ra[NUA], rb[2];
+    unsigned oa[NUA], ob[2], sa0 = 0, sb0 = 0;   // this tile's lane offsets (range-checked) and scalar origins
+    auto locate = [&](int m0, int n0) {
+#pragma unroll
+        for (int u = 0; u < NUA; ++u) oa[u] = m0 + xa[u] < M ? va[u] : kGemmOutOfRange;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ob[u] = n0 + xb[u] < N ? vb[u] : kGemmOutOfRange;
+        sa0 = (unsigned)(A_KC ? m0 * lda + kbeg : kbeg * lda + m0) * 4u;
+        sb0 = (unsigned)(B_KC ? n0 * ldb + kbeg : kbeg * ldb + n0) * 4u;
+    };
+    auto fetch = [&](int step) {
+#pragma unroll
+        for (int u = 0; u < NUA; ++u) ra[u] = gemm_ld(sa, oa[u], sa0 + step * ka);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) rb[u] = gemm_ld(sb, ob[u], sb0 + step * kb_);
+    };
+    auto stage = [&](int buf) {
+        if constexpr (A_KC) store_kc(As[buf], tid, ra); else store_xc(As[buf], tid, ra);
+        if constexpr (B_KC) store_kc(Bs[buf], tid, rb); else store_xc(Bs[buf], tid, rb);
+    };
+    auto origin = [&](int tile, int &m0, int &n0) {
+        if constexpr (OP == 2) {
+            m0 = blockIdx.y * BM;
+            n0 = blockIdx.x * GBN;
+        } else {
+            m0 = (tile / ntn) * BM;
+            n0 = (tile % ntn) * GBN;
+        }
+    };
+
+    int tile = OP == 2 ? 0 : (int)blockIdx.x, m0 = 0, n0 = 0;
+    if (tile < ntiles) {
+        origin(tile, m0, n0);
+        locate(m0, n0);
+        if (nsteps > 0) fetch(0);
+    }
+    while (tile < ntiles) {
+        // accumulators start from the bias: register e of column tile tj is column 32*tj + 8*(e>>2) + 4h + (e&3)
+        f32x16 acc[TI][2];
+        const unsigned bcol = (unsigned)(n0 + wn * 64 + 4 * h) * 4u;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 bv = gemm_ld(sbias, bcol + (32 * tj + 8 * s) * 4u, 0);   // zeros without a bias or beyond N
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[ti][tj][4 * s + c] = bv[c];
+            }
+        const int next = tile + tstep;
+        int m1 = 0, n1 = 0;
+        if (next < ntiles) origin(next, m1, n1);
+        if (nsteps > 0) stage(0);
+        __syncthreads();
+        auto step = [&](int it, auto bufc) {
+            constexpr int buf = decltype(bufc)::value;
+            if (it + 1 < nsteps) {
+                fetch(it + 1);
+            } else if (next < ntiles) {   // the next tile's first k-step rides under this one's last
+                locate(m1, n1);
+                fetch(0);
+            }
+            const float *as = As[buf] + h * GLD + wm * (BM / 2) + j;
+            const float *bs = Bs[buf] + h * GLD + wn * 64 + j;
+#pragma unroll
+            for (int kb = 0; kb < GBK / 2; ++kb) {
+                const float b0 = bs[2 * kb * GLD], b1 = bs[2 * kb * GLD + 32];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const float av = as[2 * kb * GLD + 32 * ti];
+                    acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av, acc[ti][0], 0, 0, 0);
+                    acc[ti][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, av, acc[ti][1], 0, 0, 0);
+                }
+            }
+            if (it + 1 < nsteps) {
+                stage(buf ^ 1);
+                __syncthreads();
+            }
+        };
+        for (int it = 0; it < nsteps; it += 2) {
+            step(it, std::integral_constant<int, 0>{});
+            if (it + 1 < nsteps) step(it + 1, std::integral_constant<int, 1>{});
+        }
+        // epilogue: lane j owns row j of each 32-row tile; 16-byte stores along the row
+        const bool full = m0 + BM <= M && n0 + GBN <= N;
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const int row = m0 + wm * (BM / 2) + ti * 32 + j;
+            float *crow = C + (size_t)row * ldc + n0 + wn * 64 + 4 * h;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (!full && (row >= M || n0 + wn * 64 + 4 * h + 32 * tj + 8 * s >= N)) continue;
+                    f32x4 *p = reinterpret_cast<f32x4 *>(crow + 32 * tj + 8 * s);
+                    f32x4 v = {acc[ti][tj][4 * s], acc[ti][tj][4 * s + 1], acc[ti][tj][4 * s + 2], acc[ti][tj][4 * s + 3]};
+                    if (accumulate) v += *p;
+                    *p = v;
+                }
+        }
+        __syncthreads();   // every wave is done with the LDS buffers before the next tile restages buffer 0
+        tile = next;
+        m0 = m1;
+        n0 = n1;
+    }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_z slices[z * stride + i].  64 columns per workgroup, the
 // slice index split over the 4 waves, eight loads in flight per thread; fixed summation order
 // (deterministic run to run).  Up to three outputs of n columns each, laid side by side in a slice
@@ -327,13 +493,23 @@ static bool gemm_vec_ok(int op, const float *A, const float *B, int M, int N, in
     return a && b;
 }
 
+// conditions of gemm_fast_kernel: 16-byte accesses everywhere, whole k-steps, 31-bit buffer sizes
+static bool gemm_fast_ok(int op, int M, int N, int K, int lda, int ldb, int ldc) {
+    const long long a_bytes = 4ll * (op == 2 ? K : M) * lda, b_bytes = 4ll * (op == 0 ? N : K) * ldb;
+    return !(lda & 3) && !(ldb & 3) && !(ldc & 3) && !(N & 3) && !(K % GBK) && (op != 2 || !(M & 3)) &&
+           a_bytes < 0x7ffffff0ll && b_bytes < 0x7ffffff0ll;
+}
+
 template <int OP, int BM>
 static void gemm_go(const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda, int ldb,
                     int ldc, bool accumulate, hipStream_t st) {
     const int ntiles = ((N + GBN - 1) / GBN) * ((M + BM - 1) / BM);
     const int cus = current_device_cus();
     const dim3 grid(std::min(ntiles, cus * (BM == 128 ? 2 : 4)), 1, 1);   // resident workgroups per CU (VGPR bound: 192 / 120); swept 2..8
-    if (gemm_vec_ok(OP, A, B, M, N, K, lda, ldb))
+    if (gemm_fast_ok(OP, M, N, K, lda, ldb, ldc))
+        hipLaunchKernelGGL((gemm_fast_kernel<OP, BM>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
+                           (int)accumulate);
+    else if (gemm_vec_ok(OP, A, B, M, N, K, lda, ldb))
         hipLaunchKernelGGL((gemm_kernel<OP, BM, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
                            (int)accumulate);
     else
@@ -362,7 +538,10 @@ hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slice
     const int nz = gemm_split_slices(R, tiles);
     const int chunk = ((R + nz - 1) / nz + GBK - 1) / GBK * GBK;
     const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM, nz);
-    if (gemm_vec_ok(2, A, B, M, N, R, lda, ldb))
+    if (gemm_fast_ok(2, M, N, R, lda, ldb, N))
+        hipLaunchKernelGGL((gemm_fast_kernel<2, 128>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb, N,
+                           chunk, (size_t)M * N, 0);
+    else if (gemm_vec_ok(2, A, B, M, N, R, lda, ldb))
         hipLaunchKernelGGL((gemm_kernel<2, 128, true>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb, N,
                            chunk, (size_t)M * N, 0);
     else
