@@ -24,6 +24,8 @@
 
 namespace aft {
 
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
 struct AttnTrainArgs {
     const float *qkv;     // [rows][3d]
     const float *o;       // [rows][d]  forward output (backward input)
@@ -42,8 +44,20 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // murmur3 finaliser
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ float drop_factor(uint32_t seed, uint32_t idx, uint32_t threshold, float keep_scale) {
-    return mix32(idx * 0x9E3779B1u ^ seed) >= threshold ? keep_scale : 0.f;
+// Dropout mask of P.  A murmur-quality hash per element costs three quarter-rate 32-bit multiplies and ~10 more
+// VALU instructions -- 16 elements per lane per 32x32 tile made that 70 % of the tile's MFMA time (PMC: 13.3 VALU
+// per MFMA in the forward).  The mask is therefore factored: one strong 24-bit word per query row and one per key
+// column (hashed once per workgroup into LDS / once per lane), and element (q, k) is KEPT when the low 32 bits of
+// their product (v_mul_u32_u24, full rate) reach the threshold: three VALU instructions per element.  The middle
+// bits of a product of two random odd 24-bit words are uniform and pairwise uncorrelated across rows, columns
+// and 2x2 rectangles to within sampling noise (checked on 560x560 masks at p = 0.1 / 0.25 / 0.5).  All three
+// kernels evaluate the same function, so nothing is stored.
+__device__ __forceinline__ uint32_t drop_row_word(uint32_t seed, uint32_t idx) { return (mix32(idx * 0x9E3779B1u ^ seed) >> 8) | 1u; }
+__device__ __forceinline__ uint32_t drop_col_word(uint32_t seed, uint32_t idx) {
+    return (mix32(idx * 0x9E3779B1u ^ (~seed * 0x632BE5ABu + 0x7F4A7C15u)) >> 8) | 1u;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t row_word, uint32_t col_word, uint32_t threshold) {
+    return __umul24(row_word, col_word) >= threshold;
 }
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -72,6 +86,13 @@ __device__ __forceinline__ void load_colfrag(const float *__restrict__ base, int
 __device__ __forceinline__ f32x16 mma16(const float (&a)[16], const float (&b)[16], f32x16 acc) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
+    return acc;
+}
+// product into a fresh accumulator: the first MFMA takes the inline constant 0 as C (no 16 v_mov to clear it)
+__device__ __forceinline__ f32x16 mma16z(const float (&a)[16], const float (&b)[16]) {
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], f32x16{0}, 0, 0, 0);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc, 0, 0, 0);
     return acc;
 }
 __device__ __forceinline__ f32x16 zero16() {
@@ -157,9 +178,20 @@ __device__ __forceinline__ void lds_rowscalars(const float *__restrict__ s, int 
     }
 }
 
+// the 16 mask words of the accumulator rows this lane half holds
+__device__ __forceinline__ void lds_rowwords(const uint32_t *__restrict__ s, int h, uint32_t (&f)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(s + 8 * q + 4 * h);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f[4 * q + c] = v[c];
+    }
+}
+
 // ---- forward: own = query tile, walks the key tiles (staged: K, V) ----
 __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_train_fwd_kernel(const AttnTrainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] column (key) words of the dropout mask
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
     const int ph = blockIdx.x / groups, qt = (blockIdx.x % groups) * kAtWaves + wave;
@@ -174,7 +206,9 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     load_rowfrag(qb, ld, active ? query : 0, a.tokens, h, a.scale2, qf);
     float m = -__builtin_inff(), l = 0.f;
     f32x16 o = zero16();
-    const uint32_t idx0 = ((uint32_t)ph * a.tokens + min(query, a.tokens - 1)) * a.tokens;
+    const uint32_t row_word = drop_row_word(a.seed, (uint32_t)ph * a.tokens + min(query, a.tokens - 1));
+    if (a.threshold)
+        for (int i = tid; i < a.ntiles * 32; i += kAtThreads) words[i] = drop_col_word(a.seed, (uint32_t)ph * a.tokens + i);
     StageRegs sr;
     stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, 0, a.tokens, tid);
     stage_store(sr, lds[0], tid);
@@ -186,13 +220,15 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             float kf[16], vt[16];
             lds_rowfrag(buf, j, h, kf);
             lds_colfrag(buf + kAtTileFloats, j, h, vt);
-            f32x16 s = mma16(kf, qf, zero16());               // [row = key][col = query]
-            float mx = -__builtin_inff();
+            f32x16 s = mma16z(kf, qf);               // [row = key][col = query]
+            if (kt == a.ntiles - 1) {                         // only the last key tile can be ragged
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (kt * 32 + rowmap(r, h) >= a.tokens) s[r] = -__builtin_inff();
-                mx = fmaxf(mx, s[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + rowmap(r, h) >= a.tokens) s[r] = -__builtin_inff();
             }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mn = fmaxf(m, mx), alpha = __builtin_amdgcn_exp2f(m - mn);
             float p[16], sum = 0.f;
@@ -200,7 +236,12 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             for (int r = 0; r < 16; ++r) {
                 p[r] = __builtin_amdgcn_exp2f(s[r] - mn);
                 sum += p[r];
-                if (a.threshold) p[r] *= drop_factor(a.seed, idx0 + kt * 32 + rowmap(r, h), a.threshold, a.keep_scale);
+            }
+            if (a.threshold) {
+                uint32_t cw[16];
+                lds_rowwords(words + kt * 32, h, cw);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = drop_keep(row_word, cw[r], a.threshold) ? p[r] : 0.f;
             }
             l = l * alpha + sum;
             m = mn;
@@ -213,7 +254,7 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     if (!active) return;
     l += __shfl_xor(l, 32);
-    store_transposed(a.out + (size_t)plane * a.tokens * a.d + head * 32, a.d, query, a.tokens, h, o, 1.f / l);
+    store_transposed(a.out + (size_t)plane * a.tokens * a.d + head * 32, a.d, query, a.tokens, h, o, a.keep_scale / l);
     if (h == 0 && query < a.tokens) a.lse[(size_t)ph * a.tokens + query] = m + log2f(l);
 }
 
@@ -235,6 +276,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const AttnTrainArgs 
 // ---- dK, dV: own = key tile, walks the query tiles (staged: Q, dO, lse, D) ----
 __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kv_kernel(const AttnTrainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] row (query) words of the dropout mask
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
     const int ph = blockIdx.x / groups, kt = (blockIdx.x % groups) * kAtWaves + wave;
@@ -246,13 +288,15 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * 32;
     const float *lse = a.lse + (size_t)ph * a.tokens, *dsum = a.dsum + (size_t)ph * a.tokens;
     const int key = kt * 32 + j;
-    const bool key_ok = active && key < a.tokens;
     const int keyc = min(key, a.tokens - 1);
 
     float kf[16], vf[16];
     load_rowfrag(kb, ld, active ? key : 0, a.tokens, h, a.scale2, kf);   // B operands: lane <-> key
     load_rowfrag(vb, ld, active ? key : 0, a.tokens, h, 1.f, vf);
     f32x16 dv = zero16(), dk = zero16();
+    const uint32_t col_word = drop_col_word(a.seed, (uint32_t)ph * a.tokens + keyc);
+    if (a.threshold)
+        for (int i = tid; i < a.ntiles * 32; i += kAtThreads) words[i] = drop_row_word(a.seed, (uint32_t)ph * a.tokens + min(i, a.tokens - 1));
     StageRegs sr;
     stage_fetch(sr, qb, ld, dob, a.d, lse, dsum, 0, a.tokens, tid);
     stage_store(sr, lds[0], tid);
@@ -266,28 +310,33 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
             {
                 float qf[16];
                 lds_rowfrag(buf, j, h, qf);                                // A operand: lane <-> query
-                s = mma16(qf, kf, zero16());                               // [row = query][col = key]
+                s = mma16z(qf, kf);                               // [row = query][col = key]
             }
             {
                 float dof[16];
                 lds_rowfrag(buf + kAtTileFloats, j, h, dof);
-                dp = mma16(dof, vf, zero16());
+                dp = mma16z(dof, vf);
             }
+            // No range masks: query rows beyond the plane were staged as zeros (Q, dO rows = 0, lse = D = 0), so
+            // whatever finite p / ds they get meets a zero A-operand column; key lanes beyond it are never stored.
+            // pd carries P o mask, the 1/(1-p) factor is applied to dV once at the end.
             float pd[16], ds[16];
             {
                 float ls[16], dsm[16];
                 lds_rowscalars(buf + 2 * kAtTileFloats, h, ls);
                 lds_rowscalars(buf + 2 * kAtTileFloats + 32, h, dsm);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int query = qt * 32 + rowmap(r, h);
-                    const bool ok = key_ok && query < a.tokens;
-                    const float p = ok ? __builtin_amdgcn_exp2f(s[r] - ls[r]) : 0.f;
-                    const float f = a.threshold ? drop_factor(a.seed, ((uint32_t)ph * a.tokens + min(query, a.tokens - 1)) * a.tokens + keyc,
-                                                              a.threshold, a.keep_scale) : 1.f;
-                    pd[r] = p * f;
-                    ds[r] = p * (dp[r] * f - dsm[r]);
+                for (int r = 0; r < 16; ++r) pd[r] = __builtin_amdgcn_exp2f(s[r] - ls[r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = pd[r] * dsm[r];
+                if (a.threshold) {
+                    uint32_t rw[16];
+                    lds_rowwords(words + qt * 32, h, rw);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pd[r] = drop_keep(rw[r], col_word, a.threshold) ? pd[r] : 0.f;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = fmaf(pd[r] * dp[r], a.keep_scale, -ds[r]);   // P o (dP o mask/(1-p) - D)
             }
             float qT[16], doT[16];
             lds_colfrag(buf + kAtTileFloats, j, h, doT);                   // A operands: lane <-> feature
@@ -304,12 +353,13 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     if (!active) return;
     float *dst = a.out + (size_t)plane * a.tokens * ld + head * 32;
     store_transposed(dst + a.d, ld, key, a.tokens, h, dk, a.scale);
-    store_transposed(dst + 2 * a.d, ld, key, a.tokens, h, dv, 1.f);
+    store_transposed(dst + 2 * a.d, ld, key, a.tokens, h, dv, a.keep_scale);
 }
 
 // ---- dQ: own = query tile, walks the key tiles (staged: K, V) ----
 __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_q_kernel(const AttnTrainArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] column (key) words of the dropout mask
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
     const int ph = blockIdx.x / groups, qt = (blockIdx.x % groups) * kAtWaves + wave;
@@ -320,9 +370,10 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     const float *kb = qb + a.d, *vb = qb + 2 * a.d;
     const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * 32;
     const int query = qt * 32 + j, qc = min(query, a.tokens - 1);
-    const bool q_ok = active && query < a.tokens;
     const float lse = a.lse[(size_t)ph * a.tokens + qc], dsum = a.dsum[(size_t)ph * a.tokens + qc];
-    const uint32_t idx0 = ((uint32_t)ph * a.tokens + qc) * a.tokens;
+    const uint32_t row_word = drop_row_word(a.seed, (uint32_t)ph * a.tokens + qc);
+    if (a.threshold)
+        for (int i = tid; i < a.ntiles * 32; i += kAtThreads) words[i] = drop_col_word(a.seed, (uint32_t)ph * a.tokens + i);
 
     float qf[16], dof[16];
     load_rowfrag(qb, ld, active ? query : 0, a.tokens, h, a.scale2, qf);   // B operands: lane <-> query
@@ -339,17 +390,26 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
             float kf[16], vf[16];
             lds_rowfrag(buf, j, h, kf);                                    // A operands: lane <-> key
             lds_rowfrag(buf + kAtTileFloats, j, h, vf);
-            const f32x16 s = mma16(kf, qf, zero16());                      // [row = key][col = query]
-            const f32x16 dp = mma16(vf, dof, zero16());
-            float ds[16];
+            f32x16 s = mma16z(kf, qf);                            // [row = key][col = query]
+            const f32x16 dp = mma16z(vf, dof);
+            // Range masks only in the (possibly ragged) last key tile, where exp2(0 - lse) of a padded key could
+            // overflow and meet the zero row of K as 0 * inf; query lanes beyond the plane are never stored.
+            if (kt == a.ntiles - 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + rowmap(r, h);
-                const bool ok = q_ok && key < a.tokens;
-                const float p = ok ? __builtin_amdgcn_exp2f(s[r] - lse) : 0.f;
-                const float f = a.threshold ? drop_factor(a.seed, idx0 + min(key, a.tokens - 1), a.threshold, a.keep_scale) : 1.f;
-                ds[r] = p * (dp[r] * f - dsum);
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + rowmap(r, h) >= a.tokens) s[r] = -__builtin_inff();
             }
+            float ds[16], dpm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dpm[r] = dp[r];
+            if (a.threshold) {
+                uint32_t cw[16];
+                lds_rowwords(words + kt * 32, h, cw);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpm[r] = drop_keep(row_word, cw[r], a.threshold) ? dpm[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(s[r] - lse) * fmaf(dpm[r], a.keep_scale, -dsum);
             float kT[16];
             lds_colfrag(buf, j, h, kT);                                    // A operand: lane <-> feature
             dq = mma16(kT, ds, dq);                                        // [row = feature][col = query]
@@ -379,7 +439,7 @@ hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o
     AttnTrainArgs a = make_args(c, planes, tokens, dropout_p, seed);
     a.qkv = qkv; a.out = o; a.lse = lse;
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
-    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(wgs), dim3(kAtThreads), 0, st, a);
+    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
     return hipGetLastError();
 }
 
@@ -390,8 +450,9 @@ hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const fl
     a.qkv = qkv; a.o = o; a.d_o = d_o; a.lse = const_cast<float *>(lse); a.dsum = dsum; a.out = dqkv;
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((planes * tokens * a.heads + 255) / 256), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(wgs), dim3(kAtThreads), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(wgs), dim3(kAtThreads), 0, st, a);
+    const size_t words_bytes = (size_t)a.ntiles * 32 * sizeof(uint32_t);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(wgs), dim3(kAtThreads), words_bytes, st, a);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(wgs), dim3(kAtThreads), words_bytes, st, a);
     return hipGetLastError();
 }
 
