@@ -30,3 +30,11 @@ print(f"one training step: {len(win)} dispatches, span {span:.0f} us, kernel tim
       f"({ours:.0f} us = {100 * ours / busy:.0f} % in this library's kernels)")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"  {k:<72} calls={c:4d} total={t:9.1f} us  mean={t / c:8.2f} us")
+if "--timeline" in sys.argv:   # every dispatch of the step in launch order: start offset, duration, gap to the previous kernel
+    print("\ntimeline (us): start  duration  gap  kernel")
+    prev_end = win[0][0]
+    for s, e, n in win:
+        n = re.sub(r"\(.*", "", n)
+        n = re.sub(r"^void ", "", n)[:60]
+        print(f"  {(s - win[0][0]) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {(s - prev_end) / 1e3:6.1f}  {n}")
+        prev_end = e
