@@ -27,6 +27,10 @@
 // any cross-wave exchange) over half of the symbol columns; weights fragments stay in registers for
 // the whole kernel.  HBM traffic per plane = compulsory only (pilots / x rows in, one plane out).
 // Bands carry a 4-row halo (4 stacked 3x3 convs); the default 120x14 grid is one band, 4 tiles.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "aft_internal.h"
 
 namespace aft {
@@ -49,11 +53,13 @@ struct ConvArgs {
     const float *in_plane;   // [planes][S][T]
     float *save[3];          // outputs of conv1 / conv2 / conv3 after their activation, [planes][C][T][S] (C = 8, 32, 8)
     const float *mask[3];    // backward: activation of stage k = acc where mask[k] > 0 else 0 (instead of bias + ReLU)
+    unsigned long long *stamps;   // diagnostic build only (AFT_DIAG_STAMPS): per-workgroup s_memtime at the phase boundaries
 };
 
 constexpr int kConvThreads = 512;
 constexpr int kConvWaves = kConvThreads / 64;
 constexpr int kTileRows = 30;   // valid conv3 rows per 32-lane tile
+constexpr int kW3Off = 72 * 33, kWStage = kW3Off + 96 * 33;   // LDS staging of the conv2 / conv3 weights (floats)
 
 // 32-bit-offset buffer accesses for the training variant's saved tensors (each < 2 GB)
 using ConvSrd = __amdgpu_buffer_rsrc_t;
@@ -90,6 +96,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     float *c3 = c1 + 8 * plane;        // [8][T+2][SP]   conv3 output
 
     const int tid = threadIdx.x;
+#ifdef AFT_DIAG_STAMPS
+#define CSTAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+    CSTAMP(0);
     const int n = blockIdx.x / a.nbands, band = blockIdx.x % a.nbands;
     const int frame = n >> 1, part = n & 1;
     const int gr0 = band * a.band_rows - 4;  // global row of local row 0
@@ -97,9 +109,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     // ---- stage the conv2/conv3 weights through LDS (coalesced), gather the MFMA A fragments ----
     // conv2.weight [32][8][3][3] and conv3.weight [8][32][3][3] are 2304 floats each.
     float *small = smem + a.arena;     // head: pilot plane [pf]; tail: lin2 weights [p][d] + bias [p]
+    // Staged TRANSPOSED -- conv2 as [k = (ci, ky, kx)][co], conv3 as [(ci, ky)][(kx, co)], row stride 33 -- so that the
+    // gather below reads consecutive floats across the lanes.  In torch order the lanes of a gather sit 72 (conv2) or 288
+    // (conv3) floats apart: 8-way bank conflicts on each of the 84 reads of every wave, 4 us of the 59-us kernel.
     for (int i = tid; i < 2304; i += kConvThreads) {
-        smem[i] = a.cw[1][i];
-        smem[2304 + i] = a.cw[2][i];
+        smem[(i % 72) * 33 + i / 72] = a.cw[1][i];
+        const int co = i / 288, rem = i % 288;   // conv3.weight [co 8][ci 32][ky 3][kx 3]
+        smem[kW3Off + (rem / 3) * 33 + (rem % 3) * 8 + co] = a.cw[2][i];
     }
     if (TRAIN) {
     } else if (a.mode == 0) {
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 #pragma unroll
     for (int kb = 0; kb < 36; ++kb) {        // k slot (kb, h): tap = kb>>2 = kx*3+ky, ci = 4h + (kb&3); row = co = j
         const int tap = kb >> 2, kx = tap / 3, ky = tap % 3, ci = 4 * h + (kb & 3);
-        wa2[kb] = smem[(j * 8 + ci) * 9 + ky * 3 + kx];
+        wa2[kb] = smem[(ci * 9 + ky * 3 + kx) * 33 + j];
     }
     {
         const int kx = min(j >> 3, 2), co = j & 7;   // row j = (kx, co); rows 24..31 are padding
@@ -126,10 +142,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 #pragma unroll
         for (int kb = 0; kb < 48; ++kb) {    // k slot (kb, h): ky = kb>>4, ci = C-layout row of register kb&15
             const int ky = kb >> 4, e = kb & 15, ci = (e & 3) + 8 * (e >> 2) + 4 * h;
-            wa3[kb] = keep * smem[2304 + ((co * 32 + ci) * 3 + ky) * 3 + kx];
+            wa3[kb] = keep * smem[kW3Off + (ci * 3 + ky) * 33 + kx * 8 + co];
         }
     }
     __syncthreads();
+    CSTAMP(1);
     // ---- zero LDS (border columns, rows outside the plane, halo rows nobody writes); the conv2
     //      bias in accumulator-register order sits behind `small` ----
     {
@@ -138,8 +155,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         for (int i = tid; i < n4; i += kConvThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float *bias2 = small + a.extra;    // [2 halves][16]
+    float *w1s = bias2 + 32;           // conv1: 72 weights + 8 biases
+    if (tid >= 64 && tid < 144) w1s[tid - 64] = tid < 136 ? a.cw[0][tid - 64] : ((TRAIN && !a.cb[0]) ? 0.f : a.cb[0][tid - 136]);
     if (tid < 32) bias2[tid] = (TRAIN && !a.cb[1]) ? 0.f : a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
     __syncthreads();
+    CSTAMP(2);
 
     // ---- input plane ----
     if (TRAIN && a.mode == 2) {
@@ -244,31 +264,69 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         }
     }
     __syncthreads();
+    CSTAMP(3);
 
-    // ---- conv1: 1 -> 8, ReLU, rows [1, LR-1) ----
-    for (int i = tid; i < (LR - 2) * T; i += kConvThreads) {
-        const int t = i / (LR - 2), lr = 1 + i - t * (LR - 2), gr = gr0 + lr;
-        if (gr < 0 || gr >= S) continue;
-        float win[3][3];  // [ky][kx]
+    // ---- conv1: 1 -> 8, ReLU, rows [1, LR-1); one thread = 4 consecutive rows of one column (a 6 x 3 window read once).
+    //      The 80 weights / biases come from LDS into VECTOR registers: as scalar operands they overflowed the SGPR file
+    //      (205 v_readlane per thread), and the store addresses advance by one plane per channel (no multiplies). ----
+    {
+        float w1[80];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int q = 0; q < 20; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(w1s + 4 * q);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) win[ky][kx] = in0[(t + kx) * col_stride + lr - 1 + ky];
+            for (int c = 0; c < 4; ++c) w1[4 * q + c] = v[c];
+        }
+        const int nrg = (LR - 1 + 3) >> 2;   // row groups [4 rg, 4 rg + 4)
+        for (int i = tid; i < nrg * T; i += kConvThreads) {
+            const int t = i / nrg, lr0 = 4 * (i - t * nrg);
+            float win[6][3];  // [row lr0 - 1 + r][kx]
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            float acc = (TRAIN && !a.cb[0]) ? 0.f : a.cb[0][o];
+            for (int kx = 0; kx < 3; ++kx) {
+                const float *col = in0 + (t + kx) * col_stride;
 #pragma unroll
-            for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[k9 / 3][k9 % 3], a.cw[0][o * 9 + k9], acc);
-            float v = fmaxf(acc, 0.f);
-            if constexpr (TRAIN) {
-                const size_t gi = ((size_t)(n * 8 + o) * T + t) * S + gr;
-                if (a.mask[0]) v = a.mask[0][gi] > 0.f ? acc : 0.f;
-                if (a.save[0] && lr >= 4 && lr < 4 + a.band_rows) a.save[0][gi] = v;
+                for (int r = 0; r < 6; ++r) win[r][kx] = col[min(max(lr0 - 1 + r, 0), LR - 1)];
             }
-            c1[o * plane + (t + 1) * col_stride + lr] = v;
+            bool okq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int lr = lr0 + q, gr = gr0 + lr;
+                okq[q] = lr >= 1 && lr < LR - 1 && gr >= 0 && gr < S;
+            }
+            const bool whole = lr0 + 3 < LR;   // all four rows inside the column: unconditional stores (zeros where not valid, as zeroed)
+            float *dstp = c1 + (t + 1) * col_stride + lr0;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float acc = w1[72 + o];
+#pragma unroll
+                    for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[q + k9 / 3][k9 % 3], w1[o * 9 + k9], acc);
+                    v[q] = fmaxf(acc, 0.f);
+                    if constexpr (TRAIN) {
+                        if (okq[q]) {
+                            const size_t gi = ((size_t)(n * 8 + o) * T + t) * S + gr0 + lr0 + q;
+                            if (a.mask[0]) v[q] = a.mask[0][gi] > 0.f ? acc : 0.f;
+                            if (a.save[0] && lr0 + q >= 4 && lr0 + q < 4 + a.band_rows) a.save[0][gi] = v[q];
+                        }
+                    }
+                    v[q] = okq[q] ? v[q] : 0.f;
+                }
+                if (whole) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dstp[q] = v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (okq[q]) dstp[q] = v[q];
+                }
+                dstp += plane;
+            }
         }
     }
     __syncthreads();
+    CSTAMP(4);
 
     // ---- conv2 + conv3 on the matrix cores ----
     const int r3lo = band == 0 ? 4 : 3;   // first local row whose conv3 output is needed and inside the plane
@@ -394,7 +452,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         store_col(thi, acc3[4], acc3[5], acc3[6], acc3[7]);   // overlapping sweep: only stored when thi == T-1 (column T is zero padding)
         if (EXACT) store_col(thi + 1, acc3[0], acc3[1], acc3[2], acc3[3]);   // the kx = 0 tap of column thi for the right neighbour
     }
+    CSTAMP(5);
     __syncthreads();
+    CSTAMP(6);
     if constexpr (!TRAIN) {
         // seam fix-up: c3[ch][t][row] = ReLU(own partial + neighbour's tap + bias) for the two columns at each seam
         const int nseam = (a.nseg == 2 && T + 2 >= 16) ? 1 : 0;
@@ -410,6 +470,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         }
     }
 
+    CSTAMP(7);
     // ---- conv4: 8 -> 1, no activation, rows of this band only; one thread = one row x 4 columns ----
     const int tstrips = (T + 3) >> 2;
     for (int i = tid; i < a.band_rows * tstrips; i += kConvThreads) {
@@ -444,6 +505,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                 a.out_complex[(((size_t)frame * S + gr) * T + t) * 2 + part] = acc[q];
         }
     }
+    CSTAMP(8);
+#undef CSTAMP
 }
 
 // Largest row band (divides S) whose 17 channel planes fit 160 KB of LDS.  A band needs conv3 rows
@@ -456,8 +519,8 @@ static bool plan_bands(int S, int T, int extra_floats, ConvArgs *a, size_t *lds_
         const int rows3 = nb == 1 ? br : br + 2;
         const int ntiles = (rows3 + kTileRows - 1) / kTileRows;
         const int sp = std::max(br + 8, 4 + kTileRows * ntiles + 2);
-        const int arena = (std::max(17 * (T + 2) * sp, 2 * 2304) + 3) & ~3;   // also stages the conv2/conv3 weights
-        const size_t bytes = sizeof(float) * ((size_t)arena + extra + 32);
+        const int arena = (std::max(17 * (T + 2) * sp, kWStage) + 3) & ~3;   // also stages the conv2/conv3 weights
+        const size_t bytes = sizeof(float) * ((size_t)arena + extra + 32 + 80);   // + conv2 bias in register order (32) + conv1 weights and biases (80)
         if (bytes <= 160 * 1024) {
             a->band_rows = br;
             a->nbands = nb;
@@ -486,6 +549,30 @@ static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStre
     static PerDeviceOnce lds_attr;   // per instantiation x device
     hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(conv_stack_kernel<TRAIN>), 160 * 1024);
     if (ea != hipSuccess) return ea;
+#ifdef AFT_DIAG_STAMPS
+    if (!TRAIN && getenv("AFT_STAMPS")) {   // diagnostic build only: mean cycles per phase (thread 0 of every workgroup)
+        static unsigned long long *dbuf = nullptr;
+        const int nb = planes * a.nbands;
+        if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 4096);
+        (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
+        a.stamps = dbuf;
+        hipLaunchKernelGGL(conv_stack_kernel<TRAIN>, dim3(nb), dim3(kConvThreads), lds, st, a);
+        (void)hipDeviceSynchronize();
+        static int printed = 0;
+        if (printed++ < 4 && nb <= 4096) {
+            std::vector<unsigned long long> hb(16 * (size_t)nb);
+            (void)hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
+            double sum[9] = {0};
+            for (int b = 0; b < nb; ++b)
+                for (int i = 1; i < 9; ++i) sum[i] += (double)(hb[(size_t)b * 16 + i] - hb[(size_t)b * 16 + i - 1]);
+            printf("conv mode %d stamps (mean cycles, thread 0): weights=%.0f zero=%.0f input=%.0f conv1=%.0f mfma(wave0)=%.0f "
+                   "wait=%.0f fixup=%.0f conv4=%.0f total=%.0f\n", a.mode, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, sum[5] / nb,
+                   sum[6] / nb, sum[7] / nb, sum[8] / nb, (sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[7] + sum[8]) / nb);
+        }
+        a.stamps = nullptr;
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(conv_stack_kernel<TRAIN>, dim3(planes * a.nbands), dim3(kConvThreads), lds, st, a);
     return hipGetLastError();
 }
