@@ -302,9 +302,12 @@ def test_conv_enhancer_forward_backward_matches_autograd(S, T, n):
 
 
 @pytest.mark.parametrize("rows,in_f,out_f,bias", [(560, 12, 128, True), (561, 6, 128, True), (1120, 128, 6, True),
-                                                   (37, 1, 7, True), (128, 42, 560, False), (256, 24, 1680, True)])
+                                                   (37, 1, 7, True), (128, 42, 560, False), (256, 24, 1680, True),
+                                                   # the aligned fast path (gemm_fast_kernel) with ragged row / column tiles
+                                                   (1008, 64, 144, False), (1000, 128, 132, True), (2064, 48, 200, True)])
 def test_dense_layer_forward_backward_matches_autograd(rows, in_f, out_f, bias):
-    """HipLinear on the layer shapes of the model (including row lengths that are not a multiple of 4)."""
+    """HipLinear on the layer shapes of the model (including row lengths that are not a multiple of 4) and on shapes
+    that take the aligned GEMM path with partial 64-row / 128-column tiles."""
     from adafortitran_amd.training import HipLinear
     torch.manual_seed(rows + in_f)
     lin = HipLinear(in_f, out_f, bias=bias).cuda()
