@@ -155,6 +155,10 @@ hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const f
                        int ldb, int ldc, bool accumulate, hipStream_t st);
 hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slices, int M, int N, int R, int lda, int ldb,
                           bool accumulate, hipStream_t st);
+// up to four weight gradients over the same R token rows in ONE GEMM launch; slices[j] holds gemm_tn_slice_floats(M[j], N[j], R)
+// floats (the batch never uses more slices than the single launches)
+hipError_t launch_gemm_tn_batch(const float *const *A, const float *const *B, float *const *C, float *const *slices, const int *M,
+                                const int *N, const int *lda, const int *ldb, int n, int R, bool accumulate, hipStream_t st);
 hipError_t launch_colsum(const float *x, float *out, float *slices, int rows, int n, int ld, bool accumulate, hipStream_t st);
 hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, size_t stride, bool accumulate, hipStream_t st);
 hipError_t launch_reduce_slices3(const float *slices, float *out0, float *out1, float *out2, int n, int nout, int nz,

@@ -19,7 +19,7 @@ struct Tape {   // offsets in floats
     size_t qkv, attn, lse, s1, st1, x1, a, hd, s2, st2, total;
 };
 struct Scratch {
-    size_t g1, g2, gff, dqkv, dsum, slices, total;
+    size_t g1, g2, g2b, gff, dqkv, dsum, slices, total;
 };
 
 int tokens_of_cfg(const aft_config &c) { return (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols); }
@@ -48,6 +48,7 @@ Scratch plan_scratch(const aft_config &c, int batch) {
     size_t off = 0;
     s.g1 = off;     off += al64(rows * d);
     s.g2 = off;     off += al64(rows * d);
+    s.g2b = off;    off += al64(rows * d);   // d(out_proj output): g2 stays alive for linear2's weight gradient (batched at the end)
     s.gff = off;    off += al64(rows * ff);
     s.dqkv = off;   off += al64(rows * 3 * d);
     s.dsum = off;   off += al64(rows * c.num_head);
@@ -161,7 +162,7 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     float *sc = static_cast<float *>(scratch);
     const int tokens = tokens_of_cfg(*cfg), planes = 2 * batch, rows = planes * tokens, d = cfg->model_dim, ff = 2 * d;
     const bool acc = accumulate != 0;
-    float *g1 = sc + s.g1, *g2 = sc + s.g2, *gff = sc + s.gff, *dqkv = sc + s.dqkv, *sl = sc + s.slices;
+    float *g1 = sc + s.g1, *g2 = sc + s.g2, *g2b = sc + s.g2b, *gff = sc + s.gff, *dqkv = sc + s.dqkv, *sl = sc + s.slices;
     const float *hd = tp + t.hd;
 
     // slice storage per producer (bump-allocated from the scratch's slice region), one reduction launch at the end
@@ -177,22 +178,24 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     // LN2: g1 = d(x1) through the residual, g2 = d(linear2 output) (dropout 3 applied)
     STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, g->lin2_b, sl_ln2,
                                     rows, d, dropout_p, site_seed(seed, 3), acc, st));
-    STEP("linear2 wgrad", launch_gemm_tn(g2, hd, g->lin2_w, sl_w2, d, ff, rows, d, ff, acc, st));
     STEP("linear2 dgrad", launch_gemm(1, g2, w->lin2_w, gff, nullptr, rows, ff, d, d, ff, ff, false, st));
     STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, g->lin1_b, sl_act, rows, ff, dropout_p, site_seed(seed, 2),
                                           acc, st));
-    STEP("linear1 wgrad", launch_gemm_tn(gff, tp + t.x1, g->lin1_w, sl_w1, ff, d, rows, ff, d, acc, st));
     STEP("linear1 dgrad", launch_gemm(1, gff, w->lin1_w, g1, nullptr, rows, d, ff, ff, d, d, true, st));
-    // LN1: dx_in = d(x_in) through the residual, g2 = d(out_proj output) (dropout 1 applied)
-    STEP("norm1 bwd", launch_ln_bwd(g1, tp + t.s1, tp + t.st1, w->norm1_w, dx_in, g2, g->norm1_w, g->norm1_b, g->out_proj_b, sl_ln1,
+    // LN1: dx_in = d(x_in) through the residual, g2b = d(out_proj output) (dropout 1 applied)
+    STEP("norm1 bwd", launch_ln_bwd(g1, tp + t.s1, tp + t.st1, w->norm1_w, dx_in, g2b, g->norm1_w, g->norm1_b, g->out_proj_b, sl_ln1,
                                     rows, d, dropout_p, site_seed(seed, 1), acc, st));
-    STEP("out_proj wgrad", launch_gemm_tn(g2, tp + t.attn, g->out_proj_w, sl_wo, d, d, rows, d, d, acc, st));
-    STEP("out_proj dgrad", launch_gemm(1, g2, w->out_proj_w, g1, nullptr, rows, d, d, d, d, d, false, st));
+    STEP("out_proj dgrad", launch_gemm(1, g2b, w->out_proj_w, g1, nullptr, rows, d, d, d, d, d, false, st));
     STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,
                                                 dropout_p, site_seed(seed, 0), st));
-    STEP("in_proj wgrad", launch_gemm_tn(dqkv, x_in, g->in_proj_w, sl_wq, 3 * d, d, rows, 3 * d, d, acc, st));
     STEP("in_proj bgrad", launch_colsum(dqkv, g->in_proj_b, sl_bq, rows, 3 * d, 3 * d, acc, st));
     STEP("in_proj dgrad", launch_gemm(1, dqkv, w->in_proj_w, dx_in, nullptr, rows, d, 3 * d, 3 * d, d, d, true, st));
+    {   // the layer's four weight gradients in one launch: dW2 = g2^T hd, dW1 = gff^T x1, dWo = g2b^T attn, dWqkv = dqkv^T x_in
+        const float *A[4] = {g2, gff, g2b, dqkv}, *B[4] = {hd, tp + t.x1, tp + t.attn, x_in};
+        float *C[4] = {g->lin2_w, g->lin1_w, g->out_proj_w, g->in_proj_w}, *S[4] = {sl_w2, sl_w1, sl_wo, sl_wq};
+        const int M[4] = {d, ff, d, 3 * d}, N[4] = {ff, d, d, d}, lda[4] = {d, ff, d, 3 * d}, ldb[4] = {ff, d, d, d};
+        STEP("weight gradients", launch_gemm_tn_batch(A, B, C, S, M, N, lda, ldb, 4, rows, acc, st));
+    }
     STEP("gradient reductions", reductions.flush(st));
     return AFT_OK;
 }

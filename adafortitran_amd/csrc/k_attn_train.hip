@@ -18,8 +18,8 @@
 //   dK/dV pass:       S   = Q K^T  (rows = queries) -> dV^T = dO^T P, dK^T = Q^T dS contract over queries
 // so the probabilities never leave registers.  Row statistics are base-2 (scores carry log2 e/sqrt(dh)).
 // The backward recomputes P from the saved LSE twice (once per pass) instead of using atomics, which
-// keeps it deterministic.  Dropout masks are a counter-based hash of (seed, site, plane, head, q, k),
-// recomputed in the backward, never stored.
+// keeps it deterministic.  Dropout masks are a counter-based function of (seed, site, plane, head, q, k) -- a hashed
+// word per query row times a hashed word per key column, see drop_keep below -- recomputed in the backward, never stored.
 #include "aft_internal.h"
 
 namespace aft {

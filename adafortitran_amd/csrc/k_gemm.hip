@@ -10,7 +10,10 @@
 //     NN  C[M][N] = A[M][K] . B[K][N]
 //     TN  C[M][N] = A[K][M]^T . B[K][N]      K = token rows, split over blockIdx.z into partial
 //                                            slices that reduce_slices_kernel sums (deterministic)
-// Tiling: 128x128 output tile per workgroup (4 waves, each 2x2 MFMA tiles), K step 16.  Both
+// Two kernels share the tiling below: gemm_kernel takes any shape (guarded, optionally element-wise loads);
+// gemm_fast_kernel takes the aligned shapes -- every GEMM of the encoder's training step -- with buffer-resource
+// loads, no address arithmetic in the k loop and a transposed accumulator whose epilogue is 16-byte row stores.
+// Tiling: 128x128 (TN) or 64x128 (NT / NN) output tile per workgroup (4 waves, each 2x2 or 1x2 MFMA tiles), K step 16.  Both
 // operands are staged in LDS k-major ([k][m], row stride 132 floats) so that a fragment read is
 // 32 consecutive floats per half-wave -- conflict-free for A and B alike -- and the global->LDS
 // transposition of k-contiguous sources lands on 64 distinct banks.  Global loads of step i+1 are in
@@ -202,21 +205,21 @@ __device__ __forceinline__ f32x4 gemm_ld(GemmSrd r, unsigned voff, unsigned soff
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// (bx, by, bz, gx) stand for the block indices and the grid width: the batched weight-gradient launch maps its flat
+// block index onto several products
 template <int OP, int BM>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(const float *__restrict__ A, const float *__restrict__ B,
-                                                        float *__restrict__ C, const float *__restrict__ bias, int M, int N,
-                                                        int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
-                                                        int accumulate) {
-    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+__device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*Bs)[GBK * GLD], const float *__restrict__ A,
+                                               const float *__restrict__ B, float *__restrict__ C, const float *__restrict__ bias,
+                                               int M, int N, int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
+                                               int accumulate, int bx, int by, int bz, int gx) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     constexpr int TI = BM / 64, NUA = BM / 64;
     constexpr bool A_KC = OP != 2, B_KC = OP == 0;   // operand rows contiguous in k (else contiguous in m / n)
     const int ntn = (N + GBN - 1) / GBN, ntm = (M + BM - 1) / BM;
-    const int ntiles = OP == 2 ? 1 : ntn * ntm, tstep = OP == 2 ? 1 : (int)gridDim.x;
-    const int kbeg = OP == 2 ? blockIdx.z * k_chunk : 0, kend = OP == 2 ? min(K, kbeg + k_chunk) : K;
-    if constexpr (OP == 2) C += (size_t)blockIdx.z * c_slice;
+    const int ntiles = OP == 2 ? 1 : ntn * ntm, tstep = OP == 2 ? 1 : gx;
+    const int kbeg = OP == 2 ? bz * k_chunk : 0, kend = OP == 2 ? min(K, kbeg + k_chunk) : K;
+    if constexpr (OP == 2) C += (size_t)bz * c_slice;
     const int nsteps = (kend - kbeg) / GBK;   // the k extent is a multiple of GBK (launch-side condition)
 
     const GemmSrd sa = gemm_srd(A, (unsigned)((OP == 2 ? K : M) * lda) * 4u);
@@ -261,15 +264,15 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const float *__restrict_
     };
     auto origin = [&](int tile, int &m0, int &n0) {
         if constexpr (OP == 2) {
-            m0 = blockIdx.y * BM;
-            n0 = blockIdx.x * GBN;
+            m0 = by * BM;
+            n0 = bx * GBN;
         } else {
             m0 = (tile / ntn) * BM;
             n0 = (tile % ntn) * GBN;
         }
     };
 
-    int tile = OP == 2 ? 0 : (int)blockIdx.x, m0 = 0, n0 = 0;
+    int tile = OP == 2 ? 0 : bx, m0 = 0, n0 = 0;
     if (tile < ntiles) {
         origin(tile, m0, n0);
         locate(m0, n0);
@@ -345,6 +348,42 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const float *__restrict_
         m0 = m1;
         n0 = n1;
     }
+}
+
+template <int OP, int BM>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                        float *__restrict__ C, const float *__restrict__ bias, int M, int N,
+                                                        int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
+                                                        int accumulate) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    gemm_fast_body<OP, BM>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, ldc, k_chunk, c_slice, accumulate, (int)blockIdx.x,
+                           (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x);
+}
+
+// Several weight gradients dW_j = A_j^T B_j over the SAME token rows in one launch (the four of an encoder layer): with
+// all their tiles in flight together each product needs far fewer row slices to fill the chip (8 tiles x 64 slices instead
+// of 1-3 tiles x 170-256 each), so the partial slices written here and read back by the reduction shrink 3.5x, and three
+// launch ramps per layer go away.
+constexpr int kTnBatchMax = 4;
+struct TnBatchJob {
+    const float *A, *B;
+    float *slices;
+    int M, N, lda, ldb, tiles_n, blocks_per_slice, first_block;
+};
+struct TnBatch {
+    TnBatchJob job[kTnBatchMax];
+    int njobs, R, nz, chunk;
+};
+__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(const TnBatch q) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    int jb = 0;
+    while (jb + 1 < q.njobs && (int)blockIdx.x >= q.job[jb + 1].first_block) ++jb;
+    const TnBatchJob &t = q.job[jb];
+    const int local = blockIdx.x - t.first_block, z = local / t.blocks_per_slice, tile = local % t.blocks_per_slice;
+    gemm_fast_body<2, 128>(As, Bs, t.A, t.B, t.slices, nullptr, t.M, t.N, q.R, t.lda, t.ldb, t.N, q.chunk, (size_t)t.M * t.N, 0,
+                           tile % t.tiles_n, tile / t.tiles_n, z, 1);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_z slices[z * stride + i].  64 columns per workgroup, the
@@ -548,6 +587,40 @@ hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slice
         hipLaunchKernelGGL((gemm_kernel<2, 128, false>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb,
                            N, chunk, (size_t)M * N, 0);
     return launch_reduce_slices(slices, C, M * N, nz, (size_t)M * N, accumulate, st);
+}
+
+// Batched weight gradients: dW_j[M_j][N_j] (+)= A_j[R][M_j]^T . B_j[R][N_j], j < n <= 4, one GEMM launch; the slice reductions go
+// through launch_reduce_slices as usual (queued when a ReduceBatchScope is alive).  Falls back to one launch per product
+// when a shape is not on the aligned path.
+hipError_t launch_gemm_tn_batch(const float *const *A, const float *const *B, float *const *C, float *const *slices, const int *M,
+                                const int *N, const int *lda, const int *ldb, int n, int R, bool accumulate, hipStream_t st) {
+    bool fast = n >= 1 && n <= kTnBatchMax;
+    for (int j = 0; j < n && fast; ++j) fast = gemm_fast_ok(2, M[j], N[j], R, lda[j], ldb[j], N[j]);
+    if (!fast) {
+        for (int j = 0; j < n; ++j) {
+            hipError_t e = launch_gemm_tn(A[j], B[j], C[j], slices[j], M[j], N[j], R, lda[j], ldb[j], accumulate, st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    TnBatch q{};
+    int tiles = 0;
+    for (int j = 0; j < n; ++j) tiles += ((N[j] + GBN - 1) / GBN) * ((M[j] + GBM - 1) / GBM);
+    q.njobs = n;
+    q.R = R;
+    q.nz = gemm_split_slices(R, tiles);   // <= the slice count of any single product: slices[j] is large enough
+    q.chunk = ((R + q.nz - 1) / q.nz + GBK - 1) / GBK * GBK;
+    int blocks = 0;
+    for (int j = 0; j < n; ++j) {
+        const int tn = (N[j] + GBN - 1) / GBN, tm = (M[j] + GBM - 1) / GBM;
+        q.job[j] = TnBatchJob{A[j], B[j], slices[j], M[j], N[j], lda[j], ldb[j], tn, tn * tm, blocks};
+        blocks += tn * tm * q.nz;
+    }
+    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(blocks), dim3(256), 0, st, q);
+    hipError_t e = hipGetLastError();
+    for (int j = 0; j < n && e == hipSuccess; ++j)
+        e = launch_reduce_slices(slices[j], C[j], M[j] * N[j], q.nz, (size_t)M[j] * N[j], accumulate, st);
+    return e;
 }
 
 // db[n] (+)= sum_r x[r][n]; `slices` holds colsum_slices(rows) * n floats
