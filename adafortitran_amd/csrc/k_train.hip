@@ -256,41 +256,36 @@ __global__ __launch_bounds__(256) void adapter_train_fwd_kernel(const AdapterTra
     }
 }
 
-// da1[k] = relu'(a1[k]) sum_i dout[i] W3[i][k];  da0[m] = relu'(a0[m]) sum_k da1[k] W2[k][m]   per (frame, encoder)
+// da1[k] = relu'(a1[k]) sum_i dout[i] W3[i][k];  da0[m] = relu'(a0[m]) sum_k da1[k] W2[k][m]   per (frame, encoder).
+// The first sum runs over h2 = 560 rows of W3 [h2][h1]: thread (g, k) of 256 / h1 row groups walks the rows i = g, g + G, ...
+// of column k (a wave reads consecutive k: coalesced), the groups meet in LDS.  (Round 1 gave every thread all h1
+// columns of a few rows and paid h1 x 6 cross-lane shuffles per wave: 78 us of pure latency.)
 constexpr int kAdaH1Max = 64;
 __global__ __launch_bounds__(256) void adapter_train_dgrad_kernel(const AdapterTrainArgs a) {
-    __shared__ float part[4][kAdaH1Max];
+    extern __shared__ float dout[];   // [h2]
+    __shared__ float part[256];
     __shared__ float d1[kAdaH1Max];
-    const int b = blockIdx.x, e = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float acc[kAdaH1Max];
-#pragma unroll
-    for (int k = 0; k < kAdaH1Max; ++k) acc[k] = 0.f;
-    for (int i = tid; i < a.h2; i += 256) {
-        const float g = a.dtok[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)];
-        const float *wr = a.w[e][2] + (size_t)i * a.h1;
-        if ((a.h1 & 1) == 0) {   // rows of an even length start 8-byte aligned: half as many, wider loads
-#pragma unroll
-            for (int k = 0; k < kAdaH1Max; k += 2)
-                if (k < a.h1) {
-                    const f32x2 wv = *reinterpret_cast<const f32x2 *>(wr + k);
-                    acc[k] = fmaf(g, wv[0], acc[k]);
-                    acc[k + 1] = fmaf(g, wv[1], acc[k + 1]);
-                }
-        } else {
-#pragma unroll
-            for (int k = 0; k < kAdaH1Max; ++k)
-                if (k < a.h1) acc[k] = fmaf(g, wr[k], acc[k]);
+    const int b = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < a.h2; i += 256) dout[i] = a.dtok[((size_t)b * a.tokens + (i >> 1)) * 6 + 2 * e + (i & 1)];
+    __syncthreads();
+    const int groups = 256 / a.h1, g = tid / a.h1, k = tid - g * a.h1;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (g < groups) {
+        const float *wc = a.w[e][2] + k;
+        int i = g;
+        for (; i + 3 * groups < a.h2; i += 4 * groups) {
+            s0 = fmaf(dout[i], wc[(size_t)i * a.h1], s0);
+            s1 = fmaf(dout[i + groups], wc[(size_t)(i + groups) * a.h1], s1);
+            s2 = fmaf(dout[i + 2 * groups], wc[(size_t)(i + 2 * groups) * a.h1], s2);
+            s3 = fmaf(dout[i + 3 * groups], wc[(size_t)(i + 3 * groups) * a.h1], s3);
         }
+        for (; i < a.h2; i += groups) s0 = fmaf(dout[i], wc[(size_t)i * a.h1], s0);
     }
-#pragma unroll
-    for (int k = 0; k < kAdaH1Max; ++k) {
-        if (k >= a.h1) break;
-        const float v = wave_sum(acc[k]);
-        if (lane == 0) part[wave][k] = v;
-    }
+    part[tid] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (tid < a.h1) {
-        const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        float v = 0.f;
+        for (int q = 0; q < groups; ++q) v += part[q * a.h1 + tid];
         const float r = a.a1[((size_t)b * 3 + e) * a.h1 + tid] > 0.f ? v : 0.f;
         d1[tid] = r;
         a.da1[((size_t)b * 3 + e) * a.h1 + tid] = r;
@@ -298,10 +293,12 @@ __global__ __launch_bounds__(256) void adapter_train_dgrad_kernel(const AdapterT
     __syncthreads();
     if (tid < a.h0) {
         float v = 0.f;
-        for (int k = 0; k < a.h1; ++k) v = fmaf(d1[k], a.w[e][1][k * a.h0 + tid], v);
+        for (int kk = 0; kk < a.h1; ++kk) v = fmaf(d1[kk], a.w[e][1][kk * a.h0 + tid], v);
         a.da0[((size_t)b * 3 + e) * a.h0 + tid] = a.a0[((size_t)b * 3 + e) * a.h0 + tid] > 0.f ? v : 0.f;
     }
 }
+
+__device__ const float kAdapterOne = 1.f;
 
 // all parameter gradients: element index -> (encoder, tensor, position); sum over the frames in order
 __global__ __launch_bounds__(256) void adapter_train_wgrad_kernel(const AdapterTrainArgs a) {
@@ -342,18 +339,36 @@ __global__ __launch_bounds__(256) void adapter_train_wgrad_kernel(const AdapterT
         u = a.da0 + (size_t)e * a.h0 + r; us = (size_t)3 * a.h0;
         out = a.db[e][0] + r;
     }
+    if (!v) {   // plain sums: multiply by a constant one at stride 0, so that the loop below has no branch around its loads
+        v = &kAdapterOne;
+        vs = 0;
+    }
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = 0;
+    for (; b + 15 < a.frames; b += 16) {   // 32 loads in flight per pass: the loop is a chain of L2 round trips otherwise
+        float uu[16], vv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            uu[q] = u[(size_t)(b + q) * us];
+            vv[q] = v[(size_t)(b + q) * vs];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+            s0 += (double)uu[q] * (double)vv[q];
+            s1 += (double)uu[q + 1] * (double)vv[q + 1];
+            s2 += (double)uu[q + 2] * (double)vv[q + 2];
+            s3 += (double)uu[q + 3] * (double)vv[q + 3];
+        }
+    }
     for (; b + 3 < a.frames; b += 4) {
         const float u0 = u[(size_t)b * us], u1 = u[(size_t)(b + 1) * us], u2 = u[(size_t)(b + 2) * us], u3 = u[(size_t)(b + 3) * us];
-        const float v0 = v ? v[(size_t)b * vs] : 1.f, v1 = v ? v[(size_t)(b + 1) * vs] : 1.f;
-        const float v2 = v ? v[(size_t)(b + 2) * vs] : 1.f, v3 = v ? v[(size_t)(b + 3) * vs] : 1.f;
+        const float v0 = v[(size_t)b * vs], v1 = v[(size_t)(b + 1) * vs], v2 = v[(size_t)(b + 2) * vs], v3 = v[(size_t)(b + 3) * vs];
         s0 += (double)u0 * (double)v0;
         s1 += (double)u1 * (double)v1;
         s2 += (double)u2 * (double)v2;
         s3 += (double)u3 * (double)v3;
     }
-    for (; b < a.frames; ++b) s0 += (double)u[(size_t)b * us] * (double)(v ? v[(size_t)b * vs] : 1.f);
+    for (; b < a.frames; ++b) s0 += (double)u[(size_t)b * us] * (double)v[(size_t)b * vs];
     const float t = (float)((s0 + s1) + (s2 + s3));
     *out = a.accumulate ? *out + t : t;
 }
@@ -385,14 +400,14 @@ hipError_t launch_adapter_train_bwd(const float *const cond[3], const float *con
                                     const int hidden[3], int tokens, int frames, const float *a0, const float *a1,
                                     const float *dtok, float *da0, float *da1, float *const dw[9], float *const db[9],
                                     bool accumulate, hipStream_t st) {
-    if (hidden[1] > kAdaH1Max || hidden[0] > 256) return hipErrorInvalidValue;
+    if (hidden[1] > kAdaH1Max || hidden[0] > 256 || hidden[2] > 12 * 1024) return hipErrorInvalidValue;
     AdapterTrainArgs a{};
     fill_adapter(a, cond, w, b, hidden, tokens, frames);
     a.a0 = const_cast<float *>(a0); a.a1 = const_cast<float *>(a1);
     a.dtok = dtok; a.da0 = da0; a.da1 = da1; a.accumulate = accumulate;
     for (int e = 0; e < 3; ++e)
         for (int j = 0; j < 3; ++j) { a.dw[e][j] = dw[3 * e + j]; a.db[e][j] = db[3 * e + j]; }
-    hipLaunchKernelGGL(adapter_train_dgrad_kernel, dim3(frames, 3), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(adapter_train_dgrad_kernel, dim3(frames, 3), dim3(256), sizeof(float) * a.h2, st, a);
     const int per = a.h2 * a.h1 + a.h2 + a.h1 * a.h0 + a.h1 + a.h0 + a.h0;
     hipLaunchKernelGGL(adapter_train_wgrad_kernel, dim3((3 * per + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
