@@ -187,6 +187,14 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *
     const float *bq = qbias + (ph % heads) * kHeadDim + 4 * h;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
+    // Padded query lanes of the ragged last query tile read workspace nobody wrote: their results are never stored, but
+    // the reference tests below are wave-wide (__any), so a large stale value there would switch the VALID lanes of the
+    // wave onto the rescale path -- same mathematics, different rounding, i.e. output bits that depend on what the
+    // allocator handed out (found by a NaN / 1e30-poisoned pool, tools/debug/poison_repro.py).  Zero queries never trigger.
+    if (ragged && qt == nkt - 1 && qt * kTile + r >= tokens) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qreg[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- key tile 0: plain logits, reference maximum ----
     AttnRow st;

@@ -61,10 +61,13 @@ class _InputStager:
         self.events = [None] * self.SLOTS
         self.dev = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
 
-    def stage(self, pilots: torch.Tensor, conds: Optional[List[torch.Tensor]]):
-        B = pilots.shape[0]
-        pil_bytes = pilots.numel() * 8
-        total = (pil_bytes + 15) // 16 * 16 + (3 * B * 4 if conds is not None else 0)
+    def stage(self, pilots: Optional[torch.Tensor], conds: Optional[List[torch.Tensor]], fresh: bool = False):
+        """Either part may be None (already on the device).  ``fresh``: the device copy gets its own allocation instead of
+        the stager's buffer -- training saves these tensors for the backward pass, which may run after the next forward."""
+        B = pilots.shape[0] if pilots is not None else conds[0].numel()
+        pil_bytes = pilots.numel() * 8 if pilots is not None else 0
+        off = (pil_bytes + 15) // 16 * 16
+        total = off + (3 * B * 4 if conds is not None else 0)
         if total > self.nbytes:
             self._resize(total)
         slot = self.turn
@@ -72,19 +75,20 @@ class _InputStager:
         if self.events[slot] is not None:
             self.events[slot].synchronize()          # the copy that last read this pinned buffer has finished
         host = self.host[slot]
-        host[:pil_bytes].view(torch.complex64).view(pilots.shape).copy_(pilots)
-        off = (pil_bytes + 15) // 16 * 16
+        if pilots is not None:
+            host[:pil_bytes].view(torch.complex64).view(pilots.shape).copy_(pilots)
         if conds is not None:
             for i, c in enumerate(conds):
                 host[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32).copy_(c.reshape(-1))
-        self.dev[:total].copy_(host[:total], non_blocking=True)
+        dev = torch.empty(total, dtype=torch.uint8, device=self.device) if fresh else self.dev
+        dev[:total].copy_(host[:total], non_blocking=True)
         ev = self.events[slot] or torch.cuda.Event()
         ev.record()
         self.events[slot] = ev
-        pil_dev = self.dev[:pil_bytes].view(torch.complex64).view(pilots.shape)
+        pil_dev = dev[:pil_bytes].view(torch.complex64).view(pilots.shape) if pilots is not None else None
         if conds is None:
             return pil_dev, None
-        return pil_dev, [self.dev[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32) for i in range(3)]
+        return pil_dev, [dev[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32) for i in range(3)]
 
 
 class BaseFortiTranEstimator(nn.Module):
@@ -229,25 +233,15 @@ class BaseFortiTranEstimator(nn.Module):
             conditions = [snr, delay_spread, max_dop_shift]
 
         eng = self._hip_engine() if self._hip_eligible() else None
+        # the model owns the H2D copy (fortitran.py:167-173): on a HIP device, CPU inputs as the DataLoader yields them go
+        # through the pinned staging ring in one asynchronous copy (inference AND training: a pageable .to(device) blocks
+        # the host until the device has drained the previous step, and the next forward's first launches then trickle in
+        # with the device idle -- 0.4-0.7 ms per training step); device-resident inputs pass through
+        pilot_symbols, conditions = self._inputs_to_device(pilot_symbols, conditions)
         if eng is not None:
-            # the model owns the H2D copy (fortitran.py:167-173): CPU inputs as the DataLoader yields them go
-            # through the pinned staging ring in one asynchronous copy; device-resident inputs pass through
-            if (pilot_symbols.device.type == "cpu" and pilot_symbols.dtype == torch.complex64 and pilot_symbols.dim() == 3
-                    and (conditions is None or all(c.device.type == "cpu" and c.dtype == torch.float32
-                                                   and c.numel() == pilot_symbols.shape[0] for c in conditions))):
-                if self._stager is None or self._stager.device != self.pilot_upsampler.weight.device:
-                    self._stager = _InputStager(self.pilot_upsampler.weight.device)
-                pilot_symbols, conditions = self._stager.stage(pilot_symbols, conditions)
-            else:
-                pilot_symbols = pilot_symbols.to(self.device)
-                if conditions is not None:
-                    conditions = [t.to(self.device) for t in conditions]
             if conditions is None:
                 return eng.forward(pilot_symbols)
             return eng.forward(pilot_symbols, *conditions)
-        if conditions is not None:
-            conditions = [t.to(self.device) for t in conditions]
-        pilot_symbols = pilot_symbols.to(self.device)  # the model owns the H2D copy (fortitran.py:173)
 
         if pilot_symbols.device.type == "cuda" and torch.is_grad_enabled():
             # training on the HIP device: the Re and Im planes go through the network as ONE batch of
@@ -261,6 +255,28 @@ class BaseFortiTranEstimator(nn.Module):
         real = self._forward_real_valued(pilot_symbols.real, conditions)
         imag = self._forward_real_valued(pilot_symbols.imag, conditions)
         return torch.complex(real, imag)
+
+    def _inputs_to_device(self, pilot_symbols: torch.Tensor, conditions: Optional[List[torch.Tensor]]):
+        dev = self.pilot_upsampler.weight.device
+        B = pilot_symbols.shape[0] if pilot_symbols.dim() == 3 else -1
+        pil_cpu = pilot_symbols.device.type == "cpu" and pilot_symbols.dtype == torch.complex64 and B > 0
+        cond_cpu = conditions is not None and all(c.device.type == "cpu" and c.dtype == torch.float32 and c.numel() == B
+                                                  for c in conditions)
+        if dev.type == "cuda" and (pil_cpu or cond_cpu):
+            if self._stager is None or self._stager.device != dev:
+                self._stager = _InputStager(dev)
+            pil, conds = self._stager.stage(pilot_symbols if pil_cpu else None, conditions if cond_cpu else None,
+                                            fresh=torch.is_grad_enabled())
+            if pil is None:
+                pil = pilot_symbols.to(self.device)
+            if conds is not None:   # keep each condition's [B, 1] / [B] shape
+                conds = [c.view(o.shape) for c, o in zip(conds, conditions)]
+            elif conditions is not None:
+                conds = [t.to(self.device) for t in conditions]
+            return pil, conds
+        if conditions is not None:
+            conditions = [t.to(self.device) for t in conditions]
+        return pilot_symbols.to(self.device), conditions
 
     def _forward_real_valued(self, x: torch.Tensor, channel_conditions: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         """Differentiable composite of stages S1-S8 on one real plane batch [B,Ps,Pt]."""

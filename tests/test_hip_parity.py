@@ -131,6 +131,41 @@ def test_full_size_batch128_properties(oracle_lib):
     assert abs(dev_sum - host_sum) <= 1e-9 * host_sum
 
 
+def _poison_allocator(value):
+    """Leave the caching allocator's pool full of `value`: the next torch.empty (workspaces, outputs) gets that memory."""
+    blocks = [torch.full((n,), value, device=DEV) for n in (1 << 26, 1 << 25, 1 << 24, 1 << 22, 1 << 20, 1 << 18) for _ in range(3)]
+    del blocks
+
+
+@pytest.mark.parametrize("value", [float("nan"), 1e30, -3e38, float("inf")])
+def test_output_bits_do_not_depend_on_stale_workspace(value):
+    """Workspace and pad regions nobody writes (q / k / vt rows 280..287 of every (plane, head), the tail of the out6
+    rows, ...) hold whatever the allocator hands out.  None of it may reach the arithmetic of a stored value -- not even
+    through a wave-wide branch: the output must be the same bits whatever the pool held.  (Round 2: a large stale value in
+    a padded query lane switched the valid lanes of its wave onto attention's rescale path: 1e-7 differences between a
+    B = 16 run and the same frames inside a B = 128 run, visible only when the training tests had run first.)"""
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    cases = [(DEFAULT_SPEC, (7, 42, 560), 37),                                                     # 280 tokens: ragged key / query tiles
+             (dict(ofdm=(30, 8), pilot=(6, 2), patch=(3, 2), num_layers=2, model_dim=128, num_head=4), (5, 9, 80), 5),   # 40 tokens
+             (dict(ofdm=(66, 12), pilot=(11, 3), patch=(3, 3), num_layers=2, model_dim=128, num_head=4), None, 3)]      # 88 tokens
+
+    def run(spec, hid, B):
+        sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=7)
+        cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+        eng = engine_from_numpy(cfg, sd, DEV)
+        inp = synth.make_inputs(B, ofdm=spec["ofdm"], pilot=spec["pilot"], seed=8)
+        meta = [_t(inp[k]) for k in ("snr", "ds", "dop")] if hid else []
+        return eng.forward(_t(inp["pilots"]), *meta).clone()
+
+    for spec, hid, B in cases:
+        _poison_allocator(0.0)
+        ref = run(spec, hid, B)
+        _poison_allocator(value)
+        out = run(spec, hid, B)
+        assert torch.isfinite(torch.view_as_real(out)).all()
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref)), (spec["ofdm"], value)
+
+
 @pytest.mark.parametrize("ofdm,pilot,patch,adaptive", [((30, 8), (6, 2), (3, 2), True), ((66, 12), (11, 3), (3, 3), False),
                                                         ((150, 8), (10, 2), (5, 2), True),
                                                         ((120, 14), (12, 2), (4, 2), True), ((120, 14), (12, 2), (2, 2), False),

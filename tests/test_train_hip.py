@@ -57,6 +57,39 @@ def test_layer_forward_backward_matches_autograd(d, heads, ofdm, planes, act):
         assert _rel(p.grad, rg) <= 2e-4, name
 
 
+@pytest.mark.parametrize("value", [float("nan"), 1e30])
+def test_layer_training_bits_do_not_depend_on_stale_memory(value):
+    """Tape, scratch and slice buffers come from torch.empty: the layer's output and every gradient must be the same bits
+    whatever the allocator's pool held before (ragged 280-token planes, dropout on, d = 128 and 256)."""
+    from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
+
+    def poison(v):
+        blocks = [torch.full((n,), v, device="cuda") for n in (1 << 26, 1 << 24, 1 << 22, 1 << 20, 1 << 18) for _ in range(3)]
+        del blocks
+
+    for d, heads in ((128, 4), (256, 8)):
+        cfg = _cfg(d, heads, (120, 14))
+        layer = _layer(d, heads, "gelu", 0.1).train()
+        torch.manual_seed(3)
+        x0 = torch.randn(2, cfg.tokens, d, device="cuda")
+        gout = torch.randn(2, cfg.tokens, d, device="cuda")
+
+        def run():
+            layer.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            out = HipEncoderLayerFunction.apply(x, cfg, 0.1, 77, *layer_params(layer))
+            out.backward(gout)
+            return [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer_params(layer)]
+
+        poison(0.0)
+        ref = run()
+        poison(value)
+        got = run()
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.isfinite(a).all(), (d, i)
+            assert torch.equal(a, b), (d, i)
+
+
 def test_dropout_is_consistent_between_forward_and_backward():
     """With p > 0 the layer is still a deterministic function of (x, seed): its backward must match a
     central finite difference of its forward along a random direction, and the keep rate must be 1-p."""
