@@ -147,7 +147,10 @@ def test_output_bits_do_not_depend_on_stale_workspace(value):
     from adafortitran_amd.hip_ops import engine_from_numpy
     cases = [(DEFAULT_SPEC, (7, 42, 560), 37),                                                     # 280 tokens: ragged key / query tiles
              (dict(ofdm=(30, 8), pilot=(6, 2), patch=(3, 2), num_layers=2, model_dim=128, num_head=4), (5, 9, 80), 5),   # 40 tokens
-             (dict(ofdm=(66, 12), pilot=(11, 3), patch=(3, 3), num_layers=2, model_dim=128, num_head=4), None, 3)]      # 88 tokens
+             (dict(ofdm=(66, 12), pilot=(11, 3), patch=(3, 3), num_layers=2, model_dim=128, num_head=4), None, 3),      # 88 tokens
+             (dict(ofdm=(54, 14), pilot=(6, 2), patch=(3, 2), num_layers=2, model_dim=256, num_head=8), (4, 8, 252), 3),   # d = 256, 126 tokens
+             (dict(ofdm=(54, 14), pilot=(6, 2), patch=(3, 2), num_layers=2, model_dim=64, num_head=2), None, 2),
+             (dict(ofdm=(54, 14), pilot=(6, 2), patch=(3, 2), num_layers=2, model_dim=192, num_head=6), None, 2)]
 
     def run(spec, hid, B):
         sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=7)
