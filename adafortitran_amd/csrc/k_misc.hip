@@ -278,15 +278,21 @@ __global__ __launch_bounds__(256) void pilot_gather_kernel(const float2 *__restr
     if (frame >= batch) return;
     const float2 *src = grid + (size_t)frame * n;
     int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int i = i0 + lane;
-        float2 v = make_float2(0.f, 0.f);
-        if (i < n) v = src[i];
-        const bool nz = i < n && (v.x != 0.f || v.y != 0.f);   // complex != 0, as torch compares it
-        const unsigned long long m = __ballot(nz);
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (nz && pos < expected) pilots[(size_t)frame * expected + pos] = v;
-        base += __popcll(m);
+    for (int i0 = 0; i0 < n; i0 += 8 * 64) {   // eight 512-byte loads in flight per wave, then the ordered compaction
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u + lane;
+            v[u] = i < n ? src[i] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool nz = v[u].x != 0.f || v[u].y != 0.f;   // complex != 0, as torch compares it (padding reads as 0)
+            const unsigned long long m = __ballot(nz);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (nz && pos < expected) pilots[(size_t)frame * expected + pos] = v[u];
+            base += __popcll(m);
+        }
     }
     if (lane == 0) counts[frame] = base;
 }

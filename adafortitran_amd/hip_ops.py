@@ -194,10 +194,12 @@ def mse_sum(est: torch.Tensor, ref: torch.Tensor, acc: Optional[torch.Tensor] = 
     return acc
 
 
-def pilot_gather(hzero_ls: torch.Tensor, pilot_size) -> torch.Tensor:
+def pilot_gather(hzero_ls: torch.Tensor, pilot_size, return_counts: bool = False):
     """Sparse LS grid complex64 [B,S,T] (zeros off the pilot positions) -> pilots complex64
     [B,Ps,Pt], the non-zero entries in row-major order (reference dataset.py:116-139).  Raises the
-    reference's ValueError when a frame does not hold exactly Ps*Pt non-zero entries."""
+    reference's ValueError when a frame does not hold exactly Ps*Pt non-zero entries -- which costs one
+    host sync; ``return_counts=True`` returns ``(pilots, counts int32 [B])`` instead and leaves the check
+    (``check_pilot_counts``) to the caller, who can run it off the critical path (ingest.PackedLoader)."""
     lib = _lib.load()
     if hzero_ls.dtype != torch.complex64 or hzero_ls.dim() != 3:
         raise ValueError("hzero_ls must be complex64 [B, S, T]")
@@ -208,11 +210,19 @@ def pilot_gather(hzero_ls: torch.Tensor, pilot_size) -> torch.Tensor:
     counts = torch.empty(B, dtype=torch.int32, device=hzero_ls.device)
     _lib.check(lib.aft_pilot_gather_f32(src.data_ptr(), torch.view_as_real(out).data_ptr(), counts.data_ptr(), B, n,
                                         expected, _lib.current_stream_ptr(hzero_ls.device)))
+    if return_counts:
+        return out, counts
+    check_pilot_counts(counts, expected)
+    return out
+
+
+def check_pilot_counts(counts: torch.Tensor, expected: int, first_frame: int = 0) -> None:
+    """The reference's "Expected 24 pilot values, got 25" error (dataset.py:133-139) from the kernel's per-frame counts
+    (a device or host int32 tensor)."""
     bad = (counts != expected).nonzero()
     if bad.numel():
         i = int(bad[0])
-        raise ValueError(f"Expected {expected} pilot values, got {int(counts[i])} (frame {i})")
-    return out
+        raise ValueError(f"Expected {expected} pilot values, got {int(counts[i])} (frame {first_frame + i})")
 
 
 def ls_mse_db(ls: torch.Tensor, ideal: torch.Tensor) -> torch.Tensor:

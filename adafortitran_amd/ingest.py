@@ -85,7 +85,7 @@ class PackedLoader:
     by the GPU kernel and both pilots and targets stay on the device."""
 
     def __init__(self, packed: Union[str, Path, Dict[str, np.ndarray]], pilot_size: Tuple[int, int], batch_size: int,
-                 device: Union[str, torch.device] = "cpu") -> None:
+                 device: Union[str, torch.device] = "cpu", pin_memory: bool = True) -> None:
         if not isinstance(packed, dict):
             z = np.load(packed, allow_pickle=False)
             packed = {k: z[k] for k in z.files}
@@ -94,25 +94,79 @@ class PackedLoader:
         self.batch_size = int(batch_size)
         self.device = torch.device(device)
         self.n = packed["h_ideal"].shape[0]
+        # HIP device: the two grids a batch needs are pinned once, so that every batch is two asynchronous copies and the
+        # host never waits for the device inside the sweep (a pageable .to(device) is a synchronisation point: with it
+        # the "sync-free" evaluation sweep of evaluation.py ran no faster than the reference's .item()-per-batch loop)
+        self._pinned = None
+        if self.device.type == "cuda" and pin_memory:
+            self._pinned = (torch.from_numpy(np.ascontiguousarray(packed["h_ideal"])).pin_memory(),
+                            torch.from_numpy(np.ascontiguousarray(packed["h_ls_sparse"])).pin_memory())
 
     def __len__(self) -> int:
         return (self.n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, tuple]]:
-        for lo in range(0, self.n, self.batch_size):
+        if self.device.type != "cuda":
+            for lo in range(0, self.n, self.batch_size):
+                hi = min(lo + self.batch_size, self.n)
+                ideal = torch.from_numpy(self.p["h_ideal"][lo:hi])
+                pilots = torch.from_numpy(extract_pilots_host(self.p["h_ls_sparse"][lo:hi], self.pilot_size))
+                yield pilots, ideal, self._meta(lo, hi)
+            return
+        # HIP device: the grids of batch k+1 are copied on a side stream while the consumer works on batch k (3.4 MB per
+        # 128-frame batch is ~0.15 ms of PCIe time: on the compute stream it would sit in front of every forward); the
+        # consumer's stream waits for the copy's event on the device, the host never does.  Only COPIES run on the side
+        # stream: the gather kernel is launched on the consumer's stream -- a kernel running beside the forward's
+        # persistent-grid launches takes workgroup slots from them and costs more than its own 10 us.  Pilot counts come
+        # back through a small pinned ring and are checked one batch late (the reference raises at the offending sample).
+        from .hip_ops import check_pilot_counts, pilot_gather
+        expected = self.pilot_size[0] * self.pilot_size[1]
+        side = torch.cuda.Stream(device=self.device)
+        ring = [torch.empty(self.batch_size, dtype=torch.int32).pin_memory() for _ in range(3)]
+
+        def copy(lo):
             hi = min(lo + self.batch_size, self.n)
-            ideal = torch.from_numpy(self.p["h_ideal"][lo:hi])
-            sparse = self.p["h_ls_sparse"][lo:hi]
-            if self.device.type == "cuda":
-                from .hip_ops import pilot_gather
-                ideal = ideal.to(self.device)
-                pilots = pilot_gather(torch.from_numpy(sparse).to(self.device), self.pilot_size)
-            else:
-                pilots = torch.from_numpy(extract_pilots_host(sparse, self.pilot_size))
-            m = torch.from_numpy(self.p["meta"][lo:hi])
-            meta = (m[:, 0:1], m[:, 1:2], m[:, 2:3], m[:, 3:4], m[:, 4:5],
-                    [tuple(str(c) for c in self.p["channel_type"][lo:hi])])
-            yield pilots, ideal, meta
+            with torch.cuda.stream(side):
+                if self._pinned is not None:
+                    ideal = self._pinned[0][lo:hi].to(self.device, non_blocking=True)
+                    sparse = self._pinned[1][lo:hi].to(self.device, non_blocking=True)
+                else:
+                    ideal = torch.from_numpy(self.p["h_ideal"][lo:hi]).to(self.device)
+                    sparse = torch.from_numpy(self.p["h_ls_sparse"][lo:hi]).to(self.device)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return ideal, sparse, ev, lo, hi
+
+        def settle(b):
+            b[0].synchronize()   # recorded behind that batch's gather: long done when the NEXT batch has been consumed
+            check_pilot_counts(b[1], expected, b[2])
+
+        starts = list(range(0, self.n, self.batch_size))
+        nxt = copy(starts[0]) if starts else None
+        prev = None
+        for k in range(len(starts)):
+            ideal, sparse, ev, lo, hi = nxt
+            nxt = copy(starts[k + 1]) if k + 1 < len(starts) else None
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ev)
+            ideal.record_stream(main)
+            sparse.record_stream(main)
+            pilots, counts = pilot_gather(sparse, self.pilot_size, return_counts=True)
+            host_counts = ring[k % 3][:hi - lo]
+            host_counts.copy_(counts, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(main)
+            if prev is not None:
+                settle(prev)
+            prev = (done, host_counts, lo)
+            yield pilots, ideal, self._meta(lo, hi)
+        if prev is not None:
+            settle(prev)
+
+    def _meta(self, lo: int, hi: int) -> tuple:
+        m = torch.from_numpy(self.p["meta"][lo:hi])
+        return (m[:, 0:1], m[:, 1:2], m[:, 2:3], m[:, 3:4], m[:, 4:5],
+                [tuple(str(c) for c in self.p["channel_type"][lo:hi])])
 
 
 def ls_mse_db_per_frame(h_ls_full: torch.Tensor, h_ideal: torch.Tensor) -> torch.Tensor:
