@@ -127,3 +127,31 @@ def test_packed_loader_feeds_hip_model_end_to_end(tmp_path):
         model.load_state_dict(sd)
         res[dev] = evaluate_dataloader(model, ingest.PackedLoader(str(tmp_path / "p.npz"), (12, 2), 2, device=dev))
     assert abs(res["cuda"] - res["cpu"]) <= 1e-4 * res["cpu"]
+
+
+@pytest.mark.gpu
+def test_packed_loader_on_device_matches_host_and_raises_late():
+    """PackedLoader on the HIP device (pinned grids, side-stream copies, GPU gather, counts checked one batch late):
+    same batches as the host path bit for bit; a frame with 25 non-zero entries raises the reference's error with the
+    frame's index in the folder -- while the NEXT batch is being prepared or at the end of the sweep, never silently."""
+    rng = np.random.default_rng(5)
+    N, S, T = 37, 120, 14
+    ideal = (rng.standard_normal((N, S, T)) + 1j * rng.standard_normal((N, S, T))).astype(np.complex64)
+    sparse = np.zeros((N, S, T), np.complex64)
+    rows, cols = np.arange(0, S, 10), np.array([3, 10])
+    sparse[:, rows[:, None], cols[None, :]] = ideal[:, rows[:, None], cols[None, :]]
+    meta = rng.uniform(0, 30, (N, 5)).astype(np.float32)
+    packed = {"h_ideal": ideal, "h_ls_sparse": sparse, "meta": meta, "channel_type": np.array(["TDL-A"] * N)}
+    host = list(ingest.PackedLoader(packed, (12, 2), 8, device="cpu"))
+    dev = list(ingest.PackedLoader(packed, (12, 2), 8, device="cuda"))
+    assert len(host) == len(dev) == 5
+    for (ph, ih, mh), (pd, idv, md) in zip(host, dev):
+        assert torch.equal(pd.cpu(), ph) and torch.equal(idv.cpu(), ih)
+        assert all(torch.equal(a, b) for a, b in zip(mh[:5], md[:5])) and mh[5] == md[5]
+    for bad_frame in (3, 20, 36):          # first batch, a middle batch, the last (ragged) batch
+        broken = dict(packed)
+        broken["h_ls_sparse"] = sparse.copy()
+        broken["h_ls_sparse"][bad_frame, 5, 5] = 1.0
+        with pytest.raises(ValueError, match=rf"Expected 24 pilot values, got 25 \(frame {bad_frame}\)"):
+            for _ in ingest.PackedLoader(broken, (12, 2), 8, device="cuda"):
+                pass
