@@ -51,6 +51,29 @@ __device__ __forceinline__ void set_progress_priority(int left, int total) {
 #endif
 }
 
+// Dropout masks of the training path (every site: attention probabilities, the two residual branches, the FFN hidden
+// layer).  A murmur-quality hash per element costs three quarter-rate 32-bit multiplies and ~10 more VALU instructions;
+// inside an MFMA kernel that is matrix time (the attention forward spent 70 % of a tile's MFMA time on it).  The mask is
+// therefore FACTORED: one strong 24-bit word per row and one per column of the masked matrix (hashed once per row / lane
+// / workgroup), and element (r, c) is KEPT when the low 32 bits of their product (v_mul_u32_u24, full rate) reach
+// p * 2^32: three VALU instructions per element.  The middle bits of a product of two random odd 24-bit words are
+// uniform and pairwise uncorrelated across rows, columns and 2x2 rectangles to within sampling noise
+// (tests/test_dropout_mask.py).  Forward and backward kernels of a site evaluate the same function of
+// (seed, row, column), so nothing is stored.
+__device__ __forceinline__ uint32_t dropmask_mix32(uint32_t x) {   // murmur3 finaliser
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t dropmask_row_word(uint32_t seed, uint32_t row) {
+    return (dropmask_mix32(row * 0x9E3779B1u ^ seed) >> 8) | 1u;
+}
+__device__ __forceinline__ uint32_t dropmask_col_word(uint32_t seed, uint32_t col) {
+    return (dropmask_mix32(col * 0x9E3779B1u ^ (~seed * 0x632BE5ABu + 0x7F4A7C15u)) >> 8) | 1u;
+}
+__device__ __forceinline__ bool dropmask_keep(uint32_t row_word, uint32_t col_word, uint32_t threshold) {
+    return __umul24(row_word, col_word) >= threshold;
+}
+
 // Device-resident scratch of one forward call; all offsets in floats, 256-B aligned.
 // Layout in HBM (DESIGN.md "data layout"):
 //   conv_enhanced [2B][S][T]            f32  kept for the S7 residual
@@ -174,7 +197,7 @@ hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamm
 hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, const float *gamma, float *ds, float *dbranch,
                          float *dgamma, float *dbeta, float *dbias, float *slices, int rows, int n, float dropout_p,
                          uint32_t seed, bool accumulate, hipStream_t st);
-hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dropout_p, uint32_t seed, hipStream_t st);
+hipError_t launch_act_fwd(int act, const float *a, float *h, int rows, int n, float dropout_p, uint32_t seed, hipStream_t st);
 hipError_t launch_act_bwd(int act, const float *a, float *dh, float *dbias, float *slices, int rows, int n, float dropout_p,
                           uint32_t seed, bool accumulate, hipStream_t st);
 hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t st);

@@ -40,24 +40,13 @@ struct AttnTrainArgs {
     uint32_t seed;
 };
 
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // murmur3 finaliser
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    return x;
-}
-// Dropout mask of P.  A murmur-quality hash per element costs three quarter-rate 32-bit multiplies and ~10 more
-// VALU instructions -- 16 elements per lane per 32x32 tile made that 70 % of the tile's MFMA time (PMC: 13.3 VALU
-// per MFMA in the forward).  The mask is therefore factored: one strong 24-bit word per query row and one per key
-// column (hashed once per workgroup into LDS / once per lane), and element (q, k) is KEPT when the low 32 bits of
-// their product (v_mul_u32_u24, full rate) reach the threshold: three VALU instructions per element.  The middle
-// bits of a product of two random odd 24-bit words are uniform and pairwise uncorrelated across rows, columns
-// and 2x2 rectangles to within sampling noise (checked on 560x560 masks at p = 0.1 / 0.25 / 0.5).  All three
-// kernels evaluate the same function, so nothing is stored.
-__device__ __forceinline__ uint32_t drop_row_word(uint32_t seed, uint32_t idx) { return (mix32(idx * 0x9E3779B1u ^ seed) >> 8) | 1u; }
-__device__ __forceinline__ uint32_t drop_col_word(uint32_t seed, uint32_t idx) {
-    return (mix32(idx * 0x9E3779B1u ^ (~seed * 0x632BE5ABu + 0x7F4A7C15u)) >> 8) | 1u;
-}
+// Dropout mask of P: the factored mask of aft_internal.h (dropmask_*), rows = queries, columns = keys of one (plane, head):
+// the per-key words are hashed once per workgroup into LDS, the per-query word once per lane (or the other way round in
+// the dK/dV pass), three VALU instructions per element.
+__device__ __forceinline__ uint32_t drop_row_word(uint32_t seed, uint32_t idx) { return dropmask_row_word(seed, idx); }
+__device__ __forceinline__ uint32_t drop_col_word(uint32_t seed, uint32_t idx) { return dropmask_col_word(seed, idx); }
 __device__ __forceinline__ bool drop_keep(uint32_t row_word, uint32_t col_word, uint32_t threshold) {
-    return __umul24(row_word, col_word) >= threshold;
+    return dropmask_keep(row_word, col_word, threshold);
 }
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

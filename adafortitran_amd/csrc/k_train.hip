@@ -13,12 +13,9 @@
 
 namespace aft {
 
-__device__ __forceinline__ uint32_t tmix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ float tdrop(uint32_t seed, uint32_t idx, uint32_t threshold, float keep_scale) {
-    return tmix32(idx * 0x9E3779B1u ^ seed) >= threshold ? keep_scale : 0.f;
+// dropout factor of element (row, col) of a [rows][n] activation: the factored mask of aft_internal.h
+__device__ __forceinline__ float tdrop(uint32_t row_word, uint32_t col_word, uint32_t threshold, float keep_scale) {
+    return dropmask_keep(row_word, col_word, threshold) ? keep_scale : 0.f;
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -38,11 +35,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float *__restrict
     if (row >= rows) return;
     float v[NPL];
     float sum = 0.f;
+    const uint32_t rw = dropmask_row_word(seed, (uint32_t)row);
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int col = lane + 64 * q;
         float t = y[(size_t)row * N + col];
-        if (threshold) t *= tdrop(seed, (uint32_t)row * N + col, threshold, keep_scale);
+        if (threshold) t *= tdrop(rw, dropmask_col_word(seed, (uint32_t)col), threshold, keep_scale);
         v[q] = res[(size_t)row * N + col] + t;
         sum += v[q];
     }
@@ -78,15 +76,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float dg[NPL], db[NPL], dbr[NPL], gm[NPL];
+    uint32_t cw[NPL];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         dg[q] = 0.f;
         db[q] = 0.f;
         dbr[q] = 0.f;
         gm[q] = gamma[lane + 64 * q];
+        cw[q] = dropmask_col_word(seed, (uint32_t)(lane + 64 * q));
     }
     for (int row = r0 + wave; row < r1; row += 4) {
         const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+        const uint32_t rw = dropmask_row_word(seed, (uint32_t)row);
         float g[NPL], xh[NPL], a = 0.f, b = 0.f;
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
             const int col = lane + 64 * q;
             const float v = rstd * (g[q] - a - xh[q] * b);
             ds[(size_t)row * N + col] = v;
-            const float vb = threshold ? v * tdrop(seed, (uint32_t)row * N + col, threshold, keep_scale) : v;
+            const float vb = threshold ? v * tdrop(rw, cw[q], threshold, keep_scale) : v;
             dbranch[(size_t)row * N + col] = vb;
             dbr[q] += vb;
         }
@@ -129,16 +130,18 @@ __device__ __forceinline__ float gelu_grad(float x) {
 
 // h = drop(act(a))       ACT: 0 = relu, 1 = gelu (exact erf form, torch default)
 template <int ACT>
-__global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ a, float *__restrict__ hout, size_t n4,
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ a, float *__restrict__ hout, size_t n4, int n,
                                                       uint32_t seed, uint32_t threshold, float keep_scale) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i];
+    const uint32_t row = (uint32_t)((4 * i) / (unsigned)n), col = (uint32_t)((4 * i) % (unsigned)n);
+    const uint32_t rw = dropmask_row_word(seed, row);
     f32x4 r;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float v = ACT ? gelu_exact(x[c]) : fmaxf(x[c], 0.f);
-        if (threshold) v *= tdrop(seed, (uint32_t)(4 * i + c), threshold, keep_scale);
+        if (threshold) v *= tdrop(rw, dropmask_col_word(seed, col + c), threshold, keep_scale);
         r[c] = v;
     }
     reinterpret_cast<f32x4 *>(hout)[i] = r;
@@ -155,14 +158,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
     const int groups = n >> 2, cg = threadIdx.x % groups, rsub = threadIdx.x / groups, rstep = 256 / groups;   // rsub >= rstep: idle
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    uint32_t cw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cw[c] = dropmask_col_word(seed, (uint32_t)(4 * cg + c));
     for (int row = r0 + rsub; row < r1 && rsub < rstep; row += rstep) {
         const size_t i = ((size_t)row * n >> 2) + cg;
+        const uint32_t rw = dropmask_row_word(seed, (uint32_t)row);
         const f32x4 x = reinterpret_cast<const f32x4 *>(a)[i];
         f32x4 g = reinterpret_cast<f32x4 *>(dh)[i];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float v = g[c] * (ACT ? gelu_grad(x[c]) : (x[c] > 0.f ? 1.f : 0.f));
-            if (threshold) v *= tdrop(seed, (uint32_t)(4 * i + c), threshold, keep_scale);
+            if (threshold) v *= tdrop(rw, cw[c], threshold, keep_scale);
             g[c] = v;
         }
         reinterpret_cast<f32x4 *>(dh)[i] = g;
@@ -458,13 +465,14 @@ hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, co
     return launch_reduce_slices3(slices, dgamma, dbeta, dbias, n, 3, nb, (size_t)3 * n, accumulate, st);
 }
 
-hipError_t launch_act_fwd(int act, const float *a, float *h, size_t n, float dropout_p, uint32_t seed, hipStream_t st) {
-    const size_t n4 = n / 4;
+hipError_t launch_act_fwd(int act, const float *a, float *h, int rows, int n, float dropout_p, uint32_t seed, hipStream_t st) {
+    if (n & 3) return hipErrorInvalidValue;
+    const size_t n4 = (size_t)rows * n / 4;
     const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
     if (act)
-        hipLaunchKernelGGL(act_fwd_kernel<1>, grid, block, 0, st, a, h, n4, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
+        hipLaunchKernelGGL(act_fwd_kernel<1>, grid, block, 0, st, a, h, n4, n, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
     else
-        hipLaunchKernelGGL(act_fwd_kernel<0>, grid, block, 0, st, a, h, n4, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
+        hipLaunchKernelGGL(act_fwd_kernel<0>, grid, block, 0, st, a, h, n4, n, seed, drop_threshold(dropout_p), drop_keep(dropout_p));
     return hipGetLastError();
 }
 
