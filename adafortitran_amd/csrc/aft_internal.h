@@ -178,6 +178,12 @@ hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const f
                        int ldb, int ldc, bool accumulate, hipStream_t st);
 hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slices, int M, int N, int R, int lda, int ldb,
                           bool accumulate, hipStream_t st);
+// out = LayerNorm(res + drop(A W^T + bias)) * gamma + beta with s = res + drop(..) and (mean, rstd) kept, in ONE launch
+// (N = 128 and aligned operands: gemm_add_ln_ok); `threshold` / `keep_scale` as in launch_add_ln_fwd (0 / 1 = no dropout)
+bool gemm_add_ln_ok(int M, int N, int K, int lda, int ldb);
+hipError_t launch_gemm_add_ln(const float *A, const float *W, const float *bias, const float *res, const float *gamma,
+                              const float *beta, float *s_out, float *stats, float *out, int M, int N, int K, int lda, int ldw,
+                              float eps, float keep_scale, uint32_t threshold, uint32_t seed, hipStream_t st);
 // up to four weight gradients over the same R token rows in ONE GEMM launch; slices[j] holds gemm_tn_slice_floats(M[j], N[j], R)
 // floats (the batch never uses more slices than the single launches)
 hipError_t launch_gemm_tn_batch(const float *const *A, const float *const *B, float *const *C, float *const *slices, const int *M,

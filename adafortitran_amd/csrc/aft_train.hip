@@ -133,14 +133,27 @@ int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weigh
     STEP("qkv", launch_gemm(0, x_in, w->in_proj_w, tp + t.qkv, w->in_proj_b, rows, 3 * d, d, d, d, 3 * d, false, st));
     STEP("attention", launch_attn_train_fwd(*cfg, tp + t.qkv, tp + t.attn, tp + t.lse, planes, tokens, dropout_p,
                                             site_seed(seed, 0), st));
-    STEP("out_proj", launch_gemm(0, tp + t.attn, w->out_proj_w, o, w->out_proj_b, rows, d, d, d, d, d, false, st));
-    STEP("norm1", launch_add_ln_fwd(x_in, o, w->norm1_w, w->norm1_b, tp + t.s1, tp + t.st1, tp + t.x1, rows, d, 1e-5f,
-                                    dropout_p, site_seed(seed, 1), st));
+    const uint32_t drop_th = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
+    const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    // projection + residual + dropout + LayerNorm: one launch when the fused epilogue covers the shape (d = 128)
+    if (gemm_add_ln_ok(rows, d, d, d, d)) {
+        STEP("out_proj + norm1", launch_gemm_add_ln(tp + t.attn, w->out_proj_w, w->out_proj_b, x_in, w->norm1_w, w->norm1_b, tp + t.s1,
+                                                    tp + t.st1, tp + t.x1, rows, d, d, d, d, 1e-5f, drop_ks, drop_th, site_seed(seed, 1), st));
+    } else {
+        STEP("out_proj", launch_gemm(0, tp + t.attn, w->out_proj_w, o, w->out_proj_b, rows, d, d, d, d, d, false, st));
+        STEP("norm1", launch_add_ln_fwd(x_in, o, w->norm1_w, w->norm1_b, tp + t.s1, tp + t.st1, tp + t.x1, rows, d, 1e-5f,
+                                        dropout_p, site_seed(seed, 1), st));
+    }
     STEP("linear1", launch_gemm(0, tp + t.x1, w->lin1_w, tp + t.a, w->lin1_b, rows, ff, d, d, d, ff, false, st));
     STEP("activation", launch_act_fwd(cfg->activation, tp + t.a, tp + t.hd, rows, ff, dropout_p, site_seed(seed, 2), st));
-    STEP("linear2", launch_gemm(0, tp + t.hd, w->lin2_w, o, w->lin2_b, rows, d, ff, ff, ff, d, false, st));
-    STEP("norm2", launch_add_ln_fwd(tp + t.x1, o, w->norm2_w, w->norm2_b, tp + t.s2, tp + t.st2, x_out, rows, d, 1e-5f,
-                                    dropout_p, site_seed(seed, 3), st));
+    if (gemm_add_ln_ok(rows, d, ff, ff, ff)) {
+        STEP("linear2 + norm2", launch_gemm_add_ln(tp + t.hd, w->lin2_w, w->lin2_b, tp + t.x1, w->norm2_w, w->norm2_b, tp + t.s2, tp + t.st2,
+                                                   x_out, rows, d, ff, ff, ff, 1e-5f, drop_ks, drop_th, site_seed(seed, 3), st));
+    } else {
+        STEP("linear2", launch_gemm(0, tp + t.hd, w->lin2_w, o, w->lin2_b, rows, d, ff, ff, ff, d, false, st));
+        STEP("norm2", launch_add_ln_fwd(tp + t.x1, o, w->norm2_w, w->norm2_b, tp + t.s2, tp + t.st2, x_out, rows, d, 1e-5f,
+                                        dropout_p, site_seed(seed, 3), st));
+    }
     return AFT_OK;
 }
 

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float *__restrict__ A, 
 //     row of C and its registers run along the columns, so the epilogue is eight 16-byte stores per 32x64 wave tile
 //     straight from the accumulators, and the bias is the accumulators' initial value (16-byte loads).
 using GemmSrd = __amdgpu_buffer_rsrc_t;
+using u32x4g = __attribute__((ext_vector_type(4))) uint32_t;
 constexpr unsigned kGemmOutOfRange = 0x7ffffff0u;   // >= any num_records used here: the load returns zeros
 __device__ __forceinline__ GemmSrd gemm_srd(const float *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
@@ -205,13 +206,29 @@ __device__ __forceinline__ f32x4 gemm_ld(GemmSrd r, unsigned voff, unsigned soff
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// Fused epilogue of the two projections that feed a LayerNorm (out-proj -> norm1, linear2 -> norm2; reference
+// nn.TransformerEncoderLayer, norm_first = False):  s = res + drop(A W^T + b);  C = LN(s) * gamma + beta;  s and the row
+// statistics (mean, rstd) are kept for the backward pass.  Needs N = 128 (one column tile = whole rows in a workgroup);
+// replaces add_ln_fwd_kernel and its 147 MB of traffic per call.
+struct LnArgs {
+    const float *res, *gamma, *beta;
+    float *s_out, *stats;
+    float eps, keep_scale;
+    uint32_t seed, threshold;
+};
+
 // (bx, by, bz, gx) stand for the block indices and the grid width: the batched weight-gradient launch maps its flat
 // block index onto several products
-template <int OP, int BM>
+template <int OP, int BM, bool LN = false>
 __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*Bs)[GBK * GLD], const float *__restrict__ A,
                                                const float *__restrict__ B, float *__restrict__ C, const float *__restrict__ bias,
                                                int M, int N, int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
-                                               int accumulate, int bx, int by, int bz, int gx) {
+                                               int accumulate, int bx, int by, int bz, int gx, const LnArgs *ln = nullptr) {
+    __shared__ float ln_red[LN ? 2 * 64 * 2 : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t ln_colw[LN ? GBN : 4];
+    if constexpr (LN) {   // column words of the dropout mask, once per workgroup (published by the first tile's barrier)
+        if (threadIdx.x < GBN) ln_colw[threadIdx.x] = dropmask_col_word(ln->seed, threadIdx.x);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     constexpr int TI = BM / 64, NUA = BM / 64;
@@ -295,6 +312,16 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
         const int next = tile + tstep;
         int m1 = 0, n1 = 0;
         if (next < ntiles) origin(next, m1, n1);
+        // LayerNorm epilogue: the residual rows are requested now, a whole k loop ahead of their use
+        f32x4 ln_res[LN ? 2 : 1][LN ? 4 : 1];
+        if constexpr (LN) {
+            const int row = m0 + wm * 32 + j;
+            const float *rp = ln->res + (size_t)min(row, M - 1) * N + wn * 64 + 4 * h;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) ln_res[tj][s] = *reinterpret_cast<const f32x4 *>(rp + 32 * tj + 8 * s);
+        }
         if (nsteps > 0) stage(0);
         __syncthreads();
         auto step = [&](int it, auto bufc) {
@@ -326,6 +353,63 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
             step(it, std::integral_constant<int, 0>{});
             if (it + 1 < nsteps) step(it + 1, std::integral_constant<int, 1>{});
         }
+        if constexpr (LN) {
+            // lane (j, h) of wave (wm, wn) holds 32 of the 128 values of row m0 + 32 wm + j: columns 64 wn + 32 tj + 8 s + 4 h + c
+            static_assert(BM == 64, "the LayerNorm epilogue is written for 64-row tiles");
+            const int row = m0 + wm * 32 + j, lr = wm * 32 + j;
+            const bool rowok = row < M;
+            const uint32_t rw = dropmask_row_word(ln->seed, (uint32_t)row);
+            const size_t rbase = (size_t)row * N + wn * 64 + 4 * h;
+            f32x4 v[2][4];
+            float sum = 0.f;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int col = wn * 64 + 32 * tj + 8 * s + 4 * h;
+                    f32x4 y = {acc[0][tj][4 * s], acc[0][tj][4 * s + 1], acc[0][tj][4 * s + 2], acc[0][tj][4 * s + 3]};
+                    if (ln->threshold) {
+                        const u32x4g cw = *reinterpret_cast<const u32x4g *>(ln_colw + col);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) y[c] = dropmask_keep(rw, cw[c], ln->threshold) ? y[c] * ln->keep_scale : 0.f;
+                    }
+                    v[tj][s] = ln_res[tj][s] + y;
+                    if (rowok) *reinterpret_cast<f32x4 *>(ln->s_out + rbase + 32 * tj + 8 * s) = v[tj][s];
+                    sum += (v[tj][s][0] + v[tj][s][1]) + (v[tj][s][2] + v[tj][s][3]);
+                }
+            sum += __shfl_xor(sum, 32);
+            if (h == 0) ln_red[lr * 2 + wn] = sum;
+            __syncthreads();
+            const float mean = (ln_red[lr * 2] + ln_red[lr * 2 + 1]) * (1.f / GBN);
+            float var = 0.f;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) var = fmaf(v[tj][s][c] - mean, v[tj][s][c] - mean, var);
+            var += __shfl_xor(var, 32);
+            if (h == 0) ln_red[128 + lr * 2 + wn] = var;
+            __syncthreads();
+            const float rstd = rsqrtf((ln_red[128 + lr * 2] + ln_red[128 + lr * 2 + 1]) * (1.f / GBN) + ln->eps);
+            if (rowok) {
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int col = wn * 64 + 32 * tj + 8 * s + 4 * h;
+                        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(ln->gamma + col), b4 = *reinterpret_cast<const f32x4 *>(ln->beta + col);
+                        f32x4 o;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = fmaf((v[tj][s][c] - mean) * rstd, g4[c], b4[c]);
+                        *reinterpret_cast<f32x4 *>(C + rbase + 32 * tj + 8 * s) = o;
+                    }
+                if (wn == 0 && h == 0) {
+                    ln->stats[2 * (size_t)row] = mean;
+                    ln->stats[2 * (size_t)row + 1] = rstd;
+                }
+            }
+        } else {
         // epilogue: lane j owns row j of each 32-row tile; 16-byte stores along the row
         const bool full = m0 + BM <= M && n0 + GBN <= N;
 #pragma unroll
@@ -343,6 +427,7 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
                     *p = v;
                 }
         }
+        }
         __syncthreads();   // every wave is done with the LDS buffers before the next tile restages buffer 0
         tile = next;
         m0 = m1;
@@ -359,6 +444,14 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const float *__restrict_
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
     gemm_fast_body<OP, BM>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, ldc, k_chunk, c_slice, accumulate, (int)blockIdx.x,
                            (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_add_ln_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                          float *__restrict__ C, const float *__restrict__ bias, int M, int N, int K,
+                                                          int lda, int ldb, const LnArgs ln) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    gemm_fast_body<0, 64, true>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, N, K, (size_t)0, 0, (int)blockIdx.x, 0, 0, (int)gridDim.x, &ln);
 }
 
 // Several weight gradients dW_j = A_j^T B_j over the SAME token rows in one launch (the four of an encoder layer): with
@@ -587,6 +680,20 @@ hipError_t launch_gemm_tn(const float *A, const float *B, float *C, float *slice
         hipLaunchKernelGGL((gemm_kernel<2, 128, false>), grid, dim3(256), 0, st, A, B, slices, (const float *)nullptr, M, N, R, lda, ldb,
                            N, chunk, (size_t)M * N, 0);
     return launch_reduce_slices(slices, C, M * N, nz, (size_t)M * N, accumulate, st);
+}
+
+// out = LayerNorm(res + drop(A W^T + bias)) * gamma + beta in one launch when the fused epilogue covers the shape
+// (N = 128, aligned operands); returns false without launching otherwise (the caller runs GEMM + add_ln_fwd).
+bool gemm_add_ln_ok(int M, int N, int K, int lda, int ldb) { return N == GBN && gemm_fast_ok(0, M, N, K, lda, ldb, N); }
+hipError_t launch_gemm_add_ln(const float *A, const float *W, const float *bias, const float *res, const float *gamma,
+                              const float *beta, float *s_out, float *stats, float *out, int M, int N, int K, int lda, int ldw,
+                              float eps, float keep_scale, uint32_t threshold, uint32_t seed, hipStream_t st) {
+    if (!gemm_add_ln_ok(M, N, K, lda, ldw)) return hipErrorInvalidValue;
+    const LnArgs ln{res, gamma, beta, s_out, stats, eps, keep_scale, seed, threshold};
+    const int ntiles = (M + 63) / 64;
+    hipLaunchKernelGGL(gemm_add_ln_kernel, dim3(std::min(ntiles, current_device_cus() * 4)), dim3(256), 0, st, A, W, out, bias, M, N, K,
+                       lda, ldw, ln);
+    return hipGetLastError();
 }
 
 // Batched weight gradients: dW_j[M_j][N_j] (+)= A_j[R][M_j]^T . B_j[R][N_j], j < n <= 4, one GEMM launch; the slice reductions go
