@@ -446,3 +446,8 @@ def test_random_configurations_match_oracle(oracle_lib, spec):
     ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if spec["adaptive"] else [None] * 3))
     assert np.isfinite(out).all()
     assert np.abs(out - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+    # and the same bits from a fresh engine whose workspace comes out of a 1e30-poisoned pool
+    del eng
+    _poison_allocator(1e30)
+    again = engine_from_numpy(cfg, sd, DEV).forward(_t(inp["pilots"]), *meta).cpu().numpy()
+    assert np.array_equal(again, out)
