@@ -110,22 +110,62 @@ constexpr int kAtTileFloats = 32 * kAtLd;
 
 struct StageRegs { f32x4 a[2], b[2]; float s0, s1; };
 
-// fetch tile `tile` of matrices A, B ([tokens][ld], already offset to the head's columns) and of the
-// per-row scalars s0, s1 (may be NULL) into registers; rows >= tokens read as zero
-__device__ __forceinline__ void stage_fetch(StageRegs &r, const float *__restrict__ A, int lda, const float *__restrict__ B,
-                                            int ldb, const float *__restrict__ s0, const float *__restrict__ s1, int tile,
-                                            int tokens, int tid) {
+// The fetch side of the staging: buffer resources of the two matrices ([tokens][ld], already offset to the head's
+// columns) and of the two per-row scalars (NULL -> a zero-length resource: reads return 0), and the lane's byte
+// offsets, computed ONCE per workgroup; a tile only adds a scalar offset.  (Round 2: per tile this was two 64-bit
+// multiply-adds, four selects and six compares per lane -- ~40 VALU instructions beside 32 MFMAs.)  The hardware range
+// check does not cover the scalar offset, so rows of the ragged last tile beyond `tokens` get an out-of-range lane
+// offset explicitly: they read as zero.
+using AtSrd = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kAtOutOfRange = 0x7ffffff0u;
+struct Stager {
+    AtSrd a, b, s0, s1;
+    unsigned va[2], vb[2], vs;   // lane byte offsets into a / b (two 16-byte elements per lane) and into the scalars
+    unsigned ta, tb;             // bytes per 32-row tile
+    int last_row[2];             // tokens - 1 - (row of element u): the element exists in tile t iff 32 t <= last_row
+    int last_s;
+};
+__device__ __forceinline__ AtSrd at_srd(const float *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ Stager make_stager(const float *A, int lda, const float *B, int ldb, const float *s0, const float *s1,
+                                              int tokens, int tid) {
+    Stager g;
+    g.a = at_srd(A, (unsigned)((tokens - 1) * lda + 32) * 4u);
+    g.b = at_srd(B, (unsigned)((tokens - 1) * ldb + 32) * 4u);
+    g.s0 = at_srd(s0, s0 ? (unsigned)tokens * 4u : 0u);
+    g.s1 = at_srd(s1, s1 ? (unsigned)tokens * 4u : 0u);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int e = tid + kAtThreads * u;   // vec4 index 0..255: row = e >> 3, quad = e & 7
-        const int row = e >> 3, q4 = e & 7, tok = tile * 32 + row;
-        const bool ok = e < 256 && tok < tokens;
-        r.a[u] = ok ? *reinterpret_cast<const f32x4 *>(A + (size_t)tok * lda + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        r.b[u] = ok ? *reinterpret_cast<const f32x4 *>(B + (size_t)tok * ldb + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int e = tid + kAtThreads * u, row = e >> 3, q4 = e & 7;   // vec4 index 0..255: row = e >> 3, quad = e & 7
+        g.va[u] = e < 256 ? (unsigned)(row * lda + 4 * q4) * 4u : kAtOutOfRange;
+        g.vb[u] = e < 256 ? (unsigned)(row * ldb + 4 * q4) * 4u : kAtOutOfRange;
+        g.last_row[u] = tokens - 1 - row;
     }
-    const int tok = tile * 32 + (tid & 31);
-    r.s0 = (s0 && tid < 32 && tok < tokens) ? s0[tok] : 0.f;
-    r.s1 = (s1 && tid < 32 && tok < tokens) ? s1[tok] : 0.f;
+    g.vs = tid < 32 ? (unsigned)tid * 4u : kAtOutOfRange;
+    g.last_s = tokens - 1 - (tid & 31);
+    g.ta = 32u * (unsigned)lda * 4u;
+    g.tb = 32u * (unsigned)ldb * 4u;
+    return g;
+}
+__device__ __forceinline__ f32x4 at_ld4(AtSrd r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float at_ld1(AtSrd r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+// fetch tile `tile` into registers; rows >= tokens read as zero
+__device__ __forceinline__ void stage_fetch(StageRegs &r, const Stager &g, int tile) {
+    const int t32 = tile * 32;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const bool in = t32 <= g.last_row[u];
+        r.a[u] = at_ld4(g.a, in ? g.va[u] : kAtOutOfRange, (unsigned)tile * g.ta);
+        r.b[u] = at_ld4(g.b, in ? g.vb[u] : kAtOutOfRange, (unsigned)tile * g.tb);
+    }
+    const unsigned vs = t32 <= g.last_s ? g.vs : kAtOutOfRange;
+    r.s0 = at_ld1(g.s0, vs, (unsigned)tile * 128u);
+    r.s1 = at_ld1(g.s1, vs, (unsigned)tile * 128u);
 }
 // buf: [A tile][B tile][s0 32][s1 32]
 __device__ __forceinline__ void stage_store(const StageRegs &r, float *__restrict__ buf, int tid) {
@@ -199,12 +239,13 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     if (a.threshold)
         for (int i = tid; i < a.ntiles * 32; i += kAtThreads) words[i] = drop_col_word(a.seed, (uint32_t)ph * a.tokens + i);
     StageRegs sr;
-    stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, 0, a.tokens, tid);
+    const Stager sg = make_stager(kb, ld, vb, ld, nullptr, nullptr, a.tokens, tid);
+    stage_fetch(sr, sg, 0);
     stage_store(sr, lds[0], tid);
     __syncthreads();
     for (int kt = 0; kt < a.ntiles; ++kt) {
         const float *buf = lds[kt & 1];
-        if (kt + 1 < a.ntiles) stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, kt + 1, a.tokens, tid);
+        if (kt + 1 < a.ntiles) stage_fetch(sr, sg, kt + 1);
         if (active) {
             float kf[16], vt[16];
             lds_rowfrag(buf, j, h, kf);
@@ -287,7 +328,8 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     if (a.threshold)
         for (int i = tid; i < a.ntiles * 32; i += kAtThreads) words[i] = drop_row_word(a.seed, (uint32_t)ph * a.tokens + min(i, a.tokens - 1));
     StageRegs sr;
-    stage_fetch(sr, qb, ld, dob, a.d, lse, dsum, 0, a.tokens, tid);
+    const Stager sg = make_stager(qb, ld, dob, a.d, lse, dsum, a.tokens, tid);
+    stage_fetch(sr, sg, 0);
     stage_store(sr, lds[0], tid);
     __syncthreads();
     for (int qt = 0; qt < a.ntiles; ++qt) {
@@ -334,7 +376,7 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
             dk = mma16(qT, ds, dk);
         }
         if (qt + 1 < a.ntiles) {   // fetched after the products: the 18 staging registers are not live across them
-            stage_fetch(sr, qb, ld, dob, a.d, lse, dsum, qt + 1, a.tokens, tid);
+            stage_fetch(sr, sg, qt + 1);
             stage_store(sr, lds[(qt + 1) & 1], tid);
         }
         __syncthreads();
@@ -369,12 +411,13 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     load_rowfrag(dob, a.d, active ? query : 0, a.tokens, h, 1.f, dof);
     f32x16 dq = zero16();
     StageRegs sr;
-    stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, 0, a.tokens, tid);
+    const Stager sg = make_stager(kb, ld, vb, ld, nullptr, nullptr, a.tokens, tid);
+    stage_fetch(sr, sg, 0);
     stage_store(sr, lds[0], tid);
     __syncthreads();
     for (int kt = 0; kt < a.ntiles; ++kt) {
         const float *buf = lds[kt & 1];
-        if (kt + 1 < a.ntiles) stage_fetch(sr, kb, ld, vb, ld, nullptr, nullptr, kt + 1, a.tokens, tid);
+        if (kt + 1 < a.ntiles) stage_fetch(sr, sg, kt + 1);
         if (active) {
             float kf[16], vf[16];
             lds_rowfrag(buf, j, h, kf);                                    // A operands: lane <-> key
