@@ -144,8 +144,13 @@ int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weigh
         STEP("norm1", launch_add_ln_fwd(x_in, o, w->norm1_w, w->norm1_b, tp + t.s1, tp + t.st1, tp + t.x1, rows, d, 1e-5f,
                                         dropout_p, site_seed(seed, 1), st));
     }
-    STEP("linear1", launch_gemm(0, tp + t.x1, w->lin1_w, tp + t.a, w->lin1_b, rows, ff, d, d, d, ff, false, st));
-    STEP("activation", launch_act_fwd(cfg->activation, tp + t.a, tp + t.hd, rows, ff, dropout_p, site_seed(seed, 2), st));
+    if (gemm_act_ok(rows, ff, d, d, d, ff)) {   // linear1 + activation + dropout: one launch
+        STEP("linear1 + activation", launch_gemm_act(tp + t.x1, w->lin1_w, w->lin1_b, tp + t.a, tp + t.hd, rows, ff, d, d, d, ff,
+                                                     cfg->activation, drop_ks, drop_th, site_seed(seed, 2), st));
+    } else {
+        STEP("linear1", launch_gemm(0, tp + t.x1, w->lin1_w, tp + t.a, w->lin1_b, rows, ff, d, d, d, ff, false, st));
+        STEP("activation", launch_act_fwd(cfg->activation, tp + t.a, tp + t.hd, rows, ff, dropout_p, site_seed(seed, 2), st));
+    }
     if (gemm_add_ln_ok(rows, d, ff, ff, ff)) {
         STEP("linear2 + norm2", launch_gemm_add_ln(tp + t.hd, w->lin2_w, w->lin2_b, tp + t.x1, w->norm2_w, w->norm2_b, tp + t.s2, tp + t.st2,
                                                    x_out, rows, d, ff, ff, ff, 1e-5f, drop_ks, drop_th, site_seed(seed, 3), st));

@@ -156,33 +156,6 @@ __device__ __forceinline__ void gemm_run(WRing<NT, PFS> &ring, Srd w, unsigned w
     }
 }
 
-// erf(x) = sign(x) * (1 - 2^p(|x|)), p = degree-8 fit of log2(erfc(t)) on [0,4] with p(0) = 0
-// (erfc(4) = 1.5e-8 rounds to 0 against 1 in fp32).  Branch-free; max |error| 1e-7 (<= 1 ulp of erf
-// near 1) against scipy.special.erf on 4e5 points -- libm erff cost ~40 VALU ops and a divergent
-// branch per element.  Two values at once: the polynomial runs on v_pk_fma_f32.
-template <int ACT>
-__device__ __forceinline__ f32x2 activate2(f32x2 v) {
-    if constexpr (ACT == AFT_ACT_GELU) {  // exact-erf GELU (F.gelu default, activation="gelu")
-        const f32x2 x = v * 0.70710678118654752440f;
-        const f32x2 t = {fminf(fabsf(x[0]), 4.0f), fminf(fabsf(x[1]), 4.0f)};
-        f32x2 p = {-4.535924745e-05f, -4.535924745e-05f};
-        p = __builtin_elementwise_fma(p, t, f32x2{4.455104063e-04f, 4.455104063e-04f});
-        p = __builtin_elementwise_fma(p, t, f32x2{-1.489443355e-03f, -1.489443355e-03f});
-        p = __builtin_elementwise_fma(p, t, f32x2{-7.746370393e-04f, -7.746370393e-04f});
-        p = __builtin_elementwise_fma(p, t, f32x2{2.825369500e-02f, 2.825369500e-02f});
-        p = __builtin_elementwise_fma(p, t, f32x2{-1.484816223e-01f, -1.484816223e-01f});
-        p = __builtin_elementwise_fma(p, t, f32x2{-9.184163809e-01f, -9.184163809e-01f});
-        p = __builtin_elementwise_fma(p, t, f32x2{-1.627908587e+00f, -1.627908587e+00f});
-        p = p * t;
-        const f32x2 e = {copysignf(1.0f - __builtin_amdgcn_exp2f(p[0]), x[0]),
-                         copysignf(1.0f - __builtin_amdgcn_exp2f(p[1]), x[1])};
-        const f32x2 hv = v * 0.5f;
-        return __builtin_elementwise_fma(hv, e, hv);
-    } else {  // ReLU (schemas.py:128-131 allows both)
-        return f32x2{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
-    }
-}
-
 // LayerNorm(eps = 1e-5, biased variance) over D features of the row this lane belongs to, given the
 // lane's 16 pre-norm values v (features fb + 8s + 4h + j).  Partial (mean, M2) of the wave's 32
 // features goes to `stats[row][wave]`; after the barrier every lane merges the W partials (Chan).

@@ -219,15 +219,32 @@ struct LnArgs {
 
 // (bx, by, bz, gx) stand for the block indices and the grid width: the batched weight-gradient launch maps its flat
 // block index onto several products
-template <int OP, int BM, bool LN = false>
+// Fused epilogue of linear1 (reference nn.TransformerEncoderLayer: linear2(dropout(activation(linear1(x))))):
+// C = A W^T + b is stored as the pre-activation the backward needs, and hd = drop(act(C)) goes out beside it --
+// replaces act_fwd_kernel and its re-read of C.  GELU is the exact-erf polynomial of the inference chain kernel.
+struct ActArgs {
+    float *hd;            // [M][N], leading dimension ldc
+    float keep_scale;
+    uint32_t seed, threshold;
+    int act;              // AFT_ACT_RELU / AFT_ACT_GELU
+};
+constexpr int kActMaxN = 512;   // columns whose dropout words fit the epilogue's LDS table
+
+constexpr int EPI_NONE = 0, EPI_LN = 1, EPI_ACT = 2;
+template <int OP, int BM, int EPI = EPI_NONE>
 __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*Bs)[GBK * GLD], const float *__restrict__ A,
                                                const float *__restrict__ B, float *__restrict__ C, const float *__restrict__ bias,
                                                int M, int N, int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
-                                               int accumulate, int bx, int by, int bz, int gx, const LnArgs *ln = nullptr) {
+                                               int accumulate, int bx, int by, int bz, int gx, const LnArgs *ln = nullptr,
+                                               const ActArgs *act = nullptr) {
+    constexpr bool LN = EPI == EPI_LN, ACT = EPI == EPI_ACT;
     __shared__ float ln_red[LN ? 2 * 64 * 2 : 1];
-    __shared__ __attribute__((aligned(16))) uint32_t ln_colw[LN ? GBN : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t ln_colw[LN ? GBN : ACT ? kActMaxN : 4];
     if constexpr (LN) {   // column words of the dropout mask, once per workgroup (published by the first tile's barrier)
         if (threadIdx.x < GBN) ln_colw[threadIdx.x] = dropmask_col_word(ln->seed, threadIdx.x);
+    }
+    if constexpr (ACT) {
+        for (int i = threadIdx.x; i < N; i += 256) ln_colw[i] = dropmask_col_word(act->seed, (uint32_t)i);
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -409,6 +426,35 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
                     ln->stats[2 * (size_t)row + 1] = rstd;
                 }
             }
+        } else if constexpr (ACT) {
+            static_assert(BM == 64, "the activation epilogue is written for 64-row tiles");
+            const int row = m0 + wm * 32 + j;
+            const uint32_t rw = dropmask_row_word(act->seed, (uint32_t)row);
+            const size_t rbase = (size_t)row * ldc + n0 + wn * 64 + 4 * h;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int col = n0 + wn * 64 + 32 * tj + 8 * s + 4 * h;
+                    if (row >= M || col >= N) continue;
+                    const f32x4 v = {acc[0][tj][4 * s], acc[0][tj][4 * s + 1], acc[0][tj][4 * s + 2], acc[0][tj][4 * s + 3]};
+                    *reinterpret_cast<f32x4 *>(C + rbase + 32 * tj + 8 * s) = v;
+                    f32x2 g0 = {v[0], v[1]}, g1 = {v[2], v[3]};
+                    if (act->act == AFT_ACT_GELU) {
+                        g0 = activate2<AFT_ACT_GELU>(g0);
+                        g1 = activate2<AFT_ACT_GELU>(g1);
+                    } else {
+                        g0 = activate2<AFT_ACT_RELU>(g0);
+                        g1 = activate2<AFT_ACT_RELU>(g1);
+                    }
+                    f32x4 y = {g0[0], g0[1], g1[0], g1[1]};
+                    if (act->threshold) {
+                        const u32x4g cw = *reinterpret_cast<const u32x4g *>(ln_colw + col);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) y[c] = dropmask_keep(rw, cw[c], act->threshold) ? y[c] * act->keep_scale : 0.f;
+                    }
+                    *reinterpret_cast<f32x4 *>(act->hd + rbase + 32 * tj + 8 * s) = y;
+                }
         } else {
         // epilogue: lane j owns row j of each 32-row tile; 16-byte stores along the row
         const bool full = m0 + BM <= M && n0 + GBN <= N;
@@ -451,7 +497,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                           int lda, int ldb, const LnArgs ln) {
     __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
-    gemm_fast_body<0, 64, true>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, N, K, (size_t)0, 0, (int)blockIdx.x, 0, 0, (int)gridDim.x, &ln);
+    gemm_fast_body<0, 64, EPI_LN>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, N, K, (size_t)0, 0, (int)blockIdx.x, 0, 0, (int)gridDim.x, &ln);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_act_kernel(
+    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, const float *__restrict__ bias, int M, int N, int K,
+    int lda, int ldb, int ldc, const ActArgs act) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    gemm_fast_body<0, 64, EPI_ACT>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0, 0, (int)blockIdx.x, 0, 0, (int)gridDim.x,
+                                   nullptr, &act);
 }
 
 // Several weight gradients dW_j = A_j^T B_j over the SAME token rows in one launch (the four of an encoder layer): with
@@ -693,6 +748,18 @@ hipError_t launch_gemm_add_ln(const float *A, const float *W, const float *bias,
     const int ntiles = (M + 63) / 64;
     hipLaunchKernelGGL(gemm_add_ln_kernel, dim3(std::min(ntiles, current_device_cus() * 4)), dim3(256), 0, st, A, W, out, bias, M, N, K,
                        lda, ldw, ln);
+    return hipGetLastError();
+}
+
+// a = A W^T + bias (stored) and hd = drop(act(a)) in one launch when the fused epilogue covers the shape
+bool gemm_act_ok(int M, int N, int K, int lda, int ldb, int ldc) { return N <= kActMaxN && gemm_fast_ok(0, M, N, K, lda, ldb, ldc); }
+hipError_t launch_gemm_act(const float *A, const float *W, const float *bias, float *a_out, float *hd, int M, int N, int K, int lda,
+                           int ldw, int ldc, int activation, float keep_scale, uint32_t threshold, uint32_t seed, hipStream_t st) {
+    if (!gemm_act_ok(M, N, K, lda, ldw, ldc)) return hipErrorInvalidValue;
+    const ActArgs act{hd, keep_scale, seed, threshold, activation};
+    const int ntiles = ((N + GBN - 1) / GBN) * ((M + 63) / 64);
+    hipLaunchKernelGGL(gemm_act_kernel, dim3(std::min(ntiles, current_device_cus() * 4)), dim3(256), 0, st, A, W, a_out, bias, M, N, K, lda,
+                       ldw, ldc, act);
     return hipGetLastError();
 }
 
