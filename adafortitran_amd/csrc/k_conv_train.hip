@@ -126,41 +126,65 @@ __global__ __launch_bounds__(256) void wgrad32x8_kernel(const Wgrad32x8Args a) {
 }
 
 // result[a][tap] = sum_p A8[a][p] * B1[p + sign * (tap - 1)],  A8 [planes][8][T][S], B1 [planes][S][T]
-// one thread per pixel (row fastest), 72 accumulators, one slice per workgroup
+// One thread per pixel position (row fastest) of kWg81Planes consecutive planes: the 72 accumulators run over the
+// planes in registers and meet in ONE wave reduction per workgroup (round 1 reduced after every single plane: 72 x 6
+// cross-lane steps per pixel were the whole 40 us of this kernel); one slice per workgroup.
+constexpr int kWg81Planes = 8;
 __global__ __launch_bounds__(256) void wgrad8x1_kernel(const float *__restrict__ A8, const float *__restrict__ B1,
                                                        float *__restrict__ slices, int planes, int S, int T, int sign) {
-    __shared__ float part[4][72];
-    const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;   // p = t * S + s
+    __shared__ float red[4 * 36 * 65];
+    const int p = blockIdx.x * 256 + threadIdx.x;   // p = t * S + s
+    const int n0 = blockIdx.y * kWg81Planes, n1 = min(planes, n0 + kWg81Planes);
     float acc[72];
 #pragma unroll
     for (int q = 0; q < 72; ++q) acc[q] = 0.f;
     if (p < S * T) {
         const int t = p / S, s = p - t * S;
-        float win[9];
+        int woff[9];   // offset of the tap's pixel inside a B1 plane, -1 = outside (zero padding)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ss = s + sign * (tap / 3 - 1), tt = t + sign * (tap % 3 - 1);
-            win[tap] = ss >= 0 && ss < S && tt >= 0 && tt < T ? B1[((size_t)n * S + ss) * T + tt] : 0.f;
+            woff[tap] = ss >= 0 && ss < S && tt >= 0 && tt < T ? ss * T + tt : -1;
         }
+#pragma unroll 4
+        for (int n = n0; n < n1; ++n) {
+            const float *bp = B1 + (size_t)n * S * T;
+            float win[9], av[8];
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            const float av = A8[((size_t)(n * 8 + ch) * T + t) * S + s];
+            for (int tap = 0; tap < 9; ++tap) win[tap] = woff[tap] >= 0 ? bp[woff[tap]] : 0.f;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) acc[ch * 9 + tap] = av * win[tap];
+            for (int ch = 0; ch < 8; ++ch) av[ch] = A8[((size_t)(n * 8 + ch) * T + t) * S + s];
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc[ch * 9 + tap] = fmaf(av[ch], win[tap], acc[ch * 9 + tap]);
         }
     }
+    // the 256 threads' partials meet through LDS, 36 outputs at a time: thread q < 36 adds its row of 4 x 64 values
+    // (72 x 6 cross-lane steps per wave were as slow as everything else in this kernel together)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int q = 0; q < 72; ++q) {
-        float v = acc[q];
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) part[wave][q] = v;
+        for (int q = 0; q < 36; ++q) red[(wave * 36 + q) * 65 + lane] = acc[36 * half + q];
+        __syncthreads();
+        if (threadIdx.x < 36) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float *r = red + (w * 36 + threadIdx.x) * 65;
+#pragma unroll 4
+                for (int l = 0; l < 64; l += 4) {
+                    s0 += r[l];
+                    s1 += r[l + 1];
+                    s2 += r[l + 2];
+                    s3 += r[l + 3];
+                }
+            }
+            slices[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 72 + 36 * half + threadIdx.x] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < 72)
-        slices[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 72 + threadIdx.x] =
-            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // per-channel sums of X [planes][C][npix] (bias gradients): one workgroup per (plane, channel),
@@ -205,10 +229,11 @@ hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, c
     hipLaunchKernelGGL(wgrad32x8_kernel, dim3(grid), dim3(256), lds, st, w3);
     if ((e = launch_reduce_slices(sl3, dw[2], 2304, grid, 2304, accumulate, st)) != hipSuccess) return e;
     // conv1: dW1[co][tap] = sum g1[co][p] x[p + (tap-1)];  conv4: dW4[ci][tap] = sum a3[ci][p'] dy[p' - (tap-1)]
-    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, planes), dim3(256), 0, st, g1, x, sl1, planes, S, T, +1);
-    if ((e = launch_reduce_slices(sl1, dw[0], 72, planes * pblocks, 72, accumulate, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, planes), dim3(256), 0, st, c3, dy, sl4, planes, S, T, -1);
-    if ((e = launch_reduce_slices(sl4, dw[3], 72, planes * pblocks, 72, accumulate, st)) != hipSuccess) return e;
+    const int pchunks = (planes + kWg81Planes - 1) / kWg81Planes;
+    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, pchunks), dim3(256), 0, st, g1, x, sl1, planes, S, T, +1);
+    if ((e = launch_reduce_slices(sl1, dw[0], 72, pchunks * pblocks, 72, accumulate, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, pchunks), dim3(256), 0, st, c3, dy, sl4, planes, S, T, -1);
+    if ((e = launch_reduce_slices(sl4, dw[3], 72, pchunks * pblocks, 72, accumulate, st)) != hipSuccess) return e;
     // biases: channel sums of the pre-activation gradients
     const float *gs[4] = {g1, g2, g3, dy};
     const int cs[4] = {8, 32, 8, 1};
