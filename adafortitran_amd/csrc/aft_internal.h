@@ -242,6 +242,8 @@ hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipS
 // ConvEnhancer training forward / backward-dgrad on plain planes (k_conv.hip) and its weight gradients (k_conv_train.hip)
 hipError_t launch_conv_train(const float *const w[4], const float *const b[4], const float *x, float *y, float *const save[3],
                              const float *const mask[3], int planes, int S, int T, hipStream_t st);
+constexpr int kConvFlipFloats = 72 + 2304 + 2304 + 72;   // conv4^T | conv3^T | conv2^T | conv1^T
+hipError_t launch_conv_flip_weights(const float *const w[4], float *dst, hipStream_t st);
 hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, const float *c3, const float *g1,
                              const float *g2, const float *g3, const float *dy, float *const dw[4], float *const db[4],
                              float *slices, int planes, int S, int T, bool accumulate, hipStream_t st);

@@ -260,7 +260,8 @@ int aft_dense_bwd_f32(const float *x, const float *weight, const float *dy, floa
 
 size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols) {
     if (planes <= 0 || num_scs <= 0 || num_symbols <= 0 || !conv_plan_ok(num_scs, num_symbols, 0)) return 0;
-    return sizeof(float) * (al64((size_t)planes * 48 * num_scs * num_symbols) + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols)));
+    return sizeof(float) * (al64((size_t)planes * 48 * num_scs * num_symbols) + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols)) +
+                            al64(kConvFlipFloats));
 }
 
 int aft_conv_enhancer_fwd_train_f32(const float *const weights[4], const float *const biases[4], const float *x, float *y,
@@ -275,11 +276,11 @@ int aft_conv_enhancer_fwd_train_f32(const float *const weights[4], const float *
     return AFT_OK;
 }
 
-int aft_conv_enhancer_bwd_f32(const float *const flipped_weights[4], const float *x, const float *c1, const float *c2,
+int aft_conv_enhancer_bwd_f32(const float *const weights[4], const float *x, const float *c1, const float *c2,
                               const float *c3, const float *dy, float *dx, float *const dweights[4], float *const dbiases[4],
                               int accumulate, void *scratch, size_t scratch_bytes, int planes, int num_scs, int num_symbols,
                               void *stream) {
-    if (!flipped_weights || !x || !c1 || !c2 || !c3 || !dy || !dx || !dweights || !dbiases || !scratch || planes <= 0) {
+    if (!weights || !x || !c1 || !c2 || !c3 || !dy || !dx || !dweights || !dbiases || !scratch || planes <= 0) {
         set_error("bad ConvEnhancer argument");
         return AFT_ERR_ARG;
     }
@@ -291,8 +292,11 @@ int aft_conv_enhancer_bwd_f32(const float *const flipped_weights[4], const float
     const size_t plane8 = (size_t)planes * 8 * num_scs * num_symbols;
     float *g3 = static_cast<float *>(scratch), *g2 = g3 + plane8, *g1 = g2 + 4 * plane8;
     float *slices = static_cast<float *>(scratch) + al64(6 * plane8);
+    float *flip = slices + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols));
     // dgrad: the stack run on dy with conv4^T (1->8), conv3^T (8->32), conv2^T (32->8), conv1^T (8->1);
     // stage outputs masked by the saved activations = g3, g2, g1
+    STEP("conv weight transposition", launch_conv_flip_weights(weights, flip, st));
+    const float *const flipped_weights[4] = {flip, flip + 72, flip + 72 + 2304, flip + 72 + 4608};
     float *const save[3] = {g3, g2, g1};
     const float *const mask[3] = {c3, c2, c1};
     STEP("conv dgrad", launch_conv_train(flipped_weights, nullptr, dy, dx, save, mask, planes, num_scs, num_symbols, st));

@@ -202,6 +202,32 @@ __global__ __launch_bounds__(256) void chsum_kernel(const float *__restrict__ X,
     if (threadIdx.x == 0) slices[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// The data gradient of the stack is the stack itself run on dy with the transposed, flipped weights
+// (conv4^T 1->8, conv3^T 8->32, conv2^T 32->8, conv1^T 8->1):  dst_k[ci][co][ky][kx] = w_{3-k}[co][ci][2-ky][2-kx].
+// All four in one launch (4 801 weights; PyTorch's transpose + flip + contiguous were sixteen launches per stack).
+struct FlipArgs {
+    const float *w[4];   // conv1 .. conv4 weights [Co][Ci][3][3]
+    float *dst;          // kConvFlipFloats floats: conv4^T | conv3^T | conv2^T | conv1^T
+};
+__global__ __launch_bounds__(256) void conv_flip_weights_kernel(const FlipArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kConvFlipFloats) return;
+    // destination block, source tensor and its (Co, Ci)
+    int k, off;
+    if (i < 72) { k = 3; off = 0; }
+    else if (i < 72 + 2304) { k = 2; off = 72; }
+    else if (i < 72 + 4608) { k = 1; off = 72 + 2304; }
+    else { k = 0; off = 72 + 4608; }
+    const int co_n = k == 0 ? 8 : k == 1 ? 32 : k == 2 ? 8 : 1, ci_n = k == 0 ? 1 : k == 1 ? 8 : k == 2 ? 32 : 8;
+    const int r = i - off, tap = r % 9, co = (r / 9) % co_n, ci = r / (9 * co_n);   // dst index = (ci * Co + co) * 9 + tap
+    a.dst[i] = a.w[k][(co * ci_n + ci) * 9 + (8 - tap)];                            // (2-ky)*3 + (2-kx) = 8 - tap
+}
+hipError_t launch_conv_flip_weights(const float *const w[4], float *dst, hipStream_t st) {
+    FlipArgs a{{w[0], w[1], w[2], w[3]}, dst};
+    hipLaunchKernelGGL(conv_flip_weights_kernel, dim3((kConvFlipFloats + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 size_t conv_wgrad_slice_floats(int planes, int S, int T) {   // all eight reductions keep their slices until one launch
     return 2 * (size_t)kWgradSlices * 2304 + 2 * (size_t)planes * ((S * T + 255) / 256) * 72 + (size_t)planes * 64;
 }

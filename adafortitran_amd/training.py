@@ -133,13 +133,12 @@ class HipConvEnhancerFunction(torch.autograd.Function):
         x, c1, c2, c3, *ws = ctx.saved_tensors
         n, _, S, T = x.shape
         dy = dy.contiguous()
-        flipped = [w.transpose(0, 1).flip(2, 3).contiguous() for w in reversed(ws)]   # conv4^T .. conv1^T
         objs = ctx.param_objs
         direct = direct_grad_ok(objs)
         grads = [p.grad for p in objs] if direct else [torch.empty_like(p) for p in objs]
         dx = torch.empty_like(x)
         scratch = torch.empty(lib.aft_conv_enhancer_scratch_bytes(n, S, T), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.aft_conv_enhancer_bwd_f32(C.byref(_ptr4(flipped)), x.data_ptr(), c1.data_ptr(), c2.data_ptr(),
+        _lib.check(lib.aft_conv_enhancer_bwd_f32(C.byref(_ptr4(ws)), x.data_ptr(), c1.data_ptr(), c2.data_ptr(),
                                                  c3.data_ptr(), dy.data_ptr(), dx.data_ptr(), C.byref(_ptr4(grads[0::2])),
                                                  C.byref(_ptr4(grads[1::2])), int(direct), scratch.data_ptr(), scratch.numel(),
                                                  n, S, T, _lib.current_stream_ptr(x.device)))

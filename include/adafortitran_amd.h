@@ -183,12 +183,12 @@ int aft_conv_enhancer_fwd_train_f32(const float *const weights[4], const float *
                                     float *c1, float *c2, float *c3, int planes, int num_scs, int num_symbols, void *stream);
 
 /* Backward of that call: dy = dL/dy -> dx = dL/dx and the eight parameter gradients (PyTorch layouts;
- * overwritten, or added to when accumulate != 0).  flipped_weights[k] must hold
- * weights[3-k].transpose(0,1).flip(2,3) made contiguous ([8,1,3,3], [32,8,3,3], [8,32,3,3], [1,8,3,3]):
- * the data gradient of the stack is the stack itself run on dy with those.
+ * overwritten, or added to when accumulate != 0).  weights[k] are the module's conv weights as in the forward call:
+ * the data gradient of the stack is the stack itself run on dy with weights[3-k].transpose(0,1).flip(2,3), which the
+ * call lays out in its scratch (one small kernel).
  * aft_conv_enhancer_scratch_bytes returns 0 for a grid the fused kernel has no LDS band plan for. */
 size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols);
-int aft_conv_enhancer_bwd_f32(const float *const flipped_weights[4], const float *x, const float *c1, const float *c2,
+int aft_conv_enhancer_bwd_f32(const float *const weights[4], const float *x, const float *c1, const float *c2,
                               const float *c3, const float *dy, float *dx, float *const dweights[4], float *const dbiases[4],
                               int accumulate, void *scratch, size_t scratch_bytes, int planes, int num_scs, int num_symbols,
                               void *stream);
