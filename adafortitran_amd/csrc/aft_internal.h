@@ -218,8 +218,11 @@ hipError_t launch_gemm_act(const float *A, const float *W, const float *bias, fl
                            int ldw, int ldc, int activation, float keep_scale, uint32_t threshold, uint32_t seed, hipStream_t st);
 // up to four weight gradients over the same R token rows in ONE GEMM launch; slices[j] holds gemm_tn_slice_floats(M[j], N[j], R)
 // floats (the batch never uses more slices than the single launches)
+// colsum_out[j] != NULL: also db_j[M_j] (+)= column sums of A_j (the bias gradient beside dW_j), slices in colsum_slices[j]
+// (colsum_slices(R) * M_j floats: enough for the batched path and for the fallback's launch_colsum)
 hipError_t launch_gemm_tn_batch(const float *const *A, const float *const *B, float *const *C, float *const *slices, const int *M,
-                                const int *N, const int *lda, const int *ldb, int n, int R, bool accumulate, hipStream_t st);
+                                const int *N, const int *lda, const int *ldb, int n, int R, bool accumulate, hipStream_t st,
+                                float *const *colsum_out = nullptr, float *const *colsum_slices = nullptr);
 hipError_t launch_colsum(const float *x, float *out, float *slices, int rows, int n, int ld, bool accumulate, hipStream_t st);
 hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, size_t stride, bool accumulate, hipStream_t st);
 hipError_t launch_reduce_slices3(const float *slices, float *out0, float *out1, float *out2, int n, int nout, int nz,

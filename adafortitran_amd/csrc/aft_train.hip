@@ -206,13 +206,13 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     STEP("out_proj dgrad", launch_gemm(1, g2b, w->out_proj_w, g1, nullptr, rows, d, d, d, d, d, false, st));
     STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,
                                                 dropout_p, site_seed(seed, 0), st));
-    STEP("in_proj bgrad", launch_colsum(dqkv, g->in_proj_b, sl_bq, rows, 3 * d, 3 * d, acc, st));
     STEP("in_proj dgrad", launch_gemm(1, dqkv, w->in_proj_w, dx_in, nullptr, rows, d, 3 * d, 3 * d, d, d, true, st));
     {   // the layer's four weight gradients in one launch: dW2 = g2^T hd, dW1 = gff^T x1, dWo = g2b^T attn, dWqkv = dqkv^T x_in
         const float *A[4] = {g2, gff, g2b, dqkv}, *B[4] = {hd, tp + t.x1, tp + t.attn, x_in};
         float *C[4] = {g->lin2_w, g->lin1_w, g->out_proj_w, g->in_proj_w}, *S[4] = {sl_w2, sl_w1, sl_wo, sl_wq};
         const int M[4] = {d, ff, d, 3 * d}, N[4] = {ff, d, d, d}, lda[4] = {d, ff, d, 3 * d}, ldb[4] = {ff, d, d, d};
-        STEP("weight gradients", launch_gemm_tn_batch(A, B, C, S, M, N, lda, ldb, 4, rows, acc, st));
+        float *bias_out[4] = {nullptr, nullptr, nullptr, g->in_proj_b}, *bias_sl[4] = {nullptr, nullptr, nullptr, sl_bq};   // db_qkv = dqkv^T 1
+        STEP("weight gradients", launch_gemm_tn_batch(A, B, C, S, M, N, lda, ldb, 4, rows, acc, st, bias_out, bias_sl));
     }
     STEP("gradient reductions", reductions.flush(st));
     return AFT_OK;

@@ -231,12 +231,15 @@ struct ActArgs {
 constexpr int kActMaxN = 512;   // columns whose dropout words fit the epilogue's LDS table
 
 constexpr int EPI_NONE = 0, EPI_LN = 1, EPI_ACT = 2;
-template <int OP, int BM, int EPI = EPI_NONE>
+// CSUM (TN only): also the column sums of A over this block's rows (db = A^T 1, the bias gradient that goes with
+// dW = A^T B): each lane adds up the A fragments it feeds to the matrix cores anyway, one VALU add per two MFMAs.
+template <int OP, int BM, int EPI = EPI_NONE, bool CSUM = false>
 __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*Bs)[GBK * GLD], const float *__restrict__ A,
                                                const float *__restrict__ B, float *__restrict__ C, const float *__restrict__ bias,
                                                int M, int N, int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
                                                int accumulate, int bx, int by, int bz, int gx, const LnArgs *ln = nullptr,
-                                               const ActArgs *act = nullptr) {
+                                               const ActArgs *act = nullptr, float *csum_out = nullptr) {
+    static_assert(!CSUM || OP == 2, "column sums ride on the TN product");
     constexpr bool LN = EPI == EPI_LN, ACT = EPI == EPI_ACT;
     __shared__ float ln_red[LN ? 2 * 64 * 2 : 1];
     __shared__ __attribute__((aligned(16))) uint32_t ln_colw[LN ? GBN : ACT ? kActMaxN : 4];
@@ -329,6 +332,11 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
         const int next = tile + tstep;
         int m1 = 0, n1 = 0;
         if (next < ntiles) origin(next, m1, n1);
+        float asum[CSUM ? TI : 1];
+        if constexpr (CSUM) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) asum[ti] = 0.f;
+        }
         // LayerNorm epilogue: the residual rows are requested now, a whole k loop ahead of their use
         f32x4 ln_res[LN ? 2 : 1][LN ? 4 : 1];
         if constexpr (LN) {
@@ -359,6 +367,7 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
                     const float av = as[2 * kb * GLD + 32 * ti];
                     acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av, acc[ti][0], 0, 0, 0);
                     acc[ti][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, av, acc[ti][1], 0, 0, 0);
+                    if constexpr (CSUM) asum[ti] += av;
                 }
             }
             if (it + 1 < nsteps) {
@@ -474,6 +483,16 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
                 }
         }
         }
+        if constexpr (CSUM) {   // the n-tile-0 workgroup's left column of waves holds every A column of its m tile once
+            if (bx == 0 && wn == 0 && csum_out != nullptr) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const float v = asum[ti] + __shfl_xor(asum[ti], 32);   // the two k parities
+                    const int m = m0 + wm * (BM / 2) + ti * 32 + j;
+                    if (h == 0 && m < M) csum_out[m] = v;
+                }
+            }
+        }
         __syncthreads();   // every wave is done with the LDS buffers before the next tile restages buffer 0
         tile = next;
         m0 = m1;
@@ -517,6 +536,7 @@ constexpr int kTnBatchMax = 4;
 struct TnBatchJob {
     const float *A, *B;
     float *slices;
+    float *csum_slices;   // [nz][M] column sums of A per row slice (NULL: not wanted)
     int M, N, lda, ldb, tiles_n, blocks_per_slice, first_block;
 };
 struct TnBatch {
@@ -530,8 +550,13 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(const TnBatch q) {
     while (jb + 1 < q.njobs && (int)blockIdx.x >= q.job[jb + 1].first_block) ++jb;
     const TnBatchJob &t = q.job[jb];
     const int local = blockIdx.x - t.first_block, z = local / t.blocks_per_slice, tile = local % t.blocks_per_slice;
-    gemm_fast_body<2, 128>(As, Bs, t.A, t.B, t.slices, nullptr, t.M, t.N, q.R, t.lda, t.ldb, t.N, q.chunk, (size_t)t.M * t.N, 0,
-                           tile % t.tiles_n, tile / t.tiles_n, z, 1);
+    if (t.csum_slices != nullptr)
+        gemm_fast_body<2, 128, EPI_NONE, true>(As, Bs, t.A, t.B, t.slices, nullptr, t.M, t.N, q.R, t.lda, t.ldb, t.N, q.chunk,
+                                               (size_t)t.M * t.N, 0, tile % t.tiles_n, tile / t.tiles_n, z, 1, nullptr, nullptr,
+                                               t.csum_slices + (size_t)z * t.M);
+    else
+        gemm_fast_body<2, 128>(As, Bs, t.A, t.B, t.slices, nullptr, t.M, t.N, q.R, t.lda, t.ldb, t.N, q.chunk, (size_t)t.M * t.N, 0,
+                               tile % t.tiles_n, tile / t.tiles_n, z, 1);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_z slices[z * stride + i].  64 columns per workgroup, the
@@ -767,12 +792,15 @@ hipError_t launch_gemm_act(const float *A, const float *W, const float *bias, fl
 // through launch_reduce_slices as usual (queued when a ReduceBatchScope is alive).  Falls back to one launch per product
 // when a shape is not on the aligned path.
 hipError_t launch_gemm_tn_batch(const float *const *A, const float *const *B, float *const *C, float *const *slices, const int *M,
-                                const int *N, const int *lda, const int *ldb, int n, int R, bool accumulate, hipStream_t st) {
+                                const int *N, const int *lda, const int *ldb, int n, int R, bool accumulate, hipStream_t st,
+                                float *const *colsum_out, float *const *colsum_slices) {
     bool fast = n >= 1 && n <= kTnBatchMax;
     for (int j = 0; j < n && fast; ++j) fast = gemm_fast_ok(2, M[j], N[j], R, lda[j], ldb[j], N[j]);
     if (!fast) {
         for (int j = 0; j < n; ++j) {
             hipError_t e = launch_gemm_tn(A[j], B[j], C[j], slices[j], M[j], N[j], R, lda[j], ldb[j], accumulate, st);
+            if (e == hipSuccess && colsum_out && colsum_out[j])
+                e = launch_colsum(A[j], colsum_out[j], colsum_slices[j], R, M[j], lda[j], accumulate, st);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
@@ -787,13 +815,17 @@ hipError_t launch_gemm_tn_batch(const float *const *A, const float *const *B, fl
     int blocks = 0;
     for (int j = 0; j < n; ++j) {
         const int tn = (N[j] + GBN - 1) / GBN, tm = (M[j] + GBM - 1) / GBM;
-        q.job[j] = TnBatchJob{A[j], B[j], slices[j], M[j], N[j], lda[j], ldb[j], tn, tn * tm, blocks};
+        q.job[j] = TnBatchJob{A[j], B[j], slices[j], colsum_out && colsum_out[j] ? colsum_slices[j] : nullptr, M[j], N[j], lda[j], ldb[j], tn,
+                              tn * tm, blocks};
         blocks += tn * tm * q.nz;
     }
     hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(blocks), dim3(256), 0, st, q);
     hipError_t e = hipGetLastError();
-    for (int j = 0; j < n && e == hipSuccess; ++j)
+    for (int j = 0; j < n && e == hipSuccess; ++j) {
         e = launch_reduce_slices(slices[j], C[j], M[j] * N[j], q.nz, (size_t)M[j] * N[j], accumulate, st);
+        if (e == hipSuccess && colsum_out && colsum_out[j])
+            e = launch_reduce_slices(colsum_slices[j], colsum_out[j], M[j], q.nz, (size_t)M[j], accumulate, st);
+    }
     return e;
 }
 
