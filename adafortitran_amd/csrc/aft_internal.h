@@ -78,6 +78,31 @@ __device__ __forceinline__ f32x2 activate2(f32x2 v) {
     }
 }
 
+// d act(v) / dv for the same two activations (GELU: Phi(v) + v phi(v), Phi from the erf polynomial above)
+template <int ACT>
+__device__ __forceinline__ f32x2 activate2_grad(f32x2 v) {
+    if constexpr (ACT == AFT_ACT_GELU) {
+        const f32x2 x = v * 0.70710678118654752440f;
+        const f32x2 t = {fminf(fabsf(x[0]), 4.0f), fminf(fabsf(x[1]), 4.0f)};
+        f32x2 p = {-4.535924745e-05f, -4.535924745e-05f};
+        p = __builtin_elementwise_fma(p, t, f32x2{4.455104063e-04f, 4.455104063e-04f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-1.489443355e-03f, -1.489443355e-03f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-7.746370393e-04f, -7.746370393e-04f});
+        p = __builtin_elementwise_fma(p, t, f32x2{2.825369500e-02f, 2.825369500e-02f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-1.484816223e-01f, -1.484816223e-01f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-9.184163809e-01f, -9.184163809e-01f});
+        p = __builtin_elementwise_fma(p, t, f32x2{-1.627908587e+00f, -1.627908587e+00f});
+        p = p * t;
+        const f32x2 e = {copysignf(1.0f - __builtin_amdgcn_exp2f(p[0]), x[0]),
+                         copysignf(1.0f - __builtin_amdgcn_exp2f(p[1]), x[1])};
+        const f32x2 q = v * v * -0.72134752044448170368f;   // -v^2 / 2 in base 2
+        const f32x2 phi = {0.3989422804014327f * __builtin_amdgcn_exp2f(q[0]), 0.3989422804014327f * __builtin_amdgcn_exp2f(q[1])};
+        return __builtin_elementwise_fma(v, phi, __builtin_elementwise_fma(e, f32x2{0.5f, 0.5f}, f32x2{0.5f, 0.5f}));
+    } else {
+        return f32x2{v[0] > 0.f ? 1.f : 0.f, v[1] > 0.f ? 1.f : 0.f};
+    }
+}
+
 // Dropout masks of the training path (every site: attention probabilities, the two residual branches, the FFN hidden
 // layer).  A murmur-quality hash per element costs three quarter-rate 32-bit multiplies and ~10 more VALU instructions;
 // inside an MFMA kernel that is matrix time (the attention forward spent 70 % of a tile's MFMA time on it).  The mask is
@@ -216,6 +241,11 @@ hipError_t launch_gemm_add_ln(const float *A, const float *W, const float *bias,
 bool gemm_act_ok(int M, int N, int K, int lda, int ldb, int ldc);
 hipError_t launch_gemm_act(const float *A, const float *W, const float *bias, float *a_out, float *hd, int M, int N, int K, int lda,
                            int ldw, int ldc, int activation, float keep_scale, uint32_t threshold, uint32_t seed, hipStream_t st);
+// da = (dy W) o dropout mask o act'(a): the data gradient of linear2 with the activation backward as its epilogue
+// (W [K][N] row-major as launch_gemm op 1; a, da [M][N], leading dimension ldc; gemm_act_ok-style shapes, N <= 512)
+bool gemm_actbwd_ok(int M, int N, int K, int lda, int ldb, int ldc);
+hipError_t launch_gemm_actbwd(const float *dy, const float *W, const float *a, float *da, int M, int N, int K, int lda, int ldw,
+                              int ldc, int activation, float keep_scale, uint32_t threshold, uint32_t seed, hipStream_t st);
 // up to four weight gradients over the same R token rows in ONE GEMM launch; slices[j] holds gemm_tn_slice_floats(M[j], N[j], R)
 // floats (the batch never uses more slices than the single launches)
 // colsum_out[j] != NULL: also db_j[M_j] (+)= column sums of A_j (the bias gradient beside dW_j), slices in colsum_slices[j]

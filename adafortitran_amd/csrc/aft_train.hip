@@ -196,9 +196,19 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     // LN2: g1 = d(x1) through the residual, g2 = d(linear2 output) (dropout 3 applied)
     STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, g->lin2_b, sl_ln2,
                                     rows, d, dropout_p, site_seed(seed, 3), acc, st));
-    STEP("linear2 dgrad", launch_gemm(1, g2, w->lin2_w, gff, nullptr, rows, ff, d, d, ff, ff, false, st));
-    STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, g->lin1_b, sl_act, rows, ff, dropout_p, site_seed(seed, 2),
-                                          acc, st));
+    // linear2's data gradient with the activation backward as its epilogue (gff = d(linear1 output)); linear1's bias gradient
+    // then rides on the batched weight-gradient launch below (column sums of gff)
+    const uint32_t drop_th = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
+    const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const bool fused_act = gemm_actbwd_ok(rows, ff, d, d, ff, ff);
+    if (fused_act) {
+        STEP("linear2 dgrad + activation bwd", launch_gemm_actbwd(g2, w->lin2_w, tp + t.a, gff, rows, ff, d, d, ff, ff, cfg->activation,
+                                                                  drop_ks, drop_th, site_seed(seed, 2), st));
+    } else {
+        STEP("linear2 dgrad", launch_gemm(1, g2, w->lin2_w, gff, nullptr, rows, ff, d, d, ff, ff, false, st));
+        STEP("activation bwd", launch_act_bwd(cfg->activation, tp + t.a, gff, g->lin1_b, sl_act, rows, ff, dropout_p, site_seed(seed, 2),
+                                              acc, st));
+    }
     STEP("linear1 dgrad", launch_gemm(1, gff, w->lin1_w, g1, nullptr, rows, d, ff, ff, d, d, true, st));
     // LN1: dx_in = d(x_in) through the residual, g2b = d(out_proj output) (dropout 1 applied)
     STEP("norm1 bwd", launch_ln_bwd(g1, tp + t.s1, tp + t.st1, w->norm1_w, dx_in, g2b, g->norm1_w, g->norm1_b, g->out_proj_b, sl_ln1,
@@ -211,7 +221,8 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
         const float *A[4] = {g2, gff, g2b, dqkv}, *B[4] = {hd, tp + t.x1, tp + t.attn, x_in};
         float *C[4] = {g->lin2_w, g->lin1_w, g->out_proj_w, g->in_proj_w}, *S[4] = {sl_w2, sl_w1, sl_wo, sl_wq};
         const int M[4] = {d, ff, d, 3 * d}, N[4] = {ff, d, d, d}, lda[4] = {d, ff, d, 3 * d}, ldb[4] = {ff, d, d, d};
-        float *bias_out[4] = {nullptr, nullptr, nullptr, g->in_proj_b}, *bias_sl[4] = {nullptr, nullptr, nullptr, sl_bq};   // db_qkv = dqkv^T 1
+        float *bias_out[4] = {nullptr, fused_act ? g->lin1_b : nullptr, nullptr, g->in_proj_b};   // db1 = gff^T 1, db_qkv = dqkv^T 1
+        float *bias_sl[4] = {nullptr, sl_act, nullptr, sl_bq};
         STEP("weight gradients", launch_gemm_tn_batch(A, B, C, S, M, N, lda, ldb, 4, rows, acc, st, bias_out, bias_sl));
     }
     STEP("gradient reductions", reductions.flush(st));

@@ -230,7 +230,14 @@ struct ActArgs {
 };
 constexpr int kActMaxN = 512;   // columns whose dropout words fit the epilogue's LDS table
 
-constexpr int EPI_NONE = 0, EPI_LN = 1, EPI_ACT = 2;
+// ... and of linear2's data gradient: da = (dy W2) o mask/(1-p) o act'(a), the backward of that same site
+struct ActBwdArgs {
+    const float *a;       // pre-activations [M][N], leading dimension ldc
+    float keep_scale;
+    uint32_t seed, threshold;
+    int act;
+};
+constexpr int EPI_NONE = 0, EPI_LN = 1, EPI_ACT = 2, EPI_ACTBWD = 3;
 // CSUM (TN only): also the column sums of A over this block's rows (db = A^T 1, the bias gradient that goes with
 // dW = A^T B): each lane adds up the A fragments it feeds to the matrix cores anyway, one VALU add per two MFMAs.
 template <int OP, int BM, int EPI = EPI_NONE, bool CSUM = false>
@@ -238,16 +245,20 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
                                                const float *__restrict__ B, float *__restrict__ C, const float *__restrict__ bias,
                                                int M, int N, int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
                                                int accumulate, int bx, int by, int bz, int gx, const LnArgs *ln = nullptr,
-                                               const ActArgs *act = nullptr, float *csum_out = nullptr) {
+                                               const ActArgs *act = nullptr, float *csum_out = nullptr,
+                                               const ActBwdArgs *actb = nullptr) {
     static_assert(!CSUM || OP == 2, "column sums ride on the TN product");
-    constexpr bool LN = EPI == EPI_LN, ACT = EPI == EPI_ACT;
+    constexpr bool LN = EPI == EPI_LN, ACT = EPI == EPI_ACT, ACTB = EPI == EPI_ACTBWD;
     __shared__ float ln_red[LN ? 2 * 64 * 2 : 1];
-    __shared__ __attribute__((aligned(16))) uint32_t ln_colw[LN ? GBN : ACT ? kActMaxN : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t ln_colw[LN ? GBN : (ACT || ACTB) ? kActMaxN : 4];
     if constexpr (LN) {   // column words of the dropout mask, once per workgroup (published by the first tile's barrier)
         if (threadIdx.x < GBN) ln_colw[threadIdx.x] = dropmask_col_word(ln->seed, threadIdx.x);
     }
     if constexpr (ACT) {
         for (int i = threadIdx.x; i < N; i += 256) ln_colw[i] = dropmask_col_word(act->seed, (uint32_t)i);
+    }
+    if constexpr (ACTB) {
+        for (int i = threadIdx.x; i < N; i += 256) ln_colw[i] = dropmask_col_word(actb->seed, (uint32_t)i);
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -346,6 +357,17 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
             for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) ln_res[tj][s] = *reinterpret_cast<const f32x4 *>(rp + 32 * tj + 8 * s);
+        }
+        f32x4 a_pre[ACTB ? 2 : 1][ACTB ? 4 : 1];   // activation backward: the pre-activations, requested a k loop ahead
+        if constexpr (ACTB) {
+            const int row = min(m0 + wm * 32 + j, M - 1);
+            const float *ap = actb->a + (size_t)row * ldc + min(n0 + wn * 64 + 4 * h, N - 4);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    a_pre[tj][s] = n0 + wn * 64 + 4 * h + 32 * tj + 8 * s < N ? *reinterpret_cast<const f32x4 *>(ap + 32 * tj + 8 * s)
+                                                                               : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (nsteps > 0) stage(0);
         __syncthreads();
@@ -464,6 +486,35 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
                     }
                     *reinterpret_cast<f32x4 *>(act->hd + rbase + 32 * tj + 8 * s) = y;
                 }
+        } else if constexpr (ACTB) {
+            static_assert(BM == 64, "the activation-backward epilogue is written for 64-row tiles");
+            const int row = m0 + wm * 32 + j;
+            const uint32_t rw = dropmask_row_word(actb->seed, (uint32_t)row);
+            const size_t rbase = (size_t)row * ldc + n0 + wn * 64 + 4 * h;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int col = n0 + wn * 64 + 32 * tj + 8 * s + 4 * h;
+                    if (row >= M || col >= N) continue;
+                    const f32x4 av = a_pre[tj][s];
+                    f32x2 d0 = {av[0], av[1]}, d1 = {av[2], av[3]};
+                    if (actb->act == AFT_ACT_GELU) {
+                        d0 = activate2_grad<AFT_ACT_GELU>(d0);
+                        d1 = activate2_grad<AFT_ACT_GELU>(d1);
+                    } else {
+                        d0 = activate2_grad<AFT_ACT_RELU>(d0);
+                        d1 = activate2_grad<AFT_ACT_RELU>(d1);
+                    }
+                    f32x4 y = {acc[0][tj][4 * s] * d0[0], acc[0][tj][4 * s + 1] * d0[1], acc[0][tj][4 * s + 2] * d1[0],
+                               acc[0][tj][4 * s + 3] * d1[1]};
+                    if (actb->threshold) {
+                        const u32x4g cw = *reinterpret_cast<const u32x4g *>(ln_colw + col);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) y[c] = dropmask_keep(rw, cw[c], actb->threshold) ? y[c] * actb->keep_scale : 0.f;
+                    }
+                    *reinterpret_cast<f32x4 *>(C + rbase + 32 * tj + 8 * s) = y;
+                }
         } else {
         // epilogue: lane j owns row j of each 32-row tile; 16-byte stores along the row
         const bool full = m0 + BM <= M && n0 + GBN <= N;
@@ -526,6 +577,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
     gemm_fast_body<0, 64, EPI_ACT>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0, 0, (int)blockIdx.x, 0, 0, (int)gridDim.x,
                                    nullptr, &act);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_actbwd_kernel(
+    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+    const ActBwdArgs actb) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    gemm_fast_body<1, 64, EPI_ACTBWD>(As, Bs, A, B, C, nullptr, M, N, K, lda, ldb, ldc, K, (size_t)0, 0, (int)blockIdx.x, 0, 0,
+                                      (int)gridDim.x, nullptr, nullptr, nullptr, &actb);
 }
 
 // Several weight gradients dW_j = A_j^T B_j over the SAME token rows in one launch (the four of an encoder layer): with
@@ -785,6 +845,17 @@ hipError_t launch_gemm_act(const float *A, const float *W, const float *bias, fl
     const int ntiles = ((N + GBN - 1) / GBN) * ((M + 63) / 64);
     hipLaunchKernelGGL(gemm_act_kernel, dim3(std::min(ntiles, current_device_cus() * 4)), dim3(256), 0, st, A, W, a_out, bias, M, N, K, lda,
                        ldw, ldc, act);
+    return hipGetLastError();
+}
+
+bool gemm_actbwd_ok(int M, int N, int K, int lda, int ldb, int ldc) { return N <= kActMaxN && gemm_fast_ok(1, M, N, K, lda, ldb, ldc); }
+hipError_t launch_gemm_actbwd(const float *dy, const float *W, const float *a, float *da, int M, int N, int K, int lda, int ldw,
+                              int ldc, int activation, float keep_scale, uint32_t threshold, uint32_t seed, hipStream_t st) {
+    if (!gemm_actbwd_ok(M, N, K, lda, ldw, ldc)) return hipErrorInvalidValue;
+    const ActBwdArgs actb{a, keep_scale, seed, threshold, activation};
+    const int ntiles = ((N + GBN - 1) / GBN) * ((M + 63) / 64);
+    hipLaunchKernelGGL(gemm_actbwd_kernel, dim3(std::min(ntiles, current_device_cus() * 4)), dim3(256), 0, st, dy, W, da, M, N, K, lda, ldw,
+                       ldc, actb);
     return hipGetLastError();
 }
 
