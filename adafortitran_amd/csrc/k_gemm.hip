@@ -11,8 +11,12 @@
 //     TN  C[M][N] = A[K][M]^T . B[K][N]      K = token rows, split over blockIdx.z into partial
 //                                            slices that reduce_slices_kernel sums (deterministic)
 // Two kernels share the tiling below: gemm_kernel takes any shape (guarded, optionally element-wise loads);
-// gemm_fast_kernel takes the aligned shapes -- every GEMM of the encoder's training step -- with buffer-resource
+// gemm_fast_body takes the aligned shapes -- every GEMM of the encoder's training step -- with buffer-resource
 // loads, no address arithmetic in the k loop and a transposed accumulator whose epilogue is 16-byte row stores.
+// On that accumulator (a lane owns whole row pieces) ride the row-wise operations of the layer as epilogues:
+// residual + dropout + LayerNorm (gemm_add_ln_kernel), activation + dropout (gemm_act_kernel), activation backward
+// (gemm_actbwd_kernel); the four weight gradients of a layer run as one batched launch (gemm_tn_batch_kernel) that
+// also produces the bias gradients db = A^T 1 from the A fragments it loads.
 // Tiling: 128x128 (TN) or 64x128 (NT / NN) output tile per workgroup (4 waves, each 2x2 or 1x2 MFMA tiles), K step 16.  Both
 // operands are staged in LDS k-major ([k][m], row stride 132 floats) so that a fragment read is
 // 32 consecutive floats per half-wave -- conflict-free for A and B alike -- and the global->LDS
