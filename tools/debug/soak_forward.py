@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""2 000 forwards of the benchmark workload through the module surface (graph replay path): every output must be the
+same bits as the first, and device memory must not grow."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import adafortitran_amd as A
+sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
+mc = A.ModelConfig(model_type="adafortitran", patch_size=(3, 2), num_layers=6, model_dim=128, num_head=4, activation="gelu",
+                   max_seq_len=512, pos_encoding_type="learnable", device="cuda", dropout=0.1,
+                   channel_adaptivity_hidden_sizes=[7, 42, 560], adaptive_token_length=6)
+model = A.AdaFortiTranEstimator(sc, mc).eval()
+from adafortitran_amd import synth
+inp = synth.make_inputs(128, seed=3)
+pil = torch.from_numpy(inp["pilots"])
+meta = synth.meta_tuple(inp)
+with torch.no_grad():
+    ref = model(pil, meta).clone()
+    torch.cuda.synchronize()
+    m0 = torch.cuda.memory_allocated()
+    bad = 0
+    for i in range(2000):
+        out = model(pil, meta)
+        if i % 100 == 99:
+            bad += int(not torch.equal(torch.view_as_real(out), torch.view_as_real(ref)))
+    torch.cuda.synchronize()
+    print("mismatching checks:", bad, "memory growth (bytes):", torch.cuda.memory_allocated() - m0)
+    assert bad == 0
+print("FORWARD SOAK OK")
