@@ -8,10 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, Dict, Optional
 
-AFT_ABI_VERSION = 1
+AFT_ABI_VERSION = 2
 AFT_MAX_LAYERS = 32
 AFT_OK, AFT_ERR_ARG, AFT_ERR_SHAPE, AFT_ERR_HIP = 0, 1, 2, 3
 AFT_ACT_RELU, AFT_ACT_GELU = 0, 1
+AFT_ENCODER_AUTO, AFT_ENCODER_LAUNCHES, AFT_ENCODER_PLANE = 0, 1, 2
 
 _fp = C.c_void_p  # const float* -- kept untyped so torch data_ptr() ints and numpy ptrs both fit
 
@@ -23,7 +24,7 @@ class AftConfig(C.Structure):
         ("patch_scs", C.c_int32), ("patch_symbols", C.c_int32),
         ("num_layers", C.c_int32), ("model_dim", C.c_int32), ("num_head", C.c_int32),
         ("activation", C.c_int32), ("adaptive", C.c_int32),
-        ("hidden", C.c_int32 * 3), ("reserved", C.c_int32 * 2),
+        ("hidden", C.c_int32 * 3), ("encoder_path", C.c_int32), ("reserved", C.c_int32),
     ]
 
     @property
@@ -142,4 +143,4 @@ EXPORTED_SYMBOLS = (
 #: size queries (return size_t, not a status code)
 SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
                 "aft_conv_enhancer_scratch_bytes", "aft_dense_bwd_scratch_bytes")
-KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6}
+KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6, "encoder_plane": 7}

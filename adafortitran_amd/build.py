@@ -14,7 +14,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ("aft_api.hip", "aft_train.hip", "k_chain.hip", "k_attn.hip", "k_conv.hip", "k_misc.hip", "k_gemm.hip",
+SOURCES = ("aft_api.hip", "aft_train.hip", "k_chain.hip", "k_attn.hip", "k_encoder.hip", "k_conv.hip", "k_misc.hip", "k_gemm.hip",
            "k_attn_train.hip", "k_train.hip", "k_conv_train.hip")
 LIB = os.path.join(CSRC, "libaft_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -22,8 +22,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 
 def _deps(src: str):
-    return [os.path.join(CSRC, src), os.path.join(CSRC, "aft_internal.h"),
-            os.path.join(CSRC, "..", "..", "include", "adafortitran_amd.h")]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
+    return [os.path.join(CSRC, src), *headers, os.path.join(CSRC, "..", "..", "include", "adafortitran_amd.h")]
 
 
 DIAG = False  # --diag: -DAFT_DIAG_STAMPS (in-kernel phase stamps; never for the product build)

@@ -2,6 +2,7 @@
 // the launch sequence of one forward.  No allocation, no synchronisation, no per-call state: besides a
 // thread-local error string the only things cached are per-device facts (CU count, LDS function
 // attribute) in tables indexed by device ordinal (hipGraph-capturable, re-entrant per stream).
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -110,7 +111,8 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     ws.conv_enhanced = off; off += align64((size_t)ws.planes * c.num_scs * c.num_symbols);
     ws.tokens6 = off;       off += align64((size_t)batch * ws.tokens * 6);
     ws.x = off;             off += align64(rows * c.model_dim);
-    ws.attn = off;          off += align64((size_t)round_up((int)rows, kTile) * c.model_dim);
+    // attention tiles: global 32-row tiles (layer-by-layer path) or ceil(tokens/32) tiles per plane (plane-resident path)
+    ws.attn = off;          off += align64(std::max((size_t)round_up((int)rows, kTile), (size_t)ws.planes * ws.tokpad) * c.model_dim);
     const size_t per_head = (size_t)ws.planes * c.num_head * ws.tokpad * kHeadDim;
     ws.q = off;             off += align64(per_head);
     ws.k = off;             off += align64(per_head);
@@ -138,6 +140,15 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
     // weights arrive in torch layout on every call (stateless ABI): re-lay them into fragment order
     e = launch_pack_weights(c, w, wp + first_layer * pl, first_layer, last_layer - first_layer + 1, st);
     if (e != hipSuccess) return hip_fail("pack_weights", e);
+    // whole forward and the caller asks for it: ONE launch for the encoder (k_encoder.hip).  AUTO means the launches:
+    // measured on the MI355X at B = 128 (256 planes on 256 CUs, its best case) the plane-resident kernel is 1.5 % slower
+    // (profiles/r03_ab_encoder.json), so nothing selects it by itself.
+    if (fused && c.encoder_path == AFT_ENCODER_PLANE && first_layer == 0 && last_layer == c.num_layers - 1 &&
+        encoder_plane_ok(c)) {
+        e = launch_encoder_plane(c, w, wp, base + ws.conv_enhanced, c.adaptive ? base + ws.tokens6 : nullptr, x, attn, q, k, vt,
+                                 base + ws.out6, ws.planes, ws.tokens, ws.tokpad, st);
+        return e == hipSuccess ? AFT_OK : hip_fail("encoder(plane-resident)", e);
+    }
     // in-projection of the first layer (QKV-only pass of the chain kernel)
     ChainFusion first{}, last{};
     if (fused) {
@@ -360,6 +371,12 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                                  ws.tokens, ws.tokpad, st, &f);
                 break;
             }
+            case AFT_KERNEL_ENCODER_PLANE:
+                AFT_REQUIRE(cfg->model_dim == 128, "the plane-resident encoder is instantiated for model_dim 128");
+                e = launch_encoder_plane(*cfg, *w, base + ws.wpack, base + ws.conv_enhanced,
+                                         cfg->adaptive ? base + ws.tokens6 : nullptr, x, attn, q, k, vt, base + ws.out6,
+                                         ws.planes, ws.tokens, ws.tokpad, st);
+                break;
             case AFT_KERNEL_TAIL:
                 AFT_REQUIRE(out != nullptr, "tail profile needs an output buffer");
                 e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6);

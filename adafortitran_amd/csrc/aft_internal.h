@@ -187,6 +187,12 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *mlp_w, con
                         float *q, float *k, float *vt, int rows, int tokens, int tokpad, hipStream_t st,
                         const ChainFusion *fuse = nullptr);
 size_t packed_layer_floats(int d);
+// Plane-resident encoder (k_encoder.hip): embedding + all layers + linear_2 of every plane in ONE launch, one 12-wave
+// workgroup per plane.  encoder_plane_ok: the shape is instantiated (d = 128).
+bool encoder_plane_ok(const aft_config &c);
+hipError_t launch_encoder_plane(const aft_config &c, const aft_weights &w, const float *wpack, const float *conv_enhanced,
+                                const float *tokens6, float *x, float *attn, float *q, float *k, float *vt, float *out6,
+                                int planes, int tokens, int tokpad, hipStream_t st);
 // Re-lay the encoder GEMM weights of layers [first, first+count) into MFMA-fragment order.
 hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float *packed, int first_layer, int count,
                                hipStream_t st);

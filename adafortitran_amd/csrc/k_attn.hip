@@ -1,312 +1,28 @@
-// k_attn.hip -- multi-head self-attention core on gfx950 fp32 MFMA.
-//
-// Reference semantics: the scaled-dot-product part of nn.MultiheadAttention inside
-// nn.TransformerEncoderLayer (constructed at reference src/models/blocks/encoders.py:44-55):
-// per (plane, head): P = softmax(Q K^T / sqrt(dh)) over keys, O = P V, no mask, eval mode
-// (attention dropout = identity); heads are contiguous 32-wide column slices of the packed
-// in-projection.  q/k/vt come from k_chain.hip's QKV epilogue.
-//
-// MI355X mapping
-//   * one WAVE owns one (plane, head, 32-query tile) task end to end; no LDS, no barriers:
-//     at 64 cycles per v_mfma_f32_32x32x2_f32 the matrix pipe needs only 16 operand bytes per
-//     lane per 256 cycles, which L1/L2 deliver directly (K and V^T of one head = 72 KB, hot in
-//     the XCD's L2 for all 9 query tiles of that head).  q/k/vt are stored by the producer in
-//     fragment order, so each operand load is 1 KB contiguous per wave (16 TA accesses, not 64).
-//   * "swapped" products so the softmax row lives in ONE lane:  S^T = K Q^T  (A = K tile,
-//     B = Q^T) leaves lane (q, h) holding 16 of the 32 keys of query q per tile -> row max /
-//     row sum are register reductions + one cross-half exchange; then O^T = V^T P^T takes the
-//     probability registers *as they are* for the B operand (register r of half h is key
-//     8*(r>>2) + (r&3) + 4h, which is exactly the k index lane half h must supply when the
-//     A operand is loaded as V^T[d][8g + 4h + j]) -- P never moves between lanes or to LDS.
-//   * online softmax over chunks of CH key tiles (exact running max / sum in fp32); logits are
-//     pre-scaled by log2(e)/sqrt(dh) through Q so the exponential is a bare v_exp_f32.
-//   * tokens = 280 is 8.75 tiles: keys 280..287 are masked to -inf / V^T columns zeroed in
-//     registers, query rows >= tokens are computed and dropped at the store.
-#include <math.h>
-
+// k_attn.hip -- launcher of the attention kernel (device code: attn_device.h).
 #include <algorithm>
 #include <cstdio>
-#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
-#include "aft_internal.h"
+#include "attn_device.h"
 
 namespace aft {
 
-// Buffer-resource loads (SRD + 32-bit byte offset): with several waves per SIMD streaming operands,
-// global_load's 64-bit per-lane addressing throttles the fp32 MFMA stream (tools/micro/mfma_feed2.hip:
-// 104 vs 149 TFLOP/s at 3 workgroups/CU); buffer_load does not.
-using Srd = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ Srd make_srd(const float *p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ f32x4 srd_load(Srd r, unsigned byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
-}
-__device__ __forceinline__ void srd_store(Srd r, unsigned byte_off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, byte_off, 0, 0);
-}
-
-#ifndef AFT_ATTN_WAVES
-#define AFT_ATTN_WAVES 3   // waves per SIMD the register budget is capped for (and the persistent grid sized to)
-#endif
-
-// Growth of a row's maximum (in log2 units) over the reference that is tolerated before the accumulators are rescaled:
-// the probabilities are exp2(s - m_ref) with a STALE reference m_ref, so they may reach 2^kRescaleThreshold instead
-// of 1.  In fp32 that costs no precision (only the exponent moves); 2^64 x 1120 keys x |v| is far from overflow.
-constexpr float kRescaleThreshold = 64.0f;
-// |row maximum| of the first key tile below which a wave keeps the reference at ZERO for all its rows (no subtraction
-// at all); trained encoders live here (|logit| of a few units)
-constexpr float kZeroRefThreshold = 32.0f;
-
-__device__ __forceinline__ float other_half(float x) {   // value held by lane (l ^ 32): v_permlane32_swap
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
-}
-
-__device__ __forceinline__ float max16(const f32x16 &v) {   // 8 x v_max3_f32
-    float m = __builtin_fmaxf(v[0], v[1]);
-#pragma unroll
-    for (int e = 2; e < 16; e += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, v[e]), v[e + 1]);
-    return m;
-}
-
-// S^T tile = K tile . Q^T - m_ref: 16 MFMAs on one accumulator that starts from the inline constant 0.  A non-zero
-// reference enters as ONE more MFMA of the same chain (A = 1 on the k = 0 half, B = -m_ref of the lane's query), so
-// no register tuple of initial values and no copies are needed; `zero_ref` (wave-uniform) skips it.
-__device__ __forceinline__ f32x16 qk_tile(const f32x4 (&kreg)[4], const f32x4 (&qreg)[4], bool zero_ref, float a_one,
-                                          float neg_m) {
-    f32x16 c;
-    if (zero_ref) {
-        c = mfma_f32(kreg[0][0], qreg[0][0], f32x16{0});
-    } else {
-        c = mfma_f32(a_one, neg_m, f32x16{0});
-        c = mfma_f32(kreg[0][0], qreg[0][0], c);
-    }
-#pragma unroll
-    for (int i = 1; i < 16; ++i) c = mfma_f32(kreg[i >> 2][i & 3], qreg[i >> 2][i & 3], c);
-    return c;
-}
-
-struct AttnRow {          // per-lane softmax state of the lane's query row
-    float m_ref;          // reference maximum (log2 units); logits are produced as s - m_ref
-    f32x2 lsum2;          // partial row sums of this lane's 16 keys per tile (two interleaved chains)
-    f32x16 oacc;          // O^T accumulator
-    bool zero_ref;        // wave-uniform: m_ref == 0 in every lane
-};
-
-// launch bound (256, 3): <= 168 registers keeps accumulators in VGPRs (the MFMA's VGPR form) --
-// with the default 512-register budget hipcc parks them in AGPRs and pays ~2.5 v_accvgpr moves
-// per MFMA around the softmax, which on the fp32 matrix path comes straight out of MFMA time.
-//
-// Softmax with a stale reference maximum (round 2).  A VALU instruction costs 2.6-4.3 cycles of fp32-MFMA time
-// and v_exp_f32 8 (tools/micro/valu_cost.hip) and both kernels of the encoder are ALU-bound (MFMA + VALU cycles
-// fill ~95 % of the SIMD time), so the per-tile VALU work is cut to what the arithmetic needs:
-//   * m_ref = row maximum of the FIRST key tile (or 0 for the whole wave when all those maxima are small).  Every
-//     later tile comes out of its MFMA chain as S - m_ref, is exponentiated with a bare v_exp_f32 and summed in
-//     per-lane partial sums; no running-max update, no alpha, no O rescale, no register copies per tile.
-//   * one wave-uniform test per tile (8 x v_max3 + compare): only when some row's tile maximum exceeds m_ref by
-//     more than kRescaleThreshold are m_ref, O, the partial sums and the pending logits rescaled (exact: every
-//     factor is exp2 of the change of reference).  Rows that did not grow get a factor of 1.
-//   * QK^T of tile t+1 is issued before the exponentials of tile t; two named accumulators alternate roles
-//     (the loop is unrolled by two) so neither is ever copied.
-//   * the next task's Q / K tile 0 / V tile 0 are requested during the last key tile of the current one.
+// launch bound (256, 3): <= 168 registers keeps accumulators in VGPRs, see attn_device.h
 template <int UNUSED>
 __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                       const float *__restrict__ vt, const float *__restrict__ qbias,
                                                       float *__restrict__ out, int heads, int tokens, int tokpad,
                                                       int model_dim,
                                                       float scale_log2e, int ntasks, unsigned long long *stamps) {
-    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const Srd qs = make_srd(q), ks = make_srd(k), vs = make_srd(vt), os = make_srd(out);
-    const int total_waves = gridDim.x * 4;
-    const int nkt = tokpad / kTile;
-    const int r = lane & 31, h = lane >> 5;
-    const bool ragged = (tokens & (kTile - 1)) != 0;   // last key tile holds padded keys
-    const float a_one = h == 0 ? 1.0f : 0.0f;           // A operand of the reference MFMA: 1 on the k = 0 half
     // XCD-aware task order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b and b+8 share an
     // L2.  Give each XCD a CONTIGUOUS range of tasks: the 9 query tiles of one (plane, head) then read their K / V^T
     // (72 KB) through ONE L2 instead of two or three.  A pure speed choice; any mapping is correct.
     int vblock = blockIdx.x;
     if ((gridDim.x & 7) == 0) vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-#ifdef AFT_DIAG_STAMPS
-#define ASTAMP(i) do { if (stamps && lane == 0) stamps[(size_t)task * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define ASTAMP(i) do { } while (0)
-#endif
-    // q, k, vt arrive in MFMA-fragment order from k_chain.hip: [ph][tile][s or g][lane][4] -> every
-    // operand load below is one fully coalesced 1-KB buffer_load_dwordx4 per wave
-    auto head_base = [&](int task) { return ((unsigned)(task / nkt) * tokpad * kHeadDim + lane * 4) * 4; };
-    auto load_tile = [&](Srd src, int kt, f32x4 (&dst)[4], unsigned base) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dst[s] = srd_load(src, base + (unsigned)(kt * 1024 + s * 256) * 4);
-    };
-    // padded keys of the ragged last tile: logits -> -inf (probability 0), V^T columns -> 0 (the workspace pad is
-    // never trusted: 0 x NaN would poison the row)
-    auto mask_logits = [&](f32x16 &sv, int kt) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            if (kt * kTile + (e & 3) + 8 * (e >> 2) + 4 * h >= tokens) sv[e] = -INFINITY;
-    };
-    auto mask_values = [&](f32x4 (&vv)[4], int kt) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (kt * kTile + 8 * g + 4 * h + j >= tokens) vv[g][j] = 0.f;
-    };
-
-  // wave priority by work left (set_progress_priority, aft_internal.h): keeps the waves of a SIMD abreast
-  const int rounds = (ntasks + total_waves - 1) / total_waves;
-  int round = 0;
-  int task = vblock * 4 + wave;
-  f32x4 qreg[4], kcur[4], vcur[4];
-  if (task < ntasks) {       // operands of the first task; later ones are requested during the previous task's last tile
-      const unsigned hb0 = head_base(task);
-      load_tile(qs, task % nkt, qreg, hb0);
-      load_tile(ks, 0, kcur, hb0);
-      load_tile(vs, 0, vcur, hb0);
-  }
-  for (; task < ntasks; task += total_waves, ++round) {
-    ASTAMP(0);
-#ifdef AFT_DIAG_STAMPS
-    if (stamps && lane == 0) stamps[(size_t)task * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-#endif
-    const int qt = task % nkt;
-    const int ph = task / nkt;  // plane * heads + head
-    const unsigned hb = head_base(task);   // byte offset of this (plane, head)
-    const int next_task = task + total_waves;
-    const bool has_next = next_task < ntasks;
-
-    // B operand of S^T = K Q^T : lane (q = r, h) holds Q[q][8s + 4h + j]; the query bias of the
-    // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
-    // a row constant to the logits, which softmax cancels), then everything is pre-scaled
-    const float *bq = qbias + (ph % heads) * kHeadDim + 4 * h;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
-    // Padded query lanes of the ragged last query tile read workspace nobody wrote: their results are never stored, but
-    // the reference tests below are wave-wide (__any), so a large stale value there would switch the VALID lanes of the
-    // wave onto the rescale path -- same mathematics, different rounding, i.e. output bits that depend on what the
-    // allocator handed out (found by a NaN / 1e30-poisoned pool, tools/debug/poison_repro.py).  Zero queries never trigger.
-    if (ragged && qt == nkt - 1 && qt * kTile + r >= tokens) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qreg[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    // ---- key tile 0: plain logits, reference maximum ----
-    AttnRow st;
-    f32x16 sA = qk_tile(kcur, qreg, true, a_one, 0.f), sB;
-    if (nkt > 1) load_tile(ks, 1, kcur, hb);
-    if (ragged && nkt == 1) { mask_logits(sA, 0); mask_values(vcur, 0); }
-    {
-        float m0 = max16(sA);
-        m0 = fmaxf(m0, other_half(m0));                  // finite: tile 0 holds >= 1 real key
-        st.zero_ref = !__any(fabsf(m0) > kZeroRefThreshold);
-        st.m_ref = st.zero_ref ? 0.f : m0;
-        if (!st.zero_ref) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sA[e] -= m0;
-        }
-    }
-    st.oacc = f32x16{0};
-    st.lsum2 = f32x2{0.f, 0.f};
-    ASTAMP(1);
-
-    // one key tile: `cur` holds S_kt - m_ref (its chain finished an iteration ago), `nxt` receives S_{kt+1} - m_ref.
-    // FAST (compile time) = the steady state: tiles kt+1 and kt+2 exist and are full, so there is no mask, no bounds
-    // test and no task hand-over in the body; the last two or three tiles of a task run the general form.
-    auto step = [&](auto fast, f32x16 &cur, f32x16 &nxt, int kt) {
-        constexpr bool FAST = decltype(fast)::value;
-        set_progress_priority((rounds - 1 - round) * nkt + (nkt - 1 - kt), rounds * nkt);
-        const bool more = FAST || kt + 1 < nkt;
-        if (more) {
-            nxt = qk_tile(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
-            if (FAST || kt + 2 < nkt) load_tile(ks, kt + 2, kcur, hb);
-        } else if (has_next) {      // last tile: Q and K are idle -> request the next task's
-            const unsigned hbn = head_base(next_task);
-            load_tile(qs, next_task % nkt, qreg, hbn);
-            load_tile(ks, 0, kcur, hbn);
-        }
-        // stale-reference test for THIS tile
-        const float tmax = max16(cur);
-        if (__builtin_expect(__any(tmax > kRescaleThreshold), 0)) {
-            const float tm = fmaxf(tmax, other_half(tmax));
-            const float grow = fmaxf(tm, 0.f);           // new reference = m_ref + grow  (0 for rows that stay)
-            const float f = __builtin_amdgcn_exp2f(-grow);
-            st.m_ref += grow;
-            st.zero_ref = false;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                cur[e] -= grow;
-                if (more) nxt[e] -= grow;                 // the pending tile was started from the old reference
-                st.oacc[e] *= f;
-            }
-            st.lsum2 *= f;
-        }
-        if (!FAST && ragged && more && kt + 2 == nkt) mask_logits(nxt, kt + 1);
-        // probabilities (bare v_exp_f32: logits are pre-scaled by log2 e) and per-lane partial row sums
-        f32x16 p;
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            p[e] = __builtin_amdgcn_exp2f(cur[e]);
-            p[e + 1] = __builtin_amdgcn_exp2f(cur[e + 1]);
-            st.lsum2 += f32x2{p[e], p[e + 1]};
-        }
-        // O^T += V^T P^T  (k-groups of 8 keys that are all padding -- only in the ragged last tile -- are skipped)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (!FAST && ragged && kt * kTile + 8 * g >= tokens) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                st.oacc = mfma_f32(vcur[g][j], p[4 * g + j], st.oacc);
-        }
-        if (more) {
-            load_tile(vs, kt + 1, vcur, hb);
-            if (!FAST && ragged && kt + 2 == nkt) mask_values(vcur, kt + 1);
-        } else if (has_next) {
-            load_tile(vs, 0, vcur, head_base(next_task));
-        }
-    };
-    using Fast = std::integral_constant<bool, true>;
-    using General = std::integral_constant<bool, false>;
-    int kt = 0;
-#pragma unroll 1
-    for (; kt + 3 < nkt; kt += 2) {       // both steps see tiles kt+1 .. kt+3 in range
-        step(Fast{}, sA, sB, kt);
-        step(Fast{}, sB, sA, kt + 1);
-    }
-    step(General{}, sA, sB, kt);           // the last two or three tiles (nkt - kt is 2 or 3; 1 when nkt == 1)
-    if (kt + 1 < nkt) step(General{}, sB, sA, kt + 1);
-    if (kt + 2 < nkt) step(General{}, sA, sB, kt + 2);
-    ASTAMP(2);
-    ASTAMP(3);
-
-    // O^T accumulator: lane = query r, register e = feature d = (e&3) + 8*(e>>2) + 4h -- i.e. registers
-    // 4s..4s+3 are the operand-fragment element (s, h) of this head's feature block.  Stored in the
-    // fragment order k_chain.hip consumes: [global 32-row tile][head][s][lane = row%32 + 32h][4]
-    // (global rows = plane*tokens + q; a query tile straddles two row tiles when 32 does not divide tokens).
-    float l_run = st.lsum2[0] + st.lsum2[1];
-    l_run += other_half(l_run);
-    const int qrow = qt * kTile + r;
-    if (qrow < tokens) {
-        const float inv = 1.0f / l_run;
-        const int plane = ph / heads, head = ph % heads;
-        const unsigned grow = (unsigned)plane * tokens + qrow;
-        const unsigned dst = (((grow >> 5) * (unsigned)(model_dim / kHeadDim) + head) * 1024 + ((grow & 31) + 32 * h) * 4) * 4;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o = {st.oacc[4 * g] * inv, st.oacc[4 * g + 1] * inv, st.oacc[4 * g + 2] * inv, st.oacc[4 * g + 3] * inv};
-            srd_store(os, dst + g * 1024, o);
-        }
-    }
-    ASTAMP(4);
-#ifdef AFT_DIAG_STAMPS
-    if (stamps && lane == 0) stamps[(size_t)task * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-#endif
-  }
+    attn_body(q, k, vt, qbias, out, heads, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, gridDim.x * 4, ntasks,
+              stamps);
 }
 
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,

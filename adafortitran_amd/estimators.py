@@ -40,30 +40,35 @@ from .training import HipLinear
 
 
 class _InputStager:
-    """The model-owned H2D copy of ``forward`` (reference fortitran.py:167-173) for the HIP inference path:
-    pilots + the three condition vectors of a batch (25 KB at B=128) are packed into ONE pinned host
-    buffer and moved with ONE asynchronous copy on the caller's stream, instead of four pageable
-    ``.to(device)`` copies that each end in a stream synchronisation -- the host keeps running ahead of
-    the device exactly as it does when the inputs are already resident.  A small ring of pinned buffers,
-    each guarded by an event, makes re-use safe; the device side is stream-ordered."""
+    """The model-owned H2D copy of ``forward`` (reference fortitran.py:167-173) on a HIP device: pilots + the three
+    condition vectors of a batch (25 KB at B=128) are packed into ONE pinned host buffer and moved with ONE
+    asynchronous copy on the caller's current stream of the MODEL's device, instead of four pageable ``.to(device)``
+    copies that each end in a stream synchronisation -- the host keeps running ahead of the device exactly as it
+    does when the inputs are already resident.
+
+    Safety: the pinned ring slot is guarded by an event recorded ON THE COPY'S STREAM (the model's device need not be
+    the current device); the device side of every call is its own allocation from torch's caching allocator, which
+    re-uses a block only in stream order of the stream it was allocated on -- so forwards issued from different
+    streams never share a staging buffer (a shared one was only stream-ordered, i.e. a race across streams)."""
 
     SLOTS = 4
 
     def __init__(self, device: torch.device) -> None:
         self.device = device
         self.nbytes = 0
-        self.host, self.events, self.dev = [], [], None
+        self.host, self.events = [], []
         self.turn = 0
 
     def _resize(self, nbytes: int) -> None:
+        for ev in self.events:
+            if ev is not None:
+                ev.synchronize()                         # copies still reading the old, smaller ring
         self.nbytes = max(nbytes, 4096)
         self.host = [torch.empty(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
         self.events = [None] * self.SLOTS
-        self.dev = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
 
-    def stage(self, pilots: Optional[torch.Tensor], conds: Optional[List[torch.Tensor]], fresh: bool = False):
-        """Either part may be None (already on the device).  ``fresh``: the device copy gets its own allocation instead of
-        the stager's buffer -- training saves these tensors for the backward pass, which may run after the next forward."""
+    def stage(self, pilots: Optional[torch.Tensor], conds: Optional[List[torch.Tensor]]):
+        """Either part may be None (already on the device)."""
         B = pilots.shape[0] if pilots is not None else conds[0].numel()
         pil_bytes = pilots.numel() * 8 if pilots is not None else 0
         off = (pil_bytes + 15) // 16 * 16
@@ -80,11 +85,13 @@ class _InputStager:
         if conds is not None:
             for i, c in enumerate(conds):
                 host[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32).copy_(c.reshape(-1))
-        dev = torch.empty(total, dtype=torch.uint8, device=self.device) if fresh else self.dev
-        dev[:total].copy_(host[:total], non_blocking=True)
-        ev = self.events[slot] or torch.cuda.Event()
-        ev.record()
-        self.events[slot] = ev
+        with torch.cuda.device(self.device):         # events and the copy belong to the model's device, current or not
+            stream = torch.cuda.current_stream(self.device)
+            dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+            dev.copy_(host[:total], non_blocking=True)
+            ev = self.events[slot] or torch.cuda.Event()
+            ev.record(stream)
+            self.events[slot] = ev
         pil_dev = dev[:pil_bytes].view(torch.complex64).view(pilots.shape) if pilots is not None else None
         if conds is None:
             return pil_dev, None
@@ -265,8 +272,7 @@ class BaseFortiTranEstimator(nn.Module):
         if dev.type == "cuda" and (pil_cpu or cond_cpu):
             if self._stager is None or self._stager.device != dev:
                 self._stager = _InputStager(dev)
-            pil, conds = self._stager.stage(pilot_symbols if pil_cpu else None, conditions if cond_cpu else None,
-                                            fresh=torch.is_grad_enabled())
+            pil, conds = self._stager.stage(pilot_symbols if pil_cpu else None, conditions if cond_cpu else None)
             if pil is None:
                 pil = pilot_symbols.to(self.device)
             if conds is not None:   # keep each condition's [B, 1] / [B] shape

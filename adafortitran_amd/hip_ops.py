@@ -5,6 +5,7 @@ csrc/*.hip.  Nothing in this module falls back to PyTorch math.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -55,6 +56,12 @@ class HipEngine:
                 raise ValueError(f"{k}: HIP path needs contiguous float32 (got {v.dtype})")
             self._keep[k] = v
         self.weights = _abi.make_weights(cfg, lambda k: self._keep[k].data_ptr(), pos_key=_abi.pos_key_of(self._keep))
+        # tuning knob for A/B runs (tools/ab_kernels.py, bench.py): AFT_ENCODER_PATH=launches|plane overrides the automatic
+        # choice between the layer-by-layer launches and the plane-resident encoder kernel (same output bits either way)
+        forced = os.environ.get("AFT_ENCODER_PATH", "")
+        if forced:
+            cfg.encoder_path = {"auto": _abi.AFT_ENCODER_AUTO, "launches": _abi.AFT_ENCODER_LAUNCHES,
+                                "plane": _abi.AFT_ENCODER_PLANE}[forced]
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
 

@@ -82,10 +82,13 @@ def extract_pilots_host(h_ls_sparse: np.ndarray, pilot_size: Tuple[int, int]) ->
 class PackedLoader:
     """Iterates a packed folder in file order (``shuffle=False`` as in the reference's test loaders,
     dataset.py:254-260) and yields reference-format batches.  On a HIP device the pilots are gathered
-    by the GPU kernel and both pilots and targets stay on the device."""
+    by the GPU kernel and both pilots and targets stay on the device.  There the reference's "Expected 24 pilot values,
+    got 25" ValueError (dataset.py:128-132) is raised ONE BATCH LATE (the counts come back asynchronously): when the
+    next batch is requested, or when the iterator is exhausted or closed -- never silently dropped."""
 
     def __init__(self, packed: Union[str, Path, Dict[str, np.ndarray]], pilot_size: Tuple[int, int], batch_size: int,
-                 device: Union[str, torch.device] = "cpu", pin_memory: bool = True) -> None:
+                 device: Union[str, torch.device] = "cpu", pin_memory: bool = True,
+                 max_pinned_bytes: int = 8 << 30) -> None:
         if not isinstance(packed, dict):
             z = np.load(packed, allow_pickle=False)
             packed = {k: z[k] for k in z.files}
@@ -97,10 +100,21 @@ class PackedLoader:
         # HIP device: the two grids a batch needs are pinned once, so that every batch is two asynchronous copies and the
         # host never waits for the device inside the sweep (a pageable .to(device) is a synchronisation point: with it
         # the "sync-free" evaluation sweep of evaluation.py ran no faster than the reference's .item()-per-batch loop)
+        # (the grids are held ONCE: the pinned copies replace the pageable arrays in self.p; packs above
+        # ``max_pinned_bytes`` -- page-locked memory is a scarce host resource -- stay pageable and every batch goes
+        # through a small pinned ring instead)
         self._pinned = None
+        self._stage_ring = None
         if self.device.type == "cuda" and pin_memory:
-            self._pinned = (torch.from_numpy(np.ascontiguousarray(packed["h_ideal"])).pin_memory(),
-                            torch.from_numpy(np.ascontiguousarray(packed["h_ls_sparse"])).pin_memory())
+            grids = [np.ascontiguousarray(packed[k]) for k in ("h_ideal", "h_ls_sparse")]
+            if sum(g.nbytes for g in grids) <= max_pinned_bytes:
+                self._pinned = tuple(torch.from_numpy(g).pin_memory() for g in grids)
+                self.p = dict(packed)
+                self.p["h_ideal"], self.p["h_ls_sparse"] = (t.numpy() for t in self._pinned)   # views of the pinned memory
+            else:
+                shape = (self.batch_size, *grids[0].shape[1:])
+                self._stage_ring = [(torch.empty(shape, dtype=torch.complex64).pin_memory(),
+                                     torch.empty(shape, dtype=torch.complex64).pin_memory(), None) for _ in range(3)]
 
     def __len__(self) -> int:
         return (self.n + self.batch_size - 1) // self.batch_size
@@ -124,12 +138,27 @@ class PackedLoader:
         side = torch.cuda.Stream(device=self.device)
         ring = [torch.empty(self.batch_size, dtype=torch.int32).pin_memory() for _ in range(3)]
 
+        ring_turn = [0]
+
         def copy(lo):
             hi = min(lo + self.batch_size, self.n)
             with torch.cuda.stream(side):
                 if self._pinned is not None:
                     ideal = self._pinned[0][lo:hi].to(self.device, non_blocking=True)
                     sparse = self._pinned[1][lo:hi].to(self.device, non_blocking=True)
+                elif self._stage_ring is not None:     # large pack: pageable -> pinned ring slot -> device, still async
+                    slot = ring_turn[0] % len(self._stage_ring)
+                    ring_turn[0] += 1
+                    h_i, h_s, busy = self._stage_ring[slot]
+                    if busy is not None:
+                        busy.synchronize()             # the copy that last read this slot (three batches ago)
+                    h_i[:hi - lo].copy_(torch.from_numpy(self.p["h_ideal"][lo:hi]))
+                    h_s[:hi - lo].copy_(torch.from_numpy(self.p["h_ls_sparse"][lo:hi]))
+                    ideal = h_i[:hi - lo].to(self.device, non_blocking=True)
+                    sparse = h_s[:hi - lo].to(self.device, non_blocking=True)
+                    busy = torch.cuda.Event()
+                    busy.record(side)
+                    self._stage_ring[slot] = (h_i, h_s, busy)
                 else:
                     ideal = torch.from_numpy(self.p["h_ideal"][lo:hi]).to(self.device)
                     sparse = torch.from_numpy(self.p["h_ls_sparse"][lo:hi]).to(self.device)
@@ -144,24 +173,30 @@ class PackedLoader:
         starts = list(range(0, self.n, self.batch_size))
         nxt = copy(starts[0]) if starts else None
         prev = None
-        for k in range(len(starts)):
-            ideal, sparse, ev, lo, hi = nxt
-            nxt = copy(starts[k + 1]) if k + 1 < len(starts) else None
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(ev)
-            ideal.record_stream(main)
-            sparse.record_stream(main)
-            pilots, counts = pilot_gather(sparse, self.pilot_size, return_counts=True)
-            host_counts = ring[k % 3][:hi - lo]
-            host_counts.copy_(counts, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(main)
+        try:
+            for k in range(len(starts)):
+                ideal, sparse, ev, lo, hi = nxt
+                nxt = copy(starts[k + 1]) if k + 1 < len(starts) else None
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(ev)
+                ideal.record_stream(main)
+                sparse.record_stream(main)
+                pilots, counts = pilot_gather(sparse, self.pilot_size, return_counts=True)
+                host_counts = ring[k % 3][:hi - lo]
+                host_counts.copy_(counts, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(main)
+                if prev is not None:
+                    pending, prev = prev, None
+                    settle(pending)
+                prev = (done, host_counts, lo)
+                yield pilots, ideal, self._meta(lo, hi)
+        finally:
+            # the count check of the last yielded batch is settled here -- also when the consumer stops iterating early
+            # (generator close): a bad pilot count is always reported, one batch late at most (module docstring of
+            # evaluation.py); GeneratorExit itself is not an error to convert
             if prev is not None:
                 settle(prev)
-            prev = (done, host_counts, lo)
-            yield pilots, ideal, self._meta(lo, hi)
-        if prev is not None:
-            settle(prev)
 
     def _meta(self, lo: int, hi: int) -> tuple:
         m = torch.from_numpy(self.p["meta"][lo:hi])

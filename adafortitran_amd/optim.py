@@ -29,11 +29,23 @@ same formula runs through torch ops, which is what the world_size-2 gloo tests e
 """
 from __future__ import annotations
 
+import itertools
 import weakref
 from typing import Iterable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+_TOKENS = itertools.count(1)
+_OWNERS: "weakref.WeakValueDictionary[int, FlatParameters]" = weakref.WeakValueDictionary()
+
+
+def flat_owner(p: torch.nn.Parameter) -> Optional["FlatParameters"]:
+    """The live FlatParameters that tagged ``p`` (None when there is none, or it was released / collected; a token that
+    arrived through pickle from another process matches nothing here)."""
+    tok = getattr(p, "_aft_flat_owner", None)
+    return _OWNERS.get(tok) if isinstance(tok, int) else None
 
 
 class FlatParameters:
@@ -60,13 +72,17 @@ class FlatParameters:
         self.data = torch.zeros(self.padded, dtype=dt, device=dev)
         self.grad = torch.zeros(self.padded, dtype=dt, device=dev)
         self.direct_accumulation = bool(direct_accumulation)
-        me = weakref.ref(self)
+        # the tag on a parameter is a plain integer token (picklable: Parameter.__reduce_ex__ pickles __dict__, and a
+        # weakref there made torch.save(model) / mp.spawn / DataLoader workers fail while an optimizer was alive);
+        # the token -> owner map lives on this side and holds the owner weakly
+        self.token = next(_TOKENS)
+        _OWNERS[self.token] = self
         for p, off in zip(self.params, self.offsets):
             n = p.numel()
             self.data[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.data[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
-            p._aft_flat_owner, p._aft_flat_off = me, off
+            p._aft_flat_owner, p._aft_flat_off = self.token, off
 
     def owns_grad(self, p: torch.nn.Parameter) -> bool:
         g = p.grad
@@ -76,8 +92,9 @@ class FlatParameters:
     def release(self) -> None:
         """Drop the tags (parameters and grads stay where they are)."""
         for p in self.params:
-            if getattr(p, "_aft_flat_owner", None) is not None and p._aft_flat_owner() is self:
+            if getattr(p, "_aft_flat_owner", None) == self.token:
                 p._aft_flat_owner = None
+        _OWNERS.pop(self.token, None)
 
     def zero_grad(self) -> None:
         """Keep the grad views alive (set_to_none would detach them from the flat buffer)."""
@@ -131,9 +148,15 @@ class ShardedFlatAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def reduce_gradients(self) -> None:
         """Average the flat gradient buffer over the ranks IN PLACE (one all-reduce), like DDP leaves ``.grad``:
-        call it after ``backward()`` and before ``scaler.unscale_`` / ``clip_grad_norm_`` / any inspection of
-        gradients when more than one rank trains (module docstring).  ``step()`` then skips its reduction."""
-        if self.distributed and not self._grads_reduced:
+        call it ONCE per step, after the LAST ``backward()`` (gradient accumulation included) and before
+        ``scaler.unscale_`` / ``clip_grad_norm_`` / any inspection of gradients when more than one rank trains (module
+        docstring).  ``step()`` then skips its reduction.  A second call before ``step()`` / ``zero_grad()`` raises."""
+        if self._grads_reduced:
+            # a second call would average a buffer that further backward() calls may have added rank-local gradients to
+            # (gradient accumulation): step() would then update with a mix of averaged and local gradients, silently
+            raise RuntimeError("reduce_gradients() was already called for this step: call it ONCE, after the last "
+                               "backward() of the step (gradient accumulation: accumulate first, reduce once)")
+        if self.distributed:
             dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
             if self.world > 1:
                 self.flat.grad.mul_(1.0 / self.world)
@@ -203,9 +226,10 @@ class ShardedFlatAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         """``torch.optim.Adam``-format state (``state[i] = {step, exp_avg, exp_avg_sq}`` per parameter in
-        ``param_groups[0]["params"]`` order + ``param_groups``), holding the moments of ALL ranks: with more
-        than one rank this is a collective (every rank calls it; each gets the full state, rank 0 writes it,
-        as the reference's single-process ``_save_checkpoint`` does).  Loads into ``torch.optim.Adam`` and
+        ``param_groups[0]["params"]`` order + ``param_groups``), holding the moments of ALL ranks.  WITH MORE THAN ONE
+        RANK THIS IS A COLLECTIVE: every rank must call it (each gets the full state; rank 0 writes the file).  The
+        reference's call pattern -- only the process that saves calls ``optimizer.state_dict()``
+        (``_save_checkpoint``, trainer.py:663-674) -- would hang in the all-gather; call it on all ranks and save on one.  Loads into ``torch.optim.Adam`` and
         into a ShardedFlatAdam of any world size."""
         m, v = self._full_moments()
         state = {}

@@ -23,20 +23,24 @@ import torch
 from . import _abi, _lib
 
 
+def flat_owner(p):
+    from .optim import flat_owner as _fo   # optim imports nothing from here; imported lazily to keep module load light
+    return _fo(p)
+
+
 def direct_grad_ok(params) -> bool:
     """True when EVERY tensor in ``params`` is owned by a live ``optim.FlatParameters`` that asked for direct
     accumulation and its ``.grad`` still is that owner's float32 view.  Then the backward adds the parameter
     gradients straight into those views and reports "no gradient" to autograd, which saves autograd's own
     accumulate kernel per parameter.  The behaviour is scoped to the tagged parameters of that optimizer (the
-    tag holds a weak reference and dies with the FlatParameters): models driven by any other optimizer, with
+    tag is an integer token that optim.py maps to its owner weakly: it dies with the FlatParameters): models driven by any other optimizer, with
     ``zero_grad(set_to_none=True)``, or whose ``.grad`` was re-pointed, get ordinary autograd gradients.
     ``FlatParameters(direct_accumulation=False)`` keeps autograd's AccumulateGrad path (needed for
     ``torch.autograd.grad``, ``backward(inputs=...)``, gradient hooks, torch DDP)."""
     for p in params:
         if p is None:
             continue
-        ref = getattr(p, "_aft_flat_owner", None)
-        owner = ref() if ref is not None else None
+        owner = flat_owner(p)
         if owner is None or not owner.direct_accumulation or not owner.owns_grad(p):
             return False
     return True

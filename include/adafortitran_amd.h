@@ -36,13 +36,21 @@
 extern "C" {
 #endif
 
-#define AFT_ABI_VERSION 1
+#define AFT_ABI_VERSION 2   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
 #define AFT_MAX_LAYERS 32
 
 #define AFT_OK 0
 #define AFT_ERR_ARG 1   /* NULL pointer, bad batch, workspace too small ...          */
 #define AFT_ERR_SHAPE 2 /* configuration the kernels do not cover                    */
 #define AFT_ERR_HIP 3   /* a HIP runtime call or kernel launch failed                */
+
+/* aft_config.encoder_path.  LAUNCHES: embedding+QKV, then [attention, chain] per layer (13 launches at 6 layers).
+ * PLANE: the plane-resident kernel -- embedding + all layers + linear_2 in ONE launch, one 12-wave workgroup per plane
+ * (model_dim 128 only; other shapes run the launches).  Identical output bits.  AUTO = LAUNCHES: on the MI355X the
+ * plane kernel measured 1.5 % slower even at its best case, 256 planes on 256 CUs (profiles/r03_ab_encoder.json). */
+#define AFT_ENCODER_AUTO 0
+#define AFT_ENCODER_LAUNCHES 1
+#define AFT_ENCODER_PLANE 2
 
 #define AFT_ACT_RELU 0
 #define AFT_ACT_GELU 1 /* exact erf form, as activation="gelu" in encoders.py:44-51 */
@@ -57,7 +65,8 @@ typedef struct aft_config {
     int32_t activation;               /* AFT_ACT_*                                   */
     int32_t adaptive;                 /* 1 = AdaFortiTran (adapter tokens), 0 = FortiTran */
     int32_t hidden[3];                /* channel_adaptivity_hidden_sizes (adaptive only) */
-    int32_t reserved[2];
+    int32_t encoder_path;             /* AFT_ENCODER_*: how aft_forward_f32 runs the encoder (same bits either way) */
+    int32_t reserved;
 } aft_config;
 
 /* One nn.TransformerEncoderLayer (post-LN), PyTorch layouts
@@ -246,6 +255,7 @@ int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float 
 #define AFT_KERNEL_CHAIN 4      /* chain kernel: out-proj+LN1+FFN+LN2 (layer 0) + QKV (layer 1) */
 #define AFT_KERNEL_TAIL 5       /* fold + residual + final ConvEnhancer (linear_2 done by AFT_KERNEL_CHAIN_LAST) */
 #define AFT_KERNEL_CHAIN_LAST 6 /* chain kernel of the last layer: out-proj+LN1+FFN+LN2 + linear_2             */
+#define AFT_KERNEL_ENCODER_PLANE 7 /* plane-resident encoder: embedding + all layers + linear_2 in one launch (k_encoder.hip) */
 int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int which, float *out,
                            void *workspace, size_t workspace_bytes, int batch, int reps, void *stream);
 

@@ -39,7 +39,8 @@ def test_loader_checks_version_and_host_only_calls():
     planes, tokens, tokpad, d = 256, 280, 288, 128
     # conv_enhanced + tokens6 + x + attn + q + k + vt + fragment-packed encoder weights (6 layers x 8 d^2)
     # + linear_2 output of the last chain launch (rows x 8)
-    expect = 4 * (planes * 1680 + 128 * tokens * 6 + 2 * planes * tokens * d + 3 * planes * 4 * tokpad * 32
+    # (the attention tiles are sized for per-plane row tiles, planes x tokpad rows: the plane-resident encoder's layout)
+    expect = 4 * (planes * 1680 + 128 * tokens * 6 + planes * tokens * d + planes * tokpad * d + 3 * planes * 4 * tokpad * 32
                   + 6 * 8 * d * d + planes * tokens * 8)
     assert expect <= nbytes <= expect + 8 * 256
     bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3))

@@ -451,3 +451,62 @@ def test_random_configurations_match_oracle(oracle_lib, spec):
     _poison_allocator(1e30)
     again = engine_from_numpy(cfg, sd, DEV).forward(_t(inp["pilots"]), *meta).cpu().numpy()
     assert np.array_equal(again, out)
+
+
+# ---- plane-resident encoder (k_encoder.hip): one launch for embedding + all layers + linear_2 ----
+def _with_path(eng, path):
+    eng.cfg.encoder_path = {"auto": _abi.AFT_ENCODER_AUTO, "launches": _abi.AFT_ENCODER_LAUNCHES,
+                            "plane": _abi.AFT_ENCODER_PLANE}[path]
+    return eng
+
+
+@pytest.mark.parametrize("name", DEFAULT_SETS)
+def test_plane_resident_encoder_matches_reference_golden(name):
+    """Forced plane-resident path on the reference-generated goldens (B = 8 -> 16 planes, one per workgroup)."""
+    g = Golden(name)
+    eng = _with_path(_engine(g), "plane")
+    out = eng.forward(_t(g["pilots"]), *_meta(g)).cpu().numpy()
+    ref = g["out"]
+    assert np.abs(out - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+    mse = np.mean(np.abs(out - g["target"]) ** 2)
+    assert abs(mse - g.meta["metric_2xmse"]) / g.meta["metric_2xmse"] <= TOL_HIP_MSE
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("batch", [1, 37, 128, 160])
+def test_plane_resident_encoder_matches_launch_path(adaptive, batch):
+    """Same device code, per-plane instead of global row tiles: the two encoder paths must give IDENTICAL bits.
+    160 frames = 320 planes: workgroups walk two planes (the plane loop and its LDS hand-over)."""
+    hid = (7, 42, 560) if adaptive else None
+    sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=4242, attn_gain=0.25 if adaptive else 32.0,
+                               head_gain=2.0)
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(batch, seed=99 + batch)
+    meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+    pil = _t(inp["pilots"])
+    a = _with_path(eng, "launches").forward(pil, *meta).clone()
+    b = _with_path(eng, "plane").forward(pil, *meta).clone()
+    assert torch.isfinite(torch.view_as_real(a)).all()
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+    c = _with_path(eng, "auto").forward(pil, *meta)
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(c))
+
+
+def test_plane_resident_encoder_ignores_stale_workspace():
+    """The plane path's ragged last row tile per plane reads workspace nobody wrote (rows 280..287 of the attention
+    tile, q pad rows): poison the workspace and demand the same bits."""
+    hid = (7, 42, 560)
+    sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=7)
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = _with_path(engine_from_numpy(cfg, sd, DEV), "plane")
+    inp = synth.make_inputs(16, seed=5)
+    meta = [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    pil = _t(inp["pilots"])
+    ref = eng.forward(pil, *meta).clone()
+    for poison in (float("nan"), 1e30, float("-inf")):
+        eng.workspace(16).view(torch.float32).fill_(poison)
+        out = eng.forward(pil, *meta)
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref)), poison
