@@ -130,7 +130,8 @@ def pos_key_of(state: Dict[str, object]) -> str:
 
 #: every symbol include/adafortitran_amd.h declares (tests check the .so exports them all)
 EXPORTED_SYMBOLS = (
-    "aft_version", "aft_last_error", "aft_check_config", "aft_workspace_bytes", "aft_forward_f32",
+    "aft_version", "aft_last_error", "aft_check_config", "aft_max_batch", "aft_workspace_bytes", "aft_forward_f32",
+    "aft_packed_weights_bytes", "aft_pack_weights_f32", "aft_forward_prepacked_f32",
     "aft_linear_forward_f32", "aft_mse_partial_f32", "aft_stage_upsample_f32",
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",
     "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",
@@ -141,6 +142,6 @@ EXPORTED_SYMBOLS = (
     "aft_adapter_fwd_train_f32", "aft_adapter_bwd_f32",
 )
 #: size queries (return size_t, not a status code)
-SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
+SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_packed_weights_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
                 "aft_conv_enhancer_scratch_bytes", "aft_dense_bwd_scratch_bytes")
 KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6, "encoder_plane": 7}

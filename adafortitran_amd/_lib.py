@@ -47,12 +47,18 @@ def load_path(path: str):
         if not hasattr(lib, name):
             raise AftError(f"{path} does not export {name}")
     lib.aft_version.restype = C.c_int
+    lib.aft_max_batch.restype = C.c_int
     lib.aft_last_error.restype = C.c_char_p
     lib.aft_workspace_bytes.restype = C.c_size_t
     lib.aft_workspace_bytes.argtypes = [C.POINTER(_abi.AftConfig), C.c_int]
     vp, cfgp, wp = C.c_void_p, C.POINTER(_abi.AftConfig), C.POINTER(_abi.AftWeights)
     lib.aft_check_config.argtypes = [cfgp]
+    lib.aft_max_batch.argtypes = [cfgp]
     lib.aft_forward_f32.argtypes = [cfgp, wp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
+    lib.aft_packed_weights_bytes.restype = C.c_size_t
+    lib.aft_packed_weights_bytes.argtypes = [cfgp]
+    lib.aft_pack_weights_f32.argtypes = [cfgp, wp, vp, C.c_size_t, vp]
+    lib.aft_forward_prepacked_f32.argtypes = [cfgp, wp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
     lib.aft_linear_forward_f32.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_mse_partial_f32.argtypes = [vp, vp, vp, C.c_longlong, vp]
     lib.aft_stage_upsample_f32.argtypes = [cfgp, wp, vp, vp, C.c_int, vp]
@@ -87,7 +93,7 @@ def load_path(path: str):
                                         vp, vp, C.POINTER(p9), C.POINTER(p9), C.c_int, vp]
     lib.aft_adam_step_f32.argtypes = [vp, vp, vp, vp, C.c_size_t] + [C.c_float] * 6 + [C.c_int, vp]
     for name in _abi.EXPORTED_SYMBOLS:
-        if name not in _abi.SIZE_SYMBOLS + ("aft_version", "aft_last_error"):
+        if name not in _abi.SIZE_SYMBOLS + ("aft_version", "aft_last_error", "aft_max_batch"):
             getattr(lib, name).restype = C.c_int
     if lib.aft_version() != _abi.AFT_ABI_VERSION:
         raise AftError(f"ABI mismatch: library {lib.aft_version()} vs binding {_abi.AFT_ABI_VERSION}")

@@ -123,6 +123,23 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     return ws;
 }
 
+// The kernels address every workspace region through a buffer resource with 32-bit byte offsets (srd.h: num_records
+// 0x7fffffff; a load past it silently returns 0).  The largest region of a forward is a q / k / v^T block or the
+// attention tiles: planes x tokpad x model_dim floats (tokpad >= tokens, so x is never larger).
+static size_t largest_region_bytes(const aft_config &c, int batch) {
+    const Workspace ws = plan_workspace(c, batch);
+    const size_t rows = (size_t)ws.planes * ws.tokens;
+    const size_t per_head = (size_t)ws.planes * ws.tokpad * c.model_dim;
+    const size_t biggest = std::max({rows * (size_t)c.model_dim, per_head, (size_t)ws.planes * c.num_scs * c.num_symbols,
+                                     rows * (size_t)out6_stride(c)});
+    return biggest * sizeof(float);
+}
+
+static int max_batch_of(const aft_config &c) {
+    const size_t per_frame = largest_region_bytes(c, 1);   // every region is linear in the batch
+    return (int)std::min<size_t>((((size_t)1 << 31) - 1) / per_frame, (size_t)1 << 24);
+}
+
 static int hip_fail(const char *what, hipError_t e) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return AFT_ERR_HIP;
@@ -130,16 +147,19 @@ static int hip_fail(const char *what, hipError_t e) {
 
 // `fused` (whole forward only): the first launch computes x0 from conv_enhanced / tokens6 itself (no embed kernel) and
 // the last one leaves linear_2's output in the q buffer instead of storing x (the conv tail reads it from there).
+// `prepacked`: the caller's fragment-packed image of ALL layers (aft_pack_weights_f32), or NULL = pack into the workspace now.
 static int run_encoder(const aft_config &c, const aft_weights &w, const Workspace &ws, float *base, int first_layer,
-                       int last_layer, hipStream_t st, bool fused = false) {
+                       int last_layer, hipStream_t st, bool fused = false, const float *prepacked = nullptr) {
     float *x = base + ws.x, *attn = base + ws.attn, *q = base + ws.q, *k = base + ws.k, *vt = base + ws.vt;
     const int rows = ws.planes * ws.tokens;
     const size_t pl = packed_layer_floats(c.model_dim);
-    float *wp = base + ws.wpack;
+    const float *wp = prepacked != nullptr ? prepacked : base + ws.wpack;
     hipError_t e;
-    // weights arrive in torch layout on every call (stateless ABI): re-lay them into fragment order
-    e = launch_pack_weights(c, w, wp + first_layer * pl, first_layer, last_layer - first_layer + 1, st);
-    if (e != hipSuccess) return hip_fail("pack_weights", e);
+    if (prepacked == nullptr) {
+        // weights arrive in torch layout on every call (stateless ABI): re-lay them into fragment order
+        e = launch_pack_weights(c, w, base + ws.wpack + first_layer * pl, first_layer, last_layer - first_layer + 1, st);
+        if (e != hipSuccess) return hip_fail("pack_weights", e);
+    }
     // whole forward and the caller asks for it: ONE launch for the encoder (k_encoder.hip).  AUTO means the launches:
     // measured on the MI355X at B = 128 (256 planes on 256 CUs, its best case) the plane-resident kernel is 1.5 % slower
     // (profiles/r03_ab_encoder.json), so nothing selects it by itself.
@@ -184,6 +204,11 @@ const char *aft_last_error(void) { return g_err; }
 
 int aft_check_config(const aft_config *cfg) { return check_config(cfg); }
 
+int aft_max_batch(const aft_config *cfg) {
+    if (check_config(cfg) != AFT_OK) return 0;
+    return max_batch_of(*cfg);
+}
+
 size_t aft_workspace_bytes(const aft_config *cfg, int batch) {
     if (check_config(cfg) != AFT_OK || batch <= 0) return 0;
     return plan_workspace(*cfg, batch).total_floats * sizeof(float);
@@ -197,15 +222,15 @@ size_t aft_workspace_bytes(const aft_config *cfg, int batch) {
         }                             \
     } while (0)
 
-int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pilots, const float *snr,
-                    const float *ds, const float *dop, float *out, void *workspace, size_t workspace_bytes,
-                    int batch, void *stream) {
+static int forward_impl(const aft_config *cfg, const aft_weights *w, const float *prepacked, const float *pilots,
+                        const float *snr, const float *ds, const float *dop, float *out, void *workspace,
+                        size_t workspace_bytes, int batch, void *stream) {
     int rc = check_config(cfg);
     if (rc != AFT_OK) return rc;
     AFT_REQUIRE(w && pilots && out && workspace, "NULL pointer argument");
     AFT_REQUIRE(batch > 0, "batch must be positive (got %d)", batch);
-    AFT_REQUIRE((size_t)2 * batch * tokens_of(*cfg) * cfg->model_dim * sizeof(float) < ((size_t)1 << 31),
-                "batch %d too large for 32-bit buffer offsets (split the batch)", batch);
+    AFT_REQUIRE(batch <= max_batch_of(*cfg), "batch %d exceeds aft_max_batch = %d for this configuration (32-bit buffer "
+                "offsets: no workspace region may reach 2 GiB); split the batch", batch, max_batch_of(*cfg));
     // reference fortitran.py:157-158: meta_data is required when channel adaptation is enabled
     AFT_REQUIRE(!cfg->adaptive || (snr && ds && dop), "meta_data is required when channel adaptation is enabled");
     const Workspace ws = plan_workspace(*cfg, batch);
@@ -220,11 +245,40 @@ int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pi
         if (e != hipSuccess) return hip_fail("adapter", e);
     }
     // patch embedding + linear_1 + positions run inside the first chain launch, linear_2 inside the last one
-    rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st, true);
+    rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st, true, prepacked);
     if (rc != AFT_OK) return rc;
     e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6);
     if (e != hipSuccess) return hip_fail("tail", e);
     return AFT_OK;
+}
+
+int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pilots, const float *snr,
+                    const float *ds, const float *dop, float *out, void *workspace, size_t workspace_bytes,
+                    int batch, void *stream) {
+    return forward_impl(cfg, w, nullptr, pilots, snr, ds, dop, out, workspace, workspace_bytes, batch, stream);
+}
+
+size_t aft_packed_weights_bytes(const aft_config *cfg) {
+    if (check_config(cfg) != AFT_OK) return 0;
+    return packed_layer_floats(cfg->model_dim) * cfg->num_layers * sizeof(float);
+}
+
+int aft_pack_weights_f32(const aft_config *cfg, const aft_weights *w, void *packed, size_t packed_bytes, void *stream) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    AFT_REQUIRE(w && packed, "NULL pointer argument");
+    AFT_REQUIRE(packed_bytes >= aft_packed_weights_bytes(cfg), "packed-weight buffer too small: %zu < %zu bytes", packed_bytes,
+                aft_packed_weights_bytes(cfg));
+    hipError_t e = launch_pack_weights(*cfg, *w, static_cast<float *>(packed), 0, cfg->num_layers, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("pack_weights", e);
+}
+
+int aft_forward_prepacked_f32(const aft_config *cfg, const aft_weights *w, const void *packed, const float *pilots,
+                              const float *snr, const float *ds, const float *dop, float *out, void *workspace,
+                              size_t workspace_bytes, int batch, void *stream) {
+    AFT_REQUIRE(packed != nullptr, "NULL packed-weight image");
+    return forward_impl(cfg, w, static_cast<const float *>(packed), pilots, snr, ds, dop, out, workspace, workspace_bytes, batch,
+                        stream);
 }
 
 int aft_linear_forward_f32(const float *weight, const float *bias, const float *pilots, float *out, int batch,
@@ -296,6 +350,7 @@ int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int
     if (rc != AFT_OK) return rc;
     AFT_REQUIRE(w && x && scratch && batch > 0, "bad argument");
     AFT_REQUIRE(layer >= 0 && layer < cfg->num_layers, "layer %d out of range", layer);
+    AFT_REQUIRE(batch <= max_batch_of(*cfg), "batch %d exceeds aft_max_batch = %d", batch, max_batch_of(*cfg));
     Workspace ws = plan_workspace(*cfg, batch);
     AFT_REQUIRE(scratch_bytes >= ws.total_floats * sizeof(float), "scratch too small");
     // run on the caller's x: point the plan's x slot at it (offsets are relative to scratch)
@@ -330,6 +385,7 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
     int rc = check_config(cfg);
     if (rc != AFT_OK) return rc;
     AFT_REQUIRE(w && workspace && batch > 0 && reps > 0, "bad argument");
+    AFT_REQUIRE(batch <= max_batch_of(*cfg), "batch %d exceeds aft_max_batch = %d", batch, max_batch_of(*cfg));
     const Workspace ws = plan_workspace(*cfg, batch);
     AFT_REQUIRE(workspace_bytes >= ws.total_floats * sizeof(float), "workspace too small");
     AFT_REQUIRE(cfg->num_layers >= 2 || which != AFT_KERNEL_CHAIN, "chain profile needs >= 2 layers");

@@ -190,6 +190,14 @@ class BaseFortiTranEstimator(nn.Module):
         self._engine = None
         return super().load_state_dict(*args, **kwargs)
 
+    def train(self, mode: bool = True):
+        # every train()/eval() switch drops the engine's packed-weight image: between two switches of an eval() phase
+        # the parameters can only change through torch ops (which move the version counters the engine watches), while a
+        # training phase may update them through raw pointers (optim.ShardedFlatAdam's fused kernel, RCCL all-gather)
+        if self._engine is not None:
+            self._engine.invalidate_packed()
+        return super().train(mode)
+
     def _hip_eligible(self) -> bool:
         return self._hip_covered and not self.training and not torch.is_grad_enabled()
 
@@ -246,9 +254,11 @@ class BaseFortiTranEstimator(nn.Module):
         # with the device idle -- 0.4-0.7 ms per training step); device-resident inputs pass through
         pilot_symbols, conditions = self._inputs_to_device(pilot_symbols, conditions)
         if eng is not None:
+            # the engine owns the fragment-packed encoder weights and re-packs them only when they changed (version
+            # counters; train()/eval() switches invalidate, see train() below)
             if conditions is None:
-                return eng.forward(pilot_symbols)
-            return eng.forward(pilot_symbols, *conditions)
+                return eng.forward(pilot_symbols, cache_packed=True)
+            return eng.forward(pilot_symbols, *conditions, cache_packed=True)
 
         if pilot_symbols.device.type == "cuda" and torch.is_grad_enabled():
             # training on the HIP device: the Re and Im planes go through the network as ONE batch of

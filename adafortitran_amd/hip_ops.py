@@ -64,6 +64,14 @@ class HipEngine:
                                 "plane": _abi.AFT_ENCODER_PLANE}[forced]
         self._ws: Optional[torch.Tensor] = None
         self._ws_batch = 0
+        self.max_batch = int(self.lib.aft_max_batch(C.byref(cfg)))   # 32-bit buffer offsets: larger batches run in chunks
+        # fragment-packed image of the encoder's GEMM weights, owned here and re-built only when those tensors changed
+        # (their autograd version counters; the module also calls invalidate_packed() on every train()/eval() switch)
+        lp = f"{_abi._TE}.transformer.layers."
+        self._gemm_weights = [v for k, v in self._keep.items() if k.startswith(lp) and k.endswith(
+            ("in_proj_weight", "out_proj.weight", "linear1.weight", "linear2.weight"))]
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
 
     # -- helpers ---------------------------------------------------------------------------
     @property
@@ -86,9 +94,31 @@ class HipEngine:
     def _stream(self) -> int:
         return _lib.current_stream_ptr(self.device)
 
+    def invalidate_packed(self) -> None:
+        self._packed_key = None
+
+    def packed_weights(self) -> torch.Tensor:
+        """The packed image, re-built (5 us kernel on the current stream) when a GEMM weight's version counter moved
+        or after invalidate_packed().  Stream order makes a re-build safe against forwards still in flight on the same
+        stream; callers that alternate streams get one image per stream."""
+        stream = self._stream()
+        key = (stream, tuple(t._version for t in self._gemm_weights))
+        if key != self._packed_key:
+            nbytes = self.lib.aft_packed_weights_bytes(C.byref(self.cfg))
+            if self._packed is None or self._packed_key is None or self._packed_key[0] != stream:
+                self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.aft_pack_weights_f32(C.byref(self.cfg), C.byref(self.weights), self._packed.data_ptr(),
+                                                     nbytes, stream))
+            self._packed_key = key
+        return self._packed
+
     # -- full forward ----------------------------------------------------------------------
-    def forward(self, pilots: torch.Tensor, snr=None, ds=None, dop=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """pilots complex64 [B,Ps,Pt] on the device -> complex64 [B,S,T] (same device, async)."""
+    def forward(self, pilots: torch.Tensor, snr=None, ds=None, dop=None, out: Optional[torch.Tensor] = None,
+                cache_packed: bool = False) -> torch.Tensor:
+        """pilots complex64 [B,Ps,Pt] on the device -> complex64 [B,S,T] (same device, async).  Any batch size: batches
+        above ``max_batch`` (the ABI's 32-bit-offset limit) run as consecutive chunks, as the reference accepts any B
+        (fortitran.py:145-182).  ``cache_packed``: use this engine's packed-weight image (aft_forward_prepacked_f32)
+        instead of re-packing inside the call (aft_forward_f32, stateless)."""
         c = self.cfg
         if pilots.dtype != torch.complex64:
             raise ValueError(f"pilot_symbols must be complex64, got {pilots.dtype}")
@@ -105,11 +135,24 @@ class HipEngine:
                 raise ValueError("meta_data tensors must have one value per frame")
         if out is None:
             out = torch.empty((B, c.num_scs, c.num_symbols), dtype=torch.complex64, device=self.device)
-        ws = self.workspace(B)
-        rc = self.lib.aft_forward_f32(C.byref(c), C.byref(self.weights), pil.data_ptr(), _ptr(metas[0]), _ptr(metas[1]),
-                                      _ptr(metas[2]), torch.view_as_real(out).data_ptr(), ws.data_ptr(), ws.numel(),
-                                      B, self._stream())
-        _lib.check(rc)
+        if B == 0:
+            return out
+        chunk = min(B, self.max_batch)
+        ws = self.workspace(chunk)
+        out_r = torch.view_as_real(out)
+        packed = self.packed_weights() if cache_packed else None
+        for lo in range(0, B, chunk):
+            n = min(chunk, B - lo)
+            m = [None if t is None else t[lo:lo + n].data_ptr() for t in metas]
+            if packed is None:
+                rc = self.lib.aft_forward_f32(C.byref(c), C.byref(self.weights), pil[lo:lo + n].data_ptr(), m[0], m[1], m[2],
+                                              out_r[lo:lo + n].data_ptr(), ws.data_ptr(), ws.numel(), n, self._stream())
+            else:
+                rc = self.lib.aft_forward_prepacked_f32(C.byref(c), C.byref(self.weights), packed.data_ptr(),
+                                                        pil[lo:lo + n].data_ptr(), m[0], m[1], m[2],
+                                                        out_r[lo:lo + n].data_ptr(), ws.data_ptr(), ws.numel(), n,
+                                                        self._stream())
+            _lib.check(rc)
         return out
 
     # -- per-stage entry points (tests) ----------------------------------------------------

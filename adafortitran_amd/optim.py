@@ -196,6 +196,13 @@ class ShardedFlatAdam(torch.optim.Optimizer):
         self._adam(g, scale)
         if self.distributed:
             dist.all_gather_into_tensor(self.flat.data, self.p_shard.clone(), group=self.group)
+        # the fused kernel and the all-gather write the flat buffer behind the parameters' backs: move their autograd
+        # version counters, as an in-place torch op would (saved-tensor checks, the HipEngine's packed-weight cache)
+        try:
+            torch.autograd.graph.increment_version(self.flat.params)
+        except (AttributeError, TypeError):
+            for p in self.flat.params:
+                torch._C._increment_version(p)
         self._grads_reduced = False
         return loss
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- OFDM frames/s of the AdaFortiTran forward path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2|C5] [--batch B]
 
 ``--gpus N`` with N > 1 and no torchrun environment: this process touches no GPU, starts
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` on
@@ -9,27 +9,25 @@ itself, relays rank 0's JSON line and exits with the children's status (fewer th
 devices => non-zero exit).  Under torchrun (WORLD_SIZE set) it is one rank: one process per GPU.
 
 A *step* is one pass of the hot path over one batch of synthetic input on every rank: one
-``aft_forward_f32`` (config 3: AdaFortiTran default, B=128 complex 120x14 frames, inputs already
-resident in HBM) plus the device-side channel-MSE partial sum.  Frames shard across ranks with no
-data-path collective (weak scaling: 128 frames per GPU); ONE RCCL all-gather of the per-rank
-(sum|e|^2, n) pair closes the sweep.  Rank 0 prints ONE JSON line.
+``aft_forward_f32`` plus the device-side channel-MSE partial sum, INPUTS ALREADY RESIDENT IN HBM when the
+timed region starts (that is what ``value`` is; the rate with the H2D copy of pilots + meta inside the
+step -- SURVEY.md 8(d)'s wording, through the module surface -- rides along as ``value_h2d_inclusive``).
+``--config`` picks the per-rank workload: C3 = AdaFortiTran default, 128 frames per GPU (the headline;
+``--gpus 8`` makes it BASELINE config 4), C2 = FortiTran default, C5 = 240x28 / 12 layers / d = 256 at
+64 frames per GPU (``--gpus 8`` = BASELINE config 5: batch 512 over 8 GPUs).  Frames shard across ranks
+with no data-path collective (weak scaling); ONE RCCL all-gather of the per-rank (sum|e|^2, n) pair
+closes the sweep.  Rank 0 prints ONE compact JSON line on stdout (numbers, short keys:
+DESIGN.md section 5 explains every field); ``--verbose-json PATH`` also writes the annotated record.
 
-Besides the contract fields the line carries (rank 0; the legs marked N=1 run only when one GPU is used)
-  roofline        dominant kernel (chain: out-proj+LN1+FFN+LN2+QKV) vs the fp32-MFMA roof; its duration is
-                  measured live with an event pair per launch in forward order on the launch stream, scaled so
-                  that the classes never sum to more than whole forwards bracketed by ONE event pair (the pairs
-                  alone inflate each kernel by a few us);
-  kernels         the same for every kernel class of the forward;
-  module_surface  (N=1) the metric as SURVEY.md 8(d) defines it: AdaFortiTranEstimator.forward called as the
-                  reference trainer calls it -- CPU complex64 pilots + CPU meta 6-tuple, eval()+no_grad(),
-                  H2D inside forward (reference trainer.py:280-288,332-337; fortitran.py:167-173);
-  configs         (N=1) sub-records for BASELINE.json's configs: C1 linear B=32, C2 FortiTran B=128,
-                  C3 (= the headline), C5 (240x28 grid, 12 layers, d=256, 8 heads) at 64 frames per GPU;
-  parity          (N=1) channel-estimation MSE vs the oracle on a bounded sample of the same inputs:
-                  max|h_hip - h_oracle|, mean|h_hip - h_oracle|^2, |MSE_hip - MSE_oracle| / MSE_oracle;
-  cpu_baseline    (N=1) the reference-equivalent CPU path (same torch.nn modules => same ATen / oneDNN /
-                  MKL kernels as the reference) on this box's host cores, bounded sample; CPU model,
-                  physical core count and the threads used are stated; the C oracle's rate rides along.
+Fields besides the contract: roofline (dominant kernel, live event timing) . kernels (ms / TFLOP/s per
+class) . upsampler (graded fraction (ii) of SURVEY 8d and the by-construction HBM fraction (i)) .
+encoder_mfma_util . per_rank (N > 1: step ms min/max over ranks, all-gather latency) . and at N = 1:
+parity (vs the oracle, bounded sample) . configs (C1, the other default model, C5) . next_rows (SURVEY 8f:
+training step, ingest, evaluation sweep, LS baseline) . cpu_baseline (the reference-equivalent CPU path
+on this box's host cores).
+
+``--stub`` (tests only, tests/test_bench_cli.py): the N-rank control flow with the GPU work replaced by
+CPU sleeps over gloo -- prints ``"data": "stub"`` and measures nothing.
 """
 from __future__ import annotations
 
@@ -46,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense, = fp32 vector peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 SEED = 20251114
 
 C3 = dict(name="C3", model="adafortitran", ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=6, model_dim=128,
@@ -57,6 +56,7 @@ C5 = dict(name="C5", model="adafortitran", ofdm=(240, 28), pilot=(24, 4), patch=
           num_head=8, hidden=(7, 42, 2240), max_seq_len=1120, batch=64,
           label="AdaFortiTran 12 layers / d=256 / 8 heads, 240x28 grid, patch [3,2], pilots 24x4, 64 frames per GPU "
                 "(batch 512 over 8 GPUs)")
+CONFIGS = {"C3": C3, "C2": C2, "C5": C5}
 
 
 def _spec(c):
@@ -84,6 +84,11 @@ def algorithmic_flops(c, batch):
           "tail": conv, "encoder_total": L * (qkv + proj + ffn + attn)}
     fl["forward_total"] = fl["upsample"] + emb + fl["encoder_total"] + lin2 + fl["tail"]
     return fl
+
+
+def upsampler_bytes_per_frame(c):
+    """Compulsory HBM bytes per frame of the upsampler stage: pilots in, conv_enhanced (2 planes) out."""
+    return c["pilot"][0] * c["pilot"][1] * 8 + 2 * c["ofdm"][0] * c["ofdm"][1] * 4
 
 
 def host_cpu_info():
@@ -115,11 +120,12 @@ def host_cpu_info():
 # self-launch (N > 1 without torchrun): nothing above or inside touches the GPU
 # ------------------------------------------------------------------------------------------------------------------
 def self_launch(args, argv) -> int:
-    import torch   # device_count() does not initialise the GPU on this image
-    n = torch.cuda.device_count()
-    if n < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but only {n} device(s) visible", file=sys.stderr)
-        return 2
+    if not args.stub:
+        import torch   # device_count() does not initialise the GPU on this image
+        n = torch.cuda.device_count()
+        if n < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n} device(s) visible", file=sys.stderr)
+            return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -140,7 +146,7 @@ def self_launch(args, argv) -> int:
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# measurement helpers (one rank)
+# workloads (one rank)
 # ------------------------------------------------------------------------------------------------------------------
 class Workload:
     """Engine + synthetic inputs of one config, resident on `device`."""
@@ -149,6 +155,7 @@ class Workload:
         import torch
         from adafortitran_amd import _abi, synth
         from adafortitran_amd.hip_ops import engine_from_numpy
+        from adafortitran_amd.metrics import MseAccumulator
         self.c, self.device = c, device
         self.B = batch or c["batch"]
         self.adaptive = c["hidden"] is not None
@@ -160,31 +167,74 @@ class Workload:
         self.tgt = torch.from_numpy(self.inp["target"]).to(device)
         self.meta = [torch.from_numpy(self.inp[k]).to(device) for k in ("snr", "ds", "dop")] if self.adaptive else [None] * 3
         self.out = torch.empty((self.B, *c["ofdm"]), dtype=torch.complex64, device=device)
+        self.acc = MseAccumulator(device)
+        self.sync = torch.cuda.synchronize
 
     def forward(self):
         return self.eng.forward(self.pil, *self.meta, out=self.out)
 
+    def step(self):
+        self.forward()
+        self.acc.update(self.out, self.tgt)          # device-side partial sum, no host sync
 
-def timed_steps(step, steps, warmup, fence):
+    def clock(self):
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    @staticmethod
+    def elapsed_ms(a, b):
+        return a.elapsed_time(b)
+
+
+class StubWorkload:
+    """tests/test_bench_cli.py only: the control flow of a rank (warm-up, fences, timed steps, metric all-gather,
+    rank-0-only legs, final barrier) with the GPU work replaced by a short host sleep; CPU tensors, gloo."""
+
+    def __init__(self, c, device, rank=0, batch=None):
+        import torch
+        from adafortitran_amd.metrics import MseAccumulator
+        self.c, self.device, self.B = c, torch.device("cpu"), batch or c["batch"]
+        self.adaptive = c["hidden"] is not None
+        g = torch.Generator().manual_seed(SEED + 1000 * rank)
+        shape = (self.B, *c["ofdm"])
+        self.out = torch.complex(torch.randn(shape, generator=g), torch.randn(shape, generator=g))
+        self.tgt = torch.complex(torch.randn(shape, generator=g), torch.randn(shape, generator=g))
+        self.acc = MseAccumulator("cpu")
+        self.sync = lambda: None
+        self.sleep = 0.002 * (1 + rank)                 # ranks differ: per-rank min/max must show it
+
+    def forward(self):
+        time.sleep(self.sleep)
+        return self.out
+
+    def step(self):
+        self.forward()
+        self.acc.update(self.out, self.tgt)
+
+    def clock(self):
+        return time.perf_counter()
+
+    @staticmethod
+    def elapsed_ms(a, b):
+        return (b - a) * 1e3
+
+
+def timed_steps(wl, step, steps, warmup, fence):
     """W untimed + exactly K timed steps between fences; returns (wall s, device ms, per-step device ms sorted)."""
-    import torch
     for _ in range(warmup):
         step()
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
-    marks = [ev0]
+    marks = [wl.clock()]
     for _ in range(steps):
         step()
-        m = torch.cuda.Event(enable_timing=True)
-        m.record()
-        marks.append(m)
-    ev1.record()
+        marks.append(wl.clock())
     fence()
     wall = time.perf_counter() - t0
-    per_step = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
-    return wall, ev0.elapsed_time(ev1), per_step
+    per_step = sorted(wl.elapsed_ms(a, b) for a, b in zip(marks[:-1], marks[1:]))
+    return wall, wl.elapsed_ms(marks[0], marks[-1]), per_step
 
 
 def kernel_times(wl, reps):
@@ -239,44 +289,45 @@ def kernel_times(wl, reps):
 
 
 def kernel_report(wl, reps):
+    """(kernels, roofline of the dominant kernel, encoder MFMA utilisation, forward ms, flops, upsampler record)"""
     c, B = wl.c, wl.B
     fl = algorithmic_flops(c, B)
     ms, raw, t_flow = kernel_times(wl, reps)
     L = c["num_layers"]
-    kernels = {k: {"ms": round(v, 4), "tflops": round(fl[k] / v / 1e9, 2), "ms_with_event_pair": round(raw[k], 4)}
-               for k, v in ms.items()}
+    kernels = {k: {"ms": round(v, 4), "tflops": round(fl[k] / v / 1e9, 2)} for k, v in ms.items()}
     enc_ms = ms["qkv"] + L * ms["attention"] + (L - 1) * ms["chain"] + ms["chain_last"]
     dom = max(("chain", "attention"), key=lambda k: ms[k] * ((L - 1) if k == "chain" else L))
-    names = {"chain": f"chain_kernel<{c['model_dim']},GELU,MLP=true,QKV=true> (out-proj+LN1+FFN+LN2 + next layer's QKV)",
-             "attention": "attn_kernel (softmax(QK^T/sqrt(32)) V per (plane, head))"}
+    names = {"chain": f"chain_kernel<{c['model_dim']},GELU,MLP,QKV>", "attention": "attn_kernel"}
     achieved = fl[dom] / ms[dom] / 1e9
     roof = {"kernel": names[dom], "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "flops_per_launch": fl[dom],
-            "ms_per_launch": round(ms[dom], 4), "launches_per_forward": (L - 1) if dom == "chain" else L,
-            "instruction_class": "v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (exact fp32)",
-            "timing": "event pair per launch in forward order on the launch stream, scaled so that the classes sum to at most "
-                      "the time of whole forwards bracketed by one event pair"}
-    return kernels, roof, round(fl["encoder_total"] / enc_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4), round(t_flow, 4), fl
+            "ms_per_launch": round(ms[dom], 4), "launches_per_forward": (L - 1) if dom == "chain" else L}
+    # upsampler stage (SURVEY 8d): graded fraction (ii) = achieved FLOP/s / min(peak, AI x BW) -- fused, its arithmetic
+    # intensity (2 354 FLOP/B) puts the ridge far above the fp32 peak, so the roof is the fp32 MFMA peak; (i) = compulsory
+    # bytes x frames/s / HBM peak (tiny by construction once fused)
+    ub = upsampler_bytes_per_frame(c)
+    up_tf = fl["upsample"] / ms["upsample"] / 1e9
+    ai = fl["upsample"] / (ub * B)
+    upsampler = {"tflops": round(up_tf, 2), "frac": round(up_tf / min(PEAK_FP32_MFMA_TFLOPS, ai * PEAK_HBM_GBS / 1e3), 4),
+                 "ai_flop_per_byte": round(ai), "hbm_frac": round(ub * B / (ms["upsample"] * 1e-3) / (PEAK_HBM_GBS * 1e9), 6),
+                 "tail_frac": round(fl["tail"] / ms["tail"] / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    return kernels, roof, round(fl["encoder_total"] / enc_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4), round(t_flow, 4), fl, upsampler
 
 
 def parity_vs_oracle(wl, sample):
     """HIP path vs the CPU oracle on the first `sample` frames of the workload's own inputs (oracle = checker only)."""
     import numpy as np
     from oracle import oracle
-    t0 = time.perf_counter()
     idx = slice(0, sample)
     args = [wl.inp[k][idx] for k in ("snr", "ds", "dop")] if wl.adaptive else [None] * 3
     ref = oracle.Oracle(wl.cfg, wl.sd).forward(wl.inp["pilots"][idx], *args)
-    secs = time.perf_counter() - t0
     got = wl.forward()[idx].cpu().numpy()
     tgt = wl.inp["target"][idx]
     mse_hip = float(np.mean(np.abs(got - tgt) ** 2, dtype=np.float64))
     mse_ref = float(np.mean(np.abs(ref - tgt) ** 2, dtype=np.float64))
-    return {"sample": f"first {sample} frame(s) of the timed batch, oracle/aft_oracle.c on {oracle.num_threads()} thread(s), {secs:.1f} s",
-            "max_abs_vs_oracle": float(np.abs(got - ref).max()), "ymax": float(np.abs(ref).max()),
-            "mean_sq_vs_oracle": float(np.mean(np.abs(got - ref) ** 2, dtype=np.float64)),
-            "mse_hip": mse_hip, "mse_oracle": mse_ref, "rel_dMSE": abs(mse_hip - mse_ref) / mse_ref,
-            "tolerance": {"max_abs": "5e-5*ymax", "rel_dMSE": 1e-4}}
+    return {"frames": sample, "max_abs": float(np.abs(got - ref).max()), "ymax": float(np.abs(ref).max()),
+            "mean_sq": float(np.mean(np.abs(got - ref) ** 2, dtype=np.float64)),
+            "rel_dMSE": abs(mse_hip - mse_ref) / mse_ref, "tol_max_abs_over_ymax": 5e-5, "tol_rel_dMSE": 1e-4}
 
 
 def make_module(c, device_str, sd):
@@ -310,37 +361,29 @@ def module_surface(wl, steps, warmup, engine_fps):
             est = model(pil_cpu, meta_cpu) if wl.adaptive else model(pil_cpu)
         acc.update(est, wl.tgt)
 
-    wall, dev_ms, per = timed_steps(step, steps, warmup, torch.cuda.synchronize)
+    wall, dev_ms, per = timed_steps(wl, step, steps, warmup, torch.cuda.synchronize)
     with torch.no_grad():
         est = model(pil_cpu, meta_cpu) if wl.adaptive else model(pil_cpu)
     same = bool(torch.equal(torch.view_as_real(est), torch.view_as_real(wl.forward())))
     fps = wl.B * steps / wall
-    return {"value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(wall / steps * 1e3, 4),
-            "device_ms_per_step": round(dev_ms / steps, 4), "steps": steps,
-            "ratio_to_resident_inputs": round(fps / engine_fps, 4), "bit_identical_to_engine_call": same,
-            "call": "AdaFortiTranEstimator(device='cuda').eval(); torch.no_grad(); model(pilots_cpu complex64, meta 6-tuple "
-                    "of CPU tensors) + device MSE partial; H2D of pilots+meta inside forward (one pinned async copy)"}
+    return {"value": round(fps, 1), "ms_per_step": round(wall / steps * 1e3, 4), "ratio_to_resident": round(fps / engine_fps, 4),
+            "bit_identical_to_engine": same}
 
 
 def config_record(c, device, steps, warmup, oracle_sample, kernel_reps):
     import torch
-    from adafortitran_amd.metrics import MseAccumulator
     wl = Workload(c, device)
-    acc = MseAccumulator(device)
-
-    def step():
-        wl.forward()
-        acc.update(wl.out, wl.tgt)
-
-    wall, dev_ms, per = timed_steps(step, steps, warmup, torch.cuda.synchronize)
-    kernels, roof, enc_util, t_flow, fl = kernel_report(wl, kernel_reps)
+    wall, dev_ms, per = timed_steps(wl, wl.step, steps, warmup, torch.cuda.synchronize)
+    kernels, roof, enc_util, t_flow, fl, ups = kernel_report(wl, kernel_reps)
     fps = wl.B * steps / wall
-    rec = {"workload": f"{c['label']}, batch {wl.B} per GPU, forward + device MSE partial, inputs resident in HBM",
-           "value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(wall / steps * 1e3, 4), "steps": steps,
-           "whole_path_tflops": round(fl["forward_total"] * steps / wall / 1e12 , 2),
-           "encoder_mfma_util": enc_util, "dominant_kernel": roof, "kernels": kernels}
+    rec = {"batch": wl.B, "value": round(fps, 1), "ms_per_step": round(wall / steps * 1e3, 4),
+           "tflops": round(fl["forward_total"] * steps / wall / 1e12, 2), "encoder_mfma_util": enc_util,
+           "dominant": roof["kernel"].split("<")[0], "dominant_frac": roof["frac"], "upsample_frac": ups["frac"],
+           "tail_frac": ups["tail_frac"]}
     if oracle_sample:
-        rec["parity"] = parity_vs_oracle(wl, oracle_sample)
+        p = parity_vs_oracle(wl, oracle_sample)
+        rec["parity_max_abs_over_ymax"] = p["max_abs"] / p["ymax"]
+        rec["parity_rel_dMSE"] = p["rel_dMSE"]
     del wl
     torch.cuda.empty_cache()
     return rec
@@ -368,20 +411,50 @@ def linear_record(device, steps, warmup):
         with torch.no_grad():
             model(pil_cpu)
 
-    wall, dev_ms, per = timed_steps(step, steps, warmup, torch.cuda.synchronize)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
     with torch.no_grad():
         got = model(pil_cpu).cpu().numpy()
     ref = oracle.linear_forward(w, b, inp["pilots"], (120, 14))
-    return {"workload": "Linear estimator (src/models/linear.py), 120x14 grid, batch 32, plane-wise on complex pilots -- plumbing only",
-            "value": round(B * steps / wall, 1), "unit": "frames/s", "ms_per_step": round(wall / steps * 1e3, 4), "steps": steps,
-            "bound": "launch latency (one 2.7 MFLOP kernel + one H2D copy per step)",
-            "parity": {"max_abs_vs_oracle": float(np.abs(got - ref).max()), "ymax": float(np.abs(ref).max())}}
+    return {"batch": B, "value": round(B * steps / wall, 1), "ms_per_step": round(wall / steps * 1e3, 4),
+            "parity_max_abs": float(np.abs(got - ref).max())}
+
+
+def next_rows(wl):
+    """SURVEY 8(f) rows on this GPU, bounded to a few seconds: f1 training step (forward + backward + fused Adam, B = 128,
+    dropout 0.1) with its fraction of the fp32-MFMA roof (3 x forward FLOPs per step), f2 pilot gather, f3 evaluation
+    sweep over a PackedLoader, f4 LS baseline (tools/train_bench.py, tools/next_rows_bench.py hold the measurement code)."""
+    import importlib.util
+    out = {}
+    for name in ("train_bench", "next_rows_bench"):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out[name] = mod
+    fl = algorithmic_flops(C3, 128)
+    tr = out["train_bench"].measure(batch=128, steps=10, warmup=3, model_name="adafortitran", dropout=0.1, modes=("hip",))
+    rec = {"f1_train_step_ms": round(tr["hip"], 3),
+           "f1_frac_of_fp32_roof": round(3 * fl["forward_total"] / (tr["hip"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    nr = out["next_rows_bench"].measure(frames=4096, batch=128)
+    rec.update({"f2_gather_GBs": nr["f2_pilot_gather"]["GB_per_s"], "f2_gather_hbm_frac": nr["f2_pilot_gather"]["frac_of_hbm_peak"],
+                "f2_loader_fps": nr["f2_packed_loader"]["frames_per_s"],
+                "f3_sweep_fps": nr["f3_eval_sweep"]["frames_per_s_device_accumulator"],
+                "f3_item_loop_fps": nr["f3_eval_sweep"]["frames_per_s_item_per_batch"],
+                "f4_ls_GBs": nr["f4_ls_mse_db"]["GB_per_s"], "f4_ls_hbm_frac": nr["f4_ls_mse_db"]["frac_of_hbm_peak"]})
+    return rec
 
 
 def cpu_baseline(wl):
     """Reference-equivalent CPU path: this package's estimator on device='cpu' is assembled from the same torch.nn
-    modules as the reference (nn.Linear / Conv2d / TransformerEncoder fast path), validated against reference
-    outputs in tests/test_estimators_cpu.py.  Bounded: a thread sweep + <= 10 forwards of the same B=128 batch."""
+    modules as the reference (nn.Linear / Conv2d / TransformerEncoder fast path); pinned against the imported reference
+    in the build container (tests/golden/cpu_standin.json: outputs bit-identical, forward time ratio 0.995-0.998).
+    Bounded: a thread sweep + <= 10 forwards of the same B=128 batch."""
     import numpy as np
     import torch
     from adafortitran_amd import synth
@@ -414,10 +487,10 @@ def cpu_baseline(wl):
             times.append(time.perf_counter() - t0)
         torch.set_num_threads(default_threads)
     med = float(np.median(times))
-    out = {"value": round(wl.B / med, 2), "unit": "frames/s", "cores": best_t, "kind": "port", **info,
-           "sample": f"{len(times)} forwards of B={wl.B} (the same workload), median {med * 1e3:.0f} ms, best of a thread sweep; "
-                     f"torch {torch.__version__} nn-module composite = the reference's own ATen/oneDNN/MKL CPU kernels, "
-                     f"eval()+no_grad(), fp32"}
+    out = {"value": round(wl.B / med, 2), "unit": "frames/s", "cores": best_t, "kind": "port",
+           "sample": f"{len(times)} forwards of B={wl.B} (same workload), median {med * 1e3:.0f} ms, best of a thread sweep, "
+                     f"torch {torch.__version__} CPU composite",
+           "cpu_model": info["cpu_model"], "sockets": info["sockets"], "physical_cores": info["physical_cores"]}
     try:    # the C oracle (oracle/aft_oracle.c) on a smaller bounded sample, for the record
         from oracle import oracle
         orc = oracle.Oracle(wl.cfg, wl.sd)
@@ -425,24 +498,21 @@ def cpu_baseline(wl):
         args = [wl.inp[k][:nb] for k in ("snr", "ds", "dop")] if wl.adaptive else [None] * 3
         t0 = time.perf_counter()
         orc.forward(wl.inp["pilots"][:nb], *args)
-        dt = time.perf_counter() - t0
-        out["oracle_c"] = {"value": round(nb / dt, 2), "unit": "frames/s", "cores": oracle.num_threads(),
-                           "sample": f"1 forward of B={nb}, OpenMP over planes, double accumulation"}
+        out["oracle_c_fps"] = round(nb / (time.perf_counter() - t0), 2)
+        out["oracle_c_threads"] = oracle.num_threads()
     except Exception as exc:  # the oracle is optional test infrastructure
-        out["oracle_c"] = {"error": str(exc)[:120]}
+        out["oracle_c_error"] = str(exc)[:80]
     return out
 
 
 def load_pmc_traffic():
     """HBM bytes per chain-kernel launch from the committed rocprofv3 --pmc summary (a constant of the committed
-    profile, not something this run observed)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    profile -- profiles/pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE -- not something this run observed)."""
     try:
-        with open(path) as fh:
-            return json.load(fh).get("chain_bytes_per_launch"), "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass: " \
-                "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh).get("chain_bytes_per_launch")
     except Exception:
-        return None, None
+        return None
 
 
 def main() -> int:
@@ -450,10 +520,13 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
-    ap.add_argument("--model", default="adafortitran", choices=["adafortitran", "fortitran"])
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="per-rank workload (default C3)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: the config's)")
+    ap.add_argument("--model", default=None, choices=["adafortitran", "fortitran"], help="alias: adafortitran = C3, fortitran = C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--headline-only", action="store_true", help="skip the N=1 legs (module surface, configs, parity, CPU)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the N=1 legs (module surface, configs, parity, next rows, CPU)")
+    ap.add_argument("--verbose-json", default="", help="also write the annotated record to this path")
+    ap.add_argument("--stub", action="store_true", help="tests only: control flow on CPU/gloo, measures nothing")
     args = ap.parse_args()
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
@@ -470,88 +543,120 @@ def main() -> int:
 
     import numpy as np
     import torch
-    if not torch.cuda.is_available():
-        print("bench.py needs an MI355X: the HIP path has no CPU fallback", file=sys.stderr)
-        return 2
-    if torch.cuda.device_count() <= local_rank:
-        print(f"bench.py: rank {rank} has no device {local_rank}", file=sys.stderr)
-        return 2
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     dist = None
+    if args.stub:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            print("bench.py needs an MI355X: the HIP path has no CPU fallback", file=sys.stderr)
+            return 2
+        if torch.cuda.device_count() <= local_rank:
+            print(f"bench.py: rank {rank} has no device {local_rank}", file=sys.stderr)
+            return 2
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if "WORLD_SIZE" in os.environ:   # under torchrun the RCCL path runs for every world size, 1 included
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if args.stub:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
-    from adafortitran_amd.metrics import MseAccumulator
-
-    head = dict(C3 if args.model == "adafortitran" else C2)
-    wl = Workload(head, device, rank=rank, batch=args.batch)   # a different shard of frames per rank
+    head = dict(CONFIGS[args.config or ("C2" if args.model == "fortitran" else "C3")])
+    wl = (StubWorkload if args.stub else Workload)(head, device, rank=rank, batch=args.batch or None)   # a different shard of frames per rank
     B = wl.B
-    acc = MseAccumulator(device)
-
-    def step():
-        wl.forward()
-        acc.update(wl.out, wl.tgt)          # device-side partial sum, no host sync
 
     def fence():
-        torch.cuda.synchronize()
+        wl.sync()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            wl.sync()
 
     for _ in range(args.warmup):
-        step()
-    acc.sum_sq.zero_()
-    acc.n_elements = 0
-    elapsed, dev_ms, per_step = timed_steps(step, args.steps, 0, fence)
+        wl.step()
+    wl.acc.sum_sq.zero_()
+    wl.acc.n_elements = 0
+    elapsed_local, dev_ms, per_step = timed_steps(wl, wl.step, args.steps, 0, fence)
     pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]   # noqa: E731
+    elapsed, per_rank = elapsed_local, None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # MAX over ranks of the barrier-to-barrier wall time is the step time of the job; the per-rank DEVICE time of the
+        # same K steps (no barrier wait inside) says which rank, if any, was slow
+        t = torch.tensor([elapsed_local, dev_ms / 1e3], dtype=torch.float64, device=device)
+        all_t = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        walls, devs = [float(x[0]) for x in all_t], [float(x[1]) for x in all_t]
+        elapsed = max(walls)
+        per_rank = {"device_ms_per_step_min": round(min(devs) / args.steps * 1e3, 4),
+                    "device_ms_per_step_max": round(max(devs) / args.steps * 1e3, 4),
+                    "slowest_rank": int(np.argmax(devs))}
 
     # ---- end-of-sweep metric: one all-gather of (sum|e|^2, n_frames) per rank ----
-    mse = acc.result()   # RCCL all-gather of the 16-byte (sum, n) pairs when world > 1
+    fence()
+    t0 = time.perf_counter()
+    mse = wl.acc.result()   # RCCL all-gather of the 16-byte (sum, n) pairs when a process group exists
+    t_first = time.perf_counter() - t0
+    if dist is not None:    # the collective's own latency once everything is warm (the first one may set up the ring)
+        reps = 10
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            wl.acc.result()
+        per_rank["metric_allgather_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+        per_rank["metric_allgather_first_ms"] = round(t_first * 1e3, 4)
 
     if rank == 0:
         frames = B * world * args.steps
-        kernels, roof, enc_util, t_flow, fl = kernel_report(wl, 20)
-        traffic, traffic_source = load_pmc_traffic()
-        roof["traffic"], roof["traffic_source"] = traffic, traffic_source
         fps = frames / elapsed
         result = {
             "metric": "OFDM frames/sec (120x14 grid, batch 128) + channel-estimation MSE vs reference",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{head['label']}, batch {B} frames per GPU, forward + device MSE partial, inputs resident in HBM",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub" if args.stub else "synthetic",
+            "config": {"workload": f"{head['name']}: {head['label']}; {B} frames per GPU per step; step = forward + device MSE partial; "
+                                   "value = rate with INPUTS RESIDENT IN HBM (H2D-inclusive rate: value_h2d_inclusive)",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded over {world} rank(s)"},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "device_step_ms": {"p10": round(pct(0.10), 4), "p50": round(pct(0.50), 4), "p90": round(pct(0.90), 4)},
             "mse_db_vs_random_target": round(10 * np.log10(mse), 4),
-            "roofline": roof, "kernels": kernels, "forward_ms_one_event_pair": t_flow, "encoder_mfma_util": enc_util,
-            "whole_path_tflops": round(fl["forward_total"] * world * args.steps / elapsed / 1e12, 2),
         }
-        if world == 1 and not args.headline_only:
-            result["parity"] = parity_vs_oracle(wl, 8)
-            result["module_surface"] = module_surface(wl, args.steps, args.warmup, fps / world)
-            cfgs = {}
-            cfgs["C1"] = linear_record(device, 200, 20)
-            other = C2 if head["name"] == "C3" else C3
-            cfgs[other["name"]] = config_record(other, device, 100, 10, 8, 10)
-            cfgs[head["name"]] = {"see": "top-level fields of this line (headline)", "value": result["value"],
-                                  "ms_per_step": result["ms_per_step"], "dominant_kernel_frac": roof["frac"],
-                                  "encoder_mfma_util": enc_util, "parity_rel_dMSE": result["parity"]["rel_dMSE"]}
-            cfgs["C4"] = {"see": "this command with --gpus 8: 128 frames per GPU, the headline workload per rank + one "
-                                 "RCCL all-gather of the (sum|e|^2, n) pairs"}
-            cfgs["C5@64/GPU"] = config_record(C5, device, 20, 3, 1, 3)
-            result["configs"] = cfgs
+        if per_rank is not None:
+            result["per_rank"] = per_rank
+        if not args.stub:
+            kernels, roof, enc_util, t_flow, fl, ups = kernel_report(wl, 20)
+            roof["traffic"] = load_pmc_traffic()
+            result.update({"roofline": roof, "kernels": kernels, "upsampler": ups, "forward_ms_one_event_pair": t_flow,
+                           "encoder_mfma_util": enc_util,
+                           "whole_path_tflops": round(fl["forward_total"] * world * args.steps / elapsed / 1e12, 2)})
+        if world == 1 and not args.headline_only and not args.stub:
+            result["parity"] = parity_vs_oracle(wl, 8 if head["name"] != "C5" else 1)
+            ms = module_surface(wl, args.steps, args.warmup, fps)
+            result["value_h2d_inclusive"] = ms["value"]
+            result["module_surface"] = ms
+            cfgs = {"C1": linear_record(device, 200, 20)}
+            for other in (C2, C3, C5):
+                if other["name"] == head["name"]:
+                    cfgs[other["name"]] = {"batch": B, "value": result["value"], "ms_per_step": result["ms_per_step"],
+                                           "encoder_mfma_util": enc_util, "dominant_frac": roof["frac"],
+                                           "upsample_frac": ups["frac"], "tail_frac": ups["tail_frac"],
+                                           "parity_rel_dMSE": result["parity"]["rel_dMSE"]}
+                elif other["name"] == "C5":
+                    cfgs["C5"] = config_record(C5, device, 20, 3, 1, 3)
+                else:
+                    cfgs[other["name"]] = config_record(other, device, 100, 10, 8, 10)
+            result["configs"] = cfgs     # C4 = C3 with --gpus 8; C5 as an 8-GPU config = --config C5 --gpus 8
+            try:
+                result["next_rows"] = next_rows(wl)
+            except Exception as exc:     # never lose the headline to a secondary leg
+                result["next_rows"] = {"error": f"{type(exc).__name__}: {exc}"[:160]}
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(wl)
                 result["speedup_vs_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
-        print(json.dumps(result))
+        if args.verbose_json:
+            with open(args.verbose_json, "w") as fh:
+                json.dump(result, fh, indent=1)
+        print(json.dumps(result, separators=(",", ":")))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

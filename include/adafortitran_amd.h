@@ -101,6 +101,11 @@ const char *aft_last_error(void);
  * __init__, fortitran.py:52-81), so an uncovered shape is refused before any training starts. */
 int aft_check_config(const aft_config *cfg);
 
+/* Largest `batch` one aft_forward_f32 call accepts for `cfg` (0 on a bad config): the kernels use 32-bit byte offsets
+ * into each workspace region, so no region (q / k / v^T: 2*batch*tokpad*model_dim floats) may reach 2 GiB.  The reference
+ * accepts any batch (fortitran.py:145-182); the module surface above this ABI splits larger batches into chunks. */
+int aft_max_batch(const aft_config *cfg);
+
 /* Bytes of scratch aft_forward_f32 needs for `batch` frames (0 on a bad config). */
 size_t aft_workspace_bytes(const aft_config *cfg, int batch);
 
@@ -111,6 +116,18 @@ size_t aft_workspace_bytes(const aft_config *cfg, int batch);
 int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pilots,
                     const float *snr, const float *ds, const float *dop, float *out,
                     void *workspace, size_t workspace_bytes, int batch, void *stream);
+
+/* The same forward for a caller that knows when its parameters change (an nn.Module in eval mode does: reference
+ * trainer.py:332 `model.eval()` ... the weights are constant across a whole evaluation sweep).  aft_forward_f32 re-lays
+ * the encoder's GEMM weights into MFMA-fragment order on EVERY call (5 us, 3 MB: it is stateless and always reflects the
+ * caller's current parameters); here the caller owns that image -- aft_packed_weights_bytes() of device memory, filled by
+ * aft_pack_weights_f32 whenever in_proj / out_proj / linear1 / linear2 weights of any layer changed -- and every forward
+ * reads it.  `w` is still needed (biases, LayerNorm vectors, conv / adapter / dense weights are read in place). */
+size_t aft_packed_weights_bytes(const aft_config *cfg);
+int aft_pack_weights_f32(const aft_config *cfg, const aft_weights *w, void *packed, size_t packed_bytes, void *stream);
+int aft_forward_prepacked_f32(const aft_config *cfg, const aft_weights *w, const void *packed, const float *pilots,
+                              const float *snr, const float *ds, const float *dop, float *out, void *workspace,
+                              size_t workspace_bytes, int batch, void *stream);
 
 /* Replaces LinearEstimator.forward (reference src/models/linear.py:65-97), applied to
  * the Re and Im planes separately: out[b,:,c] = W x[b,:,c] + bias. */

@@ -60,3 +60,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.AftError, match="no CPU or PyTorch fallback"):
         _lib.load()
+
+
+def test_max_batch_is_the_32_bit_offset_limit_of_the_largest_region():
+    """aft_max_batch (host-only): the q / k / v^T blocks and the attention tiles are planes x tokpad x d floats and must
+    stay under 2 GiB; one frame more is refused by aft_forward_f32 before anything is launched."""
+    lib = _lib.load()
+    for spec, hid, tokpad in ((DEFAULT_SPEC, (7, 42, 560), 288),
+                              (dict(ofdm=(240, 28), pilot=(24, 4), patch=(3, 2), num_layers=12, model_dim=256, num_head=8),
+                               (7, 42, 2240), 1120)):
+        cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+        mb = lib.aft_max_batch(ctypes.byref(cfg))
+        per_frame = 2 * tokpad * spec["model_dim"] * 4
+        assert mb == (2 ** 31 - 1) // per_frame
+        assert lib.aft_workspace_bytes(ctypes.byref(cfg), mb) > 0
+        w = _abi.AftWeights()
+        one = ctypes.c_float(0.0)
+        ptr = ctypes.addressof(one)                       # non-NULL dummies: the call must fail before touching them
+        rc = lib.aft_forward_f32(ctypes.byref(cfg), ctypes.byref(w), ptr, ptr, ptr, ptr, ptr, ptr, 1 << 40, mb + 1, None)
+        assert rc == _abi.AFT_ERR_ARG and b"aft_max_batch" in lib.aft_last_error()
+    bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3), adaptive_hidden=None)
+    assert lib.aft_max_batch(ctypes.byref(bad)) == 0 and lib.aft_packed_weights_bytes(ctypes.byref(bad)) == 0

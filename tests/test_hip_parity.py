@@ -510,3 +510,106 @@ def test_plane_resident_encoder_ignores_stale_workspace():
         eng.workspace(16).view(torch.float32).fill_(poison)
         out = eng.forward(pil, *meta)
         assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref)), poison
+
+
+# ---- robustness of the drop-in surface (round 3) ----
+def test_batches_above_the_offset_limit_run_in_chunks():
+    """The reference accepts any batch (fortitran.py:145-182); the ABI's limit (aft_max_batch: 32-bit offsets into the
+    largest workspace region) is handled by chunking in HipEngine.forward, not surfaced as an error."""
+    g = Golden("A_ada")
+    eng = _engine(g)
+    pil, meta = _t(g["pilots"]), _meta(g)
+    ref = eng.forward(pil, *meta).clone()
+    eng.max_batch = 3                                            # 8 frames -> chunks of 3, 3, 2
+    out = eng.forward(pil, *meta)
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref))
+    out2 = eng.forward(pil, *meta, cache_packed=True)
+    assert torch.equal(torch.view_as_real(out2), torch.view_as_real(ref))
+
+
+def test_largest_accepted_batch_has_no_offset_overflow():
+    """B = aft_max_batch exactly (7281 frames for the default model: q / k / v^T blocks just under 2 GiB, 11 GB of
+    workspace): frames at both ends of the batch must equal the same frames run as a small batch, bit for bit; one
+    frame more is refused by the raw ABI (and chunked by the engine)."""
+    import ctypes as C
+    from adafortitran_amd import _lib
+    hid = (7, 42, 560)
+    sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=11)
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    B = eng.max_batch
+    assert B == (2 ** 31 - 1) // (2 * 288 * 128 * 4)
+    small = synth.make_inputs(64, seed=3)
+    reps = (B + 63) // 64
+    pil = _t(small["pilots"]).repeat(reps, 1, 1)[:B].contiguous()
+    meta = [_t(small[k]).reshape(-1).repeat(reps)[:B].contiguous() for k in ("snr", "ds", "dop")]
+    ref = eng.forward(pil[:64], *[m[:64] for m in meta]).clone()
+    out = eng.forward(pil, *meta)
+    assert torch.equal(torch.view_as_real(out[:64]), torch.view_as_real(ref))
+    lo = (B - 64) // 64 * 64                                      # the last complete repetition of the 64 frames
+    assert torch.equal(torch.view_as_real(out[lo:lo + 64]), torch.view_as_real(ref))
+    tail = B - (B // 64) * 64
+    if tail:
+        assert torch.equal(torch.view_as_real(out[B - tail:]), torch.view_as_real(ref[:tail]))
+    lib = _lib.load()
+    ws = eng.workspace(B)
+    rc = lib.aft_forward_f32(C.byref(eng.cfg), C.byref(eng.weights), torch.view_as_real(pil).data_ptr(), meta[0].data_ptr(),
+                             meta[1].data_ptr(), meta[2].data_ptr(), torch.view_as_real(out).data_ptr(), ws.data_ptr(),
+                             ws.numel(), B + 1, None)
+    assert rc == _abi.AFT_ERR_ARG and b"aft_max_batch" in lib.aft_last_error()
+    del out, pil, ws
+    eng._ws = None
+    torch.cuda.empty_cache()
+
+
+def test_module_surface_from_alternating_streams():
+    """CPU inputs through the module on two streams in turn: every call stages into its own device allocation and the
+    pinned ring is guarded by events recorded on the copy's stream, so the results equal the single-stream ones."""
+    from test_estimators_cpu import _configs, golden_meta
+    g = Golden("A_ada")
+    sc, mc = _configs(g.spec, device="cuda")
+    model = A.AdaFortiTranEstimator(sc, mc)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()})
+    model.eval()
+    pil, meta = torch.from_numpy(g["pilots"]), golden_meta(g)
+    rev = torch.from_numpy(np.ascontiguousarray(g["pilots"][::-1]))
+    with torch.no_grad():
+        want_a, want_b = model(pil, meta).clone(), model(rev, meta).clone()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        got = []
+        for i in range(12):                                         # more calls than ring slots, streams alternate
+            with torch.cuda.stream(streams[i & 1]):
+                got.append((i & 1, model(pil if i & 1 == 0 else rev, meta)))
+        torch.cuda.synchronize()
+    for which, out in got:
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(want_a if which == 0 else want_b))
+
+
+def test_packed_weight_cache_follows_parameter_updates():
+    """The module's engine keeps the fragment-packed encoder weights across forwards: an in-place torch update (version
+    counter) and a raw-pointer update bracketed by train()/eval() must both be seen by the next forward."""
+    from test_estimators_cpu import _configs
+    g = Golden("D_forti")
+    sc, mc = _configs(g.spec, device="cuda")
+    model = A.FortiTranEstimator(sc, mc)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()})
+    model.eval()
+    pil = torch.from_numpy(g["pilots"])
+    w = model.transformer_encoder.transformer.layers[2].linear1.weight
+    with torch.no_grad():
+        out0 = model(pil).clone()
+        eng = model._engine
+        key0 = eng._packed_key
+        model(pil)
+        assert eng._packed_key == key0                              # nothing changed: no re-pack
+        w.mul_(1.5)                                                  # torch op: version counter moves
+        out1 = model(pil).clone()
+        assert eng._packed_key != key0 and not torch.equal(torch.view_as_real(out1), torch.view_as_real(out0))
+        fresh = eng.forward(_t(g["pilots"])).clone()                # stateless entry: packs inside the call
+        assert torch.equal(torch.view_as_real(out1), torch.view_as_real(fresh))
+        model.train()
+        w.data.view(-1)[:] = (w.data / 1.5).view(-1)                # .data writes do not move the version counter
+        model.eval()
+        out2 = model(pil)
+        assert np.abs((out2 - out0).cpu().numpy()).max() <= 1e-6 * np.abs(g["out"]).max() + 1e-7

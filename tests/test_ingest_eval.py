@@ -155,3 +155,15 @@ def test_packed_loader_on_device_matches_host_and_raises_late():
         with pytest.raises(ValueError, match=rf"Expected 24 pilot values, got 25 \(frame {bad_frame}\)"):
             for _ in ingest.PackedLoader(broken, (12, 2), 8, device="cuda"):
                 pass
+    # a consumer that STOPS iterating right after the bad batch still gets the error (generator close)
+    broken = dict(packed)
+    broken["h_ls_sparse"] = sparse.copy()
+    broken["h_ls_sparse"][2, 5, 5] = 1.0
+    it = iter(ingest.PackedLoader(broken, (12, 2), 8, device="cuda"))
+    next(it)                                               # the bad batch was yielded; its counts are still in flight
+    with pytest.raises(ValueError, match=r"Expected 24 pilot values, got 25 \(frame 2\)"):
+        it.close()
+    # packs above max_pinned_bytes go through the pinned ring instead of pinning the whole pack: same batches
+    ring = list(ingest.PackedLoader(packed, (12, 2), 8, device="cuda", max_pinned_bytes=0))
+    for (ph, ih, mh), (pd, idv, md) in zip(host, ring):
+        assert torch.equal(pd.cpu(), ph) and torch.equal(idv.cpu(), ih)

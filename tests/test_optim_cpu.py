@@ -173,3 +173,37 @@ def test_sharded_step_world_size_2_matches_single_process():
     want = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
     assert np.allclose(out[0], out[1], rtol=0, atol=0)          # ranks hold identical parameters
     assert np.allclose(out[0], want, rtol=1e-5, atol=1e-7)
+
+
+def test_flat_parameters_do_not_break_pickling_and_double_reduce_raises():
+    """the ownership tag on a Parameter is a picklable token (torch.save(model) / mp.spawn used to fail on a
+    weakref while an optimizer was alive); reduce_gradients() twice in one step raises instead of mixing averaged and
+    rank-local gradients."""
+    import io
+    import pickle
+
+    import pytest
+
+    from adafortitran_amd.optim import flat_owner
+    net = _net()
+    opt = ShardedFlatAdam(net.parameters(), lr=1e-2)
+    buf = io.BytesIO()
+    torch.save(net, buf)                                   # pickles Parameter.__dict__
+    pickle.dumps(list(net.parameters()))
+    assert all(flat_owner(p) is opt.flat for p in net.parameters())
+    buf.seek(0)
+    clone = torch.load(buf, weights_only=False)
+    assert all(flat_owner(p) is opt.flat or flat_owner(p) is None for p in clone.parameters())
+    x, y = _data()
+    torch.nn.functional.mse_loss(net(x), y).backward()
+    opt.reduce_gradients()
+    with pytest.raises(RuntimeError, match="already called"):
+        opt.reduce_gradients()
+    v0 = [p._version for p in net.parameters()]
+    opt.step()
+    assert all(p._version > v for p, v in zip(net.parameters(), v0))   # raw updates move the version counters
+    opt.zero_grad()
+    torch.nn.functional.mse_loss(net(x), y).backward()
+    opt.reduce_gradients()                                  # a new step may reduce again
+    opt.flat.release()
+    assert all(flat_owner(p) is None for p in net.parameters())
