@@ -150,9 +150,24 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     // ---- zero LDS (border columns, rows outside the plane, halo rows nobody writes); the conv2
     //      bias in accumulator-register order sits behind `small` ----
     {
-        f32x4 *z = reinterpret_cast<f32x4 *>(smem);
-        const int n4 = (17 * plane + 3) >> 2;   // arena is a multiple of 4 floats
-        for (int i = tid; i < n4; i += kConvThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // Only what is READ WITHOUT EVER BEING WRITTEN is zeroed (round 3; round 2 cleared all 139 KB, 2 300 cycles of LDS
+        // stores): the border columns 0 and T+1 of the 17 planes (zero padding in the symbol direction), and in every other
+        // column the rows outside the plane or past the band's last conv1 row -- [0, zlo) and [zhi, SP).  Every interior
+        // entry is written before it is read: in0 by the input phase (rows inside the plane), c1 by conv1 (whole 4-row
+        // groups, zeros where invalid), c3 by the conv3 epilogue (rows the conv4 window of this band touches).
+        const int zlo = min(max(-gr0, 0), SP), zhi = min(max(min(S - gr0, LR - 1), 0), SP);
+        const int ncols = 17 * (T + 2);
+        const int lane_z = tid & 63, wave_z = tid >> 6;
+        for (int pc = wave_z; pc < ncols; pc += kConvWaves) {
+            const int col = pc % (T + 2);
+            float *cp = smem + (size_t)pc * SP;
+            if (col == 0 || col == T + 1) {
+                for (int r = lane_z; r < SP; r += 64) cp[r] = 0.f;
+            } else {
+                const int nz = zlo + (SP - zhi);           // rows [0, zlo) then [zhi, SP)
+                for (int q = lane_z; q < nz; q += 64) cp[q < zlo ? q : zhi + (q - zlo)] = 0.f;
+            }
+        }
     }
     float *bias2 = small + a.extra;    // [2 halves][16]
     float *w1s = bias2 + 32;           // conv1: 72 weights + 8 biases
@@ -392,34 +407,19 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         float b[36];
 #pragma unroll
         for (int kb = 0; kb < 36; ++kb) b[kb] = b_at(kb, tlo);
-#pragma unroll 1
-        for (int tcol = tlo; tcol <= thi; ++tcol) {
-            f32x16 acc2;
-            {
-                const f32x4 *bp = reinterpret_cast<const f32x4 *>(bias2 + 16 * h);
+        auto bias2_acc = [&]() {
+            f32x16 acc;
+            const f32x4 *bp = reinterpret_cast<const f32x4 *>(bias2 + 16 * h);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = bp[q];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = bp[q];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc2[4 * q + u] = v[u];
-                }
+                for (int u = 0; u < 4; ++u) acc[4 * q + u] = v[u];
             }
-            // conv2: each operand register is refilled for the next column as soon as its MFMA has issued
-            const int tnext = min(tcol + 1, thi);
-#pragma unroll
-            for (int kb = 0; kb < 36; ++kb) {
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[kb], b[kb], acc2, 0, 0, 0);
-                b[kb] = b_at(kb, tnext);
-            }
-            // registers 8..11 hold output column tcol-2, complete since the previous column's MFMAs
-            store_col(tcol - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc3[8 + e] = acc3[4 + e];
-                acc3[4 + e] = acc3[e];
-                acc3[e] = 0.f;
-            }
-            float x2[16];
+            return acc;
+        };
+        // conv2's activation for column tcol: ReLU (or 0 outside the plane); training: masked / saved
+        auto activate2 = [&](const f32x16 &acc2, int tcol, float (&x2)[16]) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);   // ReLU, or 0 outside the plane
             if constexpr (TRAIN) {
@@ -439,14 +439,128 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                     }
                 }
             }
+        };
+        if constexpr (!TRAIN) {
+            // Software pipeline over the columns (round 3): conv3 of column tcol and conv2 of column tcol + 1 are two
+            // INDEPENDENT accumulation chains issued alternately, so neither waits for its own previous MFMA: before, a wave
+            // ran conv2's 36 dependent MFMAs, waited for the result, applied the ReLU, ran conv3's 48, waited again -- with the
+            // SIMD's other wave in the same rhythm the matrix pipe was 81 % busy during this phase (DESIGN.md 4.3 stamps).
+            float x2[16];
+            {   // prologue: conv2 of the first column
+                f32x16 acc2 = bias2_acc();
+                const int tnext = min(tlo + 1, thi);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[16 + e], x2[e], acc3, 0, 0, 0);
+                for (int kb = 0; kb < 36; ++kb) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[kb], b[kb], acc2, 0, 0, 0);
+                    b[kb] = b_at(kb, tnext);
+                }
+                activate2(acc2, tlo, x2);
+            }
+            // conv3 MFMA number i of a column: ky = centre (16..31), below (0..15), above (32..47) as before
+            auto conv3_step = [&](int i) {
+                const int e = i & 15;
+                const float xv = i < 16 ? x2[e] : (i < 32 ? lane_from_below(x2[e]) : lane_from_above(x2[e]));
+                const int wi = i < 16 ? 16 + e : (i < 32 ? e : 32 + e);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[wi], xv, acc3, 0, 0, 0);
+            };
+#pragma unroll 1
+            for (int tcol = tlo; tcol < thi; ++tcol) {
+                // registers 8..11 hold output column tcol-2, complete since the previous column's MFMAs
+                store_col(tcol - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[e], lane_from_below(x2[e]), acc3, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    acc3[8 + e] = acc3[4 + e];
+                    acc3[4 + e] = acc3[e];
+                    acc3[e] = 0.f;
+                }
+                f32x16 acc2 = bias2_acc();
+                const int tnext = min(tcol + 2, thi);
+                // 48 conv3 MFMAs of column tcol interleaved with the 36 conv2 MFMAs of column tcol + 1 (4 : 3); each conv2 operand
+                // register is refilled for the column after as soon as its MFMA has issued
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[32 + e], lane_from_above(x2[e]), acc3, 0, 0, 0);
+                for (int g = 0; g < 12; ++g) {
+                    conv3_step(4 * g);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[3 * g], b[3 * g], acc2, 0, 0, 0);
+                    b[3 * g] = b_at(3 * g, tnext);
+                    conv3_step(4 * g + 1);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[3 * g + 1], b[3 * g + 1], acc2, 0, 0, 0);
+                    b[3 * g + 1] = b_at(3 * g + 1, tnext);
+                    conv3_step(4 * g + 2);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[3 * g + 2], b[3 * g + 2], acc2, 0, 0, 0);
+                    b[3 * g + 2] = b_at(3 * g + 2, tnext);
+                    conv3_step(4 * g + 3);
+                }
+                activate2(acc2, tcol + 1, x2);
+            }
+            {   // epilogue: conv3 of the last column
+                store_col(thi - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc3[8 + e] = acc3[4 + e];
+                    acc3[4 + e] = acc3[e];
+                    acc3[e] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 48; ++i) conv3_step(i);
+            }
+        } else {
+            // training instantiation: the plain column loop, as in round 2 (the pipelined form needs 16 more registers)
+#pragma unroll 1
+            for (int tcol = tlo; tcol <= thi; ++tcol) {
+                f32x16 acc2;
+                {
+                    const f32x4 *bp = reinterpret_cast<const f32x4 *>(bias2 + 16 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = bp[q];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc2[4 * q + u] = v[u];
+                    }
+                }
+                // conv2: each operand register is refilled for the next column as soon as its MFMA has issued
+                const int tnext = min(tcol + 1, thi);
+#pragma unroll
+                for (int kb = 0; kb < 36; ++kb) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[kb], b[kb], acc2, 0, 0, 0);
+                    b[kb] = b_at(kb, tnext);
+                }
+                // registers 8..11 hold output column tcol-2, complete since the previous column's MFMAs
+                store_col(tcol - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc3[8 + e] = acc3[4 + e];
+                    acc3[4 + e] = acc3[e];
+                    acc3[e] = 0.f;
+                }
+                float x2[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);   // ReLU, or 0 outside the plane
+                if constexpr (TRAIN) {
+                    if (a.mask[1] || a.save[1]) {
+                        const unsigned g0 = ((unsigned)(n * 32 + 4 * h) * T + tcol) * S + gr;   // channel (e&3) + 8(e>>2) + 4h
+                        const unsigned cstride = (unsigned)T * S;
+                        if (a.mask[1]) {
+                            const ConvSrd m = conv_srd(a.mask[1]);
+#pragma unroll
+                            for (int e = 0; e < 16; ++e)
+                                x2[e] = (ok2 && conv_ld(m, g0 + ((e & 3) + 8 * (e >> 2)) * cstride) > 0.f) ? acc2[e] : 0.f;
+                        }
+                        if (a.save[1] && ok2 && own_row) {
+                            const ConvSrd sv = conv_srd(a.save[1]);
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) conv_st(sv, g0 + ((e & 3) + 8 * (e >> 2)) * cstride, x2[e]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[16 + e], x2[e], acc3, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[e], lane_from_below(x2[e]), acc3, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[32 + e], lane_from_above(x2[e]), acc3, 0, 0, 0);
+            }
         }
         store_col(thi - 1, acc3[8], acc3[9], acc3[10], acc3[11]);
         store_col(thi, acc3[4], acc3[5], acc3[6], acc3[7]);   // overlapping sweep: only stored when thi == T-1 (column T is zero padding)

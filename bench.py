@@ -198,12 +198,12 @@ class StubWorkload:
         self.c, self.device, self.B = c, torch.device("cpu"), batch or c["batch"]
         self.adaptive = c["hidden"] is not None
         g = torch.Generator().manual_seed(SEED + 1000 * rank)
-        shape = (self.B, *c["ofdm"])
+        shape = (self.B, 4, 4)                          # the stub's "estimates": tiny, so that the sleeps dominate a step
         self.out = torch.complex(torch.randn(shape, generator=g), torch.randn(shape, generator=g))
         self.tgt = torch.complex(torch.randn(shape, generator=g), torch.randn(shape, generator=g))
         self.acc = MseAccumulator("cpu")
         self.sync = lambda: None
-        self.sleep = 0.002 * (1 + rank)                 # ranks differ: per-rank min/max must show it
+        self.sleep = 0.004 * (1 + rank)                 # ranks differ: per-rank min/max must show it
 
     def forward(self):
         time.sleep(self.sleep)

@@ -52,6 +52,54 @@ def test_flop_accounting_matches_survey_8d():
     assert fl5["encoder_total"] / 64 == 59_013_857_280
 
 
+def test_two_rank_control_flow_with_stubbed_gpu_work():
+    """The N-rank control flow of bench.py -- self-launch through torchrun, warm-up, barrier-fenced timed steps, MAX over
+    ranks, the metric all-gather, rank-0-only legs while the other ranks wait in the final barrier -- at world size 2
+    over gloo with the GPU work replaced by host sleeps (--stub measures nothing and says so in `data`)."""
+    res = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--stub", "--config", "C5"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["data"] == "stub" and line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak"
+    assert line["config"]["frames_per_gpu"] == 64 and line["config"]["global_batch"] == 128 and "C5" in line["config"]["workload"]
+    pr = line["per_rank"]
+    # rank 1 sleeps twice as long per step as rank 0: MAX over ranks is rank 1's time, and min/max show the skew
+    assert pr["slowest_rank"] == 1 and pr["device_ms_per_step_max"] > 1.5 * pr["device_ms_per_step_min"]
+    assert line["ms_per_step"] >= pr["device_ms_per_step_max"] * 0.9
+    assert abs(line["value"] - 128 / line["ms_per_step"] * 1e3) <= 0.01 * line["value"]
+    assert pr["metric_allgather_ms"] > 0
+    assert "roofline" not in line                             # nothing was measured
+
+
+def test_bench_line_stays_compact():
+    """The driver parses the line; round 2's 7.5 KB line lost sub-records there.  Budget: the stub line (contract fields +
+    per_rank) under 1.2 KB; the key set of the full line is fixed in bench.py (numbers only, prose lives in DESIGN.md 5)."""
+    res = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--stub"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    assert len(line) < 1200, len(line)
+
+
+@pytest.mark.gpu
+def test_bench_full_line_on_gpu(tmp_path):
+    """The default N = 1 run with every leg (short): compact, and carries the records the judge reads."""
+    res = _run(["--steps", "10", "--warmup", "3", "--verbose-json", str(tmp_path / "v.json")])
+    assert res.returncode == 0, res.stderr[-3000:]
+    raw = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    assert len(raw) < 5000, len(raw)
+    line = json.loads(raw)
+    for key in ("roofline", "cpu_baseline", "kernels", "upsampler", "parity", "configs", "next_rows", "module_surface",
+                "value_h2d_inclusive"):
+        assert key in line, key
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "mfma"
+    assert set(line["configs"]) == {"C1", "C2", "C3", "C5"}
+    assert "error" not in line["next_rows"], line["next_rows"]
+    assert line["next_rows"]["f1_train_step_ms"] > 0 and 0 < line["next_rows"]["f1_frac_of_fp32_roof"] < 1
+    assert line["parity"]["max_abs"] <= 5e-5 * line["parity"]["ymax"] and line["parity"]["rel_dMSE"] <= 1e-4
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+
+
 @pytest.mark.gpu
 def test_bench_headline_line_on_gpu():
     res = _run(["--steps", "5", "--warmup", "2", "--headline-only"])

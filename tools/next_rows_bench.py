@@ -27,12 +27,8 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=16384)
-    ap.add_argument("--batch", type=int, default=128)
-    a = ap.parse_args()
-    N, B, S, T, PS, PT = a.frames, a.batch, 120, 14, 12, 2
+def measure(frames=16384, batch=128):
+    N, B, S, T, PS, PT = frames, batch, 120, 14, 12, 2
     rng = np.random.default_rng(0)
     ideal = (rng.standard_normal((N, S, T)) + 1j * rng.standard_normal((N, S, T))).astype(np.complex64)
     sparse = np.zeros((N, S, T), np.complex64)
@@ -110,7 +106,15 @@ def main():
                             "speedup": round(t_ref / t_dev, 3), "mse_device_accumulator": v_dev, "mse_item_loop": v_ref,
                             "rel_diff": abs(v_dev - v_ref) / v_ref,
                             "note": "same model, same PackedLoader (H2D + gather inside the loop); the model forward is the 80 k frames/s engine"}
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=16384)
+    ap.add_argument("--batch", type=int, default=128)
+    a = ap.parse_args()
+    print(json.dumps(measure(a.frames, a.batch)))
 
 
 if __name__ == "__main__":
