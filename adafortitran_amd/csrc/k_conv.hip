@@ -56,6 +56,9 @@ struct ConvArgs {
     unsigned long long *stamps;   // diagnostic build only (AFT_DIAG_STAMPS): per-workgroup s_memtime at the phase boundaries
 };
 
+#ifndef AFT_CONV_PIPE
+#define AFT_CONV_PIPE 1        // A/B knob: conv3(t) and conv2(t+1) as two interleaved MFMA chains
+#endif
 constexpr int kConvThreads = 512;
 constexpr int kConvWaves = kConvThreads / 64;
 constexpr int kTileRows = 30;   // valid conv3 rows per 32-lane tile
@@ -86,10 +89,17 @@ __device__ __forceinline__ float lane_from_above(float v) {   // lane i <- lane 
 // activation (backward: the ReLU derivative taken from the saved forward activation).  The backward of
 // the stack IS this kernel run on the gradient with transposed, flipped weights: conv4^T is 1->8,
 // conv3^T 8->32, conv2^T 32->8, conv1^T 8->1.
-template <bool TRAIN>
+// FIXED = the default 120 x 14 grid as ONE band (S = 120, T = 14, SP = 128, 4 row tiles x 2 column segments) with the
+// geometry as compile-time constants: every LDS offset of the matrix phase folds into the instruction's immediate (the
+// generic kernel spent ~60 of its ~175 vector instructions per column sweep on address arithmetic with the runtime plane /
+// column strides -- vector instructions cost fp32-MFMA time) and the divisions by T / band_rows of the
+// input, conv1 and conv4 loops become shifts and multiplies.  Other grids run the generic instantiation.
+template <bool TRAIN, bool FIXED>
 __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int S = a.S, T = a.T, SP = a.SP, LR = a.band_rows + 8;
+    const int S = FIXED ? 120 : a.S, T = FIXED ? 14 : a.T, SP = FIXED ? 128 : a.SP;
+    const int BR = FIXED ? 120 : a.band_rows, NB = FIXED ? 1 : a.nbands, NT = FIXED ? 4 : a.ntiles, NSEG = FIXED ? 2 : a.nseg;
+    const int LR = BR + 8;
     const int col_stride = SP, plane = (T + 2) * SP;
     float *in0 = smem;                 // [T+2][SP]      column index = symbol + 1
     float *c1 = in0 + plane;           // [8][T+2][SP]   conv1 output
@@ -102,9 +112,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 #define CSTAMP(i) do { } while (0)
 #endif
     CSTAMP(0);
-    const int n = blockIdx.x / a.nbands, band = blockIdx.x % a.nbands;
+    const int n = blockIdx.x / NB, band = blockIdx.x % NB;
     const int frame = n >> 1, part = n & 1;
-    const int gr0 = band * a.band_rows - 4;  // global row of local row 0
+    const int gr0 = band * BR - 4;  // global row of local row 0
 
     // ---- stage the conv2/conv3 weights through LDS (coalesced), gather the MFMA A fragments ----
     // conv2.weight [32][8][3][3] and conv3.weight [8][32][3][3] are 2304 floats each.
@@ -150,24 +160,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     // ---- zero LDS (border columns, rows outside the plane, halo rows nobody writes); the conv2
     //      bias in accumulator-register order sits behind `small` ----
     {
-        // Only what is READ WITHOUT EVER BEING WRITTEN is zeroed (round 3; round 2 cleared all 139 KB, 2 300 cycles of LDS
-        // stores): the border columns 0 and T+1 of the 17 planes (zero padding in the symbol direction), and in every other
-        // column the rows outside the plane or past the band's last conv1 row -- [0, zlo) and [zhi, SP).  Every interior
-        // entry is written before it is read: in0 by the input phase (rows inside the plane), c1 by conv1 (whole 4-row
-        // groups, zeros where invalid), c3 by the conv3 epilogue (rows the conv4 window of this band touches).
-        const int zlo = min(max(-gr0, 0), SP), zhi = min(max(min(S - gr0, LR - 1), 0), SP);
-        const int ncols = 17 * (T + 2);
-        const int lane_z = tid & 63, wave_z = tid >> 6;
-        for (int pc = wave_z; pc < ncols; pc += kConvWaves) {
-            const int col = pc % (T + 2);
-            float *cp = smem + (size_t)pc * SP;
-            if (col == 0 || col == T + 1) {
-                for (int r = lane_z; r < SP; r += 64) cp[r] = 0.f;
-            } else {
-                const int nz = zlo + (SP - zhi);           // rows [0, zlo) then [zhi, SP)
-                for (int q = lane_z; q < nz; q += 64) cp[q < zlo ? q : zhi + (q - zlo)] = 0.f;
-            }
-        }
+        f32x4 *z = reinterpret_cast<f32x4 *>(smem);
+        const int n4 = (17 * plane + 3) >> 2;   // arena is a multiple of 4 floats
+        for (int i = tid; i < n4; i += kConvThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float *bias2 = small + a.extra;    // [2 halves][16]
     float *w1s = bias2 + 32;           // conv1: 72 weights + 8 biases
@@ -183,7 +178,66 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
             if (gr >= 0 && gr < S) in0[(t + 1) * col_stride + lr] = a.in_plane[((size_t)n * S + gr) * T + t];
         }
     } else if (a.mode == 0) {   // pilot_upsampler row (gr*T + t): idx = sc*T + sym (view(B,1,S,T))
-        if (a.pf == 24) {   // default pilot grid: four pixels per pass, all 24 row loads in flight before the FMAs
+        if (FIXED && a.pf == 24) {
+            // Default grid and pilots (round 3): up_w [1680][24] is 161 KB that EVERY workgroup streams through its CU's L1.
+            // Round 2 gave each lane whole 96-byte rows of pixels 14 rows apart: a wave's load instruction touched 64
+            // different cache lines for 16 bytes each (8 100 cycles for this phase, TA-bound).  Now a wave reads the matrix
+            // as it lies in memory -- three 1-KB loads = 192 consecutive float4 = the rows of 32 consecutive pixels --,
+            // each lane multiplies its float4 with the matching quarter of the pilot vector, the 192 partial sums meet in
+            // LDS and lanes 0..31 add the six partials of "their" pixel.  Scratch: interior columns of conv1's channel-0
+            // plane (conv1 rewrites every entry of those columns in the next phase, behind the barrier).
+            constexpr int kPix = 120 * 14, kChunks = (kPix + 31) / 32;
+            const int lane_i = tid & 63, wave_i = tid >> 6;
+            float *scr = c1 + col_stride + wave_i * 192;              // 8 waves x 192 floats = 12 columns of 128
+            const int l6 = lane_i % 6;
+            f32x4 pq[3];                                              // pilot quarter of float4 (64 i + lane) % 6
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pq[i] = *reinterpret_cast<const f32x4 *>(small + 4 * ((l6 + 4 * i) % 6));
+            const f32x4 *w4 = reinterpret_cast<const f32x4 *>(a.up_w);
+            // the stream is latency-bound per wave (each round waits for its own three loads: 7 rounds x an L2 round trip
+            // was 7 200 cycles): the loads of the next kAhead rounds are in flight while a round is reduced
+            constexpr int kRounds = (kChunks + kConvWaves - 1) / kConvWaves, kAhead = 3;
+            f32x4 wv[kAhead + 1][3];
+            float bias[kAhead + 1];
+            auto request = [&](int rnd) {
+                const int ch = wave_i + rnd * kConvWaves;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int f = ch * 192 + 64 * i + lane_i;         // chunk ch = float4 [192 ch, 192 ch + 192) = pixels [32 ch, 32 ch + 32)
+                    wv[rnd % (kAhead + 1)][i] = f < kPix * 6 ? w4[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const int pix = 32 * ch + (lane_i & 31);
+                bias[rnd % (kAhead + 1)] = (lane_i < 32 && pix < kPix) ? a.up_b[pix] : 0.f;
+            };
+#pragma unroll
+            for (int rnd = 0; rnd < kAhead && rnd < kRounds; ++rnd) request(rnd);
+#pragma unroll
+            for (int rnd = 0; rnd < kRounds; ++rnd) {
+                if (rnd + kAhead < kRounds) request(rnd + kAhead);
+                const int ch = wave_i + rnd * kConvWaves;
+                const int pix = 32 * ch + (lane_i & 31);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    // four-term quarter sums, added in q order below (bias first)
+                    const f32x4 w = wv[rnd % (kAhead + 1)][i];
+                    float v = w[0] * pq[i][0];
+                    v = fmaf(w[1], pq[i][1], v);
+                    v = fmaf(w[2], pq[i][2], v);
+                    v = fmaf(w[3], pq[i][3], v);
+                    scr[64 * i + lane_i] = v;
+                }
+                __builtin_amdgcn_wave_barrier();                      // wave-private scratch: LDS ops of one wave complete in order
+                if (lane_i < 32 && pix < kPix) {
+                    const float *pp = scr + 6 * lane_i;
+                    float v = bias[rnd % (kAhead + 1)];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) v += pp[q];
+                    const int gr = pix / 14, t = pix - gr * 14;       // view(B, 1, S, T): pixel = sc * T + sym
+                    in0[(t + 1) * col_stride + (gr - gr0)] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (a.pf == 24) {   // default pilot grid: four pixels per pass, all 24 row loads in flight before the FMAs
             for (int i0 = tid; i0 < LR * T; i0 += 4 * kConvThreads) {
                 f32x4 wv[4][6];
                 float bv[4];
@@ -323,7 +377,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                         if (okq[q]) {
                             const size_t gi = ((size_t)(n * 8 + o) * T + t) * S + gr0 + lr0 + q;
                             if (a.mask[0]) v[q] = a.mask[0][gi] > 0.f ? acc : 0.f;
-                            if (a.save[0] && lr0 + q >= 4 && lr0 + q < 4 + a.band_rows) a.save[0][gi] = v[q];
+                            if (a.save[0] && lr0 + q >= 4 && lr0 + q < 4 + BR) a.save[0][gi] = v[q];
                         }
                     }
                     v[q] = okq[q] ? v[q] : 0.f;
@@ -345,9 +399,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 
     // ---- conv2 + conv3 on the matrix cores ----
     const int r3lo = band == 0 ? 4 : 3;   // first local row whose conv3 output is needed and inside the plane
-    for (int task = wave; task < a.ntiles * a.nseg; task += kConvWaves) {
-        const int tile = task / a.nseg, seg = task - tile * a.nseg;
-        const int ta = seg * T / a.nseg, tb = (seg + 1) * T / a.nseg;   // output columns [ta, tb)
+    for (int task = wave; task < NT * NSEG; task += kConvWaves) {
+        const int tile = task / NSEG, seg = task - tile * NSEG;
+        const int ta = seg * T / NSEG, tb = (seg + 1) * T / NSEG;   // output columns [ta, tb)
         // Inference: every conv2 column is computed ONCE.  A wave sweeps exactly its own columns [ta, tb); the two
         // output columns next to a segment seam then lack one kx tap each: the owner stores its raw partial sum in place
         // (c3), the neighbour stores the missing tap's contribution in the exchange planes (the dead input plane), and a
@@ -355,7 +409,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         // instead of 16 (the training instantiation keeps the overlapping sweep: its stage outputs are masked / saved
         // in store_col).
         // (needs 16 exchange planes of SP floats = the input plane of a grid with >= 14 symbols)
-        const bool EXACT = !TRAIN && a.nseg == 2 && T + 2 >= 16;
+        const bool EXACT = !TRAIN && NSEG == 2 && T + 2 >= 16;
         const int tlo = EXACT ? ta : max(ta - 1, 0), thi = EXACT ? tb - 1 : min(tb, T - 1);   // conv2 columns swept
         const int r = r3lo + kTileRows * tile - 1 + j;                   // this lane's local row
         const int gr = gr0 + r;
@@ -369,7 +423,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
 
-        const bool own_row = r >= 4 && r < 4 + a.band_rows;   // rows this band is responsible for (no halo)
+        const bool own_row = r >= 4 && r < 4 + BR;   // rows this band is responsible for (no halo)
         auto store_col = [&](int tout, float v0, float v1, float v2, float v3) {
             if (EXACT) {
                 if (!ok3 || tout < 0 || tout >= T) return;
@@ -440,7 +494,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                 }
             }
         };
-        if constexpr (!TRAIN) {
+        if constexpr (!TRAIN && AFT_CONV_PIPE) {
             // Software pipeline over the columns (round 3): conv3 of column tcol and conv2 of column tcol + 1 are two
             // INDEPENDENT accumulation chains issued alternately, so neither waits for its own previous MFMA: before, a wave
             // ran conv2's 36 dependent MFMAs, waited for the result, applied the ReLU, ran conv3's 48, waited again -- with the
@@ -571,11 +625,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     CSTAMP(6);
     if constexpr (!TRAIN) {
         // seam fix-up: c3[ch][t][row] = ReLU(own partial + neighbour's tap + bias) for the two columns at each seam
-        const int nseam = (a.nseg == 2 && T + 2 >= 16) ? 1 : 0;
+        const int nseam = (NSEG == 2 && T + 2 >= 16) ? 1 : 0;
         if (nseam > 0) {
             for (int i = tid; i < nseam * 2 * 8 * (LR - 6); i += kConvThreads) {
                 const int lr = 3 + i % (LR - 6), q = i / (LR - 6), ch = q & 7, side = (q >> 3) & 1, sm = q >> 4;
-                const int t = (sm + 1) * T / a.nseg - 1 + side;   // tb - 1 of the left segment, ta of the right one
+                const int t = (sm + 1) * T / NSEG - 1 + side;   // tb - 1 of the left segment, ta of the right one
                 float *pc = c3 + ch * plane + (t + 1) * col_stride + lr;
                 const int gr = gr0 + lr;
                 if (gr >= 0 && gr < S) *pc = fmaxf(*pc + in0[((t & 1) * 8 + ch) * SP + lr] + a.cb[2][ch], 0.f);
@@ -587,8 +641,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     CSTAMP(7);
     // ---- conv4: 8 -> 1, no activation, rows of this band only; one thread = one row x 4 columns ----
     const int tstrips = (T + 3) >> 2;
-    for (int i = tid; i < a.band_rows * tstrips; i += kConvThreads) {
-        const int ts = i / a.band_rows, lr = 4 + i - ts * a.band_rows, gr = gr0 + lr, t0 = 4 * ts;
+    for (int i = tid; i < BR * tstrips; i += kConvThreads) {
+        const int ts = i / BR, lr = 4 + i - ts * BR, gr = gr0 + lr, t0 = 4 * ts;
         if (gr >= S) continue;
         float acc[4];
 #pragma unroll
@@ -656,12 +710,22 @@ bool conv_plan_ok(int S, int T, int extra_floats) {
     return S > 0 && T > 0 && plan_bands(S, T, extra_floats, &a, &lds);
 }
 
+template <bool TRAIN, bool FIXED>
+static hipError_t launch_conv_geo(ConvArgs &a, int planes, size_t lds, hipStream_t st);
+
 template <bool TRAIN>
 static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStream_t st) {
     size_t lds = 0;
     if (!plan_bands(a.S, a.T, extra_floats, &a, &lds)) return hipErrorInvalidValue;
+    const bool fixed = a.S == 120 && a.T == 14 && a.SP == 128 && a.band_rows == 120 && a.nbands == 1 && a.ntiles == 4 && a.nseg == 2;
+    if (fixed) return launch_conv_geo<TRAIN, true>(a, planes, lds, st);
+    return launch_conv_geo<TRAIN, false>(a, planes, lds, st);
+}
+
+template <bool TRAIN, bool FIXED>
+static hipError_t launch_conv_geo(ConvArgs &a, int planes, size_t lds, hipStream_t st) {
     static PerDeviceOnce lds_attr;   // per instantiation x device
-    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(conv_stack_kernel<TRAIN>), 160 * 1024);
+    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(conv_stack_kernel<TRAIN, FIXED>), 160 * 1024);
     if (ea != hipSuccess) return ea;
 #ifdef AFT_DIAG_STAMPS
     if (!TRAIN && getenv("AFT_STAMPS")) {   // diagnostic build only: mean cycles per phase (thread 0 of every workgroup)
@@ -670,7 +734,7 @@ static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStre
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 4096);
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
         a.stamps = dbuf;
-        hipLaunchKernelGGL(conv_stack_kernel<TRAIN>, dim3(nb), dim3(kConvThreads), lds, st, a);
+        hipLaunchKernelGGL((conv_stack_kernel<TRAIN, FIXED>), dim3(nb), dim3(kConvThreads), lds, st, a);
         (void)hipDeviceSynchronize();
         static int printed = 0;
         if (printed++ < 4 && nb <= 4096) {
@@ -687,7 +751,7 @@ static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStre
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(conv_stack_kernel<TRAIN>, dim3(planes * a.nbands), dim3(kConvThreads), lds, st, a);
+    hipLaunchKernelGGL((conv_stack_kernel<TRAIN, FIXED>), dim3(planes * a.nbands), dim3(kConvThreads), lds, st, a);
     return hipGetLastError();
 }
 
