@@ -263,6 +263,17 @@ hipError_t launch_colsum(const float *x, float *out, float *slices, int rows, in
 hipError_t launch_reduce_slices(const float *slices, float *out, int n, int nz, size_t stride, bool accumulate, hipStream_t st);
 hipError_t launch_reduce_slices3(const float *slices, float *out0, float *out1, float *out2, int n, int nout, int nz,
                                  size_t stride, bool accumulate, hipStream_t st);
+// Fused row-local backward of an encoder layer (k_chain_bwd.hip): LayerNorm-2 backward, linear2 / linear1 data gradients with
+// the activation backward between them, LayerNorm-1 backward, out_proj data gradient -- one launch (+ the transposed weight
+// pack).  packed_t: chain_bwd_packed_floats(d) floats of scratch; lnp: chain_bwd_lnp_floats(rows, d) floats that receive the
+// per-tile column sums [tiles][4][d] = dgamma2 | dbeta2 | dgamma1 | dbeta1 (reduce with stride 4 d).
+bool chain_bwd_ok(const aft_config &c, int rows);
+size_t chain_bwd_packed_floats(int d);
+size_t chain_bwd_lnp_floats(int rows, int d);
+hipError_t launch_chain_bwd(const aft_config &c, const aft_layer_weights &w, const float *g, const float *s2, const float *st2,
+                            const float *a_pre, const float *s1, const float *st1, float *packed_t, float *g2, float *gff,
+                            float *g2b, float *d_o, float *dx, float *lnp, int rows, uint32_t seed1, uint32_t seed2,
+                            uint32_t seed3, uint32_t threshold, float keep_scale, hipStream_t st);
 hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o, float *lse, int planes, int tokens,
                                  float dropout_p, uint32_t seed, hipStream_t st);
 hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const float *o, const float *d_o, const float *lse,

@@ -6,6 +6,7 @@
 // parameter tensors.  Everything row-major fp32, rows = 2B * tokens.  The caller (PyTorch autograd,
 // adafortitran_amd/training.py) owns x_in, the tape and the gradient tensors.
 #include <cstdarg>
+#include <cstdlib>
 
 #include "aft_internal.h"
 
@@ -19,7 +20,7 @@ struct Tape {   // offsets in floats
     size_t qkv, attn, lse, s1, st1, x1, a, hd, s2, st2, total;
 };
 struct Scratch {
-    size_t g1, g2, g2b, gff, dqkv, dsum, slices, total;
+    size_t g1, g2, g2b, gff, dqkv, dsum, slices, packed_t, lnp, total;
 };
 
 int tokens_of_cfg(const aft_config &c) { return (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols); }
@@ -58,6 +59,9 @@ Scratch plan_scratch(const aft_config &c, int batch) {
     off += al64(gemm_tn_slice_floats(d, ff, r)) + al64(gemm_tn_slice_floats(ff, d, r)) + al64(gemm_tn_slice_floats(d, d, r)) +
            al64(gemm_tn_slice_floats(3 * d, d, r)) + 2 * al64((size_t)ln_bwd_blocks(r) * 3 * d) +
            al64((size_t)ln_bwd_blocks(r) * ff) + al64((size_t)colsum_slices(r) * 3 * d);
+    // fused row-local backward (k_chain_bwd.hip): transposed fragment-packed weights, per-tile LayerNorm parameter sums
+    s.packed_t = off; off += al64(chain_bwd_packed_floats((int)d));
+    s.lnp = off;      off += al64(chain_bwd_lnp_floats(r, (int)d));
     s.total = off;
     return s;
 }
@@ -193,13 +197,37 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     float *sl_wq = sl_wo + al64(gemm_tn_slice_floats(d, d, rows));
     float *sl_bq = sl_wq + al64(gemm_tn_slice_floats(3 * d, d, rows));
     ReduceBatchScope reductions;
+    const uint32_t drop_th = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
+    const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    if (chain_bwd_ok(*cfg, rows) && !getenv("AFT_TRAIN_UNFUSED_BWD")) {
+        // everything row-local in ONE launch: dx_out -> g2, gff, g2b (operands of the weight gradients), g1 = d(attention
+        // output), dx_in = the residual branch of dL/dx, per-tile LayerNorm parameter sums
+        float *lnp = sc + s.lnp;
+        STEP("row-local backward chain", launch_chain_bwd(*cfg, *w, dx_out, tp + t.s2, tp + t.st2, tp + t.a, tp + t.s1, tp + t.st1,
+                                                          sc + s.packed_t, g2, gff, g2b, g1, dx_in, lnp, rows, site_seed(seed, 1),
+                                                          site_seed(seed, 2), site_seed(seed, 3), drop_th, drop_ks, st));
+        const int ntl = (rows + 31) / 32;
+        STEP("norm2 parameter gradients", launch_reduce_slices3(lnp, g->norm2_w, g->norm2_b, nullptr, d, 2, ntl, (size_t)4 * d, acc, st));
+        STEP("norm1 parameter gradients", launch_reduce_slices3(lnp + 2 * d, g->norm1_w, g->norm1_b, nullptr, d, 2, ntl, (size_t)4 * d, acc, st));
+        STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,
+                                                    dropout_p, site_seed(seed, 0), st));
+        STEP("in_proj dgrad", launch_gemm(1, dqkv, w->in_proj_w, dx_in, nullptr, rows, d, 3 * d, 3 * d, d, d, true, st));
+        {   // the four weight gradients and all four bias gradients (column sums of the A operands) in one launch
+            const float *A[4] = {g2, gff, g2b, dqkv}, *B[4] = {hd, tp + t.x1, tp + t.attn, x_in};
+            float *C[4] = {g->lin2_w, g->lin1_w, g->out_proj_w, g->in_proj_w}, *S[4] = {sl_w2, sl_w1, sl_wo, sl_wq};
+            const int M[4] = {d, ff, d, 3 * d}, N[4] = {ff, d, d, d}, lda[4] = {d, ff, d, 3 * d}, ldb[4] = {ff, d, d, d};
+            float *bias_out[4] = {g->lin2_b, g->lin1_b, g->out_proj_b, g->in_proj_b};
+            float *bias_sl[4] = {sl_ln2, sl_act, sl_ln1, sl_bq};   // the LayerNorm slice regions are free on this path
+            STEP("weight gradients", launch_gemm_tn_batch(A, B, C, S, M, N, lda, ldb, 4, rows, acc, st, bias_out, bias_sl));
+        }
+        STEP("gradient reductions", reductions.flush(st));
+        return AFT_OK;
+    }
     // LN2: g1 = d(x1) through the residual, g2 = d(linear2 output) (dropout 3 applied)
     STEP("norm2 bwd", launch_ln_bwd(dx_out, tp + t.s2, tp + t.st2, w->norm2_w, g1, g2, g->norm2_w, g->norm2_b, g->lin2_b, sl_ln2,
                                     rows, d, dropout_p, site_seed(seed, 3), acc, st));
     // linear2's data gradient with the activation backward as its epilogue (gff = d(linear1 output)); linear1's bias gradient
     // then rides on the batched weight-gradient launch below (column sums of gff)
-    const uint32_t drop_th = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
-    const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     const bool fused_act = gemm_actbwd_ok(rows, ff, d, d, ff, ff);
     if (fused_act) {
         STEP("linear2 dgrad + activation bwd", launch_gemm_actbwd(g2, w->lin2_w, tp + t.a, gff, rows, ff, d, d, ff, ff, cfg->activation,

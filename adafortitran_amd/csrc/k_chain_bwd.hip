@@ -1,0 +1,351 @@
+// k_chain_bwd.hip -- the row-local part of an encoder layer's BACKWARD pass as one gfx950 kernel.
+//
+// Reference semantics: autograd through nn.TransformerEncoderLayer (post-LN, constructed at reference
+// src/models/blocks/encoders.py:44-55; called from TrainingLoop.train_epoch, src/main/trainer.py:195-233).  With the
+// forward of k_train.hip / k_gemm.hip
+//     s1 = x + drop1(attn Wo^T + bo)      x1 = LN1(s1)
+//     a  = x1 W1^T + b1                   hd = drop2(act(a))
+//     s2 = x1 + drop3(hd W2^T + b2)       x2 = LN2(s2)
+// everything between the gradient of x2 and the gradient of the attention output is row-local:
+//     ds2 = LN2'(g; s2)         g2  = drop3 (.) ds2                (gradient of linear2's output)
+//     gff = (g2 W2) (.) drop2 (.) act'(a)                           (gradient of linear1's output)
+//     dx1 = gff W1 + ds2        ds1 = LN1'(dx1; s1)                (ds1 = the residual branch of dL/dx)
+//     g2b = drop1 (.) ds1       d_o = g2b Wo                        (gradient of the attention output)
+// Round 2 ran this as five launches (LayerNorm backward x 2, linear2's data gradient with the activation backward as
+// its epilogue, two plain data-gradient GEMMs: 294 us per layer at B = 128, each tensor crossing HBM between them).
+// Here one workgroup owns 32 token rows through all of it -- the mirror image of chain_device.h's forward chain: the
+// same transposed MFMA products (A = weight fragment, B = activation fragment, accumulator lane = token row), with the
+// TRANSPOSED weights packed in fragment order (pack_weights_t_kernel), LayerNorm backward on registers with the two row
+// sums merged across the W waves through a 1-KB LDS table, the dropout masks of the three sites evaluated from the
+// factored hash (aft_internal.h::dropmask_*: one row word per lane and site, column words from an LDS table), the
+// activation derivative from the shared erf polynomial.  What leaves the kernel is what the remaining launches need:
+// g2 / gff / g2b row-major (operands of the batched weight-gradient GEMM, which also sums their columns into the bias
+// gradients), d_o for the attention backward, ds1 as the residual part of dx, and per-tile column sums of
+// (g (.) xhat, g) for the LayerNorm parameter gradients (cross-lane DPP reduction, fixed-order slice reduction later).
+#include <algorithm>
+
+#include "chain_device.h"
+
+namespace aft {
+
+struct ChainBwdArgs {
+    const float *g;                     // dL/dx2 [rows][D]
+    const float *s2, *st2, *a, *s1, *st1;   // tape: pre-norm sums, (mean, rstd) per row, linear1's pre-activation [rows][2D]
+    const float *w2t, *w1t, *wot;       // fragment-packed W2^T (2D x D), W1^T (D x 2D), Wo^T (D x D)
+    const float *gam2, *gam1;           // LayerNorm weights
+    float *g2, *gff, *g2b, *d_o, *dx;   // outputs, row-major
+    float *lnp;                         // [tiles][4][D]: per-tile column sums of g (.) xhat2, g, dx1 (.) xhat1, dx1
+    int rows;
+    uint32_t seed1, seed2, seed3, threshold;   // dropout sites: after out_proj, after the activation, after linear2
+    float keep_scale;
+};
+
+template <int D>
+struct ChainBwdShape {
+    using S = ChainShape<D>;
+    static constexpr int PAR = 2 * D;    // gamma2 | gamma1
+    static constexpr int COLW = 4 * D;   // column words of site 1 (D), site 2 (2D), site 3 (D)
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(S::XB + S::HB + S::ST + PAR + COLW);
+};
+
+// sum over the 32 lanes of each wave half; valid in lane 31 (h = 0) and lane 63 (h = 1)
+#define AFT_DPP_ADD(v, ctrl, row_mask, bound) \
+    ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (row_mask), 0xf, (bound))))
+__device__ __forceinline__ float half_sum_dpp(float v) {
+    v = AFT_DPP_ADD(v, 0x111, 0xf, true);    // row_shr:1 (zero fill)
+    v = AFT_DPP_ADD(v, 0x112, 0xf, true);    // row_shr:2
+    v = AFT_DPP_ADD(v, 0x114, 0xf, true);    // row_shr:4
+    v = AFT_DPP_ADD(v, 0x118, 0xf, true);    // row_shr:8  -> lane 15 of every 16-lane row holds the row's sum
+    v = AFT_DPP_ADD(v, 0x142, 0xa, false);   // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold their half's sum
+    return v;
+}
+#undef AFT_DPP_ADD
+
+// LayerNorm backward on the lane's 16 features: v = upstream gradient (in: dL/dy, out: dL/ds), sfrag = the pre-norm
+// sum of the forward, (mean, rstd) of the row.  Also returns the lane's contributions to the parameter gradients.
+template <int D>
+__device__ __forceinline__ void layernorm_bwd_rows(f32x16 &v, const f32x4 (&sfrag)[4], float mean, float rstd, float *stats,
+                                                   const float *gamma, int wave, int r, int h, f32x16 &dgam) {
+    constexpr int W = D / 32;
+    f32x16 xh;
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gamma + 8 * s + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 4 * s + j;
+            xh[e] = (sfrag[s][j] - mean) * rstd;
+            dgam[e] = v[e] * xh[e];          // dgamma contribution (dbeta's is v itself)
+            v[e] *= g4[j];
+            p1 += v[e];
+            p2 = fmaf(v[e], xh[e], p2);
+        }
+    }
+    p1 += __shfl_xor(p1, 32);
+    p2 += __shfl_xor(p2, 32);
+    if (h == 0) *reinterpret_cast<float2 *>(stats + (r * W + wave) * 2) = make_float2(p1, p2);
+    __syncthreads();
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        const float2 p = *reinterpret_cast<const float2 *>(stats + (r * W + u) * 2);
+        a += p.x;
+        b += p.y;
+    }
+    a *= (1.0f / D);
+    b *= (1.0f / D);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = rstd * (v[e] - a - xh[e] * b);
+}
+
+template <int D, int ACT>
+__global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(const ChainBwdArgs a) {
+    using S = ChainShape<D>;
+    using B = ChainBwdShape<D>;
+    constexpr int W = S::WAVES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xb = smem;              // g2 then g2b, fragment order
+    float *hb = xb + S::XB;        // gff, fragment order
+    float *stats = hb + S::HB;     // LayerNorm-backward row sums
+    float *par = stats + S::ST;    // gamma2 | gamma1
+    uint32_t *colw = reinterpret_cast<uint32_t *>(par + B::PAR);   // site 1 [D] | site 2 [2D] | site 3 [D]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int fb = 32 * w;
+    const bool drop = a.threshold != 0;
+
+    const Srd srd_g = make_srd(a.g), srd_s2 = make_srd(a.s2), srd_s1 = make_srd(a.s1), srd_a = make_srd(a.a);
+    const Srd srd_w2t = make_srd(a.w2t), srd_w1t = make_srd(a.w1t), srd_wot = make_srd(a.wot);
+    const Srd srd_g2 = make_srd(a.g2), srd_gff = make_srd(a.gff), srd_g2b = make_srd(a.g2b), srd_do = make_srd(a.d_o),
+              srd_dx = make_srd(a.dx);
+    const unsigned w2t_off = (unsigned)(2 * w) * W * 1024 + lane * 4;    // W2^T: 2W tiles x W k-blocks (like W1 in the forward)
+    const unsigned w1t_off = (unsigned)w * (2 * W) * 1024 + lane * 4;    // W1^T: W tiles x 2W k-blocks (like W2)
+    const unsigned wot_off = (unsigned)w * W * 1024 + lane * 4;
+
+    for (int i = tid; i < D; i += S::THREADS) {
+        par[i] = a.gam2[i];
+        par[D + i] = a.gam1[i];
+    }
+    if (drop) {
+        for (int i = tid; i < D; i += S::THREADS) {
+            colw[i] = dropmask_col_word(a.seed1, (uint32_t)i);
+            colw[3 * D + i] = dropmask_col_word(a.seed3, (uint32_t)i);
+        }
+        for (int i = tid; i < 2 * D; i += S::THREADS) colw[D + i] = dropmask_col_word(a.seed2, (uint32_t)i);
+    }
+    __syncthreads();
+
+    // element e of a site's mask for this lane: keep_scale where kept, else 0 (cw4 = four consecutive column words)
+    auto mask4 = [&](f32x4 v, uint32_t rw, const uint32_t *cw4) {
+        using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+        const u32x4 cw = *reinterpret_cast<const u32x4 *>(cw4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = dropmask_keep(rw, cw[j], a.threshold) ? v[j] * a.keep_scale : 0.f;
+        return o;
+    };
+
+    const int ntiles = (a.rows + 31) / 32;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * 32;
+        const int grow = min(row0 + r, a.rows - 1);
+        const bool row_ok = row0 + r < a.rows;
+        const unsigned xrow = ((unsigned)grow * D + fb + 4 * h) * 4;            // 128-wide tensors: + 32 s (bytes)
+        const unsigned hrow = ((unsigned)grow * 2 * D + 2 * fb + 4 * h) * 4;    // 256-wide tensors: + 128 t + 32 s
+        unsigned lo = 0;
+        asm volatile("" : "+v"(lo));    // keep the tile-invariant weight loads inside the loop (see chain_device.h)
+        const unsigned w2t_lane = (w2t_off + lo) * 4, w1t_lane = (w1t_off + lo) * 4, wot_lane = (wot_off + lo) * 4;
+        constexpr int PFD = 4, PFF = 2;
+        WRing<1, PFD> ring_d;
+        WRing<2, PFF> ring_ff;
+
+        // ---- LayerNorm-2 backward ----
+        f32x4 gq[4], sq[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            gq[s] = srd_load(srd_g, xrow + 32 * s);
+            sq[s] = srd_load(srd_s2, xrow + 32 * s);
+        }
+        const float2 st2 = *reinterpret_cast<const float2 *>(a.st2 + 2 * (size_t)grow);
+        gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w2t, w2t_lane);
+        // linear1's pre-activations of this lane's two hidden blocks: requested now, used behind the first product
+        f32x4 aq[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) aq[t][s] = srd_load(srd_a, hrow + 128 * t + 32 * s);
+        f32x16 cur, dgam;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[4 * s + j] = row_ok ? gq[s][j] : 0.f;   // rows past the end contribute nothing
+        // per-tile column sums for dgamma2 / dbeta2 (lanes = rows: DPP reduction over each half; lanes 31 / 63 store)
+        auto store_param_sums = [&](const f32x16 &dg, const f32x16 &db, int which) {
+            f32x16 sg, sb;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sg[e] = half_sum_dpp(dg[e]);
+                sb[e] = half_sum_dpp(db[e]);
+            }
+            if (r == 31) {
+                float *p = a.lnp + ((size_t)tile * 4 + 2 * which) * D + fb + 4 * h;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    *reinterpret_cast<f32x4 *>(p + 8 * s) = f32x4{sg[4 * s], sg[4 * s + 1], sg[4 * s + 2], sg[4 * s + 3]};
+                    *reinterpret_cast<f32x4 *>(p + D + 8 * s) = f32x4{sb[4 * s], sb[4 * s + 1], sb[4 * s + 2], sb[4 * s + 3]};
+                }
+            }
+        };
+        {
+            const f32x16 dbeta = cur;
+            layernorm_bwd_rows<D>(cur, sq, st2.x, st2.y, stats, par + fb, w, r, h, dgam);
+            store_param_sums(dgam, dbeta, 0);
+        }
+        const f32x16 ds2 = cur;     // joins dx1 behind the second product
+        uint32_t rw1 = 0, rw2 = 0, rw3 = 0;
+        if (drop) {
+            rw1 = dropmask_row_word(a.seed1, (uint32_t)grow);
+            rw2 = dropmask_row_word(a.seed2, (uint32_t)grow);
+            rw3 = dropmask_row_word(a.seed3, (uint32_t)grow);
+        }
+        // g2 = drop3 (.) ds2: stored row-major for the weight-gradient launch, published in fragment order
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 v = {cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+            if (drop) v = mask4(v, rw3, colw + 3 * D + fb + 8 * s + 4 * h);
+            if (row_ok) srd_store(srd_g2, xrow + 32 * s, v);
+            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
+        }
+        __syncthreads();
+
+        // ---- (g2 W2): hidden blocks 2w, 2w+1; epilogue = dropout-2 mask and activation derivative ----
+        f32x16 acc_h[2];
+        auto xb_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4); };
+        gemm_run<W, 2, PFF, 1, 0, decltype(xb_frag), 0x3>(ring_ff, srd_w2t, w2t_lane, acc_h, xb_frag);
+        gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w1t, w1t_lane);
+        // the pre-norm sum of LayerNorm 1: requested here, used behind the second product
+        f32x4 s1q[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) s1q[s] = srd_load(srd_s1, xrow + 32 * s);
+        const float2 st1 = *reinterpret_cast<const float2 *>(a.st1 + 2 * (size_t)grow);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x2 d0 = activate2_grad<ACT>(f32x2{aq[t][s][0], aq[t][s][1]});
+                const f32x2 d1 = activate2_grad<ACT>(f32x2{aq[t][s][2], aq[t][s][3]});
+                f32x4 v = {acc_h[t][4 * s] * d0[0], acc_h[t][4 * s + 1] * d0[1], acc_h[t][4 * s + 2] * d1[0], acc_h[t][4 * s + 3] * d1[1]};
+                if (drop) v = mask4(v, rw2, colw + D + 2 * fb + 32 * t + 8 * s + 4 * h);
+                if (row_ok) srd_store(srd_gff, hrow + 128 * t + 32 * s, v);
+                *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = v;
+            }
+        __syncthreads();
+
+        // ---- dx1 = gff W1 + ds2 (the accumulator starts from ds2) ----
+        f32x16 acc_d[1] = {ds2};
+        gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w1t, w1t_lane, acc_d, [&](int kb, int s) {
+            return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
+        });
+        gemm_preload<W, 1, PFD, 1>(ring_d, srd_wot, wot_lane);
+        cur = acc_d[0];
+        if (!row_ok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cur[e] = 0.f;
+        }
+        {
+            const f32x16 dbeta = cur;
+            layernorm_bwd_rows<D>(cur, s1q, st1.x, st1.y, stats, par + D + fb, w, r, h, dgam);
+            store_param_sums(dgam, dbeta, 1);
+        }
+        // ds1: the residual branch of dL/dx (the in-projection's data gradient is added by the next launch);
+        // g2b = drop1 (.) ds1: stored row-major, published for the last product
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 v = {cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+            if (row_ok) srd_store(srd_dx, xrow + 32 * s, v);
+            if (drop) v = mask4(v, rw1, colw + fb + 8 * s + 4 * h);
+            if (row_ok) srd_store(srd_g2b, xrow + 32 * s, v);
+            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
+        }
+        __syncthreads();
+
+        // ---- d_o = g2b Wo ----
+        f32x16 acc_o[1];
+        gemm_run<W, 1, PFD, 1, 0, decltype(xb_frag), 0x1>(ring_d, srd_wot, wot_lane, acc_o, xb_frag);
+        if (row_ok) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                srd_store(srd_do, xrow + 32 * s, f32x4{acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]});
+        }
+        // LDS hazards across tiles: xb is rewritten behind the next tile's LayerNorm-2 barrier, hb behind two barriers,
+        // the row-sum table of LayerNorm 2 behind the xb barrier above.
+    }
+}
+
+// Fragment-packed TRANSPOSES of one layer's linear2 / linear1 / out_proj weights (the data-gradient products use W, i.e.
+// the transposed-product form needs W^T as its "weight" matrix): packed[(((tile * NKB + kb) * 4 + s) * 64 + lane) * 4 + j]
+// = M[32 tile + lane % 32][32 kb + 8 s + 4 (lane / 32) + j] with M = W^T, i.e. M[row][k] = W[k][row].
+__global__ __launch_bounds__(256) void pack_weights_t_kernel(const float *__restrict__ w2, const float *__restrict__ w1,
+                                                             const float *__restrict__ wo, float *__restrict__ packed, int d) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;   // one float4 of the packed image
+    const size_t dd = (size_t)d * d;
+    if (v * 4 >= 5 * dd) return;
+    size_t off = v * 4;
+    const float *src;
+    int K, ld;      // M is [rows_out][K]; W is [K][rows_out] row-major with leading dimension ld = rows_out
+    if (off < 2 * dd) { src = w2; K = d; ld = 2 * d; }                       // W2 [d][2d]  -> M = W2^T [2d][d]
+    else if ((off -= 2 * dd) < 2 * dd) { src = w1; K = 2 * d; ld = d; }      // W1 [2d][d]  -> M = W1^T [d][2d]
+    else { off -= 2 * dd; src = wo; K = d; ld = d; }                         // Wo [d][d]   -> M = Wo^T
+    const int lane = (int)(off / 4) % 64, s = (int)(off / 256) % 4;
+    const int blk = (int)(off / 1024), nkb = K / 32, kb = blk % nkb, ct = blk / nkb;
+    const int row = ct * 32 + (lane & 31), k = kb * 32 + s * 8 + (lane >> 5) * 4;
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = src[(size_t)(k + j) * ld + row];
+    *reinterpret_cast<f32x4 *>(packed + v * 4) = o;
+}
+
+bool chain_bwd_ok(const aft_config &c, int rows) {
+    // d = 128 is instantiated; the five row-major tensors are addressed with 32-bit byte offsets
+    return c.model_dim == 128 && (size_t)rows * 2 * c.model_dim * sizeof(float) < ((size_t)1 << 31);
+}
+size_t chain_bwd_packed_floats(int d) { return (size_t)5 * d * d; }
+size_t chain_bwd_lnp_floats(int rows, int d) { return (size_t)((rows + 31) / 32) * 4 * d; }
+
+template <int ACT>
+static hipError_t launch_chain_bwd_t(const ChainBwdArgs &args, hipStream_t st) {
+    constexpr int D = 128;
+    using B = ChainBwdShape<D>;
+    static PerDeviceOnce lds_attr;
+    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_bwd_kernel<D, ACT>), B::LDS_BYTES);
+    if (ea != hipSuccess) return ea;
+    const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * 3);
+    hipLaunchKernelGGL((chain_bwd_kernel<D, ACT>), dim3(blocks), dim3(ChainShape<D>::THREADS), B::LDS_BYTES, st, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_bwd(const aft_config &c, const aft_layer_weights &w, const float *g, const float *s2, const float *st2,
+                            const float *a_pre, const float *s1, const float *st1, float *packed_t, float *g2, float *gff,
+                            float *g2b, float *d_o, float *dx, float *lnp, int rows, uint32_t seed1, uint32_t seed2,
+                            uint32_t seed3, uint32_t threshold, float keep_scale, hipStream_t st) {
+    const int d = c.model_dim;
+    const size_t dd = (size_t)d * d;
+    hipLaunchKernelGGL(pack_weights_t_kernel, dim3((unsigned)((5 * dd / 4 + 255) / 256)), dim3(256), 0, st, w.lin2_w, w.lin1_w,
+                       w.out_proj_w, packed_t, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    ChainBwdArgs a{};
+    a.g = g; a.s2 = s2; a.st2 = st2; a.a = a_pre; a.s1 = s1; a.st1 = st1;
+    a.w2t = packed_t; a.w1t = packed_t + 2 * dd; a.wot = packed_t + 4 * dd;
+    a.gam2 = w.norm2_w; a.gam1 = w.norm1_w;
+    a.g2 = g2; a.gff = gff; a.g2b = g2b; a.d_o = d_o; a.dx = dx; a.lnp = lnp;
+    a.rows = rows;
+    a.seed1 = seed1; a.seed2 = seed2; a.seed3 = seed3; a.threshold = threshold; a.keep_scale = keep_scale;
+    return c.activation == AFT_ACT_GELU ? launch_chain_bwd_t<AFT_ACT_GELU>(a, st) : launch_chain_bwd_t<AFT_ACT_RELU>(a, st);
+}
+
+}  // namespace aft
