@@ -266,10 +266,11 @@ hipError_t launch_reduce_slices3(const float *slices, float *out0, float *out1, 
 // Fused row-local backward of an encoder layer (k_chain_bwd.hip): LayerNorm-2 backward, linear2 / linear1 data gradients with
 // the activation backward between them, LayerNorm-1 backward, out_proj data gradient -- one launch (+ the transposed weight
 // pack).  packed_t: chain_bwd_packed_floats(d) floats of scratch; lnp: chain_bwd_lnp_floats(rows, d) floats that receive the
-// per-tile column sums [tiles][4][d] = dgamma2 | dbeta2 | dgamma1 | dbeta1 (reduce with stride 4 d).
+// per-workgroup column sums [chain_bwd_blocks(rows)][4][d] = dgamma2 | dbeta2 | dgamma1 | dbeta1 (reduce with stride 4 d).
 bool chain_bwd_ok(const aft_config &c, int rows);
 size_t chain_bwd_packed_floats(int d);
 size_t chain_bwd_lnp_floats(int rows, int d);
+int chain_bwd_blocks(int rows);   // workgroups of the launch = slices in lnp
 hipError_t launch_chain_bwd(const aft_config &c, const aft_layer_weights &w, const float *g, const float *s2, const float *st2,
                             const float *a_pre, const float *s1, const float *st1, float *packed_t, float *g2, float *gff,
                             float *g2b, float *d_o, float *dx, float *lnp, int rows, uint32_t seed1, uint32_t seed2,

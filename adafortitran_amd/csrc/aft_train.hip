@@ -206,7 +206,7 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
         STEP("row-local backward chain", launch_chain_bwd(*cfg, *w, dx_out, tp + t.s2, tp + t.st2, tp + t.a, tp + t.s1, tp + t.st1,
                                                           sc + s.packed_t, g2, gff, g2b, g1, dx_in, lnp, rows, site_seed(seed, 1),
                                                           site_seed(seed, 2), site_seed(seed, 3), drop_th, drop_ks, st));
-        const int ntl = (rows + 31) / 32;
+        const int ntl = chain_bwd_blocks(rows);
         STEP("norm2 parameter gradients", launch_reduce_slices3(lnp, g->norm2_w, g->norm2_b, nullptr, d, 2, ntl, (size_t)4 * d, acc, st));
         STEP("norm1 parameter gradients", launch_reduce_slices3(lnp + 2 * d, g->norm1_w, g->norm1_b, nullptr, d, 2, ntl, (size_t)4 * d, acc, st));
         STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,

@@ -34,7 +34,7 @@ struct ChainBwdArgs {
     const float *w2t, *w1t, *wot;       // fragment-packed W2^T (2D x D), W1^T (D x 2D), Wo^T (D x D)
     const float *gam2, *gam1;           // LayerNorm weights
     float *g2, *gff, *g2b, *d_o, *dx;   // outputs, row-major
-    float *lnp;                         // [tiles][4][D]: per-tile column sums of g (.) xhat2, g, dx1 (.) xhat1, dx1
+    float *lnp;                         // [workgroups][4][D]: column sums of g (.) xhat2, g, dx1 (.) xhat1, dx1 over the workgroup's tiles
     int rows;
     uint32_t seed1, seed2, seed3, threshold;   // dropout sites: after out_proj, after the activation, after linear2
     float keep_scale;
@@ -44,22 +44,13 @@ template <int D>
 struct ChainBwdShape {
     using S = ChainShape<D>;
     static constexpr int PAR = 2 * D;    // gamma2 | gamma1
+#ifdef AFT_BWD_NO_COLW
+    static constexpr int COLW = 0;       // occupancy experiment only (valid without dropout)
+#else
     static constexpr int COLW = 4 * D;   // column words of site 1 (D), site 2 (2D), site 3 (D)
+#endif
     static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(S::XB + S::HB + S::ST + PAR + COLW);
 };
-
-// sum over the 32 lanes of each wave half; valid in lane 31 (h = 0) and lane 63 (h = 1)
-#define AFT_DPP_ADD(v, ctrl, row_mask, bound) \
-    ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (row_mask), 0xf, (bound))))
-__device__ __forceinline__ float half_sum_dpp(float v) {
-    v = AFT_DPP_ADD(v, 0x111, 0xf, true);    // row_shr:1 (zero fill)
-    v = AFT_DPP_ADD(v, 0x112, 0xf, true);    // row_shr:2
-    v = AFT_DPP_ADD(v, 0x114, 0xf, true);    // row_shr:4
-    v = AFT_DPP_ADD(v, 0x118, 0xf, true);    // row_shr:8  -> lane 15 of every 16-lane row holds the row's sum
-    v = AFT_DPP_ADD(v, 0x142, 0xa, false);   // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold their half's sum
-    return v;
-}
-#undef AFT_DPP_ADD
 
 // LayerNorm backward on the lane's 16 features: v = upstream gradient (in: dL/dy, out: dL/ds), sfrag = the pre-norm
 // sum of the forward, (mean, rstd) of the row.  Also returns the lane's contributions to the parameter gradients.
@@ -149,6 +140,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
     };
 
     const int ntiles = (a.rows + 31) / 32;
+    float psum[2] = {0.f, 0.f};     // lane (r, h): column sum of feature fb + r, quantity h, for LayerNorm 2 and LayerNorm 1
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * 32;
@@ -172,33 +164,34 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         }
         const float2 st2 = *reinterpret_cast<const float2 *>(a.st2 + 2 * (size_t)grow);
         gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w2t, w2t_lane);
-        // linear1's pre-activations of this lane's two hidden blocks: requested now, used behind the first product
-        f32x4 aq[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) aq[t][s] = srd_load(srd_a, hrow + 128 * t + 32 * s);
         f32x16 cur, dgam;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = row_ok ? gq[s][j] : 0.f;   // rows past the end contribute nothing
-        // per-tile column sums for dgamma2 / dbeta2 (lanes = rows: DPP reduction over each half; lanes 31 / 63 store)
+        // per-tile column sums for the LayerNorm parameter gradients.  Lanes are rows here, so the sum over the tile's 32 rows
+        // is a cross-lane reduction: instead of 5 DPP steps per value (320 vector instructions per LayerNorm, and vector
+        // instructions cost fp32-MFMA time) the wave transposes its [32 rows][32 features] x 2 blocks through the idle hidden
+        // buffer (column index XOR row: conflict-free both ways) and lane (feature, quantity) adds its column -- 32 LDS reads
+        // (free beside MFMAs) + 32 adds.  hb is idle at both call sites: behind the LayerNorm barrier every wave has finished
+        // the product that read it.  The second wave barrier keeps the scratch from being rewritten before all lanes read it.
+        float *tsc = hb + w * 2048;               // this wave's scratch: [2 quantities][32 rows][32], column index XOR row
         auto store_param_sums = [&](const f32x16 &dg, const f32x16 &db, int which) {
-            f32x16 sg, sb;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                sg[e] = half_sum_dpp(dg[e]);
-                sb[e] = half_sum_dpp(db[e]);
-            }
-            if (r == 31) {
-                float *p = a.lnp + ((size_t)tile * 4 + 2 * which) * D + fb + 4 * h;
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    *reinterpret_cast<f32x4 *>(p + 8 * s) = f32x4{sg[4 * s], sg[4 * s + 1], sg[4 * s + 2], sg[4 * s + 3]};
-                    *reinterpret_cast<f32x4 *>(p + D + 8 * s) = f32x4{sb[4 * s], sb[4 * s + 1], sb[4 * s + 2], sb[4 * s + 3]};
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (8 * s + 4 * h + j) ^ r;
+                    tsc[r * 32 + c] = dg[4 * s + j];
+                    tsc[1024 + r * 32 + c] = db[4 * s + j];
                 }
-            }
+            __builtin_amdgcn_wave_barrier();
+            const float *col = tsc + h * 1024;               // lane (r, h): feature fb + r of quantity h (0 = dgamma, 1 = dbeta)
+            float sum = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < 32; ++q) sum += col[q * 32 + (r ^ q)];
+            psum[which] += sum;                                   // accumulated over this workgroup's tiles, stored once
+            __builtin_amdgcn_wave_barrier();
         };
         {
             const f32x16 dbeta = cur;
@@ -220,6 +213,12 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
             if (row_ok) srd_store(srd_g2, xrow + 32 * s, v);
             *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
         }
+        // linear1's pre-activations of this lane's two hidden blocks: requested now, used behind the first product
+        f32x4 aq[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) aq[t][s] = srd_load(srd_a, hrow + 128 * t + 32 * s);
         __syncthreads();
 
         // ---- (g2 W2): hidden blocks 2w, 2w+1; epilogue = dropout-2 mask and activation derivative ----
@@ -284,6 +283,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         // LDS hazards across tiles: xb is rewritten behind the next tile's LayerNorm-2 barrier, hb behind two barriers,
         // the row-sum table of LayerNorm 2 behind the xb barrier above.
     }
+    // one slice per workgroup: [blocks][4][D] = dgamma2 | dbeta2 | dgamma1 | dbeta1
+#pragma unroll
+    for (int which = 0; which < 2; ++which) a.lnp[((size_t)blockIdx.x * 4 + 2 * which + h) * D + fb + r] = psum[which];
 }
 
 // Fragment-packed TRANSPOSES of one layer's linear2 / linear1 / out_proj weights (the data-gradient products use W, i.e.
@@ -314,7 +316,8 @@ bool chain_bwd_ok(const aft_config &c, int rows) {
     return c.model_dim == 128 && (size_t)rows * 2 * c.model_dim * sizeof(float) < ((size_t)1 << 31);
 }
 size_t chain_bwd_packed_floats(int d) { return (size_t)5 * d * d; }
-size_t chain_bwd_lnp_floats(int rows, int d) { return (size_t)((rows + 31) / 32) * 4 * d; }
+int chain_bwd_blocks(int rows) { return std::min((rows + 31) / 32, current_device_cus() * 3); }
+size_t chain_bwd_lnp_floats(int rows, int d) { return (size_t)((rows + 31) / 32) * 4 * d; }   // upper bound: one slice per tile
 
 template <int ACT>
 static hipError_t launch_chain_bwd_t(const ChainBwdArgs &args, hipStream_t st) {
@@ -323,7 +326,7 @@ static hipError_t launch_chain_bwd_t(const ChainBwdArgs &args, hipStream_t st) {
     static PerDeviceOnce lds_attr;
     hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_bwd_kernel<D, ACT>), B::LDS_BYTES);
     if (ea != hipSuccess) return ea;
-    const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * 3);
+    const int blocks = chain_bwd_blocks(args.rows);
     hipLaunchKernelGGL((chain_bwd_kernel<D, ACT>), dim3(blocks), dim3(ChainShape<D>::THREADS), B::LDS_BYTES, st, args);
     return hipGetLastError();
 }
