@@ -13,6 +13,7 @@ AFT_MAX_LAYERS = 32
 AFT_OK, AFT_ERR_ARG, AFT_ERR_SHAPE, AFT_ERR_HIP = 0, 1, 2, 3
 AFT_ACT_RELU, AFT_ACT_GELU = 0, 1
 AFT_ENCODER_AUTO, AFT_ENCODER_LAUNCHES, AFT_ENCODER_PLANE = 0, 1, 2
+AFT_PRECISION_F32, AFT_PRECISION_BF16X3 = 0, 1
 
 _fp = C.c_void_p  # const float* -- kept untyped so torch data_ptr() ints and numpy ptrs both fit
 
@@ -24,7 +25,7 @@ class AftConfig(C.Structure):
         ("patch_scs", C.c_int32), ("patch_symbols", C.c_int32),
         ("num_layers", C.c_int32), ("model_dim", C.c_int32), ("num_head", C.c_int32),
         ("activation", C.c_int32), ("adaptive", C.c_int32),
-        ("hidden", C.c_int32 * 3), ("encoder_path", C.c_int32), ("reserved", C.c_int32),
+        ("hidden", C.c_int32 * 3), ("encoder_path", C.c_int32), ("precision", C.c_int32),
     ]
 
     @property

@@ -78,6 +78,10 @@ int check_config(const aft_config *c) {
         set_error("patch %dx%d has more than %d elements", c->patch_scs, c->patch_symbols, kMaxPatchFeatures);
         return AFT_ERR_SHAPE;
     }
+    if (c->precision != AFT_PRECISION_F32 && (c->precision != AFT_PRECISION_BF16X3 || c->model_dim != 128)) {
+        set_error("precision %d: the split-precision tier (AFT_PRECISION_BF16X3) is instantiated for model_dim 128 only", c->precision);
+        return AFT_ERR_SHAPE;
+    }
     if (c->activation != AFT_ACT_RELU && c->activation != AFT_ACT_GELU) {
         set_error("unknown activation %d", c->activation);
         return AFT_ERR_ARG;
@@ -163,8 +167,8 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
     // whole forward and the caller asks for it: ONE launch for the encoder (k_encoder.hip).  AUTO means the launches:
     // measured on the MI355X at B = 128 (256 planes on 256 CUs, its best case) the plane-resident kernel is 1.5 % slower
     // (profiles/r03_ab_encoder.json), so nothing selects it by itself.
-    if (fused && c.encoder_path == AFT_ENCODER_PLANE && first_layer == 0 && last_layer == c.num_layers - 1 &&
-        encoder_plane_ok(c)) {
+    if (fused && c.encoder_path == AFT_ENCODER_PLANE && c.precision == AFT_PRECISION_F32 && first_layer == 0 &&
+        last_layer == c.num_layers - 1 && encoder_plane_ok(c)) {
         e = launch_encoder_plane(c, w, wp, base + ws.conv_enhanced, c.adaptive ? base + ws.tokens6 : nullptr, x, attn, q, k, vt,
                                  base + ws.out6, ws.planes, ws.tokens, ws.tokpad, st);
         return e == hipSuccess ? AFT_OK : hip_fail("encoder(plane-resident)", e);

@@ -134,6 +134,74 @@ __device__ __forceinline__ void gemm_run(WRing<NT, PFS> &ring, Srd w, unsigned w
     }
 }
 
+// ---- split-precision tier (aft_config.precision = AFT_PRECISION_BF16X3; never the default) ----
+// Every fp32 operand x of the row-local GEMMs is split into two bf16 terms, hi = bf16(x), lo = bf16(x - hi), and a
+// product is accumulated as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; the dropped lo.lo term and
+// the split residuals are ~2^-16 relative).  Per 32-deep k-block that is 6 MFMAs of 32 cycles instead of 16 fp32 MFMAs of
+// 64: 5.3x less matrix time, and the bf16 pipe does not take the vector ALU's cycles as the fp32 MFMA does.  The data
+// flow of the fp32 kernel carries over unchanged because the 32x32x16 accumulator has the same layout as the 32x32x2 one
+// (lane = token row, register e = feature (e&3) + 8(e>>2) + 4h): registers 8m .. 8m+7 of a lane ARE its 8 k-values of
+// MFMA m of the next product, k = 16m + 8(j>>2) + 4h + (j&3) for element j (guide: "An accumulator tile as the next
+// MFMA's operand") -- the packed weights use the same k order (pack_weights_kernel, split image).
+using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+struct BsFrag {     // one MFMA's worth of an activation operand: 8 k-values as bf16 hi / lo (16 bytes each)
+    f32x4 hi, lo;
+};
+__device__ __forceinline__ BsFrag bs_split(f32x4 x0, f32x4 x1) {
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? x0[j] : x1[j - 4];
+        hi[j] = (__bf16)x;
+        lo[j] = (__bf16)(x - (float)hi[j]);
+    }
+    return BsFrag{__builtin_bit_cast(f32x4, hi), __builtin_bit_cast(f32x4, lo)};
+}
+// exchange buffers in the split tier: [feature block][m][hi | lo][lane][8 bf16] -- 4 KB per block, as the fp32 fragments
+__device__ __forceinline__ void bs_publish(float *buf, int block, int lane, const f32x16 &v) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const BsFrag f = bs_split(f32x4{v[8 * m], v[8 * m + 1], v[8 * m + 2], v[8 * m + 3]},
+                                  f32x4{v[8 * m + 4], v[8 * m + 5], v[8 * m + 6], v[8 * m + 7]});
+        *reinterpret_cast<f32x4 *>(buf + (block * 4 + 2 * m) * 256 + lane * 4) = f.hi;
+        *reinterpret_cast<f32x4 *>(buf + (block * 4 + 2 * m + 1) * 256 + lane * 4) = f.lo;
+    }
+}
+__device__ __forceinline__ BsFrag bs_fetch(const float *buf, int kb, int m, int lane) {
+    return BsFrag{*reinterpret_cast<const f32x4 *>(buf + (kb * 4 + 2 * m) * 256 + lane * 4),
+                  *reinterpret_cast<const f32x4 *>(buf + (kb * 4 + 2 * m + 1) * 256 + lane * 4)};
+}
+
+// gemm_run of the split tier.  The weight ring is the fp32 kernel's (16 bytes per step and tile): step (kb, s) now
+// carries the A operand of MFMA m = s >> 1 as bf16 hi (s even) or lo (s odd).  `act(kb, m)` yields the activation operand.
+template <int NKB, int NT, int PFS, int TS, unsigned NORMAL, class Act, unsigned ZERO = 0>
+__device__ __forceinline__ void gemm_run_bs(WRing<NT, PFS> &ring, Srd w, unsigned w_lane, f32x16 (&acc)[NT], Act act) {
+    BsFrag bfrag{};
+#pragma unroll
+    for (int step = 0; step < 4 * NKB; ++step) {
+        if (step + PFS < 4 * NKB) ring_load<NKB, NT, PFS, TS>(ring, w, w_lane, step + PFS);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool lo_step = step & 1;
+        if (!lo_step) bfrag = act(step >> 2, (step & 3) >> 1);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bfrag.hi), bl = __builtin_bit_cast(bf16x8, bfrag.lo);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, ring.b[step % (PFS + 1)][t]);
+            const bool normal = (NORMAL >> t) & 1;
+            if (((ZERO >> t) & 1) && step == 0)
+                acc[t] = normal ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wv, f32x16{0}, 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, bh, f32x16{0}, 0, 0, 0);
+            else
+                acc[t] = normal ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wv, acc[t], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, bh, acc[t], 0, 0, 0);
+            if (!lo_step)      // hi weights also meet the activation's lo term
+                acc[t] = normal ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, wv, acc[t], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, bl, acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // LayerNorm(eps = 1e-5, biased variance) over D features of the row this lane belongs to, given the
 // lane's 16 pre-norm values v (features fb + 8s + 4h + j).  Partial (mean, M2) of the wave's 32
 // features goes to `stats[row][wave]`; after the barrier every lane merges the W partials (Chan).
@@ -206,7 +274,7 @@ __device__ __forceinline__ f32x16 bias_acc(Srd bias, int f0, int h) {
 // of three groups of a 12-wave workgroup in the plane-resident encoder kernel (k_encoder.hip).  __syncthreads() is the
 // only cross-wave synchronisation, so every group of a workgroup must walk the same NUMBER of tiles (tiles past the
 // last row are computed on clamped rows and never stored).
-template <int D, int ACT, bool MLP, bool QKV>
+template <int D, int ACT, bool MLP, bool QKV, bool BS = false>
 __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, const int tid_in, const int first_tile,
                                            const int tile_stride, const int tile_end) {
     using S = ChainShape<D>;
@@ -371,7 +439,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         if (!AHEAD) request_x(tile);
         STAMP(1);
         // ---- out-projection (transposed) + bias + residual ----
-        gemm_run<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
+        if constexpr (BS)
+            gemm_run_bs<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int m) { return bs_split(of[kb][2 * m], of[kb][2 * m + 1]); });
+        else
+            gemm_run<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
         f32x16 acc_h[2] = {bias_acc(srd_b1, 2 * fb, h), bias_acc(srd_b1, 2 * fb + 32, h)};
         gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w1, w1_lane);
 #pragma unroll
@@ -381,32 +452,49 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         STAMP(2);
         layernorm_rows<D>(cur, stats, par + fb, par + D + fb, w, r, h);   // -> x1 (kept: FFN residual)
         STAMP(3);
+        if constexpr (BS) {
+            bs_publish(xb, w, lane, cur);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+            for (int s = 0; s < 4; ++s)
+                *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+        }
         __syncthreads();
         STAMP(4);
         // ---- FFN up-projection + activation -> hidden blocks 2w, 2w+1 ----
-        gemm_run<W, 2, PFF, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
-            return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
-        });
+        if constexpr (BS)
+            gemm_run_bs<W, 2, PFF, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int m) { return bs_fetch(xb, kb, m, lane); });
+        else
+            gemm_run<W, 2, PFF, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
+                return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+            });
         f32x16 acc_d[1] = {bias_acc(srd_b2, fb, h)};
         gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w2, w2_lane);
         STAMP(5);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            f32x16 hid;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x2 g0 = activate2<ACT>(f32x2{acc_h[t][4 * s], acc_h[t][4 * s + 1]});
                 const f32x2 g1 = activate2<ACT>(f32x2{acc_h[t][4 * s + 2], acc_h[t][4 * s + 3]});
-                *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                if constexpr (BS) {
+                    hid[4 * s] = g0[0]; hid[4 * s + 1] = g0[1]; hid[4 * s + 2] = g1[0]; hid[4 * s + 3] = g1[1];
+                } else {
+                    *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = f32x4{g0[0], g0[1], g1[0], g1[1]};
+                }
             }
+            if constexpr (BS) bs_publish(hb, 2 * w + t, lane, hid);
+        }
         __syncthreads();
         STAMP(6);
         // ---- FFN down-projection (transposed) + bias + residual(x1, registers) ----
-        gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
-            return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
-        });
+        if constexpr (BS)
+            gemm_run_bs<2 * W, 1, PFD, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int m) { return bs_fetch(hb, kb, m, lane); });
+        else
+            gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
+                return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
+            });
         if constexpr (QKV) gemm_preload<W, 3, PFQ, W>(ring_qkv, srd_wq, wq_lane);
 #pragma unroll
         for (int e = 0; e < 16; ++e) cur[e] += acc_d[0][e];
@@ -503,9 +591,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         // (xb / the idle hidden buffer): a re-write then sits two barriers behind the last read.
         float *xq = xb;
         if constexpr (!MLP) xq = (round & 1) ? hb : xb;
+        if constexpr (BS) {
+            bs_publish(xq, w, lane, cur);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            *reinterpret_cast<f32x4 *>(xq + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+            for (int s = 0; s < 4; ++s)
+                *reinterpret_cast<f32x4 *>(xq + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+        }
         __syncthreads();
         STAMP(9);
         f32x16 vinit;
@@ -513,8 +605,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         for (int e = 0; e < 16; ++e) vinit[e] = bias_v;
         f32x16 acc[3];
         acc[2] = vinit;
-        auto xq_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xq + (kb * 4 + s) * 256 + lane * 4); };
-        gemm_run<W, 3, PFQ, W, 0x4, decltype(xq_frag), 0x3>(ring_qkv, srd_wq, wq_lane, acc, xq_frag);   // q, k start from 0
+        if constexpr (BS) {
+            auto xq_bs = [&](int kb, int m) { return bs_fetch(xq, kb, m, lane); };
+            gemm_run_bs<W, 3, PFQ, W, 0x4, decltype(xq_bs), 0x3>(ring_qkv, srd_wq, wq_lane, acc, xq_bs);
+        } else {
+            auto xq_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xq + (kb * 4 + s) * 256 + lane * 4); };
+            gemm_run<W, 3, PFQ, W, 0x4, decltype(xq_frag), 0x3>(ring_qkv, srd_wq, wq_lane, acc, xq_frag);   // q, k start from 0
+        }
         STAMP(10);
         if (AHEAD && tile + tile_stride < ntiles) request_tile(tile + tile_stride);   // before this tile's stores
         // ---- epilogue: q, k, v of head w for 32 token rows, written in MFMA-FRAGMENT order so that

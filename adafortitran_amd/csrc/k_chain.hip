@@ -18,6 +18,32 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_kernel(const Ch
 }
 
 
+// split-precision tier (aft_config.precision = AFT_PRECISION_BF16X3): the same body with its GEMMs on bf16 hi/lo terms
+template <int D, int ACT, bool MLP, bool QKV>
+__global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_split_kernel(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    chain_body<D, ACT, MLP, QKV, true>(a, smem, threadIdx.x, blockIdx.x, gridDim.x, (a.rows + 31) / 32);
+}
+
+template <int ACT, bool MLP, bool QKV>
+static hipError_t launch_chain_split_v(const ChainArgs &args, hipStream_t st) {
+    constexpr int D = 128;
+    using S = ChainShape<D>;
+    static PerDeviceOnce lds_attr;
+    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_split_kernel<D, ACT, MLP, QKV>), S::LDS_BYTES);
+    if (ea != hipSuccess) return ea;
+    const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * 3);
+    hipLaunchKernelGGL((chain_split_kernel<D, ACT, MLP, QKV>), dim3(blocks), dim3(S::THREADS), S::LDS_BYTES, st, args);
+    return hipGetLastError();
+}
+
+template <int ACT>
+static hipError_t launch_chain_split_t(const ChainArgs &args, bool mlp, bool qkv, hipStream_t st) {
+    if (mlp && qkv) return launch_chain_split_v<ACT, true, true>(args, st);
+    if (mlp) return launch_chain_split_v<ACT, true, false>(args, st);
+    return launch_chain_split_v<ACT, false, true>(args, st);
+}
+
 template <int D, int ACT, bool MLP, bool QKV>
 static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
     using S = ChainShape<D>;
@@ -117,7 +143,7 @@ static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
 size_t packed_layer_floats(int d) { return (size_t)8 * d * d; }
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const aft_weights w, float *__restrict__ packed, int d,
-                                                           int num_layers) {
+                                                           int num_layers, int split) {
     const size_t per_layer = (size_t)8 * d * d;
     const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;   // one float4 of the packed image
     if (v * 4 >= per_layer * num_layers) return;
@@ -134,7 +160,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const aft_weights w, 
     const int lane = (int)(off / 4) % 64, s = (int)(off / 256) % 4;
     const int blk = (int)(off / 1024), nkb = K / 32, kb = blk % nkb, ct = blk / nkb;
     const int col = ct * 32 + (lane & 31), k = kb * 32 + s * 8 + (lane >> 5) * 4;
-    *reinterpret_cast<f32x4 *>(packed + v * 4) = *reinterpret_cast<const f32x4 *>(src + (size_t)col * K + k);
+    if (!split) {
+        *reinterpret_cast<f32x4 *>(packed + v * 4) = *reinterpret_cast<const f32x4 *>(src + (size_t)col * K + k);
+        return;
+    }
+    // split-precision image: slot s of a block = MFMA m = s >> 1, term hi (s even) / lo (s odd); the lane's 8 bf16 values
+    // are k = 32 kb + 16 m + 8 (j >> 2) + 4 h + (j & 3), the k order of an accumulator used as operand (chain_device.h)
+    const int m = s >> 1, hh = lane >> 5;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = src[(size_t)col * K + kb * 32 + 16 * m + 8 * (j >> 2) + 4 * hh + (j & 3)];
+        const __bf16 hi = (__bf16)x;
+        o[j] = (s & 1) ? (__bf16)(x - (float)hi) : hi;
+    }
+    *reinterpret_cast<f32x4 *>(packed + v * 4) = __builtin_bit_cast(f32x4, o);
 }
 
 hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float *packed, int first_layer, int count,
@@ -143,7 +183,7 @@ hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float 
     for (int i = 0; i < count; ++i) shifted.layers[i] = w.layers[first_layer + i];
     const size_t vecs = packed_layer_floats(c.model_dim) * count / 4;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, shifted, packed,
-                       c.model_dim, count);
+                       c.model_dim, count, c.precision == AFT_PRECISION_BF16X3 ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -189,6 +229,10 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const f
     a.heads = c.num_head;
     const bool gelu = c.activation == AFT_ACT_GELU;
     const bool mlp = m != nullptr, qkv = qw != nullptr;
+    if (c.precision == AFT_PRECISION_BF16X3) {
+        if (c.model_dim != 128) return hipErrorInvalidValue;    // refused earlier by check_config
+        return gelu ? launch_chain_split_t<AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_split_t<AFT_ACT_RELU>(a, mlp, qkv, st);
+    }
     if (c.model_dim == 64)
         return gelu ? launch_chain_t<64, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<64, AFT_ACT_RELU>(a, mlp, qkv, st);
     if (c.model_dim == 192)

@@ -102,7 +102,7 @@ class HipEngine:
         or after invalidate_packed().  Stream order makes a re-build safe against forwards still in flight on the same
         stream; callers that alternate streams get one image per stream."""
         stream = self._stream()
-        key = (stream, tuple(t._version for t in self._gemm_weights))
+        key = (stream, int(self.cfg.precision), tuple(t._version for t in self._gemm_weights))
         if key != self._packed_key:
             nbytes = self.lib.aft_packed_weights_bytes(C.byref(self.cfg))
             if self._packed is None or self._packed_key is None or self._packed_key[0] != stream:

@@ -52,6 +52,16 @@ extern "C" {
 #define AFT_ENCODER_LAUNCHES 1
 #define AFT_ENCODER_PLANE 2
 
+/* aft_config.precision.  F32: every product on exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32) -- the default, the parity
+ * contract (5e-5 |y|max, |dMSE|/MSE <= 1e-4) and the only mode the headline benchmark runs.  BF16X3 (opt-in, reported
+ * separately, SURVEY.md 8d "bf16-MFMA tier"): the encoder's ROW-LOCAL GEMMs (in-projection, out-projection, FFN) split
+ * each fp32 operand into bf16 hi + lo and accumulate hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 in fp32 (~2^-16
+ * relative per product; stated tolerance max|d| <= 1e-3 |y|max, |dMSE|/MSE <= 1e-2, observed ~1e-5 / ~1e-6: tests/
+ * test_hip_parity.py).  Attention, LayerNorm, GELU, the conv stacks and every accumulator stay fp32.  model_dim 128 only;
+ * inference only. */
+#define AFT_PRECISION_F32 0
+#define AFT_PRECISION_BF16X3 1
+
 #define AFT_ACT_RELU 0
 #define AFT_ACT_GELU 1 /* exact erf form, as activation="gelu" in encoders.py:44-51 */
 
@@ -66,7 +76,7 @@ typedef struct aft_config {
     int32_t adaptive;                 /* 1 = AdaFortiTran (adapter tokens), 0 = FortiTran */
     int32_t hidden[3];                /* channel_adaptivity_hidden_sizes (adaptive only) */
     int32_t encoder_path;             /* AFT_ENCODER_*: how aft_forward_f32 runs the encoder (same bits either way) */
-    int32_t reserved;
+    int32_t precision;                /* AFT_PRECISION_*: 0 = exact fp32 everywhere (the default and the parity contract) */
 } aft_config;
 
 /* One nn.TransformerEncoderLayer (post-LN), PyTorch layouts
