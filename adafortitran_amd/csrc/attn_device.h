@@ -100,6 +100,31 @@ struct AttnRow {          // per-lane softmax state of the lane's query row
 // One WAVE walks the tasks first_task, first_task + total_waves, ... < ntasks (task = (plane * heads + head) * nkt + query
 // tile): attn_kernel (k_attn.hip) deals them over a persistent grid, the plane-resident encoder kernel (k_encoder.hip)
 // over the 12 waves of the workgroup that owns the plane.  No LDS, no barriers.
+// S^T tile of the split-precision tier: K and Q^T arrive as bf16 hi / lo fragments (slot 2m + term of a tile = MFMA m's
+// 8 k-values, written by the chain kernel's in-projection epilogue with the query bias and the softmax scale already
+// applied): hi.hi + hi.lo + lo.hi per MFMA m on v_mfma_f32_32x32x16_bf16.  The reference enters as one more MFMA whose
+// A operand is 1 at k = 0 and whose B operand is -m_ref there: m_ref is kept bf16-representable so that this is exact.
+__device__ __forceinline__ f32x16 qk_tile_bs(const f32x4 (&kreg)[4], const f32x4 (&qreg)[4], bool zero_ref, float neg_m, int h) {
+    f32x16 c = f32x16{0};
+    if (!zero_ref) {
+        bf16x8 one = {}, mref = {};
+        one[0] = (__bf16)(h == 0 ? 1.0f : 0.0f);
+        mref[0] = (__bf16)(h == 0 ? neg_m : 0.0f);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one, mref, c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const bf16x8 kh = __builtin_bit_cast(bf16x8, kreg[2 * m]), kl = __builtin_bit_cast(bf16x8, kreg[2 * m + 1]);
+        const bf16x8 qh = __builtin_bit_cast(bf16x8, qreg[2 * m]), ql = __builtin_bit_cast(bf16x8, qreg[2 * m + 1]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, c, 0, 0, 0);
+    }
+    return c;
+}
+__device__ __forceinline__ float round_to_bf16(float x) { return (float)(__bf16)x; }
+
+template <bool BS = false>
 __device__ __forceinline__ void attn_body(const float *__restrict__ q, const float *__restrict__ k,
                                           const float *__restrict__ vt, const float *__restrict__ qbias,
                                           float *__restrict__ out, int heads, int tokens, int tokpad, int model_dim,
@@ -133,11 +158,22 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
             if (kt * kTile + (e & 3) + 8 * (e >> 2) + 4 * h >= tokens) sv[e] = -INFINITY;
     };
     auto mask_values = [&](f32x4 (&vv)[4], int kt) {
+        if constexpr (BS) {   // slot 2m + term, element j: key 16 m + 8 (j >> 2) + 4 h + (j & 3) of the tile
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int sl = 0; sl < 4; ++sl) {
+                bf16x8 e = __builtin_bit_cast(bf16x8, vv[sl]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (kt * kTile + 8 * g + 4 * h + j >= tokens) vv[g][j] = 0.f;
+                for (int j = 0; j < 8; ++j)
+                    if (kt * kTile + 16 * (sl >> 1) + 8 * (j >> 2) + 4 * h + (j & 3) >= tokens) e[j] = (__bf16)0.0f;
+                vv[sl] = __builtin_bit_cast(f32x4, e);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (kt * kTile + 8 * g + 4 * h + j >= tokens) vv[g][j] = 0.f;
+        }
     };
 
   // wave priority by work left (set_progress_priority, aft_internal.h): keeps the waves of a SIMD abreast
@@ -165,9 +201,11 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     // B operand of S^T = K Q^T : lane (q = r, h) holds Q[q][8s + 4h + j]; the query bias of the
     // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
     // a row constant to the logits, which softmax cancels), then everything is pre-scaled
-    const float *bq = qbias + (ph % heads) * kHeadDim + 4 * h;
+    if constexpr (!BS) {   // (split tier: bias and scale were applied before the bf16 split, in the chain kernel's epilogue)
+        const float *bq = qbias + (ph % heads) * kHeadDim + 4 * h;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
+        for (int s = 0; s < 4; ++s) qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
+    }
     // Padded query lanes of the ragged last query tile read workspace nobody wrote: their results are never stored, but
     // the reference tests below are wave-wide (__any), so a large stale value there would switch the VALID lanes of the
     // wave onto the rescale path -- same mathematics, different rounding, i.e. output bits that depend on what the
@@ -179,12 +217,15 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
 
     // ---- key tile 0: plain logits, reference maximum ----
     AttnRow st;
-    f32x16 sA = qk_tile(kcur, qreg, true, a_one, 0.f), sB;
+    f32x16 sA, sB;
+    if constexpr (BS) sA = qk_tile_bs(kcur, qreg, true, 0.f, h);
+    else sA = qk_tile(kcur, qreg, true, a_one, 0.f);
     if (nkt > 1) load_tile(ks, 1, kcur, hb);
     if (ragged && nkt == 1) { mask_logits(sA, 0); mask_values(vcur, 0); }
     {
         float m0 = max16(sA);
         m0 = fmaxf(m0, other_half(m0));                  // finite: tile 0 holds >= 1 real key
+        if constexpr (BS) m0 = round_to_bf16(m0);          // the reference must be exact in the reference MFMA (any value is a valid reference)
         st.zero_ref = !__any(fabsf(m0) > kZeroRefThreshold);
         st.m_ref = st.zero_ref ? 0.f : m0;
         if (!st.zero_ref) {
@@ -204,7 +245,8 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
         set_progress_priority((rounds - 1 - round) * nkt + (nkt - 1 - kt), rounds * nkt);
         const bool more = FAST || kt + 1 < nkt;
         if (more) {
-            nxt = qk_tile(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
+            if constexpr (BS) nxt = qk_tile_bs(kcur, qreg, st.zero_ref, -st.m_ref, h);
+            else nxt = qk_tile(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
             if (FAST || kt + 2 < nkt) load_tile(ks, kt + 2, kcur, hb);
         } else if (has_next) {      // last tile: Q and K are idle -> request the next task's
             const unsigned hbn = head_base(next_task);
@@ -215,7 +257,8 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
         const float tmax = max16(cur);
         if (__builtin_expect(__any(tmax > kRescaleThreshold), 0)) {
             const float tm = fmaxf(tmax, other_half(tmax));
-            const float grow = fmaxf(tm, 0.f);           // new reference = m_ref + grow  (0 for rows that stay)
+            float grow = fmaxf(tm, 0.f);                 // new reference = m_ref + grow  (0 for rows that stay)
+            if constexpr (BS) grow = round_to_bf16(st.m_ref + grow) - st.m_ref;   // keep the reference bf16-representable (the difference of two such values is exact)
             const float f = __builtin_amdgcn_exp2f(-grow);
             st.m_ref += grow;
             st.zero_ref = false;
@@ -237,12 +280,26 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
             st.lsum2 += f32x2{p[e], p[e + 1]};
         }
         // O^T += V^T P^T  (k-groups of 8 keys that are all padding -- only in the ragged last tile -- are skipped)
+        if constexpr (BS) {   // V^T slot 2m + term; P registers 8m .. 8m+7 are MFMA m's k-values (keys) as they stand
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (!FAST && ragged && kt * kTile + 8 * g >= tokens) continue;
+            for (int m = 0; m < 2; ++m) {
+                if (!FAST && ragged && kt * kTile + 16 * m >= tokens) continue;
+                const BsFrag pf = bs_split(f32x4{p[8 * m], p[8 * m + 1], p[8 * m + 2], p[8 * m + 3]},
+                                           f32x4{p[8 * m + 4], p[8 * m + 5], p[8 * m + 6], p[8 * m + 7]});
+                const bf16x8 ph8 = __builtin_bit_cast(bf16x8, pf.hi), pl8 = __builtin_bit_cast(bf16x8, pf.lo);
+                const bf16x8 vh = __builtin_bit_cast(bf16x8, vcur[2 * m]), vl = __builtin_bit_cast(bf16x8, vcur[2 * m + 1]);
+                st.oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph8, st.oacc, 0, 0, 0);
+                st.oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl8, st.oacc, 0, 0, 0);
+                st.oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph8, st.oacc, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                st.oacc = mfma_f32(vcur[g][j], p[4 * g + j], st.oacc);
+            for (int g = 0; g < 4; ++g) {
+                if (!FAST && ragged && kt * kTile + 8 * g >= tokens) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    st.oacc = mfma_f32(vcur[g][j], p[4 * g + j], st.oacc);
+            }
         }
         if (more) {
             load_tile(vs, kt + 1, vcur, hb);

@@ -143,20 +143,6 @@ __device__ __forceinline__ void gemm_run(WRing<NT, PFS> &ring, Srd w, unsigned w
 // (lane = token row, register e = feature (e&3) + 8(e>>2) + 4h): registers 8m .. 8m+7 of a lane ARE its 8 k-values of
 // MFMA m of the next product, k = 16m + 8(j>>2) + 4h + (j&3) for element j (guide: "An accumulator tile as the next
 // MFMA's operand") -- the packed weights use the same k order (pack_weights_kernel, split image).
-using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
-struct BsFrag {     // one MFMA's worth of an activation operand: 8 k-values as bf16 hi / lo (16 bytes each)
-    f32x4 hi, lo;
-};
-__device__ __forceinline__ BsFrag bs_split(f32x4 x0, f32x4 x1) {
-    bf16x8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = j < 4 ? x0[j] : x1[j - 4];
-        hi[j] = (__bf16)x;
-        lo[j] = (__bf16)(x - (float)hi[j]);
-    }
-    return BsFrag{__builtin_bit_cast(f32x4, hi), __builtin_bit_cast(f32x4, lo)};
-}
 // exchange buffers in the split tier: [feature block][m][hi | lo][lane][8 bf16] -- 4 KB per block, as the fp32 fragments
 __device__ __forceinline__ void bs_publish(float *buf, int block, int lane, const f32x16 &v) {
 #pragma unroll
@@ -606,8 +592,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         f32x16 acc[3];
         acc[2] = vinit;
         if constexpr (BS) {
+            // split tier: the attention kernel receives q as bf16 pairs, so the query bias (the accumulator's initial value)
+            // and the softmax scale are applied here, before the split
+            acc[0] = bias_acc(make_srd(a.bv - 2 * D), fb, h);
             auto xq_bs = [&](int kb, int m) { return bs_fetch(xq, kb, m, lane); };
-            gemm_run_bs<W, 3, PFQ, W, 0x4, decltype(xq_bs), 0x3>(ring_qkv, srd_wq, wq_lane, acc, xq_bs);
+            gemm_run_bs<W, 3, PFQ, W, 0x4, decltype(xq_bs), 0x2>(ring_qkv, srd_wq, wq_lane, acc, xq_bs);
         } else {
             auto xq_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xq + (kb * 4 + s) * 256 + lane * 4); };
             gemm_run<W, 3, PFQ, W, 0x4, decltype(xq_frag), 0x3>(ring_qkv, srd_wq, wq_lane, acc, xq_frag);   // q, k start from 0
@@ -624,6 +613,70 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         const unsigned head_stride = (unsigned)a.tokpad * kHeadDim;             // floats per (plane, head)
         const unsigned ph0 = (unsigned)(plane0 * a.heads + w);
         const bool full = row0 + 32 <= a.rows;
+        if constexpr (BS) {
+            // split tier: q / k / v^T leave as bf16 hi / lo fragments.  Slot 2m + term of a tile replaces slot s: the lane's
+            // registers 8m .. 8m+7 are the 8 k-values of the attention kernel's MFMA m (k = head feature for q / k, key for
+            // v^T); same bytes, same addresses as the fp32 fragments.
+            const float qscale = 1.4426950408889634f * 0.17677669529663687f;   // log2(e) / sqrt(32)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][e] *= qscale;
+            {
+                int tok = tok0 + r;
+                unsigned ph = ph0;
+                if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+                const unsigned lane_off = (ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok & 31) + 32 * h) * 4) * 4;
+                if (full || row_ok) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const BsFrag f = bs_split(f32x4{acc[t][8 * m], acc[t][8 * m + 1], acc[t][8 * m + 2], acc[t][8 * m + 3]},
+                                                      f32x4{acc[t][8 * m + 4], acc[t][8 * m + 5], acc[t][8 * m + 6], acc[t][8 * m + 7]});
+                            srd_store(t == 0 ? srd_q : srd_k, lane_off + (2 * m) * 1024, f.hi);
+                            srd_store(t == 0 ? srd_q : srd_k, lane_off + (2 * m + 1) * 1024, f.lo);
+                        }
+                }
+            }
+            // v^T: lane = head feature, registers 4gq .. 4gq+3 = tokens tok0 + 8gq + 4h + {0..3} = one half (8 bytes) of the
+            // 16-byte element (key tile, slot 2m + term) with m = (8-key group within the tile) >> 1
+            __bf16 *vt16 = reinterpret_cast<__bf16 *>(a.vt);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                int tok = tok0 + 8 * gq + 4 * h;
+                unsigned ph = ph0;
+                if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+                __bf16 vh[4], vl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vh[j] = (__bf16)acc[2][4 * gq + j];
+                    vl[j] = (__bf16)(acc[2][4 * gq + j] - (float)vh[j]);
+                }
+                const bool in_rows = full || row0 + 8 * gq + 4 * h + 3 < a.rows;
+                if ((tok & 3) == 0 && tok + 3 < a.tokens && in_rows) {
+                    // the four tokens are keys 32kt + 8g + 4hh + {0..3} of one plane: element (kt, slot 2(g>>1) + term), lane
+                    // (feature, hh), bf16 positions 4(g&1) .. 4(g&1)+3
+                    const unsigned g = (tok >> 3) & 3, hh = (tok >> 2) & 1;
+                    const size_t e16 = ((size_t)ph * head_stride + (size_t)(tok >> 5) * 1024 + (2 * (g >> 1)) * 256 + (r + 32 * hh) * 4) * 2 + 4 * (g & 1);
+                    using bf16x4 = __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16;
+                    *reinterpret_cast<bf16x4 *>(vt16 + e16) = bf16x4{vh[0], vh[1], vh[2], vh[3]};
+                    *reinterpret_cast<bf16x4 *>(vt16 + e16 + 512) = bf16x4{vl[0], vl[1], vl[2], vl[3]};   // next slot: + 256 floats
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int tj = tok + j;
+                        unsigned pj = ph;
+                        if (tj >= a.tokens) { tj -= a.tokens; pj += a.heads; }
+                        if (row0 + 8 * gq + 4 * h + j < a.rows) {
+                            const unsigned g = (tj >> 3) & 3, hh = (tj >> 2) & 1;
+                            const size_t e16 = ((size_t)pj * head_stride + (size_t)(tj >> 5) * 1024 + (2 * (g >> 1)) * 256 + (r + 32 * hh) * 4) * 2 +
+                                               4 * (g & 1) + (tj & 3);
+                            vt16[e16] = vh[j];
+                            vt16[e16 + 512] = vl[j];
+                        }
+                    }
+                }
+            }
+        } else
         if (full && tok0 + 32 <= a.tokens && (a.tokens & 7) == 0) {
             // the common case -- the tile lies inside one plane and 8 divides the token count (tok0 is then a multiple of
             // 8): every V^T group of four tokens is one whole fragment element at lane-linear offset, and all the block

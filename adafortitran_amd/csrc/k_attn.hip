@@ -25,12 +25,27 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *
               stamps);
 }
 
+// split-precision tier: K / Q^T / V^T arrive as bf16 hi / lo fragments from chain_split_kernel (attn_device.h)
+__global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_split_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                      const float *__restrict__ vt, float *__restrict__ out, int heads, int tokens,
+                                                      int tokpad, int model_dim, int ntasks) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int vblock = blockIdx.x;
+    if ((gridDim.x & 7) == 0) vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    attn_body<true>(q, k, vt, nullptr, out, heads, tokens, tokpad, model_dim, 0.f, vblock * 4 + wave, gridDim.x * 4, ntasks, nullptr);
+}
+
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
                             float *attn, int planes, int tokens, int tokpad, hipStream_t st) {
     const int ntasks = planes * c.num_head * (tokpad / kTile);
     const int resident_blocks = AFT_ATTN_WAVES * current_device_cus();   // CUs x 3 workgroups (launch bound: 3 waves / SIMD)
     const int blocks = std::min((ntasks + 3) / 4, resident_blocks);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)kHeadDim);
+    if (c.precision == AFT_PRECISION_BF16X3) {
+        hipLaunchKernelGGL(attn_split_kernel, dim3(blocks), dim3(256), 0, st, q, k, vt, attn, c.num_head, tokens, tokpad, c.model_dim,
+                           ntasks);
+        return hipGetLastError();
+    }
 #ifdef AFT_DIAG_STAMPS
     if (getenv("AFT_STAMPS")) {   // per-task stamps + in-kernel clock (diagnostic build only)
         static unsigned long long *dbuf = nullptr;

@@ -24,4 +24,20 @@ __device__ __forceinline__ void srd_store(Srd r, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, byte_off, 0, 0);
 }
 
+// split-precision tier: bf16 hi / lo terms of fp32 values (chain_device.h explains the scheme)
+using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+struct BsFrag {     // one MFMA's worth of an activation operand: 8 k-values as bf16 hi / lo (16 bytes each)
+    f32x4 hi, lo;
+};
+__device__ __forceinline__ BsFrag bs_split(f32x4 x0, f32x4 x1) {
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? x0[j] : x1[j - 4];
+        hi[j] = (__bf16)x;
+        lo[j] = (__bf16)(x - (float)hi[j]);
+    }
+    return BsFrag{__builtin_bit_cast(f32x4, hi), __builtin_bit_cast(f32x4, lo)};
+}
+
 }  // namespace aft

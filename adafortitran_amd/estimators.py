@@ -110,6 +110,7 @@ class BaseFortiTranEstimator(nn.Module):
         self.device = torch.device(model_config.device)
         self.logger = logging.getLogger(self.__class__.__name__)
         self._engine = None
+        self._hip_precision = os.environ.get("AFT_PRECISION", "f32")   # see the hip_precision property
         self._engine_entries = ()      # (owner dict, key, tensor, data_ptr) per state_dict tensor of the engine
         self._stager = None            # pinned-ring H2D staging of CPU inputs on the HIP inference path
         self._hip_covered = False
@@ -198,6 +199,21 @@ class BaseFortiTranEstimator(nn.Module):
             self._engine.invalidate_packed()
         return super().train(mode)
 
+    @property
+    def hip_precision(self) -> str:
+        """Arithmetic of the HIP inference path: ``"f32"`` (default: exact-fp32 MFMAs everywhere, the parity contract) or
+        ``"bf16x3"`` -- the opt-in split-precision tier of include/adafortitran_amd.h (AFT_PRECISION_BF16X3: the encoder's
+        GEMMs and attention products on bf16 hi/lo terms with fp32 accumulation; model_dim 128; ~1.8x the frames/s at
+        max|d| ~ 3e-5 |y|max).  Not part of the reference's YAML surface: set it on the module, or AFT_PRECISION=bf16x3."""
+        return self._hip_precision
+
+    @hip_precision.setter
+    def hip_precision(self, value: str) -> None:
+        if value not in ("f32", "bf16x3"):
+            raise ValueError("hip_precision must be 'f32' or 'bf16x3'")
+        self._hip_precision = value
+        self._engine = None
+
     def _hip_eligible(self) -> bool:
         return self._hip_covered and not self.training and not torch.is_grad_enabled()
 
@@ -216,7 +232,7 @@ class BaseFortiTranEstimator(nn.Module):
                     break
             if eng is not None:
                 return eng
-        from .hip_ops import HipEngine  # raises loudly if the extension is missing
+        from .hip_ops import HipEngine, config_coverage  # raises loudly if the extension is missing
         entries, tensors = [], {}
         for prefix, mod in self.named_modules():
             for owner in (mod._parameters, mod._buffers):
@@ -232,6 +248,11 @@ class BaseFortiTranEstimator(nn.Module):
             if not v.is_contiguous():
                 raise ValueError(f"parameter {k} is not contiguous")
         cfg = _abi.config_from_pydantic(self.system_config, self.model_config, self.use_channel_adaptation)
+        if self._hip_precision == "bf16x3":
+            cfg.precision = _abi.AFT_PRECISION_BF16X3
+            reason = config_coverage(cfg)
+            if reason is not None:
+                raise ValueError(f"hip_precision='bf16x3': {reason}")
         eng = HipEngine(cfg, {k: v.detach() for k, v in tensors.items()})
         self._engine, self._engine_entries = eng, tuple(entries)
         return eng

@@ -23,8 +23,8 @@ Fields besides the contract: roofline (dominant kernel, live event timing) . ker
 class) . upsampler (graded fraction (ii) of SURVEY 8d and the by-construction HBM fraction (i)) .
 encoder_mfma_util . per_rank (N > 1: step ms min/max over ranks, all-gather latency) . and at N = 1:
 parity (vs the oracle, bounded sample) . configs (C1, the other default model, C5) . next_rows (SURVEY 8f:
-training step, ingest, evaluation sweep, LS baseline) . cpu_baseline (the reference-equivalent CPU path
-on this box's host cores).
+training step, ingest, evaluation sweep, LS baseline) . split_precision (the opt-in bf16x3 tier, reported
+separately, never `value`) . cpu_baseline (the reference-equivalent CPU path on this box's host cores).
 
 ``--stub`` (tests only, tests/test_bench_cli.py): the N-rank control flow with the GPU work replaced by
 CPU sleeps over gloo -- prints ``"data": "stub"`` and measures nothing.
@@ -389,6 +389,23 @@ def config_record(c, device, steps, warmup, oracle_sample, kernel_reps):
     return rec
 
 
+def split_precision_record(c, device, steps, warmup, oracle_sample):
+    """The opt-in split-precision tier (aft_config.precision = AFT_PRECISION_BF16X3: encoder GEMMs and attention products on
+    bf16 hi/lo terms, fp32 accumulation) on the headline workload -- REPORTED SEPARATELY, never `value`."""
+    import torch
+    from adafortitran_amd import _abi
+    wl = Workload(c, device)
+    wl.cfg.precision = _abi.AFT_PRECISION_BF16X3
+    wall, dev_ms, per = timed_steps(wl, wl.step, steps, warmup, torch.cuda.synchronize)
+    p = parity_vs_oracle(wl, oracle_sample)
+    rec = {"dtype": "bf16x3 split operands, f32 accumulate", "value": round(wl.B * steps / wall, 1),
+           "ms_per_step": round(wall / steps * 1e3, 4), "max_abs_over_ymax": p["max_abs"] / p["ymax"], "rel_dMSE": p["rel_dMSE"],
+           "tol_max_abs_over_ymax": 1e-3, "tol_rel_dMSE": 1e-2}
+    del wl
+    torch.cuda.empty_cache()
+    return rec
+
+
 def linear_record(device, steps, warmup):
     """BASELINE config 1: LinearEstimator, 120x14 grid, batch 32 -- plumbing only.  Module surface (CPU complex64 pilots in),
     plane-wise; checked against the oracle's linear restatement."""
@@ -646,6 +663,8 @@ def main() -> int:
                 else:
                     cfgs[other["name"]] = config_record(other, device, 100, 10, 8, 10)
             result["configs"] = cfgs     # C4 = C3 with --gpus 8; C5 as an 8-GPU config = --config C5 --gpus 8
+            if head["model_dim"] == 128:
+                result["split_precision"] = split_precision_record(head, device, min(args.steps, 100), min(args.warmup, 10), 8)
             try:
                 result["next_rows"] = next_rows(wl)
             except Exception as exc:     # never lose the headline to a secondary leg

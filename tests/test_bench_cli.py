@@ -90,7 +90,7 @@ def test_bench_full_line_on_gpu(tmp_path):
     assert len(raw) < 5000, len(raw)
     line = json.loads(raw)
     for key in ("roofline", "cpu_baseline", "kernels", "upsampler", "parity", "configs", "next_rows", "module_surface",
-                "value_h2d_inclusive"):
+                "value_h2d_inclusive", "split_precision"):
         assert key in line, key
     assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "mfma"
     assert set(line["configs"]) == {"C1", "C2", "C3", "C5"}
@@ -98,6 +98,9 @@ def test_bench_full_line_on_gpu(tmp_path):
     assert line["next_rows"]["f1_train_step_ms"] > 0 and 0 < line["next_rows"]["f1_frac_of_fp32_roof"] < 1
     assert line["parity"]["max_abs"] <= 5e-5 * line["parity"]["ymax"] and line["parity"]["rel_dMSE"] <= 1e-4
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+    sp = line["split_precision"]                              # reported separately: faster, inside its own stated tolerance
+    assert line["dtype"] == "f32" and sp["dtype"].startswith("bf16x3") and sp["value"] > line["value"]
+    assert sp["max_abs_over_ymax"] <= sp["tol_max_abs_over_ymax"] and sp["rel_dMSE"] <= sp["tol_rel_dMSE"]
 
 
 @pytest.mark.gpu
