@@ -18,6 +18,8 @@ B = int(os.environ.get("AFT_BATCH", "128"))
 REPS = int(os.environ.get("AFT_REPS", "5"))
 sd = synth.make_state_dict(**SPEC, adaptive_hidden=HID, seed=20251114)
 cfg = _abi.make_config(**SPEC, adaptive_hidden=HID)
+if os.environ.get("AFT_PRECISION") == "bf16x3":      # the opt-in split-precision tier (reported separately)
+    cfg.precision = _abi.AFT_PRECISION_BF16X3
 eng = engine_from_numpy(cfg, sd, "cuda:0")
 inp = synth.make_inputs(B, seed=20251114)
 dev = lambda a: torch.from_numpy(a).to("cuda:0")  # noqa: E731
@@ -27,7 +29,10 @@ for _ in range(int(os.environ.get("AFT_FWD", "3"))):
     eng.forward(pil, *meta, out=out)
 torch.cuda.synchronize()
 only = os.environ.get("AFT_ONLY")
-for name, io in (("upsample", pil), ("embed", None), ("qkv", None), ("attention", None), ("chain", None), ("tail", out)):
+for name, io in (("upsample", pil), ("embed", None), ("qkv", None), ("attention", None), ("chain", None), ("chain_last", None),
+                 ("tail", out), ("encoder_plane", None)):
+    if name == "encoder_plane" and not only:
+        continue
     if only and name not in only.split(","):
         continue
     profile_kernel(eng, name, B, REPS, io)
