@@ -308,7 +308,11 @@ struct ChainTrainArgs {
 template <int D>
 struct ChainTrainShape {
     using S = ChainShape<D>;
+#ifdef AFT_BWD_NO_COLW
+    static constexpr int COLW = 0;       // occupancy experiment only (valid without dropout)
+#else
     static constexpr int COLW = 4 * D;
+#endif
     static constexpr size_t LDS_BYTES = S::LDS_BYTES + sizeof(float) * COLW;
 };
 
