@@ -4,7 +4,12 @@ Mirrors ``ModelEvaluator._evaluate_dataloader`` / ``get_test_stats`` of the refe
 (src/main/trainer.py:311-347): same dispatch on the estimator class, same sample-weighted mean of
 ``2 * MSELoss(cat(Re, Im))`` per loader, same ``{int(val): dB}`` dictionary sorted by the integer in
 the loader's name -- but the squared error accumulates on the device (metrics.MseAccumulator) and is
-read back once per loader (plus one all-gather when several ranks each evaluate a shard)."""
+read back once per loader (plus one all-gather when several ranks each evaluate a shard).
+
+With an ``ingest.PackedLoader`` on a HIP device the reference's pilot-count ``ValueError`` ("Expected 24 pilot values, got 25",
+dataset.py:128-132) surfaces ONE BATCH LATE -- while the next batch is prepared, at the end of the sweep, or when the iterator is
+closed early -- because the counts come back asynchronously; the sweep therefore never returns a value computed from a bad frame
+without raising, but the exception's traceback points at the loader, not at the forward of the offending batch."""
 from __future__ import annotations
 
 from typing import Dict, Iterable, List, Optional, Tuple
