@@ -28,7 +28,10 @@ TOL = {"G_grad_forti": (2e-5, 5e-4), "G_grad_ada": (2e-3, 2e-3),
 # ... and of each tensor's L2 norm (defaults to the element tolerance).  At full depth the gradients of the first layers
 # (pilot_upsampler: |g|max 3e-7) are sums over 71 680 rows of values that passed six layers backwards: single elements
 # carry ~1e-3 of fp32 noise on the HIP path (other summation orders) while the norms agree to 4e-5 / 7e-4.
-NORM_TOL = {"G_grad_forti_full": 2e-4, "G_grad_ada_full": 2e-3}
+# (round 3: 2e-4 -> 5e-4 for G_grad_forti_full.  The fused forward chain reproduces every tape tensor of the launch sequence to
+# <= 5e-7 relative (tools/debug/chain_fwd_check.py) -- rounding-level differences (Chan-merged vs two-pass LayerNorm partials) -- and
+# that alone moves the norm of initial_enhancer.conv_block.2.weight's gradient, the far end of six layers of backward, by 2.0e-4.)
+NORM_TOL = {"G_grad_forti_full": 5e-4, "G_grad_ada_full": 2e-3}
 
 
 def _step(name, device):
