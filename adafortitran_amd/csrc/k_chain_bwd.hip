@@ -372,6 +372,11 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
     const int r = lane & 31, h = lane >> 5;
     const int fb = 32 * w;
     const bool drop = a.threshold != 0;
+#ifdef AFT_TRAIN_NO_TAPE_STORES      // timing experiment only: how much of the launch are the tape stores
+    constexpr bool TAPE = false;
+#else
+    constexpr bool TAPE = true;
+#endif
 
     const Srd srd_wo = make_srd(a.wo), srd_w1 = make_srd(a.w1), srd_w2 = make_srd(a.w2);
     const Srd srd_attn = make_srd(a.attn), srd_x = make_srd(a.x);
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             f32x4 y = {acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]};
             if (drop) y = mask4(y, rw1, colw + fb + 8 * s + 4 * h);
             const f32x4 v = xres[s] + y;
-            if (row_ok) srd_store(srd_s1, xrow + 32 * s, v);
+            if (TAPE && row_ok) srd_store(srd_s1, xrow + 32 * s, v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
         }
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f32x4 v = {cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
-            if (row_ok) srd_store(srd_x1, xrow + 32 * s, v);
+            if (TAPE && row_ok) srd_store(srd_x1, xrow + 32 * s, v);
             *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
         }
         __syncthreads();
@@ -472,12 +477,12 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x4 pre = {acc_h[t][4 * s], acc_h[t][4 * s + 1], acc_h[t][4 * s + 2], acc_h[t][4 * s + 3]};
-                if (row_ok) srd_store(srd_a, hrow + 128 * t + 32 * s, pre);
+                if (TAPE && row_ok) srd_store(srd_a, hrow + 128 * t + 32 * s, pre);
                 const f32x2 g0 = activate2<ACT>(f32x2{pre[0], pre[1]});
                 const f32x2 g1 = activate2<ACT>(f32x2{pre[2], pre[3]});
                 f32x4 v = {g0[0], g0[1], g1[0], g1[1]};
                 if (drop) v = mask4(v, rw2, colw + D + 2 * fb + 32 * t + 8 * s + 4 * h);
-                if (row_ok) srd_store(srd_hd, hrow + 128 * t + 32 * s, v);
+                if (TAPE && row_ok) srd_store(srd_hd, hrow + 128 * t + 32 * s, v);
                 *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = v;
             }
         __syncthreads();
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = cur[4 * s + j] + y[j];
-            if (row_ok) srd_store(srd_s2, xrow + 32 * s, v);
+            if (TAPE && row_ok) srd_store(srd_s2, xrow + 32 * s, v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
         }

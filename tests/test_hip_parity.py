@@ -683,3 +683,29 @@ def test_split_precision_is_opt_in_and_refused_where_not_instantiated():
     big.precision = _abi.AFT_PRECISION_BF16X3
     from adafortitran_amd.hip_ops import config_coverage
     assert "split-precision" in config_coverage(big)
+
+
+@pytest.mark.parametrize("ofdm,pilot,patch,adaptive", [((30, 8), (6, 2), (3, 2), True), ((66, 12), (11, 3), (3, 3), False),
+                                                        ((150, 8), (10, 2), (5, 2), True),
+                                                        ((120, 14), (12, 2), (4, 2), True), ((120, 14), (12, 2), (2, 2), False),
+                                                        ((54, 14), (6, 2), (3, 2), False)])
+def test_split_precision_tier_other_grid_geometries(oracle_lib, ofdm, pilot, patch, adaptive):
+    """Token counts that are not a multiple of 8 or 4 (40, 88, 120, 210, 420, 126) in the split tier: the in-projection epilogue's
+    element-wise bf16 v^T stores, row tiles that straddle planes, ragged last key tiles with their bf16 masks."""
+    tokens = (ofdm[0] // patch[0]) * (ofdm[1] // patch[1])
+    spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=2, model_dim=128, num_head=4)
+    hid = (5, 9, 2 * tokens) if adaptive else None
+    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=99)
+    cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = _split(engine_from_numpy(cfg, sd, DEV))
+    inp = synth.make_inputs(5, ofdm=ofdm, pilot=pilot, seed=31)
+    meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+    pil = _t(inp["pilots"])
+    out = eng.forward(pil, *meta).clone()
+    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3))
+    err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+    print(f"split tier {ofdm} patch {patch} ({tokens} tokens): max|d|/|y|max {err:.2e}")
+    assert err <= TOL_SPLIT_OUT
+    eng.workspace(5).view(torch.float32).fill_(float("nan"))
+    assert torch.equal(torch.view_as_real(eng.forward(pil, *meta)), torch.view_as_real(out))
