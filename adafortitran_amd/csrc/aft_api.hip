@@ -78,8 +78,8 @@ int check_config(const aft_config *c) {
         set_error("patch %dx%d has more than %d elements", c->patch_scs, c->patch_symbols, kMaxPatchFeatures);
         return AFT_ERR_SHAPE;
     }
-    if (c->precision != AFT_PRECISION_F32 && (c->precision != AFT_PRECISION_BF16X3 || c->model_dim != 128)) {
-        set_error("precision %d: the split-precision tier (AFT_PRECISION_BF16X3) is instantiated for model_dim 128 only", c->precision);
+    if (c->precision != AFT_PRECISION_F32 && (c->precision != AFT_PRECISION_BF16X3 || (c->model_dim != 128 && c->model_dim != 256))) {
+        set_error("precision %d: the split-precision tier (AFT_PRECISION_BF16X3) is instantiated for model_dim 128 and 256", c->precision);
         return AFT_ERR_SHAPE;
     }
     if (c->activation != AFT_ACT_RELU && c->activation != AFT_ACT_GELU) {

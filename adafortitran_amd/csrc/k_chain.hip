@@ -25,23 +25,22 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_split_kernel(co
     chain_body<D, ACT, MLP, QKV, true>(a, smem, threadIdx.x, blockIdx.x, gridDim.x, (a.rows + 31) / 32);
 }
 
-template <int ACT, bool MLP, bool QKV>
+template <int D, int ACT, bool MLP, bool QKV>
 static hipError_t launch_chain_split_v(const ChainArgs &args, hipStream_t st) {
-    constexpr int D = 128;
     using S = ChainShape<D>;
     static PerDeviceOnce lds_attr;
     hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_split_kernel<D, ACT, MLP, QKV>), S::LDS_BYTES);
     if (ea != hipSuccess) return ea;
-    const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * 3);
+    const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * (D <= 128 ? 3 : 1));
     hipLaunchKernelGGL((chain_split_kernel<D, ACT, MLP, QKV>), dim3(blocks), dim3(S::THREADS), S::LDS_BYTES, st, args);
     return hipGetLastError();
 }
 
-template <int ACT>
+template <int D, int ACT>
 static hipError_t launch_chain_split_t(const ChainArgs &args, bool mlp, bool qkv, hipStream_t st) {
-    if (mlp && qkv) return launch_chain_split_v<ACT, true, true>(args, st);
-    if (mlp) return launch_chain_split_v<ACT, true, false>(args, st);
-    return launch_chain_split_v<ACT, false, true>(args, st);
+    if (mlp && qkv) return launch_chain_split_v<D, ACT, true, true>(args, st);
+    if (mlp) return launch_chain_split_v<D, ACT, true, false>(args, st);
+    return launch_chain_split_v<D, ACT, false, true>(args, st);
 }
 
 template <int D, int ACT, bool MLP, bool QKV>
@@ -230,8 +229,11 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const f
     const bool gelu = c.activation == AFT_ACT_GELU;
     const bool mlp = m != nullptr, qkv = qw != nullptr;
     if (c.precision == AFT_PRECISION_BF16X3) {
-        if (c.model_dim != 128) return hipErrorInvalidValue;    // refused earlier by check_config
-        return gelu ? launch_chain_split_t<AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_split_t<AFT_ACT_RELU>(a, mlp, qkv, st);
+        if (c.model_dim == 128)
+            return gelu ? launch_chain_split_t<128, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_split_t<128, AFT_ACT_RELU>(a, mlp, qkv, st);
+        if (c.model_dim == 256)
+            return gelu ? launch_chain_split_t<256, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_split_t<256, AFT_ACT_RELU>(a, mlp, qkv, st);
+        return hipErrorInvalidValue;    // refused earlier by check_config
     }
     if (c.model_dim == 64)
         return gelu ? launch_chain_t<64, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<64, AFT_ACT_RELU>(a, mlp, qkv, st);

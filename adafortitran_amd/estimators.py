@@ -203,7 +203,7 @@ class BaseFortiTranEstimator(nn.Module):
     def hip_precision(self) -> str:
         """Arithmetic of the HIP inference path: ``"f32"`` (default: exact-fp32 MFMAs everywhere, the parity contract) or
         ``"bf16x3"`` -- the opt-in split-precision tier of include/adafortitran_amd.h (AFT_PRECISION_BF16X3: the encoder's
-        GEMMs and attention products on bf16 hi/lo terms with fp32 accumulation; model_dim 128; ~1.8x the frames/s at
+        GEMMs and attention products on bf16 hi/lo terms with fp32 accumulation; model_dim 128 or 256; ~1.8-2x the frames/s at
         max|d| ~ 3e-5 |y|max).  Not part of the reference's YAML surface: set it on the module, or AFT_PRECISION=bf16x3."""
         return self._hip_precision
 

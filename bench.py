@@ -387,6 +387,14 @@ def config_record(c, device, steps, warmup, oracle_sample, kernel_reps):
         p = parity_vs_oracle(wl, oracle_sample)
         rec["parity_max_abs_over_ymax"] = p["max_abs"] / p["ymax"]
         rec["parity_rel_dMSE"] = p["rel_dMSE"]
+    if c["model_dim"] in (128, 256):      # the opt-in split-precision tier on the same workload (reported separately)
+        from adafortitran_amd import _abi
+        wl.cfg.precision = _abi.AFT_PRECISION_BF16X3
+        wl.eng.invalidate_packed()
+        w2, _, _ = timed_steps(wl, wl.step, max(steps // 2, 5), 2, torch.cuda.synchronize)
+        rec["split_precision_value"] = round(wl.B * max(steps // 2, 5) / w2, 1)
+        if oracle_sample:
+            rec["split_precision_max_abs_over_ymax"] = (lambda q: q["max_abs"] / q["ymax"])(parity_vs_oracle(wl, oracle_sample))
     del wl
     torch.cuda.empty_cache()
     return rec
@@ -674,7 +682,7 @@ def main() -> int:
                 else:
                     cfgs[other["name"]] = config_record(other, device, 100, 10, 8, 10)
             result["configs"] = cfgs     # C4 = C3 with --gpus 8; C5 as an 8-GPU config = --config C5 --gpus 8
-            if head["model_dim"] == 128:
+            if head["model_dim"] in (128, 256):
                 result["split_precision"] = split_precision_record(head, device, min(args.steps, 100), min(args.warmup, 10), 8)
             try:
                 result["next_rows"] = next_rows(wl)

@@ -54,10 +54,10 @@ extern "C" {
 
 /* aft_config.precision.  F32: every product on exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32) -- the default, the parity
  * contract (5e-5 |y|max, |dMSE|/MSE <= 1e-4) and the only mode the headline benchmark runs.  BF16X3 (opt-in, reported
- * separately, SURVEY.md 8d "bf16-MFMA tier"): the encoder's ROW-LOCAL GEMMs (in-projection, out-projection, FFN) split
+ * separately, SURVEY.md 8d "bf16-MFMA tier"): the encoder's GEMMs (in-projection, out-projection, FFN) and attention products split
  * each fp32 operand into bf16 hi + lo and accumulate hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 in fp32 (~2^-16
  * relative per product; stated tolerance max|d| <= 1e-3 |y|max, |dMSE|/MSE <= 1e-2, observed ~1e-5 / ~1e-6: tests/
- * test_hip_parity.py).  Attention, LayerNorm, GELU, the conv stacks and every accumulator stay fp32.  model_dim 128 only;
+ * test_hip_parity.py).  The softmax, LayerNorm, GELU, the conv stacks and every accumulator stay fp32.  model_dim 128 or 256;
  * inference only. */
 #define AFT_PRECISION_F32 0
 #define AFT_PRECISION_BF16X3 1

@@ -679,10 +679,20 @@ def test_split_precision_is_opt_in_and_refused_where_not_instantiated():
         assert model._engine.cfg.precision == _abi.AFT_PRECISION_BF16X3
     d = (fast - exact).abs().max().item() / exact.abs().max().item()
     assert 0 < d <= TOL_SPLIT_OUT
-    big = Golden("C5_ada_large").abi_config()                             # model_dim 256: not instantiated for the tier
-    big.precision = _abi.AFT_PRECISION_BF16X3
+    odd = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=192, num_head=6))   # model_dim 192: not instantiated for the tier
+    odd.precision = _abi.AFT_PRECISION_BF16X3
     from adafortitran_amd.hip_ops import config_coverage
-    assert "split-precision" in config_coverage(big)
+    assert "split-precision" in config_coverage(odd)
+
+
+def test_split_precision_tier_config5(oracle_lib):
+    """BASELINE config 5 (240x28, 12 layers, d = 256, 8 heads, 1120 tokens) in the split tier against the reference-generated golden."""
+    g = Golden("C5_ada_large")
+    eng = _split(_engine(g))
+    out = eng.forward(_t(g["pilots"]), *_meta(g)).cpu().numpy()
+    err = np.abs(out - g["out"]).max() / np.abs(g["out"]).max()
+    print(f"split tier C5: max|d|/|y|max {err:.2e}")
+    assert err <= TOL_SPLIT_OUT
 
 
 @pytest.mark.parametrize("ofdm,pilot,patch,adaptive", [((30, 8), (6, 2), (3, 2), True), ((66, 12), (11, 3), (3, 3), False),

@@ -19,7 +19,7 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--json", default="")
 args = ap.parse_args()
-c = {"C3": bench.C3, "C2": bench.C2}[args.config]
+c = {"C3": bench.C3, "C2": bench.C2, "C5": bench.C5}[args.config]
 B = args.batch or c["batch"]
 spec = bench._spec(c)
 sd = synth.make_state_dict(**spec, adaptive_hidden=c["hidden"], max_seq_len=c["max_seq_len"], seed=bench.SEED)
