@@ -651,7 +651,8 @@ def main() -> int:
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub" if args.stub else "synthetic",
             "config": {"workload": f"{head['name']}: {head['label']}; {B} frames per GPU per step; step = forward + device MSE partial; "
-                                   "value = rate with INPUTS RESIDENT IN HBM (H2D-inclusive rate: value_h2d_inclusive)",
+                                   "value = rate with INPUTS RESIDENT IN HBM (H2D-inclusive rate: value_h2d_inclusive); encoder weights fragment-packed once "
+                                   "(aft_forward_prepacked_f32, as the module surface runs in eval mode)",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded over {world} rank(s)"},
             "device_ms_per_step": round(dev_ms / args.steps, 4),
             "device_step_ms": {"p10": round(pct(0.10), 4), "p50": round(pct(0.50), 4), "p90": round(pct(0.90), 4)},
