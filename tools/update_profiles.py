@@ -77,6 +77,10 @@ attn = block("attn", "attn_kernel", 6, 3 * planes * heads * tokpad * 32 * 4 + ro
              "attn_kernel, B=128 frames (1024 (plane, head) problems, 9 query tiles each); algorithmic = q + k + v^T read once, attention tiles written once")
 if attn:
     out["attention"] = attn
+plane = block("plane", "encoder_plane_kernel", 0, 128 * 13644 + 3_950_000,
+              "encoder_plane_kernel<128,GELU>: the whole encoder of B=128 as one launch (algorithmic = the forward's compulsory bytes)")
+if plane:
+    out["encoder_plane"] = plane
 # conv stacks: compulsory bytes per frame: head 192 B pilots in + 13,440 B conv_enhanced out (+ 187 KB of weights once per
 # launch); tail reads conv_enhanced (13,440) + the linear_2 output (280 tokens x 8 floats x 2 planes = 17,920) and writes 13,440
 head = block("conv_head", "conv_stack_kernel", 2, frames * 13632 + 187 * 1024, "conv_stack_kernel<false,true> HEAD (pilot split + Linear 24->1680 + 4 convs), B=128")
