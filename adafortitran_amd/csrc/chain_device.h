@@ -352,6 +352,38 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         if (MLP || a.emb_conv == nullptr) request_x(t);
     };
     if (AHEAD && first_tile < ntiles) request_tile(first_tile);
+    // Fused embedding (<!MLP,QKV> with emb_conv set): the operands a tile starts from -- b1 + pos[token] (the accumulator's
+    // initial value) and the row's K input features -- are requested ONE TILE AHEAD, before the previous tile's q / k / v^T
+    // stores: round 2 issued them at the tile start, where 19 dependent global loads per lane sat in front of the first MFMA
+    // (the launch ran 22 us over its 50-us MFMA time).  27 registers carried across the in-projection (111 -> 138 VGPRs).
+    f32x16 emb_acc0;
+    float emb_bv[kEmbSteps];
+    auto emb_request = [&](int t) {
+        const int grow_n = min(t * 32 + r, a.rows - 1);
+        const int plane = grow_n / a.tokens, tok = grow_n - plane * a.tokens;
+        const int tpr = a.emb_T / a.emb_p1, g = tok / tpr, tc = tok - g * tpr;
+        const float *cplane = a.emb_conv + ((size_t)plane * a.emb_S + g * a.emb_p0) * a.emb_T + tc * a.emb_p1;
+        const float *t6 = a.emb_tok6 ? a.emb_tok6 + ((size_t)(plane >> 1) * a.tokens + tok) * 6 : nullptr;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(a.emb_b1 + fb + 8 * s + 4 * h);
+            const f32x4 ps = *reinterpret_cast<const f32x4 *>(a.emb_pos + (size_t)tok * D + fb + 8 * s + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) emb_acc0[4 * s + j] = b[j] + ps[j];
+        }
+#pragma unroll
+        for (int st = 0; st < kEmbSteps; ++st) {
+            const int k = 2 * st + h;      // this lane half's k index of step st
+            emb_bv[st] = 0.f;
+            if (k < a.emb_K) {
+                const int off = emb_offs[k];
+                emb_bv[st] = off >= 0 ? cplane[off] : t6[~off];
+            }
+        }
+    };
+    if constexpr (!MLP) {
+        if (a.emb_conv != nullptr && first_tile < tile_end) emb_request(first_tile);
+    }
     // linear_2 partials of the previous tile (fused variant of <MLP,!QKV>): sum the W per-wave partials in wave order, add
     // the bias, store [row][out6_stride].  Called by ONE wave per tile, after the barrier that ended that tile.
     int pending_row0 = -1;
@@ -532,33 +564,16 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
             // x0 = [patch features | adapter features] W1^T + b1 + pos[token]: ceil(K/2) MFMAs of the same transposed
             // form (A = W1 rows of this wave's feature block, B = the row's input features), the accumulator starting
             // from b1 + pos -- it comes out in operand layout like any other `cur`.
-            const int plane = grow / a.tokens, tok = grow - plane * a.tokens;
-            const int tpr = a.emb_T / a.emb_p1, g = tok / tpr, tc = tok - g * tpr;
-            const float *cplane = a.emb_conv + ((size_t)plane * a.emb_S + g * a.emb_p0) * a.emb_T + tc * a.emb_p1;
-            const float *t6 = a.emb_tok6 ? a.emb_tok6 + ((size_t)(plane >> 1) * a.tokens + tok) * 6 : nullptr;
-            f32x16 acc0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(a.emb_b1 + fb + 8 * s + 4 * h);
-                const f32x4 ps = *reinterpret_cast<const f32x4 *>(a.emb_pos + (size_t)tok * D + fb + 8 * s + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc0[4 * s + j] = b[j] + ps[j];
-            }
-            float av[kEmbSteps], bv[kEmbSteps];   // all operand loads in flight before the first MFMA
+            f32x16 acc0 = emb_acc0;
+            float av[kEmbSteps];
 #pragma unroll
             for (int st = 0; st < kEmbSteps; ++st) {
-                const int k = 2 * st + h;      // this lane half's k index of step st
-                av[st] = 0.f;
-                bv[st] = 0.f;
-                if (k < a.emb_K) {
-                    const int off = emb_offs[k];
-                    av[st] = emb_w[(fb + r) * a.emb_K + k];
-                    bv[st] = off >= 0 ? cplane[off] : t6[~off];
-                }
+                const int k = 2 * st + h;
+                av[st] = k < a.emb_K ? emb_w[(fb + r) * a.emb_K + k] : 0.f;
             }
 #pragma unroll
             for (int st = 0; st < kEmbSteps; ++st)
-                if (2 * st < a.emb_K) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv[st], acc0, 0, 0, 0);
+                if (2 * st < a.emb_K) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], emb_bv[st], acc0, 0, 0, 0);
             cur = acc0;
             if (row_ok) {
 #pragma unroll
@@ -603,6 +618,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         }
         STAMP(10);
         if (AHEAD && tile + tile_stride < ntiles) request_tile(tile + tile_stride);   // before this tile's stores
+        if constexpr (!MLP) {
+            if (a.emb_conv != nullptr && tile + tile_stride < tile_end) emb_request(tile + tile_stride);
+        }
         // ---- epilogue: q, k, v of head w for 32 token rows, written in MFMA-FRAGMENT order so that
         // k_attn.hip reads every operand with fully coalesced 1-KB loads:
         //   q, k : [plane*H + head][key tile][s][lane = key%32 + 32*hh][4]   value (key, d = 8s + 4hh + j)
