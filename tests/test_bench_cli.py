@@ -110,3 +110,24 @@ def test_bench_headline_line_on_gpu():
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["unit"] == "frames/s" and line["value"] > 1000
     assert 0 < line["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_runs_the_rccl_path_and_config5():
+    """bench.py as ONE rank under torchrun (the driver's N > 1 launch shape at world size 1): RCCL process group, per_rank record,
+    the metric all-gather, --config C5 as the per-rank workload."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), BENCH, "--gpus", "1", "--steps", "5", "--warmup", "2", "--headline-only", "--config", "C5"],
+                         capture_output=True, text=True, env=e, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["frames_per_gpu"] == 64 and "C5" in line["config"]["workload"]
+    assert line["per_rank"]["metric_allgather_ms"] > 0 and line["per_rank"]["slowest_rank"] == 0
+    assert line["value"] > 500 and 0 < line["roofline"]["frac"] < 1
