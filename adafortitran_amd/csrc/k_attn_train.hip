@@ -17,9 +17,14 @@
 //   forward, dQ pass: S^T = K Q^T  (rows = keys)    -> O^T = V^T P^T, dQ^T = K^T dS^T contract over keys
 //   dK/dV pass:       S   = Q K^T  (rows = queries) -> dV^T = dO^T P, dK^T = Q^T dS contract over queries
 // so the probabilities never leave registers.  Row statistics are base-2 (scores carry log2 e/sqrt(dh)).
-// The backward recomputes P from the saved LSE twice (once per pass) instead of using atomics, which
-// keeps it deterministic.  Dropout masks are a counter-based function of (seed, site, plane, head, q, k) -- a hashed
+// The backward recomputes P from the saved LSE.  attn_bwd_kernel (the default) produces dQ, dK and dV in ONE pass over the
+// (query tile, key tile) pairs: dK / dV in the second orientation, the pair's dS tile through LDS for dQ, the per-tile dQ
+// contributions added in a fixed order -- deterministic, no atomics.  attn_bwd_q_kernel + attn_bwd_kv_kernel are the two-pass
+// form it replaced (S and dP recomputed once per pass), kept for shapes whose LDS tables do not fit and as the A/B reference
+// (AFT_TRAIN_ATTN_BWD_SPLIT).  Dropout masks are a counter-based function of (seed, site, plane, head, q, k) -- a hashed
 // word per query row times a hashed word per key column, see drop_keep below -- recomputed in the backward, never stored.
+#include <cstdlib>
+
 #include "aft_internal.h"
 
 namespace aft {
@@ -36,6 +41,7 @@ struct AttnTrainArgs {
     int planes, tokens, heads, d, ntiles;
     float scale2, scale;  // log2(e)/sqrt(dh), 1/sqrt(dh)
     float keep_scale;     // 1/(1-p)
+    float dq_scale;       // scale / scale2: attn_bwd_kernel stages K x scale2
     uint32_t threshold;   // drop when hash < threshold (0 = no dropout)
     uint32_t seed;
 };
@@ -450,6 +456,235 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     store_transposed(a.out + (size_t)plane * a.tokens * ld + head * 32, ld, query, a.tokens, h, dq, a.scale);
 }
 
+// ---- dQ, dK and dV in ONE pass (round 3): own = key tile, walks the query tiles (staged: Q, dO) ----
+// The two-kernel backward recomputes S and dP in both passes: 7 products of 16 MFMAs per (query tile, key tile) pair for 5
+// useful ones.  Here a workgroup owns one whole (plane, head): its three waves take the key tiles three at a time (pass p:
+// tiles 3p .. 3p+2), keep dK / dV in registers exactly as attn_bwd_kv_kernel does, and ALSO produce the pair's dQ
+// contribution dS K: that product contracts over the keys, i.e. over the COLUMNS of the dS accumulator, so the tile goes
+// through LDS once (16 writes, 4 wide reads -- a fraction of the 32 MFMAs + exp2 + mask of recomputing it in the other
+// orientation).  The three waves' contributions to the same query tile meet in LDS behind the step's barrier and are added
+// in a fixed order (wave 0 + 1 + 2) to what the previous passes left in dqkv's q block -- a read-modify-write by the SAME
+// thread in every pass, so the result is deterministic; the 1/sqrt(dh) factor goes on with the last pass.
+// D_i = dO_i . O_i and the LSE of the whole (plane, head) sit in LDS tables filled by the prologue (no dsum round trip).
+// Registers: 3 waves per SIMD leave 168; the wave's own K tile therefore lives in LDS (scaled by log2 e / sqrt(dh), which the
+// dQ product takes back out with its final factor) and is read in both operand forms, only V's stays in registers.
+// LDS per workgroup at 9 tiles: staging 9.2 KB (single: the step has two barriers anyway) + exchange 13.8 + K tiles 13.8 +
+// tables 3.4 = 40.3 KB, four workgroups per CU.
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kernel(const AttnTrainArgs a) {
+
+    __shared__ __attribute__((aligned(16))) float stage[2 * kAtTileFloats];         // Q tile | dO tile of the step
+    __shared__ __attribute__((aligned(16))) float xch[kAtWaves][kAtTileFloats];     // per wave: dS transposed, then its dQ contribution
+    __shared__ __attribute__((aligned(16))) float ktile[kAtWaves][kAtTileFloats];   // per wave: its own K tile x scale2
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] row (query) words | lse | D
+    const int nrow = a.ntiles * 32;
+    // the two float tables behind the mask words, as LDS-address-space float pointers: float stores, float4 loads (reading them
+    // back as uint32 vectors and bit-casting the elements made hipcc use element 0 for all four)
+    using LdsF = __attribute__((address_space(3))) float;
+    using LdsF4 = __attribute__((address_space(3))) f32x4;
+    LdsF *lse_t = (LdsF *)(words + nrow), *dsum_t = lse_t + nrow;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int ph = blockIdx.x, head = ph % a.heads, plane = ph / a.heads;
+    const int ld = 3 * a.d;
+    const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * 32;
+    const float *kb = qb + a.d, *vb = qb + 2 * a.d;
+    const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * 32;
+    const float *ob = a.o + (size_t)plane * a.tokens * a.d + head * 32;
+    float *dst = a.out + (size_t)plane * a.tokens * ld + head * 32;
+
+    for (int i = tid; i < nrow; i += kAtThreads) {
+        words[i] = drop_row_word(a.seed, (uint32_t)ph * a.tokens + min(i, a.tokens - 1));
+        lse_t[i] = i < a.tokens ? a.lse[(size_t)ph * a.tokens + i] : 0.f;
+    }
+    // D: eight lanes per row, one float4 of dO and of O each; six row groups' loads in flight at a time (all four workgroups of a
+    // CU run this prologue at the same moment: a load round trip per row group, one after the other, was 20 us of idle CU)
+    for (int r0 = 0; r0 < nrow; r0 += 6 * (kAtThreads / 8)) {
+        const int q4 = tid & 7;
+        f32x4 x[6], y[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int row = min(r0 + u * (kAtThreads / 8) + (tid >> 3), a.tokens - 1);
+            x[u] = *reinterpret_cast<const f32x4 *>(dob + (size_t)row * a.d + 4 * q4);
+            y[u] = *reinterpret_cast<const f32x4 *>(ob + (size_t)row * a.d + 4 * q4);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int row = r0 + u * (kAtThreads / 8) + (tid >> 3);
+            float part = fmaf(x[u][3], y[u][3], fmaf(x[u][2], y[u][2], fmaf(x[u][1], y[u][1], x[u][0] * y[u][0])));
+            part += __shfl_xor(part, 1);
+            part += __shfl_xor(part, 2);
+            part += __shfl_xor(part, 4);
+            if (q4 == 0 && row < nrow) dsum_t[row] = row < a.tokens ? part : 0.f;
+        }
+    }
+
+    // Staging and reduce share one element map: float4 e = tid (and tid + 192 for wave 0) <-> row e >> 3, quad e & 7 of a 32 x 32
+    // tile.  The tile's offset goes into the LANE offset of the buffer access, so the hardware range check zeroes the rows of the
+    // ragged last tile on load and drops them on store (a scalar offset is not range-checked).
+    const AtSrd q_rs = at_srd(qb, (unsigned)((a.tokens - 1) * ld + 32) * 4u);
+    const AtSrd do_rs = at_srd(dob, (unsigned)((a.tokens - 1) * a.d + 32) * 4u);
+    const AtSrd dq_rs = at_srd(dst, (unsigned)((a.tokens - 1) * ld + 32) * 4u);
+    const unsigned tile_q = 32u * (unsigned)ld * 4u, tile_do = 32u * (unsigned)a.d * 4u;
+    const int e1 = tid + kAtThreads;
+    // (element e1 exists for wave 0 only; the other waves give it an out-of-range offset -- an unconditional load of zeros --
+    // rather than a branch: a conditionally written register is live around the whole loop)
+    const unsigned vq0 = (unsigned)((tid >> 3) * ld + 4 * (tid & 7)) * 4u, vd0 = (unsigned)((tid >> 3) * a.d + 4 * (tid & 7)) * 4u;
+    const unsigned vq1 = wave == 0 ? (unsigned)((e1 >> 3) * ld + 4 * (e1 & 7)) * 4u : kAtOutOfRange;
+    const unsigned vd1 = wave == 0 ? (unsigned)((e1 >> 3) * a.d + 4 * (e1 & 7)) * 4u : kAtOutOfRange;
+    const int l0 = (tid >> 3) * kAtLd + 4 * (tid & 7), l1 = (e1 >> 3) * kAtLd + 4 * (e1 & 7);   // the element's place in an LDS tile
+    f32x4 sq0, sq1, sd0, sd1;
+    auto stage_load = [&](int tile) {
+        sq0 = at_ld4(q_rs, vq0 + (unsigned)tile * tile_q, 0);
+        sd0 = at_ld4(do_rs, vd0 + (unsigned)tile * tile_do, 0);
+        sq1 = at_ld4(q_rs, vq1 + (unsigned)tile * tile_q, 0);
+        sd1 = at_ld4(do_rs, vd1 + (unsigned)tile * tile_do, 0);
+    };
+    auto stage_put = [&]() {
+        *reinterpret_cast<f32x4 *>(stage + l0) = sq0;
+        *reinterpret_cast<f32x4 *>(stage + kAtTileFloats + l0) = sd0;
+        if (wave == 0) {
+            *reinterpret_cast<f32x4 *>(stage + l1) = sq1;
+            *reinterpret_cast<f32x4 *>(stage + kAtTileFloats + l1) = sd1;
+        }
+    };
+    const int npass = (a.ntiles + kAtWaves - 1) / kAtWaves;
+    float *T = xch[wave];
+    const float *KT = ktile[wave];
+    for (int pass = 0; pass < npass; ++pass) {
+        const int kt = pass * kAtWaves + wave;
+        const bool active = kt < a.ntiles;
+        const int nact = min(kAtWaves, a.ntiles - pass * kAtWaves);
+        const int key = kt * 32 + j;
+        const bool ragged = active && kt * 32 + 32 > a.tokens;
+        const float dq_mul = pass == npass - 1 ? a.dq_scale : 1.f;
+        // pass prologue: every global read first (first query tile, own V fragment, own K tile), then the LDS writes
+        stage_load(0);
+        float vf[16];
+        load_rowfrag(vb, ld, active ? key : 0, a.tokens, h, 1.f, vf);   // B operand: lane <-> key
+        {   // own K tile x scale2 -> LDS (wave-private; rows beyond the plane are zero)
+            f32x4 kv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = lane + 64 * u, row = e >> 3, q4 = e & 7, tok = (active ? kt : 0) * 32 + row;
+                kv[u] = *reinterpret_cast<const f32x4 *>(kb + (size_t)min(tok, a.tokens - 1) * ld + 4 * q4);
+                if (tok >= a.tokens) kv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = lane + 64 * u, row = e >> 3, q4 = e & 7;
+                *reinterpret_cast<f32x4 *>(ktile[wave] + row * kAtLd + 4 * q4) = kv[u] * a.scale2;
+            }
+        }
+        f32x16 dv = zero16(), dk = zero16();
+        const uint32_t col_word = drop_col_word(a.seed, (uint32_t)ph * a.tokens + min(key, a.tokens - 1));
+        stage_put();
+        __syncthreads();
+        for (int qt = 0; qt < a.ntiles; ++qt) {
+            // The step's global reads -- what the earlier passes left of this query tile's dQ, and the next tile's Q / dO --
+            // are issued in the middle of the products, two MFMA chains and the barrier before their first use: all four
+            // workgroups of a CU run in lock-step, so a latency a wave does not cover itself is covered by nobody.
+            const unsigned t_off = (unsigned)qt * tile_q;
+            f32x4 old0 = f32x4{0.f, 0.f, 0.f, 0.f}, old1 = old0;
+            auto issue_loads = [&]() {
+                if (pass > 0) {
+                    old0 = at_ld4(dq_rs, vq0 + t_off, 0);
+                    old1 = at_ld4(dq_rs, vq1 + t_off, 0);
+                }
+                if (qt + 1 < a.ntiles) stage_load(qt + 1);
+            };
+            if (!active) issue_loads();
+            if (active) {
+                f32x16 s, dp;
+                {
+                    float qf[16], kf[16];
+                    lds_rowfrag(stage, j, h, qf);                              // A operand: lane <-> query
+                    lds_rowfrag(KT, j, h, kf);                                 // B operand: lane <-> key
+                    s = mma16z(qf, kf);                                        // [row = query][col = key]
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    float dof[16];
+                    lds_rowfrag(stage + kAtTileFloats, j, h, dof);
+                    dp = mma16z(dof, vf);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float pd[16], ds[16];
+                // a quarter of the tile at a time: the three table reads of a quarter are 12 registers, not 48
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 ls = *(const LdsF4 *)(lse_t + qt * 32 + 8 * q + 4 * h);
+                    const f32x4 dsm = *(const LdsF4 *)(dsum_t + qt * 32 + 8 * q + 4 * h);
+                    const u32x4 rw = *reinterpret_cast<const u32x4 *>(words + qt * 32 + 8 * q + 4 * h);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int r = 4 * q + c;
+                        const float p = __builtin_amdgcn_exp2f(s[r] - ls[c]);
+                        const float pm = (!a.threshold || drop_keep(rw[c], col_word, a.threshold)) ? p : 0.f;
+                        pd[r] = pm;
+                        ds[r] = fmaf(pm * dp[r], a.keep_scale, -(p * dsm[c]));   // P o (dP o mask/(1-p) - D)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ragged && key >= a.tokens) {   // key lanes beyond the plane: never stored as dK / dV, but dS K sums over them
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ds[r] = 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    float doT[16];
+                    lds_colfrag(stage + kAtTileFloats, j, h, doT);             // A operands: lane <-> feature
+                    dv = mma16(doT, pd, dv);                                   // [row = feature][col = key]
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                issue_loads();
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    float qT[16];
+                    lds_colfrag(stage, j, h, qT);
+                    dk = mma16(qT, ds, dk);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // dS -> LDS [query][key] -> B operand with lane <-> query (wave-private region: LDS ops of a wave complete in order)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[rowmap(r, h) * kAtLd + j] = ds[r];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // orders the wave's LDS writes before its reads of other lanes' elements
+                __builtin_amdgcn_wave_barrier();
+                f32x16 dq;
+                {
+                    float dsT[16], kT[16];
+                    lds_rowfrag(T, j, h, dsT);
+                    lds_colfrag(KT, j, h, kT);                                 // A operand: lane <-> feature, slot <-> key
+                    dq = mma16z(kT, dsT);                                      // [row = feature][col = query]
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // orders the wave's LDS writes before its reads of other lanes' elements
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4 *>(T + j * kAtLd + 8 * q + 4 * h) = f32x4{dq[4 * q], dq[4 * q + 1], dq[4 * q + 2], dq[4 * q + 3]};
+            }
+            __syncthreads();
+            // the waves' contributions to query tile qt, added in wave order to what the earlier passes left
+            {
+                f32x4 v0 = *reinterpret_cast<const f32x4 *>(xch[0] + l0);
+                if (nact > 1) v0 += *reinterpret_cast<const f32x4 *>(xch[1] + l0);
+                if (nact > 2) v0 += *reinterpret_cast<const f32x4 *>(xch[2] + l0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (v0 + old0) * dq_mul), dq_rs, vq0 + t_off, 0, 0);
+                if (wave == 0) {
+                    f32x4 v1 = *reinterpret_cast<const f32x4 *>(xch[0] + l1);
+                    if (nact > 1) v1 += *reinterpret_cast<const f32x4 *>(xch[1] + l1);
+                    if (nact > 2) v1 += *reinterpret_cast<const f32x4 *>(xch[2] + l1);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (v1 + old1) * dq_mul), dq_rs, vq1 + t_off, 0, 0);
+                }
+            }
+            if (qt + 1 < a.ntiles) stage_put();
+            __syncthreads();
+        }
+        if (active) {
+            store_transposed(dst + a.d, ld, key, a.tokens, h, dk, a.scale);
+            store_transposed(dst + 2 * a.d, ld, key, a.tokens, h, dv, a.keep_scale);
+        }
+    }
+}
+
 static AttnTrainArgs make_args(const aft_config &c, int planes, int tokens, float dropout_p, uint32_t seed) {
     AttnTrainArgs a{};
     a.planes = planes; a.tokens = tokens; a.heads = c.num_head; a.d = c.model_dim;
@@ -457,6 +692,7 @@ static AttnTrainArgs make_args(const aft_config &c, int planes, int tokens, floa
     const float inv = 1.f / sqrtf((float)(c.model_dim / c.num_head));
     a.scale = inv;
     a.scale2 = inv * 1.4426950408889634f;
+    a.dq_scale = (float)(1.0 / 1.4426950408889634);
     a.keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     a.threshold = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
     a.seed = seed;
@@ -479,6 +715,13 @@ hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const fl
     a.qkv = qkv; a.o = o; a.d_o = d_o; a.lse = const_cast<float *>(lse); a.dsum = dsum; a.out = dqkv;
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
     const size_t words_bytes = (size_t)a.ntiles * 32 * sizeof(uint32_t);
+    // one pass (attn_bwd_kernel) unless its three LDS tables do not fit beside the static staging, or the two-pass form is asked for (A/B)
+    const bool two_pass = getenv("AFT_TRAIN_ATTN_BWD_SPLIT") != nullptr;   // read per call: tools/debug/attn_bwd_check.py flips it
+    const size_t static_lds = sizeof(float) * (2 * kAtTileFloats + 2 * kAtWaves * kAtTileFloats);
+    if (!two_pass && static_lds + 3 * words_bytes <= 64 * 1024) {
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(planes * a.heads), dim3(kAtThreads), 3 * words_bytes, st, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(wgs), dim3(kAtThreads), words_bytes, st, a);    // also writes D_i = dO_i . O_i
     hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(wgs), dim3(kAtThreads), words_bytes, st, a);   // reads it
     return hipGetLastError();

@@ -90,6 +90,37 @@ def test_layer_training_bits_do_not_depend_on_stale_memory(value):
             assert torch.equal(a, b), (d, i)
 
 
+@pytest.mark.parametrize("ofdm,heads,d", [((120, 14), 4, 128), ((24, 14), 4, 128), ((240, 28), 4, 128), ((48, 14), 8, 256)])
+def test_one_pass_attention_backward_agrees_with_the_two_pass_form(ofdm, heads, d, monkeypatch):
+    """attn_bwd_kernel (dQ, dK, dV in one pass, the default) against the two kernels it replaced
+    (AFT_TRAIN_ATTN_BWD_SPLIT, read per launch): same masks, same products, sums in a different order --
+    every gradient within 2e-6 of its tensor's |g|max; both forms bit-reproducible run to run.  Geometries: 9 key tiles
+    (three full passes), 2 (one pass, one idle wave), 35 (twelve passes, the last with two waves; 13 KB of LDS tables),
+    4 tiles of a 8-head layer; all ragged, dropout on."""
+    from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
+    cfg = _cfg(d, heads, ofdm)
+    layer = _layer(d, heads, "gelu", 0.1).train()
+    torch.manual_seed(5)
+    x0 = torch.randn(2, cfg.tokens, d, device="cuda")
+    gout = torch.randn(2, cfg.tokens, d, device="cuda")
+
+    def run():
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        out = HipEncoderLayerFunction.apply(x, cfg, 0.1, 31, *layer_params(layer))
+        out.backward(gout)
+        return [x.grad.clone()] + [p.grad.clone() for p in layer_params(layer)]
+
+    monkeypatch.delenv("AFT_TRAIN_ATTN_BWD_SPLIT", raising=False)
+    one, one_again = run(), run()
+    monkeypatch.setenv("AFT_TRAIN_ATTN_BWD_SPLIT", "1")
+    two = run()
+    for i, (a, b, c) in enumerate(zip(one, one_again, two)):
+        assert torch.equal(a, b), i
+        assert _rel(a, c) <= 2e-6, (i, _rel(a, c))
+    assert any(not torch.equal(a, c) for a, c in zip(one, two))   # the switch did select another kernel
+
+
 def test_dropout_is_consistent_between_forward_and_backward():
     """With p > 0 the layer is still a deterministic function of (x, seed): its backward must match a
     central finite difference of its forward along a random direction, and the keep rate must be 1-p."""
