@@ -27,6 +27,7 @@
 // any cross-wave exchange) over half of the symbol columns; weights fragments stay in registers for
 // the whole kernel.  HBM traffic per plane = compulsory only (pilots / x rows in, one plane out).
 // Bands carry a 4-row halo (4 stacked 3x3 convs); the default 120x14 grid is one band, 4 tiles.
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -38,6 +39,8 @@ namespace aft {
 struct ConvArgs {
     int mode;  // 0 = head (pilots -> conv_enhanced), 1 = tail (x, conv_enhanced -> complex out), 2 = plain (training)
     int S, T, SP, band_rows, nbands, ntiles, nseg, arena, extra;   // SP = LDS row-vector length (>= band_rows + 8)
+    int stream_ok;   // head: pf is a multiple of 8 and the streaming scratch fits the conv1 / conv3 planes
+    int xoff;   // inference: the seam exchange rows [(seam, side)][8 channels][SP] start here (floats; 0 = the dead input plane), -1 = overlapping sweeps
     // head
     const float *pilots, *up_w, *up_b;
     int pf;
@@ -267,6 +270,59 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                     if (dsti[u] >= 0) in0[dsti[u]] = v;
                 }
             }
+        } else if (a.stream_ok) {
+            // Any pilot count that is a multiple of 8 (round 3; config 5 has 96): the band's rows of up_w are one contiguous range,
+            // streamed as it lies in memory like the default grid's -- a wave takes 32 pixels = 32 nq float4 (nq = pf / 4), every
+            // lane multiplies its float4 with the matching quarter of the pilot vector, the partial sums meet in the wave's scratch
+            // (row stride nq + 1: conflict-free) and lanes 0..31 add the nq partials of "their" pixel in k order.  Before, each
+            // lane walked whole rows 4 pf bytes apart with scalar loads: 44 600 of config 5's 158 000 cycles per band.
+            // Scratch: the conv1 / conv3 planes from conv1's column 1 on; it is zeroed again below (it covers border columns).
+            const int nq = a.pf >> 2, nld = nq >> 1;                  // float4 per pixel; 64-lane loads per 32-pixel chunk
+            const int lane_i = tid & 63, wave_i = tid >> 6;
+            const int g_lo = max(gr0, 0), g_hi = min(gr0 + LR, S);    // band rows inside the plane
+            const int pix0 = g_lo * T, npix = (g_hi - g_lo) * T, nchunk = (npix + 31) >> 5;
+            const int sstride = 32 * (nq + 1);
+            float *scr = c1 + col_stride + wave_i * sstride;
+            const f32x4 *w4 = reinterpret_cast<const f32x4 *>(a.up_w) + (size_t)pix0 * nq;
+            const int total4 = npix * nq;
+            constexpr int kGroup = 6;                                 // loads in flight per wave (each waits an L2 round trip)
+            for (int ch = wave_i; ch < nchunk; ch += kConvWaves) {
+                const int base4 = ch * 32 * nq;
+                for (int i0 = 0; i0 < nld; i0 += kGroup) {
+                    f32x4 wv[kGroup];
+#pragma unroll
+                    for (int u = 0; u < kGroup; ++u) {
+                        const int f = 64 * (i0 + u) + lane_i;         // float4 index inside the chunk: pixel f / nq, quarter f % nq
+                        wv[u] = (i0 + u < nld && base4 + f < total4) ? w4[base4 + f] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGroup; ++u) {
+                        if (i0 + u >= nld) break;
+                        const int f = 64 * (i0 + u) + lane_i;
+                        const int pq = f / nq, q = f - pq * nq;
+                        const f32x4 pv = *reinterpret_cast<const f32x4 *>(small + 4 * q);
+                        float v = wv[u][0] * pv[0];
+                        v = fmaf(wv[u][1], pv[1], v);
+                        v = fmaf(wv[u][2], pv[2], v);
+                        v = fmaf(wv[u][3], pv[3], v);
+                        scr[pq * (nq + 1) + q] = v;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();                      // wave-private scratch: LDS ops of one wave complete in order
+                const int pl = 32 * ch + (lane_i & 31);
+                if (lane_i < 32 && pl < npix) {
+                    const float *pp = scr + lane_i * (nq + 1);
+                    float v = a.up_b[pix0 + pl];
+                    for (int q = 0; q < nq; ++q) v += pp[q];
+                    const int gr = g_lo + pl / T, t = pl - (pl / T) * T;
+                    in0[(t + 1) * col_stride + (gr - gr0)] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+            for (int i = tid; i < kConvWaves * sstride; i += kConvThreads) c1[col_stride + i] = 0.f;
         } else {
             for (int i = tid; i < LR * T; i += kConvThreads) {
                 const int t = i / LR, lr = i - t * LR, gr = gr0 + lr;
@@ -408,8 +464,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
         // small fix-up pass behind the barrier adds them and applies bias + ReLU.  14 column sweeps for 14 columns
         // instead of 16 (the training instantiation keeps the overlapping sweep: its stage outputs are masked / saved
         // in store_col).
-        // (needs 16 exchange planes of SP floats = the input plane of a grid with >= 14 symbols)
-        const bool EXACT = !TRAIN && NSEG == 2 && T + 2 >= 16;
+        // Seam s between segments s and s + 1 has two exchange slots of 8 channel rows: side 0 = column tb_s - 1 (owner: the left
+        // segment), side 1 = column tb_s (owner: the right one).  They live in the input plane (dead after conv1) when its T + 2
+        // row vectors hold them, else behind the arena (plan_bands).  Grids whose bands have two row tiles run FOUR column
+        // segments this way (round 3: all eight waves in the matrix phase, every column still swept once).
+        const bool EXACT = !TRAIN && NSEG >= 2 && (FIXED || a.xoff >= 0);
+        float *xch = smem + (FIXED ? 0 : a.xoff);
         const int tlo = EXACT ? ta : max(ta - 1, 0), thi = EXACT ? tb - 1 : min(tb, T - 1);   // conv2 columns swept
         const int r = r3lo + kTileRows * tile - 1 + j;                   // this lane's local row
         const int gr = gr0 + r;
@@ -431,8 +491,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
                 const bool seam = (tout == ta && ta > 0) || (tout == tb - 1 && tb < T);   // own column next to a seam
                 if (!mine || seam) {
                     if (!mine && !(tout == ta - 1 || tout == tb)) return;
-                    // raw sums: own seam column -> c3 in place, neighbour's seam column -> exchange plane (tout & 1)
-                    float *p = mine ? dst + (tout + 1) * col_stride : in0 + ((tout & 1) * 8 + 4 * h) * SP + r;
+                    // raw sums: own seam column -> c3 in place, neighbour's seam column -> its exchange slot (seam, side)
+                    const int slot = tout == ta - 1 ? (seg - 1) * 2 : seg * 2 + 1;
+                    float *p = mine ? dst + (tout + 1) * col_stride : xch + (slot * 8 + 4 * h) * SP + r;
                     const int cs = mine ? plane : SP;
                     p[0] = v0; p[cs] = v1; p[2 * cs] = v2; p[3 * cs] = v3;
                     return;
@@ -625,14 +686,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
     CSTAMP(6);
     if constexpr (!TRAIN) {
         // seam fix-up: c3[ch][t][row] = ReLU(own partial + neighbour's tap + bias) for the two columns at each seam
-        const int nseam = (NSEG == 2 && T + 2 >= 16) ? 1 : 0;
+        const int nseam = (NSEG >= 2 && (FIXED || a.xoff >= 0)) ? NSEG - 1 : 0;
         if (nseam > 0) {
+            const float *xch = smem + (FIXED ? 0 : a.xoff);
             for (int i = tid; i < nseam * 2 * 8 * (LR - 6); i += kConvThreads) {
                 const int lr = 3 + i % (LR - 6), q = i / (LR - 6), ch = q & 7, side = (q >> 3) & 1, sm = q >> 4;
                 const int t = (sm + 1) * T / NSEG - 1 + side;   // tb - 1 of the left segment, ta of the right one
                 float *pc = c3 + ch * plane + (t + 1) * col_stride + lr;
                 const int gr = gr0 + lr;
-                if (gr >= 0 && gr < S) *pc = fmaxf(*pc + in0[((t & 1) * 8 + ch) * SP + lr] + a.cb[2][ch], 0.f);
+                if (gr >= 0 && gr < S) *pc = fmaxf(*pc + xch[((sm * 2 + side) * 8 + ch) * SP + lr] + a.cb[2][ch], 0.f);
             }
             __syncthreads();
         }
@@ -679,7 +741,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
 
 // Largest row band (divides S) whose 17 channel planes fit 160 KB of LDS.  A band needs conv3 rows
 // [-1, band_rows+1) around it, covered by 30-row tiles; SP spans the last tile's halo lane.
-static bool plan_bands(int S, int T, int extra_floats, ConvArgs *a, size_t *lds_bytes) {
+static bool plan_bands(int S, int T, int extra_floats, ConvArgs *a, size_t *lds_bytes, bool train = false) {
     const int extra = (extra_floats + 3) & ~3;
     for (int nb = 1; nb <= S; ++nb) {
         if (S % nb) continue;
@@ -697,7 +759,20 @@ static bool plan_bands(int S, int T, int extra_floats, ConvArgs *a, size_t *lds_
             a->SP = sp;
             a->arena = arena;
             a->extra = extra;
+            a->xoff = (!train && a->nseg == 2 && T + 2 >= 16) ? 0 : -1;   // one seam: its 16 exchange rows are the dead input plane
             *lds_bytes = bytes;
+            // Bands of one or two row tiles leave half of the eight waves without a task: four column segments instead (inference
+            // only: the three seams' 48 exchange rows go behind the arena when the input plane has fewer row vectors)
+            if (!train && ntiles * 2 <= kConvWaves / 2 && T >= 16) {
+                const int xrows = 3 * 16;
+                const int xoff = xrows <= T + 2 ? 0 : ((arena + extra + 32 + 80 + 3) & ~3);
+                const size_t b4 = xoff == 0 ? bytes : sizeof(float) * ((size_t)xoff + (size_t)xrows * sp);
+                if (b4 <= 160 * 1024) {
+                    a->nseg = 4;
+                    a->xoff = xoff;
+                    *lds_bytes = b4;
+                }
+            }
             return true;
         }
     }
@@ -716,7 +791,10 @@ static hipError_t launch_conv_geo(ConvArgs &a, int planes, size_t lds, hipStream
 template <bool TRAIN>
 static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStream_t st) {
     size_t lds = 0;
-    if (!plan_bands(a.S, a.T, extra_floats, &a, &lds)) return hipErrorInvalidValue;
+    if (!plan_bands(a.S, a.T, extra_floats, &a, &lds, TRAIN)) return hipErrorInvalidValue;
+    if (a.stream_ok < 0)   // streaming upsampler: 8 waves x 32 pixels x (pf / 4 + 1) partial sums inside the 16 conv1 / conv3 planes
+        a.stream_ok = (a.pf % 8 == 0 && a.up_w && (reinterpret_cast<uintptr_t>(a.up_w) & 15) == 0 &&
+                       (size_t)kConvWaves * 32 * (a.pf / 4 + 1) + a.SP <= (size_t)16 * (a.T + 2) * a.SP) ? 1 : 0;
     const bool fixed = a.S == 120 && a.T == 14 && a.SP == 128 && a.band_rows == 120 && a.nbands == 1 && a.ntiles == 4 && a.nseg == 2;
     if (fixed) return launch_conv_geo<TRAIN, true>(a, planes, lds, st);
     return launch_conv_geo<TRAIN, false>(a, planes, lds, st);
@@ -778,6 +856,7 @@ hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const floa
     a.pf = c.pilot_scs * c.pilot_symbols;
     for (int i = 0; i < 4; ++i) { a.cw[i] = w.enh_w[i]; a.cb[i] = w.enh_b[i]; }
     a.out_plane = conv_enhanced;
+    a.stream_ok = -1;   // decided by launch_conv once the band plan is known
     return launch_conv<false>(a, 2 * batch, a.pf, st);
 }
 

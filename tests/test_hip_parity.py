@@ -172,11 +172,15 @@ def test_output_bits_do_not_depend_on_stale_workspace(value):
 @pytest.mark.parametrize("ofdm,pilot,patch,adaptive", [((30, 8), (6, 2), (3, 2), True), ((66, 12), (11, 3), (3, 3), False),
                                                         ((150, 8), (10, 2), (5, 2), True),
                                                         ((120, 14), (12, 2), (4, 2), True), ((120, 14), (12, 2), (2, 2), False),
-                                                        ((54, 14), (6, 2), (3, 2), False)])
+                                                        ((54, 14), (6, 2), (3, 2), False),
+                                                        ((48, 16), (8, 2), (3, 2), False), ((30, 50), (6, 5), (3, 2), True),
+                                                        ((60, 18), (6, 3), (3, 2), False)])
 def test_other_grid_geometries_match_oracle(oracle_lib, ofdm, pilot, patch, adaptive):
     """Grids whose row count is not a multiple of 4 / of the 30-row conv tiles, other patch shapes, a
     grid taller than the default (one band, five conv tiles): conv tiling, patch addressing, ragged
-    attention tiles; token counts that are not a multiple of 8 or 4 (210, 420, 126)."""
+    attention tiles; token counts that are not a multiple of 8 or 4 (210, 420, 126).  The last three have bands of one or
+    two conv row tiles and >= 16 symbols: FOUR column segments with three exact seams (exchange rows behind the arena for
+    16 / 18 symbols, in the dead input plane for 50; segments of 4 / 5 columns for 18)."""
     tokens = (ofdm[0] // patch[0]) * (ofdm[1] // patch[1])
     spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=2, model_dim=128, num_head=4)
     hid = (5, 9, 2 * tokens) if adaptive else None

@@ -8,14 +8,19 @@ from adafortitran_amd.hip_ops import engine_from_numpy, profile_kernel
 SPEC = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=6, model_dim=128, num_head=4)
 HID = (7, 42, 560)
 B = int(os.environ.get("AFT_BATCH", "128"))
+if os.environ.get("AFT_CONFIG") == "C5":   # BASELINE config 5 per GPU: 240 x 28 grid, 12 layers, d = 256, 64 frames
+    SPEC = dict(ofdm=(240, 28), pilot=(24, 4), patch=(3, 2), num_layers=12, model_dim=256, num_head=8)
+    HID = (7, 42, 2240)
+    B = int(os.environ.get("AFT_BATCH", "64"))
 which = sys.argv[1:] or ["upsample", "embed", "qkv", "attention", "chain", "tail"]
-sd = synth.make_state_dict(**SPEC, adaptive_hidden=HID, seed=20251114)
+tokens = (SPEC["ofdm"][0] // 3) * (SPEC["ofdm"][1] // 2)
+sd = synth.make_state_dict(**SPEC, adaptive_hidden=HID, max_seq_len=max(512, tokens), seed=20251114)
 cfg = _abi.make_config(**SPEC, adaptive_hidden=HID)
 eng = engine_from_numpy(cfg, sd, "cuda:0")
-inp = synth.make_inputs(B, seed=20251114)
+inp = synth.make_inputs(B, ofdm=SPEC["ofdm"], pilot=SPEC["pilot"], seed=20251114)
 dev = lambda a: torch.from_numpy(a).to("cuda:0")
 pil, meta = dev(inp["pilots"]), [dev(inp[k]) for k in ("snr", "ds", "dop")]
-out = torch.empty((B, 120, 14), dtype=torch.complex64, device="cuda:0")
+out = torch.empty((B, *SPEC["ofdm"]), dtype=torch.complex64, device="cuda:0")
 stamps = os.environ.pop("AFT_STAMPS", None)   # only meaningful with a --diag build
 eng.forward(pil, *meta, out=out); torch.cuda.synchronize()
 if stamps: os.environ["AFT_STAMPS"] = stamps
