@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, Dict, Optional
 
-AFT_ABI_VERSION = 2
+AFT_ABI_VERSION = 3
 AFT_MAX_LAYERS = 32
 AFT_OK, AFT_ERR_ARG, AFT_ERR_SHAPE, AFT_ERR_HIP = 0, 1, 2, 3
 AFT_ACT_RELU, AFT_ACT_GELU = 0, 1
@@ -137,7 +137,7 @@ EXPORTED_SYMBOLS = (
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",
     "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",
     "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
-    "aft_encoder_layer_fwd_train_f32", "aft_encoder_layer_bwd_f32", "aft_adam_step_f32",
+    "aft_encoder_layer_fwd_train_f32", "aft_encoder_layer_fwd_train_chained_f32", "aft_encoder_layer_bwd_f32", "aft_adam_step_f32",
     "aft_conv_enhancer_fwd_train_f32", "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_bwd_f32",
     "aft_dense_fwd_f32", "aft_dense_bwd_scratch_bytes", "aft_dense_bwd_f32",
     "aft_adapter_fwd_train_f32", "aft_adapter_bwd_f32",

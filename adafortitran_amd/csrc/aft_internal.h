@@ -280,7 +280,8 @@ bool chain_fwd_train_ok(const aft_config &c, int rows);
 hipError_t launch_chain_fwd_train(const aft_config &c, const aft_layer_weights &w, const float *attn, const float *x, float *packed,
                                   float *s1, float *st1, float *x1, float *a_pre, float *hd, float *s2, float *st2, float *x_out,
                                   int rows, uint32_t seed1, uint32_t seed2, uint32_t seed3, uint32_t threshold, float keep_scale,
-                                  hipStream_t st);
+                                  hipStream_t st, const float *next_in_proj_w = nullptr, const float *next_in_proj_b = nullptr,
+                                  float *next_qkv = nullptr);   // all three set: + the next layer's in-projection, row-major [rows][3 d]
 hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o, float *lse, int planes, int tokens,
                                  float dropout_p, uint32_t seed, hipStream_t st);
 hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const float *o, const float *d_o, const float *lse,

@@ -118,9 +118,11 @@ size_t aft_encoder_train_scratch_bytes(const aft_config *cfg, int batch) {
     return plan_scratch(*cfg, batch).total * sizeof(float);
 }
 
-int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
-                                    void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
-                                    float dropout_p, uint64_t seed, void *stream) {
+int aft_encoder_layer_fwd_train_chained_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
+                                            void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
+                                            float dropout_p, uint64_t seed, int qkv_ready, const aft_layer_weights *next_w,
+                                            void *next_tape, int *next_qkv_written, void *stream) {
+    if (next_qkv_written) *next_qkv_written = 0;
     int rc = check_train(cfg, batch, dropout_p);
     if (rc != AFT_OK) return rc;
     if (!w || !x_in || !x_out || !tape || !scratch) { set_error("NULL pointer argument"); return AFT_ERR_ARG; }
@@ -135,17 +137,23 @@ int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weigh
     const int tokens = tokens_of_cfg(*cfg), planes = 2 * batch, rows = planes * tokens, d = cfg->model_dim, ff = 2 * d;
     float *o = sc + s.g1;   // projection outputs before the residual joins
 
-    STEP("qkv", launch_gemm(0, x_in, w->in_proj_w, tp + t.qkv, w->in_proj_b, rows, 3 * d, d, d, d, 3 * d, false, st));
+    if (!qkv_ready)   // (else the previous layer's row-local kernel already left this layer's in-projection in the tape)
+        STEP("qkv", launch_gemm(0, x_in, w->in_proj_w, tp + t.qkv, w->in_proj_b, rows, 3 * d, d, d, d, 3 * d, false, st));
     STEP("attention", launch_attn_train_fwd(*cfg, tp + t.qkv, tp + t.attn, tp + t.lse, planes, tokens, dropout_p,
                                             site_seed(seed, 0), st));
     const uint32_t drop_th = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
     const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    // the NEXT layer's in-projection as the tail of this layer's row-local kernel (same tape layout: the layers share cfg and batch)
+    const bool chain_next = next_w && next_w->in_proj_w && next_w->in_proj_b && next_tape && next_qkv_written;
     if (chain_fwd_train_ok(*cfg, rows) && !getenv("AFT_TRAIN_UNFUSED_FWD")) {
         // everything row-local behind the attention in ONE launch, the tape written from its epilogues (k_chain_bwd.hip);
         // the packed weight image lives in the scratch's packed_t region (8 d^2 floats needed, see plan_scratch)
         STEP("row-local forward chain", launch_chain_fwd_train(*cfg, *w, tp + t.attn, x_in, sc + s.packed_t, tp + t.s1, tp + t.st1, tp + t.x1,
                                                               tp + t.a, tp + t.hd, tp + t.s2, tp + t.st2, x_out, rows, site_seed(seed, 1),
-                                                              site_seed(seed, 2), site_seed(seed, 3), drop_th, drop_ks, st));
+                                                              site_seed(seed, 2), site_seed(seed, 3), drop_th, drop_ks, st,
+                                                              chain_next ? next_w->in_proj_w : nullptr, chain_next ? next_w->in_proj_b : nullptr,
+                                                              chain_next ? static_cast<float *>(next_tape) + t.qkv : nullptr));
+        if (chain_next && next_qkv_written) *next_qkv_written = 1;
         return AFT_OK;
     }
     // projection + residual + dropout + LayerNorm: one launch when the fused epilogue covers the shape (d = 128)
@@ -173,6 +181,13 @@ int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weigh
                                         dropout_p, site_seed(seed, 3), st));
     }
     return AFT_OK;
+}
+
+int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
+                                    void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
+                                    float dropout_p, uint64_t seed, void *stream) {
+    return aft_encoder_layer_fwd_train_chained_f32(cfg, w, x_in, x_out, tape, tape_bytes, scratch, scratch_bytes, batch, dropout_p, seed, 0,
+                                                   nullptr, nullptr, nullptr, stream);
 }
 
 int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, const void *tape,

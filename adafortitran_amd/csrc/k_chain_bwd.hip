@@ -296,6 +296,9 @@ struct ChainTrainArgs {
     const float *wo, *w1, *w2;          // fragment-packed weights (pack_weights_kernel, fp32 image)
     const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;
     float *s1, *st1, *x1, *a, *hd, *s2, *st2, *x_out;   // the tape + the layer output, row-major
+    // QKV instantiation: the NEXT layer's in-projection on this layer's output, row-major [rows][3 D] into the next layer's tape
+    const float *wqkv, *bqkv;
+    float *qkv_next;
     int rows;
     uint32_t seed1, seed2, seed3, threshold;
     float keep_scale;
@@ -348,7 +351,7 @@ __device__ __forceinline__ void layernorm_rows_stats(f32x16 &v, float *stats, co
     }
 }
 
-template <int D, int ACT>
+template <int D, int ACT, bool QKV>
 __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kernel(const ChainTrainArgs a) {
     using S = ChainShape<D>;
     constexpr int W = S::WAVES;
@@ -375,6 +378,8 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
               srd_out = make_srd(a.x_out);
     const unsigned wo_off = (unsigned)w * W * 1024 + lane * 4, w1_off = (unsigned)(2 * w) * W * 1024 + lane * 4;
     const unsigned w2_off = (unsigned)w * (2 * W) * 1024 + lane * 4;
+    const Srd srd_wq = make_srd(a.wqkv), srd_bq = make_srd(a.bqkv), srd_qkv = make_srd(a.qkv_next);
+    const unsigned wq_off = (unsigned)w * W * 1024 + lane * 4;   // tiles w, W + w, 2 W + w: the q, k, v features of block w
 
     for (int i = tid; i < D; i += S::THREADS) {
         par[i] = a.g1[i];
@@ -498,23 +503,48 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             for (int s = 0; s < 4; ++s)
                 srd_store(srd_out, xrow + 32 * s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
         }
+        if constexpr (QKV) {
+            // ---- the next layer's in-projection on x2 (the tile is still in registers): q | k | v of feature block w, bias as the
+            //      accumulators' initial value, row-major into the next layer's tape.  x1's readers are past the hidden barrier. ----
+            constexpr int PFQ = 2;
+            const unsigned wq_lane = (wq_off + lo) * 4;
+            WRing<3, PFQ> ring_q;
+            gemm_preload<W, 3, PFQ, W>(ring_q, srd_wq, wq_lane);
+            f32x16 acc_q[3] = {bias_acc(srd_bq, fb, h), bias_acc(srd_bq, D + fb, h), bias_acc(srd_bq, 2 * D + fb, h)};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
+            __syncthreads();
+            gemm_run<W, 3, PFQ, W, 0>(ring_q, srd_wq, wq_lane, acc_q, [&](int kb, int s) {
+                return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+            });
+            if (row_ok) {
+                const unsigned qrow = ((unsigned)grow * 3 * D + fb + 4 * h) * 4;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        srd_store(srd_qkv, qrow + (unsigned)t * D * 4 + 32 * s,
+                                  f32x4{acc_q[t][4 * s], acc_q[t][4 * s + 1], acc_q[t][4 * s + 2], acc_q[t][4 * s + 3]});
+            }
+        }
         __syncthreads();    // the next tile's LayerNorm-1 partials must not overtake this tile's LayerNorm-2 readers
     }
 }
 
 bool chain_fwd_train_ok(const aft_config &c, int rows) {
-    return c.model_dim == 128 && (size_t)rows * 2 * c.model_dim * sizeof(float) < ((size_t)1 << 31);
+    return c.model_dim == 128 && (size_t)rows * 3 * c.model_dim * sizeof(float) < ((size_t)1 << 31);
 }
 
-template <int ACT>
+template <int ACT, bool QKV>
 static hipError_t launch_chain_fwd_train_t(const ChainTrainArgs &args, hipStream_t st) {
     constexpr int D = 128;
     using T = ChainTrainShape<D>;
     static PerDeviceOnce lds_attr;
-    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_fwd_train_kernel<D, ACT>), T::LDS_BYTES);
+    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_fwd_train_kernel<D, ACT, QKV>), T::LDS_BYTES);
     if (ea != hipSuccess) return ea;
     const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * 3);
-    hipLaunchKernelGGL((chain_fwd_train_kernel<D, ACT>), dim3(blocks), dim3(ChainShape<D>::THREADS), T::LDS_BYTES, st, args);
+    hipLaunchKernelGGL((chain_fwd_train_kernel<D, ACT, QKV>), dim3(blocks), dim3(ChainShape<D>::THREADS), T::LDS_BYTES, st, args);
     return hipGetLastError();
 }
 
@@ -522,9 +552,11 @@ static hipError_t launch_chain_fwd_train_t(const ChainTrainArgs &args, hipStream
 hipError_t launch_chain_fwd_train(const aft_config &c, const aft_layer_weights &w, const float *attn, const float *x, float *packed,
                                   float *s1, float *st1, float *x1, float *a_pre, float *hd, float *s2, float *st2, float *x_out,
                                   int rows, uint32_t seed1, uint32_t seed2, uint32_t seed3, uint32_t threshold, float keep_scale,
-                                  hipStream_t st) {
+                                  hipStream_t st, const float *next_in_proj_w, const float *next_in_proj_b, float *next_qkv) {
     aft_weights one{};
     one.layers[0] = w;
+    const bool qkv = next_in_proj_w && next_in_proj_b && next_qkv;
+    if (qkv) one.layers[0].in_proj_w = next_in_proj_w;   // the image's in-projection slot carries the NEXT layer's matrix
     aft_config c1 = c;
     c1.precision = AFT_PRECISION_F32;
     hipError_t e = launch_pack_weights(c1, one, packed, 0, 1, st);
@@ -538,7 +570,11 @@ hipError_t launch_chain_fwd_train(const aft_config &c, const aft_layer_weights &
     a.s1 = s1; a.st1 = st1; a.x1 = x1; a.a = a_pre; a.hd = hd; a.s2 = s2; a.st2 = st2; a.x_out = x_out;
     a.rows = rows;
     a.seed1 = seed1; a.seed2 = seed2; a.seed3 = seed3; a.threshold = threshold; a.keep_scale = keep_scale;
-    return c.activation == AFT_ACT_GELU ? launch_chain_fwd_train_t<AFT_ACT_GELU>(a, st) : launch_chain_fwd_train_t<AFT_ACT_RELU>(a, st);
+    if (qkv) {
+        a.wqkv = packed; a.bqkv = next_in_proj_b; a.qkv_next = next_qkv;
+        return c.activation == AFT_ACT_GELU ? launch_chain_fwd_train_t<AFT_ACT_GELU, true>(a, st) : launch_chain_fwd_train_t<AFT_ACT_RELU, true>(a, st);
+    }
+    return c.activation == AFT_ACT_GELU ? launch_chain_fwd_train_t<AFT_ACT_GELU, false>(a, st) : launch_chain_fwd_train_t<AFT_ACT_RELU, false>(a, st);
 }
 
 // Fragment-packed TRANSPOSES of one layer's linear2 / linear1 / out_proj weights (the data-gradient products use W, i.e.

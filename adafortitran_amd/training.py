@@ -16,6 +16,7 @@ stream, as any other implementation's would.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Sequence
 
 import torch
@@ -53,9 +54,22 @@ def _layer_struct(cls, tensors: Sequence[torch.Tensor]):
     return st
 
 
+class StackLink:
+    """What a layer inside ``encoder_stack_train`` knows about its neighbours (passed in place of the bare seed): its own
+    pre-allocated tape, whether the previous layer already left this layer's in-projection there, and the next layer's
+    parameters + tape so that this layer's row-local kernel can compute the next in-projection as its tail
+    (``aft_encoder_layer_fwd_train_chained_f32``).  Nothing here is differentiated: the in-projection's gradients still come
+    from the layer that owns it, out of its own tape."""
+
+    def __init__(self, seed, tape, qkv_ready=False, next_params=None, next_tape=None):
+        self.seed, self.tape, self.qkv_ready = int(seed), tape, bool(qkv_ready)
+        self.next_params, self.next_tape = next_params, next_tape
+        self.next_qkv_written = False
+
+
 class HipEncoderLayerFunction(torch.autograd.Function):
     """x [planes, tokens, d] -> layer(x); ``params`` are the layer's twelve tensors in
-    ``_abi.LAYER_PARAM_NAMES`` order."""
+    ``_abi.LAYER_PARAM_NAMES`` order.  ``seed`` is an int, or a ``StackLink`` when the layer runs inside a stack."""
 
     @staticmethod
     def forward(ctx, x, cfg, dropout_p, seed, *params):
@@ -67,13 +81,29 @@ class HipEncoderLayerFunction(torch.autograd.Function):
         params = tuple(p.detach().contiguous() for p in params)
         planes = x.shape[0]
         batch = planes // 2
-        tape = torch.empty(lib.aft_encoder_tape_bytes(C.byref(cfg), batch), dtype=torch.uint8, device=x.device)
+        link = seed if isinstance(seed, StackLink) else None
+        if link is not None:
+            seed, tape = link.seed, link.tape
+        else:
+            tape = torch.empty(lib.aft_encoder_tape_bytes(C.byref(cfg), batch), dtype=torch.uint8, device=x.device)
         scratch = torch.empty(lib.aft_encoder_train_scratch_bytes(C.byref(cfg), batch), dtype=torch.uint8, device=x.device)
         out = torch.empty_like(x)
         w = _layer_struct(_abi.AftLayerWeights, params)
-        _lib.check(lib.aft_encoder_layer_fwd_train_f32(
-            C.byref(cfg), C.byref(w), x.data_ptr(), out.data_ptr(), tape.data_ptr(), tape.numel(),
-            scratch.data_ptr(), scratch.numel(), batch, float(dropout_p), int(seed), _lib.current_stream_ptr(x.device)))
+        if link is None:
+            _lib.check(lib.aft_encoder_layer_fwd_train_f32(
+                C.byref(cfg), C.byref(w), x.data_ptr(), out.data_ptr(), tape.data_ptr(), tape.numel(),
+                scratch.data_ptr(), scratch.numel(), batch, float(dropout_p), int(seed), _lib.current_stream_ptr(x.device)))
+        else:
+            nxt, wrote = None, C.c_int(0)
+            if link.next_params is not None and link.next_tape is not None:
+                next_params = tuple(p.detach().contiguous() for p in link.next_params)   # kept alive until the call returns
+                nxt = _layer_struct(_abi.AftLayerWeights, next_params)
+            _lib.check(lib.aft_encoder_layer_fwd_train_chained_f32(
+                C.byref(cfg), C.byref(w), x.data_ptr(), out.data_ptr(), tape.data_ptr(), tape.numel(),
+                scratch.data_ptr(), scratch.numel(), batch, float(dropout_p), int(seed), int(link.qkv_ready),
+                C.byref(nxt) if nxt is not None else None, link.next_tape.data_ptr() if nxt is not None else None,
+                C.byref(wrote), _lib.current_stream_ptr(x.device)))
+            link.next_qkv_written = bool(wrote.value)
         ctx.save_for_backward(x, tape, *params)
         ctx.cfg, ctx.dropout_p, ctx.seed, ctx.batch = cfg, float(dropout_p), int(seed), batch
         ctx.param_objs = param_objs
@@ -269,7 +299,22 @@ def layer_params(layer: torch.nn.Module):
 
 def encoder_stack_train(x: torch.Tensor, layers, cfg: _abi.AftConfig, dropout_p: float) -> torch.Tensor:
     """Run ``layers`` (an iterable of nn.TransformerEncoderLayer) in training mode on the HIP path."""
+    layers = list(layers)
     seeds = torch.randint(0, 2 ** 62, (len(layers),), dtype=torch.int64).tolist()
-    for layer, seed in zip(layers, seeds):
-        x = HipEncoderLayerFunction.apply(x, cfg, dropout_p, seed, *layer_params(layer))
+    if os.environ.get("AFT_TRAIN_NO_QKV_CHAIN") or not layers:   # A/B switch: every layer runs its own in-projection GEMM
+        for layer, seed in zip(layers, seeds):
+            x = HipEncoderLayerFunction.apply(x, cfg, dropout_p, seed, *layer_params(layer))
+        return x
+    # Layers chained through their tapes: layer l's row-local kernel leaves layer l + 1's in-projection in layer l + 1's tape
+    # (one GEMM launch per layer less; the product runs where the output tile is still in registers).
+    lib = _lib.load()
+    nbytes = lib.aft_encoder_tape_bytes(C.byref(cfg), x.shape[0] // 2)
+    tapes = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in layers]
+    params = [layer_params(layer) for layer in layers]
+    ready = False
+    for i, seed in enumerate(seeds):
+        last = i + 1 == len(layers)
+        link = StackLink(seed, tapes[i], ready, None if last else params[i + 1], None if last else tapes[i + 1])
+        x = HipEncoderLayerFunction.apply(x, cfg, dropout_p, link, *params[i])
+        ready = link.next_qkv_written
     return x

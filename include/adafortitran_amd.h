@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AFT_ABI_VERSION 2   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
+#define AFT_ABI_VERSION 3   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
 #define AFT_MAX_LAYERS 32
 
 #define AFT_OK 0
@@ -191,6 +191,18 @@ size_t aft_encoder_train_scratch_bytes(const aft_config *cfg, int batch);
 int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
                                     void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
                                     float dropout_p, uint64_t seed, void *stream);
+
+/* The same layer inside a stack (reference blocks/encoders.py:69 loops over the layers): what changes is only WHERE the
+ * in-projection of a layer runs.  `qkv_ready` != 0: the previous call already left this layer's q | k | v in `tape`
+ * (skip the in-projection GEMM).  `next_w` + `next_tape` (the NEXT layer's parameters and its tape, same cfg and batch) +
+ * `next_qkv_written`: when the fused row-local kernel covers the shape, the next layer's in-projection is computed as its
+ * tail while the output tile is still in registers and written into `next_tape`; *next_qkv_written says whether that
+ * happened (pass it as the next call's qkv_ready).  The backward is unchanged: each layer's aft_encoder_layer_bwd_f32
+ * still produces its own in-projection gradients from its own tape. */
+int aft_encoder_layer_fwd_train_chained_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
+                                            void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
+                                            float dropout_p, uint64_t seed, int qkv_ready, const aft_layer_weights *next_w,
+                                            void *next_tape, int *next_qkv_written, void *stream);
 
 /* Replaces autograd's backward through that layer: dx_out = dL/dx_out [2B*tokens, d] ->
  * dx_in = dL/dx_in (may alias dx_out) and the twelve parameter gradients in `grads`

@@ -121,6 +121,63 @@ def test_one_pass_attention_backward_agrees_with_the_two_pass_form(ofdm, heads, 
     assert any(not torch.equal(a, c) for a, c in zip(one, two))   # the switch did select another kernel
 
 
+@pytest.mark.parametrize("d,heads,ofdm", [(128, 4, (120, 14)), (128, 4, (24, 14)), (256, 8, (48, 14))])
+def test_stack_with_chained_in_projections_matches_the_unchained_stack(d, heads, ofdm, monkeypatch):
+    """encoder_stack_train links the layers through their tapes: layer l's row-local kernel computes layer l + 1's
+    in-projection (aft_encoder_layer_fwd_train_chained_f32).  Against the same stack with every layer running its own
+    in-projection GEMM (AFT_TRAIN_NO_QKV_CHAIN): same seeds, same masks; output and every gradient within 2e-6 of the
+    tensor's max (the product is summed in a different order), and against autograd as the layer test does.  d = 256 has
+    no fused row-local kernel: the link must fall back to the GEMM (next_qkv_written = 0) and give identical bits."""
+    from adafortitran_amd.training import encoder_stack_train, layer_params
+    cfg = _cfg(d, heads, ofdm)
+    layers = [_layer(d, heads, "gelu", 0.1, seed=10 + i).train() for i in range(3)]
+    torch.manual_seed(8)
+    x0 = torch.randn(4, cfg.tokens, d, device="cuda")
+    gout = torch.randn(4, cfg.tokens, d, device="cuda")
+
+    def run():
+        for layer in layers:
+            layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        torch.manual_seed(99)                      # the per-layer dropout seeds are drawn from torch's generator
+        out = encoder_stack_train(x, layers, cfg, 0.1)
+        out.backward(gout)
+        return [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for layer in layers for p in layer_params(layer)]
+
+    monkeypatch.delenv("AFT_TRAIN_NO_QKV_CHAIN", raising=False)
+    chained = run()
+    monkeypatch.setenv("AFT_TRAIN_NO_QKV_CHAIN", "1")
+    plain = run()
+    for i, (a, b) in enumerate(zip(chained, plain)):
+        if d == 256:
+            assert torch.equal(a, b), i
+        else:
+            assert _rel(a, b) <= 2e-6, (i, _rel(a, b))
+    if d != 256:
+        assert any(not torch.equal(a, b) for a, b in zip(chained, plain))   # the link did change where the product runs
+
+    # and against autograd through the same three nn.TransformerEncoderLayer modules, dropout off
+    for layer in layers:
+        layer.zero_grad()
+    xr = x0.clone().requires_grad_(True)
+    ref = xr
+    for layer in layers:
+        layer.dropout.p = layer.dropout1.p = layer.dropout2.p = layer.self_attn.dropout = 0.0
+        ref = layer(ref)
+    ref.backward(gout)
+    ref_g = [xr.grad.clone()] + [p.grad.clone() for layer in layers for p in layer_params(layer)]
+    monkeypatch.delenv("AFT_TRAIN_NO_QKV_CHAIN", raising=False)
+    for layer in layers:
+        layer.zero_grad()
+    xh = x0.clone().requires_grad_(True)
+    out = encoder_stack_train(xh, layers, cfg, 0.0)
+    out.backward(gout)
+    got = [xh.grad.clone()] + [p.grad.clone() for layer in layers for p in layer_params(layer)]
+    assert _rel(out.detach(), ref.detach()) <= 5e-5
+    for i, (a, b) in enumerate(zip(got, ref_g)):
+        assert _rel(a, b) <= 3e-4, (i, _rel(a, b))
+
+
 def test_dropout_is_consistent_between_forward_and_backward():
     """With p > 0 the layer is still a deterministic function of (x, seed): its backward must match a
     central finite difference of its forward along a random direction, and the keep rate must be 1-p."""
