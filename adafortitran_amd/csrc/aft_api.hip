@@ -242,7 +242,9 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
                 workspace_bytes, ws.total_floats * sizeof(float));
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *base = static_cast<float *>(workspace);
-    hipError_t e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st);
+    // the activation buffer x is idle until the first encoder launch: it lends the upsampler its plane scratch when it is large enough
+    const size_t x_floats = (size_t)ws.planes * ws.tokens * cfg->model_dim, up_floats = (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
+    hipError_t e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr);
     if (e != hipSuccess) return hip_fail("upsample", e);
     if (cfg->adaptive) {
         e = launch_adapter(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, st);
@@ -402,7 +404,8 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
         switch (which) {
             case AFT_KERNEL_UPSAMPLE:
                 AFT_REQUIRE(out != nullptr, "upsample profile needs the pilots pointer in `out`");
-                e = launch_upsample(*cfg, *w, out, base + ws.conv_enhanced, batch, st);
+                e = launch_upsample(*cfg, *w, out, base + ws.conv_enhanced, batch, st,   // as the forward: x lends the plane scratch
+                                    (size_t)ws.planes * ws.tokens * cfg->model_dim >= (size_t)ws.planes * cfg->num_scs * cfg->num_symbols ? x : nullptr);
                 break;
             case AFT_KERNEL_EMBED:
                 e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, x, batch, st);

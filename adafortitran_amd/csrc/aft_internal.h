@@ -164,8 +164,10 @@ struct PerDeviceOnce {       // one flag per device; `static PerDeviceOnce x;` i
 hipError_t ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, size_t bytes);
 
 // ---- kernel launchers (each enqueues on `st`, returns hipError_t of the launch) ----
+// scratch_planes (optional, 2 B * S * T floats, free to overwrite): grids other than the default one compute the upsampler as one
+// product over all planes into it and the conv head reads the planes; NULL = inside the conv head
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots,
-                           float *conv_enhanced, int batch, hipStream_t st);
+                           float *conv_enhanced, int batch, hipStream_t st, float *scratch_planes = nullptr);
 hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
                           const float *dop, float *tokens6, int batch, hipStream_t st);
 hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced,

@@ -180,6 +180,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_stack_kernel(const ConvArgs
             const int lr = i / T, t = i - lr * T, gr = gr0 + lr;
             if (gr >= 0 && gr < S) in0[(t + 1) * col_stride + lr] = a.in_plane[((size_t)n * S + gr) * T + t];
         }
+    } else if (a.mode == 0 && a.in_plane != nullptr) {
+        // the upsampled planes were computed by upsample_planes_kernel (one product over all planes): copy the band's rows
+        for (int i = tid; i < LR * T; i += kConvThreads) {
+            const int lr = i / T, t = i - lr * T, gr = gr0 + lr;
+            if (gr >= 0 && gr < S) in0[(t + 1) * col_stride + lr] = a.in_plane[((size_t)n * S + gr) * T + t];
+        }
     } else if (a.mode == 0) {   // pilot_upsampler row (gr*T + t): idx = sc*T + sym (view(B,1,S,T))
         if (FIXED && a.pf == 24) {
             // Default grid and pilots (round 3): up_w [1680][24] is 161 KB that EVERY workgroup streams through its CU's L1.
@@ -847,8 +853,61 @@ hipError_t launch_conv_train(const float *const w[4], const float *const b[4], c
     return launch_conv<true>(a, planes, 0, st);
 }
 
+// pilot_upsampler (reference fortitran.py:86,203-206: Linear(Ps*Pt -> S*T) on the Re and the Im plane) as ONE product over all
+// planes: planes[n][pix] = up_b[pix] + sum_k up_w[pix][k] * pilot[n][k], n = 2 frame + part.  Used for grids other than the
+// default one when the caller can lend a scratch buffer: inside the conv head every (plane, band) workgroup streams its rows of
+// up_w again -- config 5: 602 KB per workgroup, 385 MB per launch out of the L2s, 34 500 of its 147 000 cycles.
+// One workgroup = 64 pixels x 64 planes: the 64 rows of up_w (coalesced) and the 64 pilot vectors sit in LDS, thread
+// (pixel, plane group g) accumulates 16 planes; k runs 0 .. pf-1 in order with the bias first (the per-pixel loop's order).
+constexpr int kUpPix = 64, kUpPlanes = 64;
+__global__ __launch_bounds__(256) void upsample_planes_kernel(const float *__restrict__ up_w, const float *__restrict__ up_b,
+                                                              const float *__restrict__ pilots, float *__restrict__ planes_out,
+                                                              int npix, int pf, int nplanes) {
+    extern __shared__ __attribute__((aligned(16))) float ups[];
+    const int wld = pf + 4;                       // row stride of the weight tile: 16-byte rows, conflict-free float4 reads
+    float *Ws = ups, *Ps = ups + kUpPix * wld;    // [64][pf + 4] | [64][pf]
+    const int tid = threadIdx.x, pix0 = blockIdx.x * kUpPix, plane0 = blockIdx.y * kUpPlanes;
+    const int nq = pf >> 2;
+    for (int i = tid; i < kUpPix * nq; i += 256) {
+        const int r = i / nq, q = i - r * nq;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pix0 + r < npix) v = *reinterpret_cast<const f32x4 *>(up_w + (size_t)(pix0 + r) * pf + 4 * q);
+        *reinterpret_cast<f32x4 *>(Ws + r * wld + 4 * q) = v;
+    }
+    for (int i = tid; i < kUpPlanes * pf; i += 256) {
+        const int pl = i / pf, k = i - pl * pf, n = plane0 + pl;
+        Ps[i] = n < nplanes ? pilots[((size_t)(n >> 1) * pf + k) * 2 + (n & 1)] : 0.f;
+    }
+    __syncthreads();
+    const int px = tid & 63, g = tid >> 6;
+    const float b = pix0 + px < npix ? up_b[pix0 + px] : 0.f;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = b;
+    for (int q = 0; q < nq; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(Ws + px * wld + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 pv = *reinterpret_cast<const f32x4 *>(Ps + (g * 16 + i) * pf + 4 * q);   // wave-uniform address: broadcast
+            float v = acc[i];
+            v = fmaf(wv[0], pv[0], v);
+            v = fmaf(wv[1], pv[1], v);
+            v = fmaf(wv[2], pv[2], v);
+            v = fmaf(wv[3], pv[3], v);
+            acc[i] = v;
+        }
+    }
+    if (pix0 + px < npix) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = plane0 + g * 16 + i;
+            if (n < nplanes) planes_out[(size_t)n * npix + pix0 + px] = acc[i];
+        }
+    }
+}
+
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots, float *conv_enhanced,
-                           int batch, hipStream_t st) {
+                           int batch, hipStream_t st, float *scratch_planes) {
     ConvArgs a{};
     a.mode = 0;
     a.S = c.num_scs; a.T = c.num_symbols;
@@ -857,6 +916,16 @@ hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const floa
     for (int i = 0; i < 4; ++i) { a.cw[i] = w.enh_w[i]; a.cb[i] = w.enh_b[i]; }
     a.out_plane = conv_enhanced;
     a.stream_ok = -1;   // decided by launch_conv once the band plan is known
+    const bool default_grid = c.num_scs == 120 && c.num_symbols == 14 && a.pf == 24;   // streams up_w inside the head (161 KB per workgroup)
+    const size_t up_lds = sizeof(float) * ((size_t)kUpPix * (a.pf + 4) + (size_t)kUpPlanes * a.pf);
+    if (scratch_planes && !default_grid && a.pf % 4 == 0 && up_lds <= 64 * 1024 && (reinterpret_cast<uintptr_t>(w.up_w) & 15) == 0) {
+        const int npix = c.num_scs * c.num_symbols, nplanes = 2 * batch;
+        hipLaunchKernelGGL(upsample_planes_kernel, dim3((npix + kUpPix - 1) / kUpPix, (nplanes + kUpPlanes - 1) / kUpPlanes), dim3(256), up_lds,
+                           st, w.up_w, w.up_b, pilots, scratch_planes, npix, a.pf, nplanes);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        a.in_plane = scratch_planes;
+    }
     return launch_conv<false>(a, 2 * batch, a.pf, st);
 }
 
