@@ -121,7 +121,7 @@ def host_cpu_info():
 # self-launch (N > 1 without torchrun): nothing above or inside touches the GPU
 # ------------------------------------------------------------------------------------------------------------------
 def self_launch(args, argv) -> int:
-    if not args.stub:
+    if not args.stub and not args.share_gpu:
         import torch   # device_count() does not initialise the GPU on this image
         n = torch.cuda.device_count()
         if n < args.gpus:
@@ -555,6 +555,8 @@ def main() -> int:
     ap.add_argument("--headline-only", action="store_true", help="skip the N=1 legs (module surface, configs, parity, next rows, CPU)")
     ap.add_argument("--verbose-json", default="", help="also write the annotated record to this path")
     ap.add_argument("--stub", action="store_true", help="tests only: control flow on CPU/gloo, measures nothing")
+    ap.add_argument("--share-gpu", action="store_true", help="tests only: every rank on device 0, collectives over gloo (RCCL refuses two "
+                    "ranks on one device); runs the N-rank path with the real kernels on a 1-GPU box, the numbers mean nothing")
     args = ap.parse_args()
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
@@ -578,6 +580,8 @@ def main() -> int:
         if not torch.cuda.is_available():
             print("bench.py needs an MI355X: the HIP path has no CPU fallback", file=sys.stderr)
             return 2
+        if args.share_gpu:
+            local_rank = 0
         if torch.cuda.device_count() <= local_rank:
             print(f"bench.py: rank {rank} has no device {local_rank}", file=sys.stderr)
             return 2
@@ -586,7 +590,7 @@ def main() -> int:
     if "WORLD_SIZE" in os.environ:   # under torchrun the RCCL path runs for every world size, 1 included
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.stub:
+        if args.stub or args.share_gpu:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
@@ -649,7 +653,8 @@ def main() -> int:
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "prewarm_steps": 0 if args.stub else PREWARM_STEPS,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub" if args.stub else "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "stub" if args.stub else ("synthetic (TEST RUN: all ranks share device 0, gloo)" if args.share_gpu else "synthetic"),
             "config": {"workload": f"{head['name']}: {head['label']}; {B} frames per GPU per step; step = forward + device MSE partial; "
                                    "value = rate with INPUTS RESIDENT IN HBM (H2D-inclusive rate: value_h2d_inclusive); encoder weights fragment-packed once "
                                    "(aft_forward_prepacked_f32, as the module surface runs in eval mode)",

@@ -131,3 +131,33 @@ def test_bench_under_torchrun_runs_the_rccl_path_and_config5():
     assert line["n_gpus"] == 1 and line["config"]["frames_per_gpu"] == 64 and "C5" in line["config"]["workload"]
     assert line["per_rank"]["metric_allgather_ms"] > 0 and line["per_rank"]["slowest_rank"] == 0
     assert line["value"] > 500 and 0 < line["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_two_ranks_sharing_the_gpu_run_the_sharded_forward_and_training_paths():
+    """RCCL refuses two ranks on one device, so a 1-GPU box cannot run backend nccl at world size 2 -- but everything ELSE of the
+    N-rank path can run there with the real kernels: `--share-gpu` puts every rank on device 0 and the collectives on gloo.
+    bench.py: per-rank frame shards (SEED + 1000 rank), barrier-to-barrier timing with the MAX over ranks, the all-gathered
+    device times and the metric's all-gather.  tools/train_bench.py: ShardedFlatAdam's reduce-scatter -> fused Adam on the
+    rank's shard -> all-gather on device buffers inside the step.  The numbers mean nothing (two ranks share one GPU) and the
+    line says so; checked: two ranks took part, both finished their steps, the aggregate is about one GPU's throughput."""
+    res = _run(["--gpus", "2", "--share-gpu", "--steps", "6", "--warmup", "2", "--headline-only"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 256
+    assert "TEST RUN" in line["data"]
+    pr = line["per_rank"]
+    assert 0 < pr["device_ms_per_step_min"] <= pr["device_ms_per_step_max"] and pr["slowest_rank"] in (0, 1)
+    assert pr["metric_allgather_ms"] > 0
+    assert 30e3 < line["value"] < 100e3            # two forwards share one GPU: about the 1-GPU rate in aggregate
+    assert line["mse_db_vs_random_target"] == line["mse_db_vs_random_target"]   # finite
+
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--gpus", "2", "--share-gpu", "--steps", "4",
+                          "--warmup", "2", "--batch", "32", "--only", "hip"], capture_output=True, text=True, env=e, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ms_per_step"]["hip"] > 0
+    assert line["per_rank"]["collectives_ms_per_step"] > 0 and line["per_rank"]["flat_buffer_bytes"] > 3_000_000

@@ -69,3 +69,68 @@ def test_rccl_allgather_metric_and_sharded_adam_step():
         assert w == world
         assert abs(mse - want) <= 1e-6 * want          # global value on every rank
         assert err <= 1e-6                             # sharded step == torch.optim.Adam step
+
+
+def _dp_worker(rank, world, port, out):
+    """Data-parallel training of the whole AdaFortiTran on the HIP training kernels, two ranks SHARING device 0 with the
+    collectives on gloo (RCCL refuses two ranks on one device): each rank trains on its half of the frames."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out[rank] = _dp_train(rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dp_model_and_data(frames):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import train_bench
+    from adafortitran_amd import synth
+    torch.manual_seed(0)
+    model = train_bench.build("adafortitran", 0.0).train()      # dropout 0: the ranks' masks would differ from one process's
+    inp = synth.make_inputs(frames, seed=21)
+    pil = torch.from_numpy(inp["pilots"]).cuda()
+    meta = tuple(m.cuda() if hasattr(m, "cuda") else m for m in synth.meta_tuple(inp))
+    tgt = torch.from_numpy(inp["target"]).cuda()
+    return model, pil, meta, tgt
+
+
+def _dp_train(rank, world, steps=3):
+    from adafortitran_amd.optim import ShardedFlatAdam
+    frames = 8
+    model, pil, meta, tgt = _dp_model_and_data(frames)
+    lo, hi = rank * frames // world, (rank + 1) * frames // world
+    opt = ShardedFlatAdam(model.parameters(), lr=1e-3) if world > 1 else torch.optim.Adam(model.parameters(), lr=1e-3)
+    first_grad = None
+    for it in range(steps):
+        opt.zero_grad()
+        est = model(pil[lo:hi], tuple(m[lo:hi] for m in meta))
+        torch.nn.functional.mse_loss(torch.view_as_real(est), torch.view_as_real(tgt[lo:hi])).backward()   # equal shards: mean of means
+        if it == 0:
+            if world > 1:
+                opt.reduce_gradients()        # the averaged gradient in every .grad, as DDP leaves it; step() then skips its own reduction
+            first_grad = torch.cat([p.grad.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+        opt.step()
+    torch.cuda.synchronize()
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy(), first_grad
+
+
+def test_two_ranks_sharing_the_gpu_train_like_one_process():
+    """SURVEY 8e/8f-1 on hardware at world size 2, as far as a 1-GPU box allows: frames sharded over the ranks, every rank's
+    forward + backward on the HIP training kernels, ShardedFlatAdam's reduce-scatter -> fused Adam on the shard -> all-gather
+    on device buffers.  The ranks' averaged first gradient must equal ONE process's gradient on all the frames to 1e-5 of its
+    maximum (fp32 sums in another order); after three steps both ranks hold bit-identical parameters, within 3 % of the distance
+    the parameters travelled of the single process's (Adam's g / sqrt(v) turns rounding noise in near-zero gradients into
+    differences of a fraction of lr, so parameters are compared loosely and the gradient tightly)."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+        got = dict(ret)
+    want, want_grad = _dp_train(0, 1)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    gerr = np.abs(got[0][1] - want_grad).max()
+    assert gerr <= 1e-5 * np.abs(want_grad).max(), (gerr, np.abs(want_grad).max())
+    assert np.abs(got[0][0] - want).max() <= 0.03 * 3 * 1e-3

@@ -115,7 +115,7 @@ def measure(batch=128, steps=20, warmup=5, model_name="adafortitran", dropout=0.
 
 def self_launch(a, argv):
     import torch
-    if torch.cuda.device_count() < a.gpus:
+    if not a.share_gpu and torch.cuda.device_count() < a.gpus:
         print(f"train_bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--only", default="", help="hip | torch")
     ap.add_argument("--dense", default="hip", choices=["blas", "hip"], help="thin dense layers: the library GEMM (default) or hipBLASLt")
     ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"], help="flat = ShardedFlatAdam (fused kernel)")
+    ap.add_argument("--share-gpu", action="store_true", help="tests only: every rank on device 0, collectives over gloo (RCCL refuses "
+                    "two ranks on one device); the numbers mean nothing")
     a = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         return self_launch(a, sys.argv[1:])
@@ -146,12 +148,17 @@ def main():
         print(f"train_bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
     import torch
+    if a.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if a.share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     modes = (a.only,) if a.only else (("hip", "torch") if world == 1 else ("hip",))
     detail = {}
     res = measure(a.batch, a.steps, a.warmup, a.model, a.dropout, modes, a.dense, a.optimizer, dist, rank, detail)
