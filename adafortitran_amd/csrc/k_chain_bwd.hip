@@ -24,6 +24,10 @@
 // (g (.) xhat, g) for the LayerNorm parameter gradients (cross-lane DPP reduction, fixed-order slice reduction later).
 #include <algorithm>
 
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "chain_device.h"
 
 namespace aft {
@@ -299,6 +303,7 @@ struct ChainTrainArgs {
     // QKV instantiation: the NEXT layer's in-projection on this layer's output, row-major [rows][3 D] into the next layer's tape
     const float *wqkv, *bqkv;
     float *qkv_next;
+    unsigned long long *stamps;   // diagnostic build only (AFT_DIAG_STAMPS): per tile, s_memtime of wave 0 at the phase boundaries [0..8], s_memrealtime at the start [9]
     int rows;
     uint32_t seed1, seed2, seed3, threshold;
     float keep_scale;
@@ -307,15 +312,24 @@ struct ChainTrainArgs {
 template <int D>
 struct ChainTrainShape {
     using S = ChainShape<D>;
-    static constexpr int COLW = 4 * D;   // (measured: 51 vs 55 KB of LDS makes no difference to this launch)
-    static constexpr size_t LDS_BYTES = S::LDS_BYTES + sizeof(float) * COLW;
+    static constexpr int COLW = 4 * D;
+    // The two LayerNorm BETAS are read from global memory (below), which takes 2 D floats off the inference chain's parameter block:
+    // 53 248 B.  At 54 272 B (betas in LDS too) only TWO workgroups are resident per CU although hipOccupancyMaxActiveBlocksPerMultiprocessor
+    // says three -- LDS is handed out in 1 280-byte granules (tools/micro/lds_residency: 53 760 B is the last size of which three
+    // fit) -- and the launch ran a full round of 512 workgroups and a second one of 256 at one workgroup per CU.
+    static constexpr int PAR = 2 * D;    // g1 | g2
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(S::XB + S::HB + S::ST + PAR + COLW);
+    static_assert(3 * ((LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024 || D != 128, "three workgroups per CU need <= 53 760 B of LDS each");
 };
 
 // LayerNorm over D features on the lane's 16 values (chain_device.h::layernorm_rows) that also hands back (mean, rstd)
 template <int D>
-__device__ __forceinline__ void layernorm_rows_stats(f32x16 &v, float *stats, const float *gamma, const float *beta, int wave, int r,
+__device__ __forceinline__ void layernorm_rows_stats(f32x16 &v, float *stats, const float *gamma, Srd beta, int beta_f0, int wave, int r,
                                                      int h, float &mean_out, float &rstd_out) {
     constexpr int W = D / 32;
+    f32x4 bfrag[4];                       // beta of the lane's 16 features, from global memory: in flight across the barrier below
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) bfrag[s4] = srd_load(beta, (unsigned)(beta_f0 + 8 * s4 + 4 * h) * 4);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s += v[e];
@@ -345,7 +359,7 @@ __device__ __forceinline__ void layernorm_rows_stats(f32x16 &v, float *stats, co
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
         const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + 8 * s4 + 4 * h);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + 8 * s4 + 4 * h);
+        const f32x4 b = bfrag[s4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * s4 + j] = (v[4 * s4 + j] - mean) * rstd * g[j] + b[j];
     }
@@ -359,8 +373,8 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
     float *xb = smem;
     float *hb = xb + S::XB;
     float *stats = hb + S::HB;
-    float *par = stats + S::ST;                                     // g1 | be1 | g2 | be2
-    uint32_t *colw = reinterpret_cast<uint32_t *>(par + S::PAR);   // site 1 [D] | site 2 [2D] | site 3 [D]
+    float *par = stats + S::ST;                                     // g1 | g2
+    uint32_t *colw = reinterpret_cast<uint32_t *>(par + ChainTrainShape<D>::PAR);   // site 1 [D] | site 2 [2D] | site 3 [D]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -370,10 +384,16 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
     // (timing experiment, round 3: without the five tape stores below the launch takes 106 us instead of 145 -- the inference chain's
     //  time for the same products; the 39 us are store waits)
     constexpr bool TAPE = true;
+#ifdef AFT_DIAG_STAMPS
+#define TSTAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)tile * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
 
     const Srd srd_wo = make_srd(a.wo), srd_w1 = make_srd(a.w1), srd_w2 = make_srd(a.w2);
     const Srd srd_attn = make_srd(a.attn), srd_x = make_srd(a.x);
     const Srd srd_bo = make_srd(a.bo), srd_b1 = make_srd(a.b1), srd_b2 = make_srd(a.b2);
+    const Srd srd_be1 = make_srd(a.be1), srd_be2 = make_srd(a.be2);
     const Srd srd_s1 = make_srd(a.s1), srd_x1 = make_srd(a.x1), srd_a = make_srd(a.a), srd_hd = make_srd(a.hd), srd_s2 = make_srd(a.s2),
               srd_out = make_srd(a.x_out);
     const unsigned wo_off = (unsigned)w * W * 1024 + lane * 4, w1_off = (unsigned)(2 * w) * W * 1024 + lane * 4;
@@ -383,9 +403,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
 
     for (int i = tid; i < D; i += S::THREADS) {
         par[i] = a.g1[i];
-        par[D + i] = a.be1[i];
-        par[2 * D + i] = a.g2[i];
-        par[3 * D + i] = a.be2[i];
+        par[D + i] = a.g2[i];
     }
     if (drop) {
         for (int i = tid; i < D; i += S::THREADS) {
@@ -419,6 +437,10 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
         WRing<1, PFD> ring_d;
         WRing<2, PFF> ring_ff;
 
+        TSTAMP(0);
+#ifdef AFT_DIAG_STAMPS
+        if (a.stamps && tid == 0) a.stamps[(size_t)tile * 16 + 9] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, one clock for the chip
+#endif
         // ---- out-projection + bias, dropout 1, residual ----
         f32x16 acc_o[1] = {bias_acc(srd_bo, fb, h)};
         gemm_preload<W, 1, PFD, 1>(ring_d, srd_wo, wo_lane);
@@ -433,6 +455,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             for (int s = 0; s < 4; ++s) xres[s] = srd_load(srd_x, xrow + 32 * s);
         }
         gemm_run<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
+        TSTAMP(1);
         f32x16 acc_h[2] = {bias_acc(srd_b1, 2 * fb, h), bias_acc(srd_b1, 2 * fb + 32, h)};
         gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w1, w1_lane);
         uint32_t rw1 = 0, rw2 = 0, rw3 = 0;
@@ -452,7 +475,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
         }
         float mean, rstd;
-        layernorm_rows_stats<D>(cur, stats, par + fb, par + D + fb, w, r, h, mean, rstd);   // -> x1
+        layernorm_rows_stats<D>(cur, stats, par + fb, srd_be1, fb, w, r, h, mean, rstd);   // -> x1
         if (row_ok && w == 0 && h == 0) *reinterpret_cast<float2 *>(a.st1 + 2 * (size_t)grow) = make_float2(mean, rstd);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -461,10 +484,12 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
         }
         __syncthreads();
+        TSTAMP(2);
         // ---- linear1 + bias -> a (kept), activation, dropout 2 -> hd (kept, published) ----
         gemm_run<W, 2, PFF, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
         });
+        TSTAMP(3);
         f32x16 acc_d[1] = {bias_acc(srd_b2, fb, h)};
         gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w2, w2_lane);
 #pragma unroll
@@ -481,10 +506,12 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
                 *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = v;
             }
         __syncthreads();
+        TSTAMP(4);
         // ---- linear2 + bias, dropout 3, residual (x1, registers) ----
         gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
         });
+        TSTAMP(5);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f32x4 y = {acc_d[0][4 * s], acc_d[0][4 * s + 1], acc_d[0][4 * s + 2], acc_d[0][4 * s + 3]};
@@ -496,13 +523,14 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
         }
-        layernorm_rows_stats<D>(cur, stats, par + 2 * D + fb, par + 3 * D + fb, w, r, h, mean, rstd);   // -> x2
+        layernorm_rows_stats<D>(cur, stats, par + D + fb, srd_be2, fb, w, r, h, mean, rstd);   // -> x2
         if (row_ok && w == 0 && h == 0) *reinterpret_cast<float2 *>(a.st2 + 2 * (size_t)grow) = make_float2(mean, rstd);
         if (row_ok) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 srd_store(srd_out, xrow + 32 * s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
         }
+        TSTAMP(6);
         if constexpr (QKV) {
             // ---- the next layer's in-projection on x2 (the tile is still in registers): q | k | v of feature block w, bias as the
             //      accumulators' initial value, row-major into the next layer's tape.  x1's readers are past the hidden barrier. ----
@@ -528,7 +556,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
                                   f32x4{acc_q[t][4 * s], acc_q[t][4 * s + 1], acc_q[t][4 * s + 2], acc_q[t][4 * s + 3]});
             }
         }
+        TSTAMP(7);
         __syncthreads();    // the next tile's LayerNorm-1 partials must not overtake this tile's LayerNorm-2 readers
+        TSTAMP(8);
     }
 }
 
@@ -544,6 +574,43 @@ static hipError_t launch_chain_fwd_train_t(const ChainTrainArgs &args, hipStream
     hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_fwd_train_kernel<D, ACT, QKV>), T::LDS_BYTES);
     if (ea != hipSuccess) return ea;
     const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * 3);
+#ifdef AFT_DIAG_STAMPS
+    if (getenv("AFT_STAMPS")) {   // diagnostic build only: mean cycles per phase of a tile (wave 0), and when the workgroups started
+        const int ntiles = (args.rows + 31) / 32;
+        static unsigned long long *dbuf = nullptr;
+        if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 8192);
+        (void)hipMemsetAsync(dbuf, 0, sizeof(unsigned long long) * 16 * 8192, st);
+        ChainTrainArgs a2 = args;
+        a2.stamps = ntiles <= 8192 ? dbuf : nullptr;
+        hipLaunchKernelGGL((chain_fwd_train_kernel<D, ACT, QKV>), dim3(blocks), dim3(ChainShape<D>::THREADS), T::LDS_BYTES, st, a2);
+        (void)hipStreamSynchronize(st);
+        static int printed = 0;
+        if (a2.stamps && printed++ < 3) {
+            std::vector<unsigned long long> hb(16 * (size_t)ntiles);
+            (void)hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
+            const int nb = std::min(blocks, ntiles);
+            unsigned long long t0 = ~0ull, tend = 0;
+            for (int t = 0; t < nb; ++t) t0 = std::min(t0, hb[(size_t)t * 16 + 9]);
+            for (int t = 0; t < ntiles; ++t) tend = std::max(tend, hb[(size_t)t * 16 + 9]);
+            int late = 0;
+            double mean = 0, mx = 0;
+            for (int t = 0; t < nb; ++t) {
+                const double us = (double)(hb[(size_t)t * 16 + 9] - t0) * 0.01;
+                mean += us; mx = std::max(mx, us); late += us > 20.0;
+            }
+            printf("chain_fwd_train<QKV=%d>: %d workgroups, first tile starts %.1f us (mean) / %.1f us (max) after the earliest, %d later than 20 us; "
+                   "the launch's last tile starts at %.1f us\n", (int)QKV, nb, mean / nb, mx, late, (double)(tend - t0) * 0.01);
+            double sum[9] = {0};
+            for (int t = 0; t < ntiles; ++t)
+                for (int i = 1; i < 9; ++i) sum[i] += (double)(hb[(size_t)t * 16 + i] - hb[(size_t)t * 16 + i - 1]);
+            printf("  mean cycles per tile: outproj=%.0f s1+LN1+x1+barrier=%.0f ffn_up=%.0f act+a+hd+barrier=%.0f ffn_down=%.0f s2+LN2+out=%.0f "
+                   "qkv=%.0f end_barrier=%.0f total=%.0f\n", sum[1] / ntiles, sum[2] / ntiles, sum[3] / ntiles, sum[4] / ntiles, sum[5] / ntiles,
+                   sum[6] / ntiles, sum[7] / ntiles, sum[8] / ntiles,
+                   (sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[7] + sum[8]) / ntiles);
+        }
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((chain_fwd_train_kernel<D, ACT, QKV>), dim3(blocks), dim3(ChainShape<D>::THREADS), T::LDS_BYTES, st, args);
     return hipGetLastError();
 }
