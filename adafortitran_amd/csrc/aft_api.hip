@@ -242,16 +242,17 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
                 workspace_bytes, ws.total_floats * sizeof(float));
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *base = static_cast<float *>(workspace);
+    // prologue: the channel adapter and -- unless the caller owns a packed image -- the re-lay of the encoder weights into
+    // fragment order, in ONE launch (neither depends on anything the forward computes)
+    float *wpack = prepacked != nullptr ? nullptr : base + ws.wpack;
+    hipError_t e = launch_prologue(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, wpack, st);
+    if (e != hipSuccess) return hip_fail("prologue(adapter + pack_weights)", e);
     // the activation buffer x is idle until the first encoder launch: it lends the upsampler its plane scratch when it is large enough
     const size_t x_floats = (size_t)ws.planes * ws.tokens * cfg->model_dim, up_floats = (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
-    hipError_t e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr);
+    e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr);
     if (e != hipSuccess) return hip_fail("upsample", e);
-    if (cfg->adaptive) {
-        e = launch_adapter(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, st);
-        if (e != hipSuccess) return hip_fail("adapter", e);
-    }
     // patch embedding + linear_1 + positions run inside the first chain launch, linear_2 inside the last one
-    rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st, true, prepacked);
+    rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st, true, prepacked != nullptr ? prepacked : wpack);
     if (rc != AFT_OK) return rc;
     e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6);
     if (e != hipSuccess) return hip_fail("tail", e);

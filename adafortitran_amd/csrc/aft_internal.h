@@ -170,6 +170,9 @@ hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const floa
                            float *conv_enhanced, int batch, hipStream_t st, float *scratch_planes = nullptr);
 hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
                           const float *dop, float *tokens6, int batch, hipStream_t st);
+// Whole forward: adapter (if c.adaptive) and the weight re-pack (if packed != NULL, all layers) as ONE launch (k_misc.hip)
+hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const float *snr, const float *ds, const float *dop,
+                           float *tokens6, int batch, float *packed, hipStream_t st);
 hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced,
                         const float *tokens6, float *x, int batch, hipStream_t st);
 // Row-local chain on [rows, d]: (mlp) x <- LN2(x1 + FFN(x1)), x1 = LN1(x + attn Wo^T + bo);

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "chain_device.h"
+#include "pack_device.h"
 
 namespace aft {
 
@@ -143,37 +144,7 @@ size_t packed_layer_floats(int d) { return (size_t)8 * d * d; }
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const aft_weights w, float *__restrict__ packed, int d,
                                                            int num_layers, int split) {
-    const size_t per_layer = (size_t)8 * d * d;
-    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;   // one float4 of the packed image
-    if (v * 4 >= per_layer * num_layers) return;
-    const int layer = (int)(v * 4 / per_layer);
-    size_t off = v * 4 - (size_t)layer * per_layer;
-    const aft_layer_weights &lw = w.layers[layer];
-    const float *src;
-    int K;
-    if (off < (size_t)3 * d * d) { src = lw.in_proj_w; K = d; }
-    else if ((off -= (size_t)3 * d * d) < (size_t)d * d) { src = lw.out_proj_w; K = d; }
-    else if ((off -= (size_t)d * d) < (size_t)2 * d * d) { src = lw.lin1_w; K = d; }
-    else { off -= (size_t)2 * d * d; src = lw.lin2_w; K = 2 * d; }
-    // off = (((tile*NKB + kb)*4 + s)*64 + lane)*4 ; element (row = 32 tile + lane%32, k = 32kb + 8s + 4(lane/32) + j)
-    const int lane = (int)(off / 4) % 64, s = (int)(off / 256) % 4;
-    const int blk = (int)(off / 1024), nkb = K / 32, kb = blk % nkb, ct = blk / nkb;
-    const int col = ct * 32 + (lane & 31), k = kb * 32 + s * 8 + (lane >> 5) * 4;
-    if (!split) {
-        *reinterpret_cast<f32x4 *>(packed + v * 4) = *reinterpret_cast<const f32x4 *>(src + (size_t)col * K + k);
-        return;
-    }
-    // split-precision image: slot s of a block = MFMA m = s >> 1, term hi (s even) / lo (s odd); the lane's 8 bf16 values
-    // are k = 32 kb + 16 m + 8 (j >> 2) + 4 h + (j & 3), the k order of an accumulator used as operand (chain_device.h)
-    const int m = s >> 1, hh = lane >> 5;
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = src[(size_t)col * K + kb * 32 + 16 * m + 8 * (j >> 2) + 4 * hh + (j & 3)];
-        const __bf16 hi = (__bf16)x;
-        o[j] = (s & 1) ? (__bf16)(x - (float)hi) : hi;
-    }
-    *reinterpret_cast<f32x4 *>(packed + v * 4) = __builtin_bit_cast(f32x4, o);
+    pack_weights_vec(w, packed, d, 0, num_layers, split, (size_t)blockIdx.x * 256 + threadIdx.x);   // one float4 of the image
 }
 
 hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float *packed, int first_layer, int count,

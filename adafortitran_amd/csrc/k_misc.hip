@@ -1,6 +1,7 @@
 // k_misc.hip -- the small VALU stages: channel adapter, patch embedding + linear_1 + positional
 // table, the LinearEstimator, and the MSE metric.  None of them is MFMA-shaped (K = 1..42, 12, 24).
 #include "aft_internal.h"
+#include "pack_device.h"
 
 namespace aft {
 
@@ -18,10 +19,10 @@ struct AdapterArgs {
     int h0, h1, h2, tokens;
 };
 
-__global__ __launch_bounds__(256) void adapter_kernel(const AdapterArgs a) {
-    extern __shared__ float sm[];
+// one (frame b, encoder e) of the adapter; sm = h0 + h1 floats of LDS
+__device__ __forceinline__ void adapter_body(const AdapterArgs &a, int b, int e, float *sm) {
     float *a0 = sm, *a1 = sm + a.h0;
-    const int b = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const float x = a.cond[e][b];
     for (int i = tid; i < a.h0; i += 256) a0[i] = fmaxf(fmaf(a.w[e][0][i], x, a.b[e][0][i]), 0.f);
     __syncthreads();
@@ -53,8 +54,13 @@ __global__ __launch_bounds__(256) void adapter_kernel(const AdapterArgs a) {
     }
 }
 
-hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
-                          const float *dop, float *tokens6, int batch, hipStream_t st) {
+__global__ __launch_bounds__(256) void adapter_kernel(const AdapterArgs a) {
+    extern __shared__ float sm[];
+    adapter_body(a, blockIdx.x, blockIdx.y, sm);
+}
+
+static AdapterArgs adapter_args(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
+                                const float *dop, float *tokens6) {
     AdapterArgs a{};
     a.cond[0] = snr; a.cond[1] = ds; a.cond[2] = dop;
     for (int e = 0; e < 3; ++e)
@@ -62,7 +68,56 @@ hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float
     a.tokens6 = tokens6;
     a.h0 = c.hidden[0]; a.h1 = c.hidden[1]; a.h2 = c.hidden[2];
     a.tokens = (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols);
+    return a;
+}
+
+hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
+                          const float *dop, float *tokens6, int batch, hipStream_t st) {
+    const AdapterArgs a = adapter_args(c, w, snr, ds, dop, tokens6);
     hipLaunchKernelGGL(adapter_kernel, dim3(batch, 3), dim3(256), sizeof(float) * (a.h0 + a.h1), st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Prologue of a whole forward: the two small jobs that depend on nothing the forward computes -- the channel adapter
+// (3 B workgroups) and the re-lay of the encoder's GEMM weights into fragment order (8 d^2 L / 1024 workgroups) -- as ONE
+// launch.  As two launches they cost 7.6 + 5.1 us of a 1.57-ms forward; together they take as long as the longer one,
+// which makes the stateless entry point (weights re-packed on every call: the image can never be stale) as fast as a
+// cached image.  Either part may be absent (FortiTran has no adapter; a caller-owned image needs no pack).
+// ---------------------------------------------------------------------------------------------
+struct PrologueArgs {
+    AdapterArgs ad;
+    float *packed;
+    int adapter_blocks, d, num_layers, split;
+};
+
+__global__ __launch_bounds__(256) void prologue_kernel(const aft_weights w, const PrologueArgs a) {
+    extern __shared__ float sm[];
+    const int blk = blockIdx.x;
+    if (blk < a.adapter_blocks) {            // workgroup-uniform: the barriers inside are safe
+        adapter_body(a.ad, blk / 3, blk % 3, sm);
+        return;
+    }
+    pack_weights_vec(w, a.packed, a.d, 0, a.num_layers, a.split, (size_t)(blk - a.adapter_blocks) * 256 + threadIdx.x);
+}
+
+hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const float *snr, const float *ds, const float *dop,
+                           float *tokens6, int batch, float *packed, hipStream_t st) {
+    PrologueArgs a{};
+    size_t lds = 0;
+    if (c.adaptive) {
+        a.ad = adapter_args(c, w, snr, ds, dop, tokens6);
+        a.adapter_blocks = 3 * batch;
+        lds = sizeof(float) * (a.ad.h0 + a.ad.h1);
+    }
+    unsigned pack_blocks = 0;
+    if (packed != nullptr) {
+        a.packed = packed; a.d = c.model_dim; a.num_layers = c.num_layers;
+        a.split = c.precision == AFT_PRECISION_BF16X3 ? 1 : 0;
+        pack_blocks = (unsigned)((packed_layer_floats(c.model_dim) * c.num_layers / 4 + 255) / 256);
+    }
+    if (a.adapter_blocks + pack_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(prologue_kernel, dim3(a.adapter_blocks + pack_blocks), dim3(256), lds, st, w, a);
     return hipGetLastError();
 }
 

@@ -40,18 +40,25 @@ from .training import HipLinear
 
 
 class _InputStager:
-    """The model-owned H2D copy of ``forward`` (reference fortitran.py:167-173) on a HIP device: pilots + the three
-    condition vectors of a batch (25 KB at B=128) are packed into ONE pinned host buffer and moved with ONE
-    asynchronous copy on the caller's current stream of the MODEL's device, instead of four pageable ``.to(device)``
-    copies that each end in a stream synchronisation -- the host keeps running ahead of the device exactly as it
-    does when the inputs are already resident.
+    """The model-owned H2D transfer of ``forward`` (reference fortitran.py:167-173) on a HIP device.  Pilots + the three
+    condition vectors of a batch (25 KB at B=128) are packed into ONE slot of a ring of pinned host buffers.
 
-    Safety: the pinned ring slot is guarded by an event recorded ON THE COPY'S STREAM (the model's device need not be
-    the current device); the device side of every call is its own allocation from torch's caching allocator, which
-    re-uses a block only in stream order of the stream it was allocated on -- so forwards issued from different
-    streams never share a staging buffer (a shared one was only stream-ordered, i.e. a race across streams)."""
+    * Inference (the HIP engine): **no copy is enqueued at all** -- pinned host memory is device-addressable, so the
+      conv head and the adapter kernel read the slot directly over PCIe (``host_views``; the ABI takes any
+      device-addressable pointer).  A copy-engine transfer in front of the first launch cost ~80 us per forward (the
+      hop between the copy engine and the compute queue), 5 % of the 1.57-ms step; the direct read is hidden under the
+      conv head's weight-staging phase.
+    * Training (torch ops consume the inputs): ONE asynchronous copy on the caller's current stream into a per-call
+      device allocation (``to_device``), instead of four pageable ``.to(device)`` copies that each end in a stream
+      synchronisation.
 
-    SLOTS = 4
+    Safety: a slot is re-used only after the event recorded behind its last reader (``release``: the kernels of the
+    forward that read it, or the copy) has completed; the event is recorded on the reader's stream of the MODEL's device
+    (which need not be the current device).  Device-side staging buffers are per call (torch's caching allocator re-uses
+    a block only in stream order of the stream it was allocated on), so forwards issued from different streams never
+    share one."""
+
+    SLOTS = 8
 
     def __init__(self, device: torch.device) -> None:
         self.device = device
@@ -62,13 +69,14 @@ class _InputStager:
     def _resize(self, nbytes: int) -> None:
         for ev in self.events:
             if ev is not None:
-                ev.synchronize()                         # copies still reading the old, smaller ring
+                ev.synchronize()                         # readers of the old, smaller ring
         self.nbytes = max(nbytes, 4096)
         self.host = [torch.empty(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
         self.events = [None] * self.SLOTS
 
-    def stage(self, pilots: Optional[torch.Tensor], conds: Optional[List[torch.Tensor]]):
-        """Either part may be None (already on the device)."""
+    def fill(self, pilots: Optional[torch.Tensor], conds: Optional[List[torch.Tensor]]):
+        """Copy the CPU inputs into the next ring slot (either part may be None = already on the device).
+        Returns (slot, total bytes, pinned pilots view | None, pinned [snr, ds, dop] views | None)."""
         B = pilots.shape[0] if pilots is not None else conds[0].numel()
         pil_bytes = pilots.numel() * 8 if pilots is not None else 0
         off = (pil_bytes + 15) // 16 * 16
@@ -78,24 +86,40 @@ class _InputStager:
         slot = self.turn
         self.turn = (slot + 1) % self.SLOTS
         if self.events[slot] is not None:
-            self.events[slot].synchronize()          # the copy that last read this pinned buffer has finished
+            self.events[slot].synchronize()          # whatever last read this pinned buffer has finished
         host = self.host[slot]
+        pil_h = cond_h = None
         if pilots is not None:
-            host[:pil_bytes].view(torch.complex64).view(pilots.shape).copy_(pilots)
+            pil_h = host[:pil_bytes].view(torch.complex64).view(pilots.shape)
+            pil_h.copy_(pilots)
         if conds is not None:
-            for i, c in enumerate(conds):
-                host[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32).copy_(c.reshape(-1))
-        with torch.cuda.device(self.device):         # events and the copy belong to the model's device, current or not
-            stream = torch.cuda.current_stream(self.device)
-            dev = torch.empty(total, dtype=torch.uint8, device=self.device)
-            dev.copy_(host[:total], non_blocking=True)
+            cond_h = [host[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32) for i in range(3)]
+            for dst, c in zip(cond_h, conds):
+                dst.copy_(c.reshape(-1))
+        return slot, total, pil_h, cond_h
+
+    def release(self, slot: int) -> None:
+        """Record the slot's guard behind everything enqueued so far on the current stream of the model's device."""
+        with torch.cuda.device(self.device):
             ev = self.events[slot] or torch.cuda.Event()
-            ev.record(stream)
+            ev.record(torch.cuda.current_stream(self.device))
             self.events[slot] = ev
-        pil_dev = dev[:pil_bytes].view(torch.complex64).view(pilots.shape) if pilots is not None else None
-        if conds is None:
+
+    def to_device(self, pilots: Optional[torch.Tensor], conds: Optional[List[torch.Tensor]]):
+        """The training path's single asynchronous copy; returns device views (pilots | None, conds | None)."""
+        slot, total, pil_h, cond_h = self.fill(pilots, conds)
+        with torch.cuda.device(self.device):         # the copy belongs to the model's device, current or not
+            dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+            dev.copy_(self.host[slot][:total], non_blocking=True)
+        self.release(slot)
+        base = self.host[slot].data_ptr()
+        pil_dev = None
+        if pil_h is not None:
+            pil_dev = dev[:pil_h.numel() * 8].view(torch.complex64).view(pil_h.shape)
+        if cond_h is None:
             return pil_dev, None
-        return pil_dev, [dev[off + 4 * B * i: off + 4 * B * (i + 1)].view(torch.float32) for i in range(3)]
+        offs = [c.data_ptr() - base for c in cond_h]
+        return pil_dev, [dev[o: o + c.numel() * 4].view(torch.float32) for o, c in zip(offs, cond_h)]
 
 
 class BaseFortiTranEstimator(nn.Module):
@@ -191,14 +215,6 @@ class BaseFortiTranEstimator(nn.Module):
         self._engine = None
         return super().load_state_dict(*args, **kwargs)
 
-    def train(self, mode: bool = True):
-        # every train()/eval() switch drops the engine's packed-weight image: between two switches of an eval() phase
-        # the parameters can only change through torch ops (which move the version counters the engine watches), while a
-        # training phase may update them through raw pointers (optim.ShardedFlatAdam's fused kernel, RCCL all-gather)
-        if self._engine is not None:
-            self._engine.invalidate_packed()
-        return super().train(mode)
-
     @property
     def hip_precision(self) -> str:
         """Arithmetic of the HIP inference path: ``"f32"`` (default: exact-fp32 MFMAs everywhere, the parity contract) or
@@ -269,17 +285,13 @@ class BaseFortiTranEstimator(nn.Module):
             conditions = [snr, delay_spread, max_dop_shift]
 
         eng = self._hip_engine() if self._hip_eligible() else None
-        # the model owns the H2D copy (fortitran.py:167-173): on a HIP device, CPU inputs as the DataLoader yields them go
-        # through the pinned staging ring in one asynchronous copy (inference AND training: a pageable .to(device) blocks
-        # the host until the device has drained the previous step, and the next forward's first launches then trickle in
-        # with the device idle -- 0.4-0.7 ms per training step); device-resident inputs pass through
-        pilot_symbols, conditions = self._inputs_to_device(pilot_symbols, conditions)
         if eng is not None:
-            # the engine owns the fragment-packed encoder weights and re-packs them only when they changed (version
-            # counters; train()/eval() switches invalidate, see train() below)
-            if conditions is None:
-                return eng.forward(pilot_symbols, cache_packed=True)
-            return eng.forward(pilot_symbols, *conditions, cache_packed=True)
+            return self._forward_hip(eng, pilot_symbols, conditions)
+        # the model owns the H2D copy (fortitran.py:167-173): on a HIP device, CPU inputs as the DataLoader yields them go
+        # through the pinned staging ring in one asynchronous copy (a pageable .to(device) blocks the host until the device
+        # has drained the previous step, and the next forward's first launches then trickle in with the device idle --
+        # 0.4-0.7 ms per training step); device-resident inputs pass through
+        pilot_symbols, conditions = self._inputs_to_device(pilot_symbols, conditions)
 
         if pilot_symbols.device.type == "cuda" and torch.is_grad_enabled():
             # training on the HIP device: the Re and Im planes go through the network as ONE batch of
@@ -294,16 +306,42 @@ class BaseFortiTranEstimator(nn.Module):
         imag = self._forward_real_valued(pilot_symbols.imag, conditions)
         return torch.complex(real, imag)
 
-    def _inputs_to_device(self, pilot_symbols: torch.Tensor, conditions: Optional[List[torch.Tensor]]):
-        dev = self.pilot_upsampler.weight.device
+    def _stageable(self, pilot_symbols: torch.Tensor, conditions: Optional[List[torch.Tensor]]):
+        """Which inputs can go through the pinned ring: CPU complex64 [B, ., .] pilots, CPU float32 conditions of B values."""
         B = pilot_symbols.shape[0] if pilot_symbols.dim() == 3 else -1
         pil_cpu = pilot_symbols.device.type == "cpu" and pilot_symbols.dtype == torch.complex64 and B > 0
-        cond_cpu = conditions is not None and all(c.device.type == "cpu" and c.dtype == torch.float32 and c.numel() == B
-                                                  for c in conditions)
+        cond_cpu = conditions is not None and B > 0 and all(
+            c.device.type == "cpu" and c.dtype == torch.float32 and c.numel() == B for c in conditions)
+        return pil_cpu, cond_cpu
+
+    def _ring(self, dev: torch.device) -> _InputStager:
+        if self._stager is None or self._stager.device != dev:
+            self._stager = _InputStager(dev)
+        return self._stager
+
+    def _forward_hip(self, eng, pilot_symbols: torch.Tensor, conditions: Optional[List[torch.Tensor]]) -> torch.Tensor:
+        """The inference path: ONE stateless ``aft_forward_f32`` call (the encoder weights are re-laid into fragment order
+        inside it, in the same launch as the channel adapter -- nothing cached, nothing that could go stale).  CPU inputs
+        are placed in a pinned ring slot that the kernels read directly; no copy is enqueued (see _InputStager)."""
+        pil_cpu, cond_cpu = self._stageable(pilot_symbols, conditions)
+        if not (pil_cpu or cond_cpu):
+            if conditions is not None:
+                conditions = [t.to(self.device) for t in conditions]
+            return eng.forward(pilot_symbols.to(self.device), *(conditions or ()))
+        ring = self._ring(eng.device)
+        slot, _, pil_h, cond_h = ring.fill(pilot_symbols if pil_cpu else None, conditions if cond_cpu else None)
+        try:
+            pil = pil_h if pil_cpu else pilot_symbols.to(self.device)
+            conds = cond_h if cond_cpu else (None if conditions is None else [t.to(self.device) for t in conditions])
+            return eng.forward(pil, *(conds or ()), pinned_inputs=True)
+        finally:
+            ring.release(slot)
+
+    def _inputs_to_device(self, pilot_symbols: torch.Tensor, conditions: Optional[List[torch.Tensor]]):
+        dev = self.pilot_upsampler.weight.device
+        pil_cpu, cond_cpu = self._stageable(pilot_symbols, conditions)
         if dev.type == "cuda" and (pil_cpu or cond_cpu):
-            if self._stager is None or self._stager.device != dev:
-                self._stager = _InputStager(dev)
-            pil, conds = self._stager.stage(pilot_symbols if pil_cpu else None, conditions if cond_cpu else None)
+            pil, conds = self._ring(dev).to_device(pilot_symbols if pil_cpu else None, conditions if cond_cpu else None)
             if pil is None:
                 pil = pilot_symbols.to(self.device)
             if conds is not None:   # keep each condition's [B, 1] / [B] shape

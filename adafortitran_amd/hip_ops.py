@@ -62,16 +62,21 @@ class HipEngine:
         if forced:
             cfg.encoder_path = {"auto": _abi.AFT_ENCODER_AUTO, "launches": _abi.AFT_ENCODER_LAUNCHES,
                                 "plane": _abi.AFT_ENCODER_PLANE}[forced]
-        self._ws: Optional[torch.Tensor] = None
-        self._ws_batch = 0
+        # scratch is PER STREAM: forwards in flight on different streams must not share the conv_enhanced / x / q / k / v^T
+        # regions (nothing orders them against each other); each buffer is allocated with its stream current, so torch's
+        # caching allocator re-uses it only in that stream's order
+        self._ws: Dict[int, torch.Tensor] = {}
+        self._ws_batch: Dict[int, int] = {}
         self.max_batch = int(self.lib.aft_max_batch(C.byref(cfg)))   # 32-bit buffer offsets: larger batches run in chunks
-        # fragment-packed image of the encoder's GEMM weights, owned here and re-built only when those tensors changed
-        # (their autograd version counters; the module also calls invalidate_packed() on every train()/eval() switch)
+        # OPT-IN fragment-packed image of the encoder's GEMM weights (forward(cache_packed=True): for callers that know
+        # their weights are constant, e.g. A/B tools); the default forward is stateless and re-packs inside the call
         lp = f"{_abi._TE}.transformer.layers."
         self._gemm_weights = [v for k, v in self._keep.items() if k.startswith(lp) and k.endswith(
             ("in_proj_weight", "out_proj.weight", "linear1.weight", "linear2.weight"))]
-        self._packed: Optional[torch.Tensor] = None
-        self._packed_key = None
+        self._packed: Dict[int, torch.Tensor] = {}
+        self._packed_key: Dict[int, tuple] = {}
+
+    MAX_STREAMS = 8      # scratch buffers kept (one per stream that ran a forward); the oldest is dropped beyond that
 
     # -- helpers ---------------------------------------------------------------------------
     @property
@@ -82,55 +87,71 @@ class HipEngine:
         return tuple(v.data_ptr() for v in self._keep.values())
 
     def workspace(self, batch: int) -> torch.Tensor:
-        if self._ws is None or batch > self._ws_batch:
+        """The calling stream's scratch buffer (grown on demand)."""
+        stream = self._stream()
+        ws = self._ws.get(stream)
+        if ws is None or batch > self._ws_batch[stream]:
             nbytes = self.lib.aft_workspace_bytes(C.byref(self.cfg), batch)
             if nbytes == 0:
                 _lib.check(self.lib.aft_forward_f32(C.byref(self.cfg), None, None, None, None, None, None, None, 0, batch, None))
                 raise ValueError("unsupported configuration")
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws_batch = batch
-        return self._ws
+            if ws is None and len(self._ws) >= self.MAX_STREAMS:
+                oldest = next(iter(self._ws))
+                for table in (self._ws, self._ws_batch, self._packed, self._packed_key):
+                    table.pop(oldest, None)
+            with torch.cuda.device(self.device):
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[stream], self._ws_batch[stream] = ws, batch
+        return ws
 
     def _stream(self) -> int:
         return _lib.current_stream_ptr(self.device)
 
     def invalidate_packed(self) -> None:
-        self._packed_key = None
+        self._packed_key.clear()
 
     def packed_weights(self) -> torch.Tensor:
-        """The packed image, re-built (5 us kernel on the current stream) when a GEMM weight's version counter moved
-        or after invalidate_packed().  Stream order makes a re-build safe against forwards still in flight on the same
-        stream; callers that alternate streams get one image per stream."""
+        """OPT-IN (cache_packed=True): this stream's packed image, re-built (5 us kernel on the current stream) when a GEMM
+        weight's autograd version counter moved or after invalidate_packed().  Raw writes through ``.data`` / device
+        pointers do NOT move the counters: a caller who makes them must call invalidate_packed() -- which is why the module
+        surface does not use the cache."""
         stream = self._stream()
-        key = (stream, int(self.cfg.precision), tuple(t._version for t in self._gemm_weights))
-        if key != self._packed_key:
+        key = (int(self.cfg.precision), tuple(t._version for t in self._gemm_weights))
+        if self._packed_key.get(stream) != key:
             nbytes = self.lib.aft_packed_weights_bytes(C.byref(self.cfg))
-            if self._packed is None or self._packed_key is None or self._packed_key[0] != stream:
-                self._packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            _lib.check(self.lib.aft_pack_weights_f32(C.byref(self.cfg), C.byref(self.weights), self._packed.data_ptr(),
+            if stream not in self._packed:
+                with torch.cuda.device(self.device):
+                    self._packed[stream] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.aft_pack_weights_f32(C.byref(self.cfg), C.byref(self.weights), self._packed[stream].data_ptr(),
                                                      nbytes, stream))
-            self._packed_key = key
-        return self._packed
+            self._packed_key[stream] = key
+        return self._packed[stream]
 
     # -- full forward ----------------------------------------------------------------------
     def forward(self, pilots: torch.Tensor, snr=None, ds=None, dop=None, out: Optional[torch.Tensor] = None,
-                cache_packed: bool = False) -> torch.Tensor:
-        """pilots complex64 [B,Ps,Pt] on the device -> complex64 [B,S,T] (same device, async).  Any batch size: batches
-        above ``max_batch`` (the ABI's 32-bit-offset limit) run as consecutive chunks, as the reference accepts any B
-        (fortitran.py:145-182).  ``cache_packed``: use this engine's packed-weight image (aft_forward_prepacked_f32)
-        instead of re-packing inside the call (aft_forward_f32, stateless)."""
+                cache_packed: bool = False, pinned_inputs: bool = False) -> torch.Tensor:
+        """pilots complex64 [B,Ps,Pt] -> complex64 [B,S,T] on the device, asynchronous on the current stream.  Any batch
+        size: batches above ``max_batch`` (the ABI's 32-bit-offset limit) run as consecutive chunks, as the reference
+        accepts any B (fortitran.py:145-182).  Default = aft_forward_f32, stateless: the encoder weights are re-laid
+        into fragment order inside the call.  ``cache_packed``: use this engine's packed image instead
+        (aft_forward_prepacked_f32; see packed_weights).  ``pinned_inputs``: pilots / conditions that live on the CPU are
+        PINNED host tensors which the kernels read directly (device-addressable; the caller keeps them unchanged until the
+        forward has run -- estimators._InputStager); without it every input must be on the engine's device."""
         c = self.cfg
         if pilots.dtype != torch.complex64:
             raise ValueError(f"pilot_symbols must be complex64, got {pilots.dtype}")
         if pilots.dim() != 3 or pilots.shape[1] * pilots.shape[2] != c.pilot_scs * c.pilot_symbols:
             raise ValueError(f"Expected pilot shape (B, {c.pilot_scs}, {c.pilot_symbols}), got {tuple(pilots.shape)}")
         B = pilots.shape[0]
+        if pilots.device.type == "cpu" and not pinned_inputs:
+            raise ValueError("pilot_symbols must be on the engine's device (or pinned, with pinned_inputs=True)")
         pil = torch.view_as_real(pilots.contiguous())
         metas = [None, None, None]
         if c.adaptive:
             if snr is None or ds is None or dop is None:
                 raise ValueError("meta_data is required when channel adaptation is enabled")
-            metas = [_dev_f32(m.reshape(-1), self.device) for m in (snr, ds, dop)]
+            metas = [m.reshape(-1) if (pinned_inputs and m.device.type == "cpu" and m.dtype == torch.float32 and m.is_contiguous())
+                     else _dev_f32(m.reshape(-1), self.device) for m in (snr, ds, dop)]
             if any(m.numel() != B for m in metas):
                 raise ValueError("meta_data tensors must have one value per frame")
         if out is None:

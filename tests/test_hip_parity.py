@@ -563,13 +563,15 @@ def test_largest_accepted_batch_has_no_offset_overflow():
                              ws.numel(), B + 1, None)
     assert rc == _abi.AFT_ERR_ARG and b"aft_max_batch" in lib.aft_last_error()
     del out, pil, ws
-    eng._ws = None
+    eng._ws.clear()
     torch.cuda.empty_cache()
 
 
 def test_module_surface_from_alternating_streams():
-    """CPU inputs through the module on two streams in turn: every call stages into its own device allocation and the
-    pinned ring is guarded by events recorded on the copy's stream, so the results equal the single-stream ones."""
+    """CPU inputs through the module on two streams in turn: the kernels read each call's pinned ring slot directly (no
+    H2D copy is enqueued), the slot is guarded by an event recorded behind the forward on ITS stream, and every stream
+    has its own scratch buffer -- so forwards in flight on different streams do not disturb each other and the results
+    equal the single-stream ones."""
     from test_estimators_cpu import _configs, golden_meta
     g = Golden("A_ada")
     sc, mc = _configs(g.spec, device="cuda")
@@ -582,17 +584,45 @@ def test_module_surface_from_alternating_streams():
         want_a, want_b = model(pil, meta).clone(), model(rev, meta).clone()
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         got = []
-        for i in range(12):                                         # more calls than ring slots, streams alternate
+        for i in range(24):                                         # more calls than ring slots, streams alternate
             with torch.cuda.stream(streams[i & 1]):
                 got.append((i & 1, model(pil if i & 1 == 0 else rev, meta)))
         torch.cuda.synchronize()
+    eng = model._engine
+    assert len({eng._ws[int(st.cuda_stream)].data_ptr() for st in streams}) == 2    # one scratch buffer per stream
     for which, out in got:
         assert torch.equal(torch.view_as_real(out), torch.view_as_real(want_a if which == 0 else want_b))
 
 
-def test_packed_weight_cache_follows_parameter_updates():
-    """The module's engine keeps the fragment-packed encoder weights across forwards: an in-place torch update (version
-    counter) and a raw-pointer update bracketed by train()/eval() must both be seen by the next forward."""
+def test_concurrent_streams_do_not_share_scratch():
+    """Two engines' worth of work on ONE engine: B = 64 forwards of different frames issued back to back on two streams
+    (nothing orders them, the persistent grids of one leave CUs for the other) must each equal the serial result."""
+    hid = (7, 42, 560)
+    sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=5)
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(128, seed=6)
+    halves = []
+    for lo in (0, 64):
+        halves.append((_t(inp["pilots"][lo:lo + 64]), [_t(inp[k][lo:lo + 64]) for k in ("snr", "ds", "dop")]))
+    want = [eng.forward(p, *m).clone() for p, m in halves]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(5):
+        outs = []
+        for st, (p, m) in zip(streams, halves):
+            with torch.cuda.stream(st):
+                outs.append(eng.forward(p, *m))
+        torch.cuda.synchronize()
+        for o, w in zip(outs, want):
+            assert torch.equal(torch.view_as_real(o), torch.view_as_real(w))
+
+
+def test_module_forward_never_runs_stale_weights():
+    """The module's inference path is stateless (aft_forward_f32 re-lays the encoder weights inside every call, in the
+    adapter's launch): an in-place torch update, a raw ``.data`` write in eval() (EMA swap, dist.broadcast(p.data), an
+    optimizer that writes through device pointers) and a train()/eval() bracket are all seen by the next forward."""
     from test_estimators_cpu import _configs
     g = Golden("D_forti")
     sc, mc = _configs(g.spec, device="cuda")
@@ -604,19 +634,30 @@ def test_packed_weight_cache_follows_parameter_updates():
     with torch.no_grad():
         out0 = model(pil).clone()
         eng = model._engine
-        key0 = eng._packed_key
-        model(pil)
-        assert eng._packed_key == key0                              # nothing changed: no re-pack
         w.mul_(1.5)                                                  # torch op: version counter moves
         out1 = model(pil).clone()
-        assert eng._packed_key != key0 and not torch.equal(torch.view_as_real(out1), torch.view_as_real(out0))
-        fresh = eng.forward(_t(g["pilots"])).clone()                # stateless entry: packs inside the call
-        assert torch.equal(torch.view_as_real(out1), torch.view_as_real(fresh))
-        model.train()
-        w.data.view(-1)[:] = (w.data / 1.5).view(-1)                # .data writes do not move the version counter
-        model.eval()
-        out2 = model(pil)
+        assert model._engine is eng and not torch.equal(torch.view_as_real(out1), torch.view_as_real(out0))
+        v0 = w._version
+        w.data.copy_(w.data / 1.5)                                   # raw write in eval(): the version counter does NOT move
+        assert w._version == v0
+        out2 = model(pil).clone()
         assert np.abs((out2 - out0).cpu().numpy()).max() <= 1e-6 * np.abs(g["out"]).max() + 1e-7
+        saved = w.data.clone()
+        w.data.mul_(2.0)
+        out3 = model(pil).clone()
+        assert not torch.equal(torch.view_as_real(out3), torch.view_as_real(out2))
+        model.train()
+        w.data.copy_(saved)
+        model.eval()
+        out4 = model(pil)
+        assert torch.equal(torch.view_as_real(out4), torch.view_as_real(out2))
+        # the engine-level cache is opt-in and documents the caller's duty
+        c1 = eng.forward(_t(g["pilots"]), cache_packed=True).clone()
+        assert torch.equal(torch.view_as_real(c1), torch.view_as_real(out4))
+        w.data.mul_(2.0)                                             # raw write: the cached image is now stale ...
+        eng.invalidate_packed()                                      # ... until the caller says so
+        c2 = eng.forward(_t(g["pilots"]), cache_packed=True)
+        assert torch.equal(torch.view_as_real(c2), torch.view_as_real(out3))
 
 
 # ---- split-precision tier (AFT_PRECISION_BF16X3): opt-in, reported separately, its own stated tolerance ----
