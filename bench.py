@@ -224,6 +224,32 @@ class StubWorkload:
         return (b - a) * 1e3
 
 
+def rank_identity(rank, local_rank, device, args):
+    """What this rank ran on, for the N-rank record (bench line `per_rank.ranks`)."""
+    import torch
+    ident = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid()}
+    if device.type != "cuda":
+        ident.update({"device": "cpu", "pci": f"cpu:{os.getpid()}"})
+        return ident
+    props = torch.cuda.get_device_properties(device)
+    dom, bus, dev = (getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    pci = f"{dom:04x}:{bus:02x}:{dev:02x}" if None not in (dom, bus, dev) else str(getattr(props, "uuid", f"index{device.index}"))
+    ident.update({"device": device.index, "pci": pci, "name": props.name,
+                  "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))})
+    return ident
+
+
+def collective_lib_version(args):
+    """RCCL's version as torch reports it (backend "nccl" IS RCCL on ROCm); gloo has none."""
+    if args.stub or args.share_gpu:
+        return "gloo"
+    try:
+        import torch
+        return "rccl " + ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as exc:
+        return f"unknown ({type(exc).__name__})"
+
+
 def timed_steps(wl, step, steps, warmup, fence):
     """W untimed + exactly K timed steps between fences; returns (wall s, device ms, per-step device ms sorted)."""
     for _ in range(warmup):
@@ -639,6 +665,29 @@ def main() -> int:
         per_rank = {"device_ms_per_step_min": round(min(devs) / args.steps * 1e3, 4),
                     "device_ms_per_step_max": round(max(devs) / args.steps * 1e3, 4),
                     "slowest_rank": int(np.argmax(devs))}
+
+    if dist is not None:
+        # who took part (so that a SCALE record proves N distinct GPUs by itself): every rank's (RANK, LOCAL_RANK, device
+        # index, PCI bus id, device name, host, pid) through the process group; two ranks on one PCI device => exit 4
+        # (--share-gpu and --stub are test modes and say so in `data`)
+        ident = rank_identity(rank, local_rank, device, args)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, ident)
+        per_rank["world_size"] = dist.get_world_size()
+        per_rank["backend"] = dist.get_backend()
+        per_rank["collective_lib"] = collective_lib_version(args)
+        per_rank["ranks"] = [[r["rank"], r["local_rank"], r["device"], r["pci"]] for r in ranks]   # compact: the line is parsed
+        per_rank["rank_fields"] = "rank,local_rank,device,pci"
+        per_rank["device_names"] = sorted({r.get("name", "cpu") for r in ranks})
+        per_rank["hosts"] = sorted({r["host"] for r in ranks})
+        per_rank["pids"] = len({(r["host"], r["pid"]) for r in ranks})
+        bus = [r["pci"] for r in ranks]
+        per_rank["distinct_devices"] = len(set(bus))
+        if not (args.stub or args.share_gpu) and len(set(bus)) != world:
+            print(f"bench.py: {world} ranks but only {len(set(bus))} distinct PCI devices: {bus}", file=sys.stderr)
+            dist.barrier()
+            dist.destroy_process_group()
+            return 4
 
     # ---- end-of-sweep metric: one all-gather of (sum|e|^2, n_frames) per rank ----
     fence()

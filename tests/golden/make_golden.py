@@ -195,6 +195,59 @@ def run_grad(name, spec, batch, store_inputs=True):
     print(f"{name}: B={batch} loss={loss.item():.6f} params={len(names)} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def _grad64(spec, batch, perturb=0.0):
+    model, sd = build_reference(spec)
+    model.double().train()
+    if perturb:
+        rng = np.random.default_rng(2024)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1 + perturb * torch.from_numpy(rng.uniform(-1, 1, tuple(p.shape))))
+    inp = synth.make_inputs(batch, ofdm=tuple(spec["ofdm"]), pilot=tuple(spec["pilot"]), seed=spec["seed"] + 1)
+    pil, tgt = torch.from_numpy(inp["pilots"]).to(torch.complex128), torch.from_numpy(inp["target"]).to(torch.complex128)
+    meta = None
+    if spec.get("adaptive_hidden"):
+        meta = tuple(t.double() if torch.is_tensor(t) and t.is_floating_point() else t for t in synth.meta_tuple(inp))
+    out = model(pil, meta) if meta is not None else model(pil)
+    assert out.dtype == torch.complex128
+    cat = lambda z: torch.cat((torch.real(z), torch.imag(z)), dim=1)  # noqa: E731
+    loss = torch.nn.MSELoss()(cat(out), cat(tgt))
+    loss.backward()
+    return {n: p.grad.detach().reshape(-1).numpy().copy() for n, p in model.named_parameters()}, float(loss), sd
+
+
+def run_grad64(name, spec, batch):
+    """The same training step as run_grad, computed by the reference in FLOAT64 (model.double(), complex128 inputs): the
+    "true" gradient that both fp32 computations -- the reference's own (fixture G_grad_*) and the HIP path's -- are
+    measured against (tests/test_train_golden.py).  Kept per parameter: the same every-7th-element sample, L2 norm and
+    max|g| in float64 -- and `gcond`, the CONDITIONING of that tensor's gradient at fp32 resolution: the max-relative change
+    of the float64 gradient when every parameter is multiplied by (1 + 6e-8 u), u uniform in [-1, 1] (half an fp32 ulp).
+    A coherent half-ulp perturbation bounds what ANY fp32 evaluation can promise for that tensor (its intermediate
+    roundings are perturbations of that size): 2e-5 for the encoder's weights, 2e-3 for pilot_upsampler.weight at full
+    depth -- the far end of six layers of backward."""
+    grads, loss, sd = _grad64(spec, batch)
+    pert, _, _ = _grad64(spec, batch, perturb=6e-8)
+    arrays = {"loss": np.float64(loss)}
+    names = []
+    for n, g in grads.items():
+        assert g.dtype == np.float64
+        names.append(n)
+        arrays[f"gnorm__{n}"] = np.float64(np.sqrt((g ** 2).sum()))
+        arrays[f"gmax__{n}"] = np.float64(np.abs(g).max())
+        arrays[f"gsample__{n}"] = g[::GRAD_SAMPLE_STRIDE][:GRAD_SAMPLE_MAX].copy()
+        arrays[f"gcond__{n}"] = np.float64(np.abs(pert[n] - g).max() / np.abs(g).max())
+        arrays[f"gcondnorm__{n}"] = np.float64(abs(np.sqrt((pert[n] ** 2).sum()) - arrays[f"gnorm__{n}"]) / arrays[f"gnorm__{n}"])
+    arrays["names"] = np.asarray(names)
+    meta_json = dict(spec=spec, batch=batch, torch=torch.__version__, weights_crc=synth.state_dict_checksum(sd), dtype="float64",
+                     cond_perturbation=6e-8)
+    arrays["meta_json"] = np.frombuffer(json.dumps(meta_json).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **arrays)
+    worst = max(names, key=lambda n: arrays[f"gcond__{n}"])
+    print(f"{name}: B={batch} fp64 loss={loss:.9f} params={len(names)} worst conditioning {arrays['gcond__' + worst]:.1e} ({worst}) "
+          f"-> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def run_linear(name, batch, seed):
     """Config #1: the reference LinearEstimator driven plane-wise (it raises on complex input,
     SURVEY.md B5): its real nn.Linear applied to .real and .imag, recombined."""
@@ -315,5 +368,13 @@ if __name__ == "__main__":
         run_grad("G_grad_forti_full", dict(DEFAULT, dropout=0.0, seed=779), 128, store_inputs=False)
     if not only or "G_grad_ada_full" in only:
         run_grad("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128, store_inputs=False)
+    # float64 runs of the reference on the same steps: the yardstick for the fp32 gradient tolerances
+    GRAD64 = {"G_grad64_forti": ("G_grad_forti", dict(DEFAULT, num_layers=2, dropout=0.0, activation="relu", seed=778), 2),
+              "G_grad64_ada": ("G_grad_ada", dict(DEFAULT, num_layers=2, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=777), 3),
+              "G_grad64_forti_full": ("G_grad_forti_full", dict(DEFAULT, dropout=0.0, seed=779), 128),
+              "G_grad64_ada_full": ("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128)}
+    for nm, (_f32, spec, batch) in GRAD64.items():
+        if not only or nm in only:
+            run_grad64(nm, spec, batch)
     leftovers = [os.path.join(r, f) for r, _d, fs in os.walk(REF) for f in fs if f.endswith(".pyc") and "cpython-310" in f]
     assert not leftovers, f"bytecode leaked into the reference mount: {leftovers}"

@@ -70,15 +70,19 @@ def test_two_rank_control_flow_with_stubbed_gpu_work():
     assert abs(line["value"] - 128 / line["ms_per_step"] * 1e3) <= 0.01 * line["value"]
     assert pr["metric_allgather_ms"] > 0
     assert "roofline" not in line                             # nothing was measured
+    # the record proves by itself who took part: world size from the process group, the backend, one entry per rank
+    assert pr["world_size"] == 2 and pr["backend"] == "gloo" and pr["collective_lib"] == "gloo"
+    assert [r[0] for r in pr["ranks"]] == [0, 1] and [r[1] for r in pr["ranks"]] == [0, 1]    # rank, local_rank, device, pci
+    assert pr["distinct_devices"] == 2 and pr["pids"] == 2
 
 
 def test_bench_line_stays_compact():
     """The driver parses the line; round 2's 7.5 KB line lost sub-records there.  Budget: the stub line (contract fields +
-    per_rank) under 1.2 KB; the key set of the full line is fixed in bench.py (numbers only, prose lives in DESIGN.md 5)."""
+    per_rank) under 1.5 KB; the key set of the full line is fixed in bench.py (numbers only, prose lives in DESIGN.md 5)."""
     res = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--stub"])
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-    assert len(line) < 1200, len(line)
+    assert len(line) < 1500, len(line)
 
 
 @pytest.mark.gpu
@@ -130,6 +134,9 @@ def test_bench_under_torchrun_runs_the_rccl_path_and_config5():
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["frames_per_gpu"] == 64 and "C5" in line["config"]["workload"]
     assert line["per_rank"]["metric_allgather_ms"] > 0 and line["per_rank"]["slowest_rank"] == 0
+    pr = line["per_rank"]
+    assert pr["world_size"] == 1 and pr["backend"] == "nccl" and pr["collective_lib"].startswith("rccl ")
+    assert pr["ranks"][0][2] == 0 and pr["ranks"][0][3] and pr["distinct_devices"] == 1
     assert line["value"] > 500 and 0 < line["roofline"]["frac"] < 1
 
 
@@ -149,6 +156,7 @@ def test_two_ranks_sharing_the_gpu_run_the_sharded_forward_and_training_paths():
     pr = line["per_rank"]
     assert 0 < pr["device_ms_per_step_min"] <= pr["device_ms_per_step_max"] and pr["slowest_rank"] in (0, 1)
     assert pr["metric_allgather_ms"] > 0
+    assert pr["world_size"] == 2 and pr["distinct_devices"] == 1 and len(pr["ranks"]) == 2    # shared device: a TEST RUN
     assert 30e3 < line["value"] < 100e3            # two forwards share one GPU: about the 1-GPU rate in aggregate
     assert line["mse_db_vs_random_target"] == line["mse_db_vs_random_target"]   # finite
 
