@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, Dict, Optional
 
-AFT_ABI_VERSION = 3
+AFT_ABI_VERSION = 4
 AFT_MAX_LAYERS = 32
 AFT_OK, AFT_ERR_ARG, AFT_ERR_SHAPE, AFT_ERR_HIP = 0, 1, 2, 3
 AFT_ACT_RELU, AFT_ACT_GELU = 0, 1

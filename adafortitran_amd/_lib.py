@@ -76,7 +76,7 @@ def load_path(path: str):
     lib.aft_encoder_layer_fwd_train_f32.argtypes = [cfgp, lwp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
                                                     C.c_float, C.c_uint64, vp]
     lib.aft_encoder_layer_fwd_train_chained_f32.argtypes = [cfgp, lwp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
-                                                            C.c_float, C.c_uint64, C.c_int, lwp, vp, C.POINTER(C.c_int), vp]
+                                                            C.c_float, C.c_uint64, C.c_int, lwp, vp, C.c_size_t, C.POINTER(C.c_int), vp]
     lib.aft_encoder_layer_bwd_f32.argtypes = [cfgp, lwp, vp, vp, C.c_size_t, vp, vp, lgp, C.c_int, vp, C.c_size_t,
                                               C.c_int, C.c_float, C.c_uint64, vp]
     p4 = C.c_void_p * 4

@@ -66,20 +66,25 @@ int check_config(const aft_config *c) {
         set_error("model_dim %d not covered by the gfx950 kernels (64, 128, 192 or 256)", c->model_dim);
         return AFT_ERR_SHAPE;
     }
-    if (c->num_head <= 0 || c->model_dim % c->num_head || c->model_dim / c->num_head != kHeadDim) {
-        set_error("head dim must be %d (model_dim=%d, num_head=%d)", kHeadDim, c->model_dim, c->num_head);
+    // nn.MultiheadAttention takes any num_head that divides model_dim (reference blocks/encoders.py:44-51, schemas.py:124-127);
+    // the attention kernel is instantiated for head dimensions 16, 32 (the tuned shape) and 64
+    const int hd = c->num_head > 0 && c->model_dim % c->num_head == 0 ? c->model_dim / c->num_head : 0;
+    if (hd != 16 && hd != 32 && hd != 64) {
+        set_error("head dim must be 16, 32 or 64 (model_dim=%d, num_head=%d)", c->model_dim, c->num_head);
         return AFT_ERR_SHAPE;
     }
-    if (tokens_of(*c) < 32) {
-        set_error("token count %d must be >= 32 (one MFMA tile of keys)", tokens_of(*c));
+    if (tokens_of(*c) < 1) {
+        set_error("no tokens");
         return AFT_ERR_SHAPE;
     }
     if (c->patch_scs * c->patch_symbols > kMaxPatchFeatures) {
         set_error("patch %dx%d has more than %d elements", c->patch_scs, c->patch_symbols, kMaxPatchFeatures);
         return AFT_ERR_SHAPE;
     }
-    if (c->precision != AFT_PRECISION_F32 && (c->precision != AFT_PRECISION_BF16X3 || (c->model_dim != 128 && c->model_dim != 256))) {
-        set_error("precision %d: the split-precision tier (AFT_PRECISION_BF16X3) is instantiated for model_dim 128 and 256", c->precision);
+    if (c->precision != AFT_PRECISION_F32 && (c->precision != AFT_PRECISION_BF16X3 || (c->model_dim != 128 && c->model_dim != 256) ||
+                                              hd != kHeadDim || tokens_of(*c) < kTile)) {
+        set_error("precision %d: the split-precision tier (AFT_PRECISION_BF16X3) is instantiated for model_dim 128 and 256, head dim 32, "
+                  ">= 32 tokens", c->precision);
         return AFT_ERR_SHAPE;
     }
     if (c->activation != AFT_ACT_RELU && c->activation != AFT_ACT_GELU) {
@@ -117,7 +122,7 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     ws.x = off;             off += align64(rows * c.model_dim);
     // attention tiles: global 32-row tiles (layer-by-layer path) or ceil(tokens/32) tiles per plane (plane-resident path)
     ws.attn = off;          off += align64(std::max((size_t)round_up((int)rows, kTile), (size_t)ws.planes * ws.tokpad) * c.model_dim);
-    const size_t per_head = (size_t)ws.planes * c.num_head * ws.tokpad * kHeadDim;
+    const size_t per_head = (size_t)ws.planes * ws.tokpad * c.model_dim;   // planes x (model_dim / 32) blocks x tokpad x 32
     ws.q = off;             off += align64(per_head);
     ws.k = off;             off += align64(per_head);
     ws.vt = off;            off += align64(per_head);

@@ -93,6 +93,11 @@ int check_train(const aft_config *cfg, int batch, float dropout_p) {
         set_error("bad batch %d or dropout %g", batch, (double)dropout_p);
         return AFT_ERR_ARG;
     }
+    if (cfg->model_dim / cfg->num_head != kHeadDim || tokens_of_cfg(*cfg) < kTile) {
+        set_error("the training kernels cover head dim %d and >= %d tokens (model_dim=%d, num_head=%d, tokens=%d)", kHeadDim, kTile,
+                  cfg->model_dim, cfg->num_head, tokens_of_cfg(*cfg));
+        return AFT_ERR_SHAPE;
+    }
     if ((size_t)2 * batch * tokens_of_cfg(*cfg) * 3 * cfg->model_dim >= ((size_t)1 << 32)) {
         set_error("batch %d: dropout counters are 32-bit", batch);
         return AFT_ERR_ARG;
@@ -121,7 +126,7 @@ size_t aft_encoder_train_scratch_bytes(const aft_config *cfg, int batch) {
 int aft_encoder_layer_fwd_train_chained_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
                                             void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
                                             float dropout_p, uint64_t seed, int qkv_ready, const aft_layer_weights *next_w,
-                                            void *next_tape, int *next_qkv_written, void *stream) {
+                                            void *next_tape, size_t next_tape_bytes, int *next_qkv_written, void *stream) {
     if (next_qkv_written) *next_qkv_written = 0;
     int rc = check_train(cfg, batch, dropout_p);
     if (rc != AFT_OK) return rc;
@@ -130,6 +135,10 @@ int aft_encoder_layer_fwd_train_chained_f32(const aft_config *cfg, const aft_lay
     const Scratch s = plan_scratch(*cfg, batch);
     if (tape_bytes < t.total * sizeof(float) || scratch_bytes < s.total * sizeof(float)) {
         set_error("tape or scratch too small");
+        return AFT_ERR_ARG;
+    }
+    if (next_w && next_tape && next_tape_bytes < t.total * sizeof(float)) {   // this call writes rows x 3d floats into next_tape's qkv block
+        set_error("next_tape too small: %zu < %zu bytes (the linked layers share cfg and batch)", next_tape_bytes, t.total * sizeof(float));
         return AFT_ERR_ARG;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -187,7 +196,7 @@ int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weigh
                                     void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
                                     float dropout_p, uint64_t seed, void *stream) {
     return aft_encoder_layer_fwd_train_chained_f32(cfg, w, x_in, x_out, tape, tape_bytes, scratch, scratch_bytes, batch, dropout_p, seed, 0,
-                                                   nullptr, nullptr, nullptr, stream);
+                                                   nullptr, nullptr, 0, nullptr, stream);
 }
 
 int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, const void *tape,

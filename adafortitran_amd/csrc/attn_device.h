@@ -60,24 +60,26 @@ __device__ __forceinline__ float max16(const f32x16 &v) {   // 8 x v_max3_f32
 // S^T tile = K tile . Q^T - m_ref: 16 MFMAs on one accumulator that starts from the inline constant 0.  A non-zero
 // reference enters as ONE more MFMA of the same chain (A = 1 on the k = 0 half, B = -m_ref of the lane's query), so
 // no register tuple of initial values and no copies are needed; `zero_ref` (wave-uniform) skips it.
-__device__ __forceinline__ f32x16 qk_tile(const f32x4 (&kreg)[4], const f32x4 (&qreg)[4], bool zero_ref, float a_one,
+template <int NB>
+__device__ __forceinline__ f32x16 qk_tile(const f32x4 (&kreg)[NB][4], const f32x4 (&qreg)[NB][4], bool zero_ref, float a_one,
                                           float neg_m) {
     f32x16 c;
     if (zero_ref) {
-        c = mfma_f32(kreg[0][0], qreg[0][0], f32x16{0});
+        c = mfma_f32(kreg[0][0][0], qreg[0][0][0], f32x16{0});
     } else {
         c = mfma_f32(a_one, neg_m, f32x16{0});
-        c = mfma_f32(kreg[0][0], qreg[0][0], c);
+        c = mfma_f32(kreg[0][0][0], qreg[0][0][0], c);
     }
 #pragma unroll
-    for (int i = 1; i < 16; ++i) c = mfma_f32(kreg[i >> 2][i & 3], qreg[i >> 2][i & 3], c);
+    for (int i = 1; i < 16 * NB; ++i) c = mfma_f32(kreg[i >> 4][(i >> 2) & 3][i & 3], qreg[i >> 4][(i >> 2) & 3][i & 3], c);
     return c;
 }
 
+template <int NB>
 struct AttnRow {          // per-lane softmax state of the lane's query row
     float m_ref;          // reference maximum (log2 units); logits are produced as s - m_ref
     f32x2 lsum2;          // partial row sums of this lane's 16 keys per tile (two interleaved chains)
-    f32x16 oacc;          // O^T accumulator
+    f32x16 oacc[NB];      // O^T accumulator, one per 32-feature block of the head
     bool zero_ref;        // wave-uniform: m_ref == 0 in every lane
 };
 
@@ -124,16 +126,26 @@ __device__ __forceinline__ f32x16 qk_tile_bs(const f32x4 (&kreg)[4], const f32x4
 }
 __device__ __forceinline__ float round_to_bf16(float x) { return (float)(__bf16)x; }
 
-template <bool BS = false>
+// HD = head dimension.  q / k / v^T and the output are laid out per 32-FEATURE BLOCK of the model dimension (`nblk` = model_dim / 32
+// blocks per plane), whatever the head count: for HD = 32 a block is a head.  HD = 64: a head is two adjacent blocks -- S^T sums
+// both blocks' products in one 32-MFMA chain, O^T is one accumulator per block.  HD = 16: a block holds two heads -- a task takes
+// ONE of them (`sub`): the other head's query features are zeroed, so the unchanged 16-MFMA chain yields exactly this head's
+// logits, O^T is computed for the whole block and only this head's 16 rows are stored (half the matrix work of such a task is
+// wasted: the shape is covered, not tuned).  nn.MultiheadAttention as built at reference blocks/encoders.py:44-51 accepts any
+// num_head that divides model_dim (schemas.py:124-127).
+template <bool BS = false, int HD = 32>
 __device__ __forceinline__ void attn_body(const float *__restrict__ q, const float *__restrict__ k,
                                           const float *__restrict__ vt, const float *__restrict__ qbias,
-                                          float *__restrict__ out, int heads, int tokens, int tokpad, int model_dim,
+                                          float *__restrict__ out, int nblk, int tokens, int tokpad, int model_dim,
                                           float scale_log2e, const int first_task, const int total_waves, int ntasks,
                                           unsigned long long *stamps) {
     int lane_l = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_l));   // laundered: lane-dependent offsets are recomputed per call, not hoisted out of the caller's loops
     const int lane = lane_l;
     const Srd qs = make_srd(q), ks = make_srd(k), vs = make_srd(vt), os = make_srd(out);
+    static_assert(HD == 16 || HD == 32 || HD == 64, "head dimension");
+    static_assert(!BS || HD == 32, "the split-precision tier is instantiated for head dimension 32");
+    constexpr int NB = HD == 64 ? 2 : 1;                // 32-feature blocks per head
     const int nkt = tokpad / kTile;
     const int r = lane & 31, h = lane >> 5;
     const bool ragged = (tokens & (kTile - 1)) != 0;   // last key tile holds padded keys
@@ -145,10 +157,15 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
 #endif
     // q, k, vt arrive in MFMA-fragment order from k_chain.hip: [ph][tile][s or g][lane][4] -> every
     // operand load below is one fully coalesced 1-KB buffer_load_dwordx4 per wave
-    auto head_base = [&](int task) { return ((unsigned)(task / nkt) * tokpad * kHeadDim + lane * 4) * 4; };
-    auto load_tile = [&](Srd src, int kt, f32x4 (&dst)[4], unsigned base) {
+    // (plane, block) index of a task's first block: task / nkt is (plane, head)
+    auto first_block = [&](int task) { const int ph = task / nkt; return HD == 16 ? ph >> 1 : ph * NB; };
+    auto head_base = [&](int task) { return ((unsigned)first_block(task) * tokpad * kHeadDim + lane * 4) * 4; };
+    const unsigned blk_bytes = (unsigned)tokpad * kHeadDim * 4;     // one (plane, block) of q / k / v^T
+    auto load_tile = [&](Srd src, int kt, f32x4 (&dst)[NB][4], unsigned base) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) dst[s] = srd_load(src, base + (unsigned)(kt * 1024 + s * 256) * 4);
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dst[b][s] = srd_load(src, base + b * blk_bytes + (unsigned)(kt * 1024 + s * 256) * 4);
     };
     // padded keys of the ragged last tile: logits -> -inf (probability 0), V^T columns -> 0 (the workspace pad is
     // never trusted: 0 x NaN would poison the row)
@@ -157,7 +174,10 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
         for (int e = 0; e < 16; ++e)
             if (kt * kTile + (e & 3) + 8 * (e >> 2) + 4 * h >= tokens) sv[e] = -INFINITY;
     };
-    auto mask_values = [&](f32x4 (&vv)[4], int kt) {
+    auto mask_values = [&](f32x4 (&vvb)[NB][4], int kt) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        f32x4 (&vv)[4] = vvb[b];
         if constexpr (BS) {   // slot 2m + term, element j: key 16 m + 8 (j >> 2) + 4 h + (j & 3) of the tile
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
@@ -174,13 +194,14 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
                 for (int j = 0; j < 4; ++j)
                     if (kt * kTile + 8 * g + 4 * h + j >= tokens) vv[g][j] = 0.f;
         }
+      }
     };
 
   // wave priority by work left (set_progress_priority, aft_internal.h): keeps the waves of a SIMD abreast
   const int rounds = (ntasks + total_waves - 1) / total_waves;
   int round = 0;
   int task = first_task;
-  f32x4 qreg[4], kcur[4], vcur[4];
+  f32x4 qreg[NB][4], kcur[NB][4], vcur[NB][4];
   if (task < ntasks) {       // operands of the first task; later ones are requested during the previous task's last tile
       const unsigned hb0 = head_base(task);
       load_tile(qs, task % nkt, qreg, hb0);
@@ -193,8 +214,9 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     if (stamps && lane == 0) stamps[(size_t)task * 8 + 6] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int qt = task % nkt;
-    const int ph = task / nkt;  // plane * heads + head
-    const unsigned hb = head_base(task);   // byte offset of this (plane, head)
+    const int pb = first_block(task);       // plane * nblk + the head's first block
+    const int sub = HD == 16 ? (task / nkt) & 1 : 0;   // HD = 16: which of the block's two heads
+    const unsigned hb = head_base(task);   // byte offset of this (plane, block)
     const int next_task = task + total_waves;
     const bool has_next = next_task < ntasks;
 
@@ -202,9 +224,16 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
     // a row constant to the logits, which softmax cancels), then everything is pre-scaled
     if constexpr (!BS) {   // (split tier: bias and scale were applied before the bf16 split, in the chain kernel's epilogue)
-        const float *bq = qbias + (ph % heads) * kHeadDim + 4 * h;
+        const float *bq = qbias + (pb % nblk) * kHeadDim + 4 * h;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qreg[s] = (qreg[s] + *reinterpret_cast<const f32x4 *>(bq + 8 * s)) * scale_log2e;
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                qreg[b][s] = (qreg[b][s] + *reinterpret_cast<const f32x4 *>(bq + 32 * b + 8 * s)) * scale_log2e;
+                if constexpr (HD == 16) {   // slots s = 2 sub, 2 sub + 1 are this head's 16 features; the other head's contribute 0
+                    if ((s >> 1) != sub) qreg[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
     }
     // Padded query lanes of the ragged last query tile read workspace nobody wrote: their results are never stored, but
     // the reference tests below are wave-wide (__any), so a large stale value there would switch the VALID lanes of the
@@ -212,14 +241,16 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     // allocator handed out (found by a NaN / 1e30-poisoned pool, tools/debug/poison_repro.py).  Zero queries never trigger.
     if (ragged && qt == nkt - 1 && qt * kTile + r >= tokens) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qreg[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qreg[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // ---- key tile 0: plain logits, reference maximum ----
-    AttnRow st;
+    AttnRow<NB> st;
     f32x16 sA, sB;
-    if constexpr (BS) sA = qk_tile_bs(kcur, qreg, true, 0.f, h);
-    else sA = qk_tile(kcur, qreg, true, a_one, 0.f);
+    if constexpr (BS) sA = qk_tile_bs(kcur[0], qreg[0], true, 0.f, h);
+    else sA = qk_tile<NB>(kcur, qreg, true, a_one, 0.f);
     if (nkt > 1) load_tile(ks, 1, kcur, hb);
     if (ragged && nkt == 1) { mask_logits(sA, 0); mask_values(vcur, 0); }
     {
@@ -233,7 +264,8 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
             for (int e = 0; e < 16; ++e) sA[e] -= m0;
         }
     }
-    st.oacc = f32x16{0};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) st.oacc[b] = f32x16{0};
     st.lsum2 = f32x2{0.f, 0.f};
     ASTAMP(1);
 
@@ -245,8 +277,8 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
         set_progress_priority((rounds - 1 - round) * nkt + (nkt - 1 - kt), rounds * nkt);
         const bool more = FAST || kt + 1 < nkt;
         if (more) {
-            if constexpr (BS) nxt = qk_tile_bs(kcur, qreg, st.zero_ref, -st.m_ref, h);
-            else nxt = qk_tile(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
+            if constexpr (BS) nxt = qk_tile_bs(kcur[0], qreg[0], st.zero_ref, -st.m_ref, h);
+            else nxt = qk_tile<NB>(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
             if (FAST || kt + 2 < nkt) load_tile(ks, kt + 2, kcur, hb);
         } else if (has_next) {      // last tile: Q and K are idle -> request the next task's
             const unsigned hbn = head_base(next_task);
@@ -266,7 +298,8 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
             for (int e = 0; e < 16; ++e) {
                 cur[e] -= grow;
                 if (more) nxt[e] -= grow;                 // the pending tile was started from the old reference
-                st.oacc[e] *= f;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) st.oacc[b][e] *= f;
             }
             st.lsum2 *= f;
         }
@@ -287,19 +320,21 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
                 const BsFrag pf = bs_split(f32x4{p[8 * m], p[8 * m + 1], p[8 * m + 2], p[8 * m + 3]},
                                            f32x4{p[8 * m + 4], p[8 * m + 5], p[8 * m + 6], p[8 * m + 7]});
                 const bf16x8 ph8 = __builtin_bit_cast(bf16x8, pf.hi), pl8 = __builtin_bit_cast(bf16x8, pf.lo);
-                const bf16x8 vh = __builtin_bit_cast(bf16x8, vcur[2 * m]), vl = __builtin_bit_cast(bf16x8, vcur[2 * m + 1]);
-                st.oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph8, st.oacc, 0, 0, 0);
-                st.oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl8, st.oacc, 0, 0, 0);
-                st.oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph8, st.oacc, 0, 0, 0);
+                const bf16x8 vh = __builtin_bit_cast(bf16x8, vcur[0][2 * m]), vl = __builtin_bit_cast(bf16x8, vcur[0][2 * m + 1]);
+                st.oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph8, st.oacc[0], 0, 0, 0);
+                st.oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl8, st.oacc[0], 0, 0, 0);
+                st.oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph8, st.oacc[0], 0, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (!FAST && ragged && kt * kTile + 8 * g >= tokens) continue;
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    st.oacc = mfma_f32(vcur[g][j], p[4 * g + j], st.oacc);
-            }
+                for (int g = 0; g < 4; ++g) {
+                    if (!FAST && ragged && kt * kTile + 8 * g >= tokens) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        st.oacc[b] = mfma_f32(vcur[b][g][j], p[4 * g + j], st.oacc[b]);
+                }
         }
         if (more) {
             load_tile(vs, kt + 1, vcur, hb);
@@ -331,14 +366,17 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     const int qrow = qt * kTile + r;
     if (qrow < tokens) {
         const float inv = 1.0f / l_run;
-        const int plane = ph / heads, head = ph % heads;
+        const int plane = pb / nblk, blk = pb % nblk;
         const unsigned grow = (unsigned)plane * tokens + qrow;
-        const unsigned dst = (((grow >> 5) * (unsigned)(model_dim / kHeadDim) + head) * 1024 + ((grow & 31) + 32 * h) * 4) * 4;
+        const unsigned dst = (((grow >> 5) * (unsigned)nblk + blk) * 1024 + ((grow & 31) + 32 * h) * 4) * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 o = {st.oacc[4 * g] * inv, st.oacc[4 * g + 1] * inv, st.oacc[4 * g + 2] * inv, st.oacc[4 * g + 3] * inv};
-            srd_store(os, dst + g * 1024, o);
-        }
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (HD == 16 && (g >> 1) != sub) continue;   // rows 8g .. 8g+7 of the block belong to the other head
+                f32x4 o = {st.oacc[b][4 * g] * inv, st.oacc[b][4 * g + 1] * inv, st.oacc[b][4 * g + 2] * inv, st.oacc[b][4 * g + 3] * inv};
+                srd_store(os, dst + (b * 4 + g) * 1024, o);
+            }
     }
     ASTAMP(4);
 #ifdef AFT_DIAG_STAMPS

@@ -629,6 +629,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         // 16-byte fragment element; the v tile (lane = feature, registers = tokens) likewise.
         const int plane0 = row0 / a.tokens, tok0 = row0 - plane0 * a.tokens;
         const unsigned head_stride = (unsigned)a.tokpad * kHeadDim;             // floats per (plane, head)
+        // token index past the end of its plane -> the next plane's (plane, head) block.  A 32-row tile crosses at most one
+        // plane boundary when tokens >= 32; grids with fewer tokens (a whole plane inside a tile) walk on
+        auto wrap_plane = [&](int &tok, unsigned &ph) {
+            if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+            if (a.tokens < kTile)
+                while (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+        };
         const unsigned ph0 = (unsigned)(plane0 * a.heads + w);
         const bool full = row0 + 32 <= a.rows;
         if constexpr (BS) {
@@ -641,7 +648,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
             {
                 int tok = tok0 + r;
                 unsigned ph = ph0;
-                if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+                wrap_plane(tok, ph);
                 const unsigned lane_off = (ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok & 31) + 32 * h) * 4) * 4;
                 if (full || row_ok) {
 #pragma unroll
@@ -662,7 +669,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
             for (int gq = 0; gq < 4; ++gq) {
                 int tok = tok0 + 8 * gq + 4 * h;
                 unsigned ph = ph0;
-                if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+                wrap_plane(tok, ph);
                 __bf16 vh[4], vl[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -683,7 +690,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
                     for (int j = 0; j < 4; ++j) {
                         int tj = tok + j;
                         unsigned pj = ph;
-                        if (tj >= a.tokens) { tj -= a.tokens; pj += a.heads; }
+                        wrap_plane(tj, pj);
                         if (row0 + 8 * gq + 4 * h + j < a.rows) {
                             const unsigned g = (tj >> 3) & 3, hh = (tj >> 2) & 1;
                             const size_t e16 = ((size_t)pj * head_stride + (size_t)(tj >> 5) * 1024 + (2 * (g >> 1)) * 256 + (r + 32 * hh) * 4) * 2 +
@@ -718,7 +725,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         {
             int tok = tok0 + r;
             unsigned ph = ph0;
-            if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+            wrap_plane(tok, ph);
             const unsigned lane_off = ph * head_stride + (unsigned)(tok >> 5) * 1024 + ((tok & 31) + 32 * h) * 4;
             if (full || row_ok) {
 #pragma unroll
@@ -734,7 +741,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
         for (int gq = 0; gq < 4; ++gq) {   // registers 4gq..4gq+3 = tokens tok0 + 8gq + 4h + {0..3}
             int tok = tok0 + 8 * gq + 4 * h;
             unsigned ph = ph0;
-            if (tok >= a.tokens) { tok -= a.tokens; ph += a.heads; }
+            wrap_plane(tok, ph);
             const f32x4 v = {acc[2][4 * gq], acc[2][4 * gq + 1], acc[2][4 * gq + 2], acc[2][4 * gq + 3]};
             const bool in_rows = full || row0 + 8 * gq + 4 * h + 3 < a.rows;
             if ((tok & 3) == 0 && tok + 3 < a.tokens && in_rows) {
@@ -747,7 +754,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs &a, float *smem, cons
                 for (int j = 0; j < 4; ++j) {
                     int tj = tok + j;
                     unsigned pj = ph;
-                    if (tj >= a.tokens) { tj -= a.tokens; pj += a.heads; }
+                    wrap_plane(tj, pj);
                     if (row0 + 8 * gq + 4 * h + j < a.rows)
                         a.vt[pj * head_stride + (unsigned)(tj >> 5) * 1024 + ((tj >> 3) & 3) * 256 +
                              (r + 32 * ((tj >> 2) & 1)) * 4 + (tj & 3)] = v[j];

@@ -9,10 +9,11 @@
 namespace aft {
 
 // launch bound (256, 3): <= 168 registers keeps accumulators in VGPRs, see attn_device.h
-template <int UNUSED>
-__global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
+// HD = 32: three waves per SIMD (the tuned shape).  HD = 64 holds two blocks of q / k / v^T and two accumulators (~210 VGPRs): two.
+template <int HD>
+__global__ __launch_bounds__(256, HD == 64 ? 2 : AFT_ATTN_WAVES) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                       const float *__restrict__ vt, const float *__restrict__ qbias,
-                                                      float *__restrict__ out, int heads, int tokens, int tokpad,
+                                                      float *__restrict__ out, int nblk, int tokens, int tokpad,
                                                       int model_dim,
                                                       float scale_log2e, int ntasks, unsigned long long *stamps) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -21,8 +22,8 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_kernel(const float *
     // (72 KB) through ONE L2 instead of two or three.  A pure speed choice; any mapping is correct.
     int vblock = blockIdx.x;
     if ((gridDim.x & 7) == 0) vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    attn_body(q, k, vt, qbias, out, heads, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, gridDim.x * 4, ntasks,
-              stamps);
+    attn_body<false, HD>(q, k, vt, qbias, out, nblk, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, gridDim.x * 4, ntasks,
+                         stamps);
 }
 
 // split-precision tier: K / Q^T / V^T arrive as bf16 hi / lo fragments from chain_split_kernel (attn_device.h)
@@ -37,12 +38,13 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_split_kernel(const f
 
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
                             float *attn, int planes, int tokens, int tokpad, hipStream_t st) {
+    const int hd = c.model_dim / c.num_head, nblk = c.model_dim / kHeadDim;   // head dimension 16 | 32 | 64 (check_config); 32-feature blocks
     const int ntasks = planes * c.num_head * (tokpad / kTile);
-    const int resident_blocks = AFT_ATTN_WAVES * current_device_cus();   // CUs x 3 workgroups (launch bound: 3 waves / SIMD)
+    const int resident_blocks = (hd == 64 ? 2 : AFT_ATTN_WAVES) * current_device_cus();   // CUs x workgroups (launch bound: waves / SIMD)
     const int blocks = std::min((ntasks + 3) / 4, resident_blocks);
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)kHeadDim);
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
     if (c.precision == AFT_PRECISION_BF16X3) {
-        hipLaunchKernelGGL(attn_split_kernel, dim3(blocks), dim3(256), 0, st, q, k, vt, attn, c.num_head, tokens, tokpad, c.model_dim,
+        hipLaunchKernelGGL(attn_split_kernel, dim3(blocks), dim3(256), 0, st, q, k, vt, attn, nblk, tokens, tokpad, c.model_dim,
                            ntasks);
         return hipGetLastError();
     }
@@ -51,7 +53,7 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
         static unsigned long long *dbuf = nullptr;
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 8 * 16384);
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 8 * 16384);
-        hipLaunchKernelGGL((attn_kernel<3>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, c.num_head, tokens,
+        hipLaunchKernelGGL((attn_kernel<32>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens,
                            tokpad, c.model_dim, scale_log2e, ntasks, dbuf);
         (void)hipDeviceSynchronize();
         static int printed = 0;
@@ -91,8 +93,16 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((attn_kernel<3>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, c.num_head, tokens,
-                       tokpad, c.model_dim, scale_log2e, ntasks, (unsigned long long *)nullptr);
+    unsigned long long *no_stamps = nullptr;
+    if (hd == 16)
+        hipLaunchKernelGGL((attn_kernel<16>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
+                           scale_log2e, ntasks, no_stamps);
+    else if (hd == 64)
+        hipLaunchKernelGGL((attn_kernel<64>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
+                           scale_log2e, ntasks, no_stamps);
+    else
+        hipLaunchKernelGGL((attn_kernel<32>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
+                           scale_log2e, ntasks, no_stamps);
     return hipGetLastError();
 }
 

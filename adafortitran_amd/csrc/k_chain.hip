@@ -196,7 +196,7 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const f
     }
     a.q = q; a.k = k; a.vt = vt;
     a.rows = rows; a.tokens = tokens; a.tokpad = tokpad;
-    a.heads = c.num_head;
+    a.heads = c.model_dim / kHeadDim;   // q / k / v^T are laid out per 32-feature block, whatever the head count (attn_device.h)
     const bool gelu = c.activation == AFT_ACT_GELU;
     const bool mlp = m != nullptr, qkv = qw != nullptr;
     if (c.precision == AFT_PRECISION_BF16X3) {

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(EncoderShape<D>::THREADS, EncoderShape<D>::THREADS 
 }
 
 bool encoder_plane_ok(const aft_config &c) {
-    return c.model_dim == 128;    // 3 groups x 51 KB of LDS, 12 waves: the d = 128 shape is the one instantiated
+    // 3 groups x 51 KB of LDS, 12 waves: the d = 128 / head dim 32 shape is the one instantiated (>= 32 tokens: a row tile inside one plane)
+    return c.model_dim == 128 && c.num_head == 4 && (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols) >= kTile;
 }
 
 template <int ACT>

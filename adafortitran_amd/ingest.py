@@ -84,7 +84,10 @@ class PackedLoader:
     dataset.py:254-260) and yields reference-format batches.  On a HIP device the pilots are gathered
     by the GPU kernel and both pilots and targets stay on the device.  There the reference's "Expected 24 pilot values,
     got 25" ValueError (dataset.py:128-132) is raised ONE BATCH LATE (the counts come back asynchronously): when the
-    next batch is requested, or when the iterator is exhausted or closed -- never silently dropped."""
+    next batch is requested, when the iterator is exhausted, or when it is CLOSED.  A consumer that leaves the loop early
+    with ``break`` should close the iterator (``with contextlib.closing(iter(loader)) as it:`` or ``it.close()``): left to
+    the garbage collector, an error raised while the generator is finalised is only printed ("Exception ignored in
+    generator"), not raised.  An exception from the consumer's own loop body propagates unchanged."""
 
     def __init__(self, packed: Union[str, Path, Dict[str, np.ndarray]], pilot_size: Tuple[int, int], batch_size: int,
                  device: Union[str, torch.device] = "cpu", pin_memory: bool = True,
@@ -113,8 +116,9 @@ class PackedLoader:
                 self.p["h_ideal"], self.p["h_ls_sparse"] = (t.numpy() for t in self._pinned)   # views of the pinned memory
             else:
                 shape = (self.batch_size, *grids[0].shape[1:])
-                self._stage_ring = [(torch.empty(shape, dtype=torch.complex64).pin_memory(),
-                                     torch.empty(shape, dtype=torch.complex64).pin_memory(), None) for _ in range(3)]
+                dt_i, dt_s = (torch.from_numpy(self.p[k][:0]).dtype for k in ("h_ideal", "h_ls_sparse"))   # the grids' own dtypes
+                self._stage_ring = [(torch.empty(shape, dtype=dt_i).pin_memory(),
+                                     torch.empty(shape, dtype=dt_s).pin_memory(), None) for _ in range(3)]
 
     def __len__(self) -> int:
         return (self.n + self.batch_size - 1) // self.batch_size
@@ -191,12 +195,18 @@ class PackedLoader:
                     settle(pending)
                 prev = (done, host_counts, lo)
                 yield pilots, ideal, self._meta(lo, hi)
-        finally:
-            # the count check of the last yielded batch is settled here -- also when the consumer stops iterating early
-            # (generator close): a bad pilot count is always reported, one batch late at most (module docstring of
-            # evaluation.py); GeneratorExit itself is not an error to convert
+        except GeneratorExit:
+            # the consumer stopped early and CLOSED the iterator (``it.close()``, ``contextlib.closing``, or -- with the
+            # caveat in the class docstring -- garbage collection after ``break``): the last yielded batch's count check is
+            # settled before the generator goes away; a ValueError raised here propagates out of close()
             if prev is not None:
-                settle(prev)
+                pending, prev = prev, None
+                settle(pending)
+            raise
+        # normal exhaustion: the count check of the last batch.  (An exception thrown by the consumer's loop body is NOT
+        # intercepted: it propagates unchanged, and the pending check is dropped with the failed sweep.)
+        if prev is not None:
+            settle(prev)
 
     def _meta(self, lo: int, hi: int) -> tuple:
         m = torch.from_numpy(self.p["meta"][lo:hi])

@@ -102,7 +102,7 @@ class HipEncoderLayerFunction(torch.autograd.Function):
                 C.byref(cfg), C.byref(w), x.data_ptr(), out.data_ptr(), tape.data_ptr(), tape.numel(),
                 scratch.data_ptr(), scratch.numel(), batch, float(dropout_p), int(seed), int(link.qkv_ready),
                 C.byref(nxt) if nxt is not None else None, link.next_tape.data_ptr() if nxt is not None else None,
-                C.byref(wrote), _lib.current_stream_ptr(x.device)))
+                link.next_tape.numel() if nxt is not None else 0, C.byref(wrote), _lib.current_stream_ptr(x.device)))
             link.next_qkv_written = bool(wrote.value)
         ctx.save_for_backward(x, tape, *params)
         ctx.cfg, ctx.dropout_p, ctx.seed, ctx.batch = cfg, float(dropout_p), int(seed), batch

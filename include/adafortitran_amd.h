@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AFT_ABI_VERSION 3   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
+#define AFT_ABI_VERSION 4   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
 #define AFT_MAX_LAYERS 32
 
 #define AFT_OK 0
@@ -122,7 +122,13 @@ size_t aft_workspace_bytes(const aft_config *cfg, int batch);
 /* Replaces BaseFortiTranEstimator.forward (reference src/models/fortitran.py:145-182):
  * pilots complex64 [B,Ps,Pt] -> out complex64 [B,S,T].  snr/ds/dop are float32 [B]
  * raw (un-normalised) channel conditions, NULL for FortiTran (meta_data[1..3],
- * fortitran.py:166-170). */
+ * fortitran.py:166-170).
+ * `pilots`, `snr`, `ds`, `dop` may be ANY device-addressable memory, pinned host memory (hipHostMalloc / torch's
+ * pin_memory()) included: the conv head and the adapter read them directly, so the model-owned H2D transfer of
+ * fortitran.py:167-173 needs no copy engine hop in front of the first launch -- the caller keeps the buffer unchanged until
+ * the call's kernels have run (record an event behind the call).  `out`, `workspace` and the weights are device memory.
+ * Launches: [adapter + weight re-lay] (one prologue launch), conv head, embedding + in-projection, L x (attention, row-local
+ * chain), conv tail. */
 int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pilots,
                     const float *snr, const float *ds, const float *dop, float *out,
                     void *workspace, size_t workspace_bytes, int batch, void *stream);
@@ -132,7 +138,12 @@ int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pi
  * the encoder's GEMM weights into MFMA-fragment order on EVERY call (5 us, 3 MB: it is stateless and always reflects the
  * caller's current parameters); here the caller owns that image -- aft_packed_weights_bytes() of device memory, filled by
  * aft_pack_weights_f32 whenever in_proj / out_proj / linear1 / linear2 weights of any layer changed -- and every forward
- * reads it.  `w` is still needed (biases, LayerNorm vectors, conv / adapter / dense weights are read in place). */
+ * reads it.  `w` is still needed (biases, LayerNorm vectors, conv / adapter / dense weights are read in place).
+ * THE CALLER'S DUTY: the image must have been packed with the SAME cfg (model_dim, num_layers AND precision: the fp32 and
+ * the split-precision layouts have the same size) from the CURRENT weights; the library cannot check either without a
+ * device-to-host synchronisation, which this ABI never performs.  Since ABI 4 aft_forward_f32 packs in the same launch as
+ * the channel adapter, so the stateless entry point costs no more than this one: prefer it unless the 3 MB of weight reads
+ * per call matter. */
 size_t aft_packed_weights_bytes(const aft_config *cfg);
 int aft_pack_weights_f32(const aft_config *cfg, const aft_weights *w, void *packed, size_t packed_bytes, void *stream);
 int aft_forward_prepacked_f32(const aft_config *cfg, const aft_weights *w, const void *packed, const float *pilots,
@@ -202,7 +213,7 @@ int aft_encoder_layer_fwd_train_f32(const aft_config *cfg, const aft_layer_weigh
 int aft_encoder_layer_fwd_train_chained_f32(const aft_config *cfg, const aft_layer_weights *w, const float *x_in, float *x_out,
                                             void *tape, size_t tape_bytes, void *scratch, size_t scratch_bytes, int batch,
                                             float dropout_p, uint64_t seed, int qkv_ready, const aft_layer_weights *next_w,
-                                            void *next_tape, int *next_qkv_written, void *stream);
+                                            void *next_tape, size_t next_tape_bytes, int *next_qkv_written, void *stream);
 
 /* Replaces autograd's backward through that layer: dx_out = dL/dx_out [2B*tokens, d] ->
  * dx_in = dL/dx_in (may alias dx_out) and the twelve parameter gradients in `grads`

@@ -344,6 +344,14 @@ SETS = {
                    4, ["conv_enhanced", "x0_f0", "layer_first_last_p0", "enc_out", "residual"]),
     "AS_ada_sin_relu": (dict(DEFAULT, adaptive_hidden=[7, 42, 560], seed=5, activation="relu",
                              pos_encoding_type="sinusoidal", attn_gain=0.5, head_gain=4.0), 4, ["enc_out"]),
+    # head dimensions other than 32 (nn.MultiheadAttention takes any num_head | model_dim, reference encoders.py:44-51) and a grid
+    # with fewer than 32 tokens (one masked key tile; a 32-row tile of the row-local chain spans several planes)
+    "H16_ada_heads8": (dict(DEFAULT, num_layers=2, num_head=8, adaptive_hidden=[7, 42, 560], seed=161, attn_gain=0.25, head_gain=2.0), 4,
+                       ["enc_out"]),
+    "H64_forti_heads2": (dict(DEFAULT, num_layers=2, num_head=2, seed=641, attn_gain=24.0, ffn_gain=2.0, head_gain=4.0), 4, ["enc_out"]),
+    "S28_ada_tokens28": (dict(ofdm=[12, 14], pilot=[4, 2], patch=[3, 2], num_layers=2, model_dim=64, num_head=2,
+                              adaptive_hidden=[7, 42, 56], max_seq_len=32, seed=281, attn_gain=0.5, head_gain=2.0), 5,
+                         ["conv_enhanced", "enc_out"]),
     "C5_ada_large": (dict(ofdm=[240, 28], pilot=[24, 4], patch=[3, 2], num_layers=12, model_dim=256, num_head=8,
                           adaptive_hidden=[7, 42, 2240], max_seq_len=1120, seed=55, attn_gain=0.5, head_gain=2.0),
                      1, []),

@@ -18,6 +18,8 @@ def _configs(spec, device="cpu"):
               num_head=spec["num_head"], activation=spec.get("activation", "gelu"),
               max_seq_len=spec.get("max_seq_len", 512), pos_encoding_type=spec.get("pos_encoding_type", "learnable"),
               device=device)
+    if "dropout" in spec:
+        kw["dropout"] = spec["dropout"]
     if spec.get("adaptive_hidden"):
         kw.update(channel_adaptivity_hidden_sizes=list(spec["adaptive_hidden"]), adaptive_token_length=6)
     return sc, A.ModelConfig(**kw)

@@ -39,7 +39,10 @@ def test_extension_is_loaded_in_tree():
     assert "libaft_hip.so" in maps
 
 
-@pytest.mark.parametrize("name", DEFAULT_SETS + ["C5_ada_large"])
+OTHER_SHAPE_SETS = ["H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28"]   # head dim 16 / 64; 28 tokens (one masked key tile)
+
+
+@pytest.mark.parametrize("name", DEFAULT_SETS + ["C5_ada_large"] + OTHER_SHAPE_SETS)
 def test_forward_matches_reference_golden(name):
     g = Golden(name)
     eng = _engine(g)
@@ -196,12 +199,16 @@ def test_other_grid_geometries_match_oracle(oracle_lib, ofdm, pilot, patch, adap
 
 
 @pytest.mark.parametrize("adaptive", [False, True])
-@pytest.mark.parametrize("d", [64, 192])
-def test_other_model_dims_match_oracle(oracle_lib, adaptive, d):
-    """d = 64 / 192 with head dim 32: two / six waves per chain workgroup."""
-    spec = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=3, model_dim=d, num_head=d // 32)
+@pytest.mark.parametrize("d,heads", [(64, 2), (192, 6),                    # head dim 32: two / six waves per chain workgroup
+                                     (128, 8), (64, 4), (192, 12), (256, 16),   # head dim 16: two heads per 32-feature block
+                                     (128, 2), (64, 1), (192, 3), (256, 4)])    # head dim 64: a head spans two blocks
+def test_other_model_dims_match_oracle(oracle_lib, adaptive, d, heads):
+    """Every (model_dim, num_head) the kernels cover besides the default: nn.MultiheadAttention takes any num_head that divides
+    model_dim (reference blocks/encoders.py:44-51).  Non-uniform softmax (attn_gain), 9 frames = ragged row tiles, run-to-run
+    determinism, every encoder layer on the oracle's own layer input, the whole forward against the oracle."""
+    spec = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=3, model_dim=d, num_head=heads)
     hid = (7, 42, 560) if adaptive else None
-    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=64)
+    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=64 + heads, attn_gain=0.25 if adaptive else 16.0, head_gain=2.0)
     cfg = _abi.make_config(**spec, adaptive_hidden=hid)
     from adafortitran_amd.hip_ops import engine_from_numpy
     eng = engine_from_numpy(cfg, sd, DEV)
@@ -209,7 +216,38 @@ def test_other_model_dims_match_oracle(oracle_lib, adaptive, d):
     meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
     out = eng.forward(_t(inp["pilots"]), *meta)
     assert torch.equal(torch.view_as_real(eng.forward(_t(inp["pilots"]), *meta)), torch.view_as_real(out))
-    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3))
+    orc = oracle_lib.Oracle(cfg, sd)
+    ref, dump = orc.forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3), dump=True)
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+    xin = dump["x0"]
+    for layer in range(spec["num_layers"]):
+        y = eng.stage_encoder_layer(layer, _t(xin)).cpu().numpy()
+        assert max_rel(y, dump["layer_out"][layer]) <= TOL_HIP_OUT, layer
+        xin = dump["layer_out"][layer]
+
+
+@pytest.mark.parametrize("ofdm,pilot,patch,d,heads", [((12, 14), (4, 2), (3, 2), 64, 2),     # 28 tokens
+                                                       ((12, 4), (4, 2), (3, 2), 128, 4),     # 8 tokens: four planes per row tile
+                                                       ((6, 14), (2, 2), (3, 2), 128, 8),     # 14 tokens, head dim 16
+                                                       ((24, 6), (4, 2), (3, 2), 64, 1),      # 24 tokens, head dim 64
+                                                       ((30, 6), (6, 2), (3, 2), 192, 6),     # 30 tokens
+                                                       ((3, 2), (1, 1), (3, 2), 64, 2)])      # ONE token per plane
+@pytest.mark.parametrize("batch", [1, 7, 33])
+def test_grids_with_fewer_than_32_tokens_match_oracle(oracle_lib, ofdm, pilot, patch, d, heads, batch):
+    """Token counts below one MFMA tile (the reference accepts any grid divisible by the patch, fortitran.py:52-81): attention
+    runs one masked key tile per (plane, head), a 32-row tile of the row-local chain holds several whole planes."""
+    tokens = (ofdm[0] // patch[0]) * (ofdm[1] // patch[1])
+    spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=2, model_dim=d, num_head=heads)
+    hid = (7, 42, 2 * tokens)
+    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, max_seq_len=32, seed=500 + tokens, attn_gain=0.5, head_gain=2.0)
+    cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(batch, ofdm=ofdm, pilot=pilot, seed=600 + batch)
+    meta = [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    out = eng.forward(_t(inp["pilots"]), *meta)
+    assert torch.equal(torch.view_as_real(eng.forward(_t(inp["pilots"]), *meta)), torch.view_as_real(out))
+    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], inp["snr"], inp["ds"], inp["dop"])
     assert np.abs(out.cpu().numpy() - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
 
 
@@ -321,9 +359,9 @@ def test_uncovered_configuration_is_refused_at_construction(monkeypatch):
     """One coverage predicate, asked at construction on the HIP device: a shape the reference accepts but
     the kernels do not cover raises a ValueError before any training, unless the caller opts
     into the PyTorch-ROCm composite."""
-    # head dim 16: accepted by the reference's schema, not by the kernels
+    # model_dim 96 (3 heads of 32): accepted by the reference's schema, not by the kernels
     sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
-    kw = dict(model_type="fortitran", patch_size=(3, 2), num_layers=2, model_dim=128, num_head=8)
+    kw = dict(model_type="fortitran", patch_size=(3, 2), num_layers=2, model_dim=96, num_head=3)
     assert A.FortiTranEstimator(sc, A.ModelConfig(device="cpu", **kw)) is not None      # CPU: the reference's own path
     monkeypatch.delenv("AFT_ALLOW_COMPOSITE", raising=False)
     with pytest.raises(ValueError, match="not covered by the gfx950 kernels"):
@@ -334,6 +372,41 @@ def test_uncovered_configuration_is_refused_at_construction(monkeypatch):
     with torch.no_grad():
         out = model(pil)
     assert out.shape == (2, 120, 14) and model._engine is None          # composite ran, no C-ABI engine
+
+
+@pytest.mark.parametrize("name", ["H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28"])
+def test_module_surface_with_other_head_dims_and_small_grids(name):
+    """`num_head: 8` at `model_dim: 128` (head dim 16), `num_head: 2` (head dim 64) and a 28-token grid through the MODULE, as the
+    reference's YAML would configure them: eval() runs the HIP engine (golden parity, CPU inputs), train() differentiates -- the
+    encoder through PyTorch-ROCm autograd there (the training kernels cover head dim 32 and >= 32 tokens), everything else through
+    the library -- and the gradients agree with the CPU composite."""
+    from test_estimators_cpu import _configs, golden_meta
+    g = Golden(name)
+    sc, mc = _configs(g.spec, device="cuda")
+    cls = A.AdaFortiTranEstimator if g.adaptive else A.FortiTranEstimator
+    model = cls(sc, mc)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()})
+    model.eval()
+    pil = torch.from_numpy(g["pilots"])
+    meta = golden_meta(g) if g.adaptive else None
+    with torch.no_grad():
+        out = model(pil, meta) if g.adaptive else model(pil)
+    assert model._engine is not None                                     # the C-ABI engine ran
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_HIP_OUT * np.abs(g["out"]).max()
+    # one training step on the GPU against the same step on the CPU composite
+    sc_c, mc_c = _configs(dict(g.spec, dropout=0.0), device="cpu")
+    sc_g, mc_g = _configs(dict(g.spec, dropout=0.0), device="cuda")
+    grads = []
+    for s_, m_, dev in ((sc_c, mc_c, "cpu"), (sc_g, mc_g, "cuda")):
+        mdl = cls(s_, m_)
+        mdl.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()})
+        mdl.train()
+        est = mdl(pil, meta) if g.adaptive else mdl(pil)
+        tgt = torch.from_numpy(g["target"]).to(dev)
+        torch.view_as_real(est - tgt).pow(2).mean().backward()
+        grads.append({n: p.grad.detach().cpu().numpy() for n, p in mdl.named_parameters()})
+    for n, ref in grads[0].items():
+        assert np.abs(grads[1][n] - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-12, n
 
 
 def test_stream_and_graph_semantics():
@@ -413,27 +486,29 @@ def test_linear_and_mse_kernels(oracle_lib):
 
 
 def _random_specs(n, seed):
-    """Random valid configurations: any grid the patch divides, >= 32 tokens, patches of <= 16 elements,
-    model_dim in {64, 128, 192, 256} (head dim 32), 1-3 layers, both activations / positional encodings."""
+    """Random valid configurations: any grid the patch divides (token counts from 1 to 512, below one MFMA tile included), patches of
+    <= 16 elements, model_dim in {64, 128, 192, 256} with head dim 16 / 32 / 64, 1-3 layers, both activations / positional encodings."""
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
         p0, p1 = int(rng.integers(1, 6)), int(rng.integers(1, 5))
         if p0 * p1 > 16:
             continue
-        gs, gt = int(rng.integers(4, 30)), int(rng.integers(2, 9))
-        if gs * gt < 32 or gs * gt > 512 or gs * p0 > 160 or gt * p1 > 28:
+        small = rng.integers(0, 4) == 0                                   # a quarter of the draws: fewer than 32 tokens
+        gs, gt = (int(rng.integers(1, 8)), int(rng.integers(1, 5))) if small else (int(rng.integers(4, 30)), int(rng.integers(2, 9)))
+        if (not small and gs * gt < 32) or (small and gs * gt >= 32) or gs * gt > 512 or gs * p0 > 160 or gt * p1 > 28:
             continue
         d = int(rng.choice([64, 128, 192, 256]))
+        hd = int(rng.choice([16, 32, 64]))
         ps, pt = int(rng.integers(2, 13)), int(rng.integers(1, 4))
         out.append(dict(ofdm=(gs * p0, gt * p1), pilot=(ps, pt), patch=(p0, p1), num_layers=int(rng.integers(1, 4)),
-                        model_dim=d, num_head=d // 32, activation=str(rng.choice(["gelu", "relu"])),
+                        model_dim=d, num_head=d // hd, activation=str(rng.choice(["gelu", "relu"])),
                         pos=str(rng.choice(["learnable", "sinusoidal"])), adaptive=bool(rng.integers(0, 2)),
                         batch=int(rng.integers(1, 6))))
     return out
 
 
-@pytest.mark.parametrize("spec", _random_specs(16, 2026), ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['model_dim']}{'a' if s['adaptive'] else 'f'}")
+@pytest.mark.parametrize("spec", _random_specs(28, 2026), ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['model_dim']}h{s['num_head']}{'a' if s['adaptive'] else 'f'}")
 def test_random_configurations_match_oracle(oracle_lib, spec):
     tokens = (spec["ofdm"][0] // spec["patch"][0]) * (spec["ofdm"][1] // spec["patch"][1])
     base = dict(ofdm=spec["ofdm"], pilot=spec["pilot"], patch=spec["patch"], num_layers=spec["num_layers"],

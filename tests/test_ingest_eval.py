@@ -163,6 +163,12 @@ def test_packed_loader_on_device_matches_host_and_raises_late():
     next(it)                                               # the bad batch was yielded; its counts are still in flight
     with pytest.raises(ValueError, match=r"Expected 24 pilot values, got 25 \(frame 2\)"):
         it.close()
+    # an exception from the consumer's own loop body propagates UNCHANGED (the pending count error does not replace it)
+    class Boom(Exception):
+        pass
+    with pytest.raises(Boom):
+        for _ in ingest.PackedLoader(broken, (12, 2), 8, device="cuda"):
+            raise Boom()
     # packs above max_pinned_bytes go through the pinned ring instead of pinning the whole pack: same batches
     ring = list(ingest.PackedLoader(packed, (12, 2), 8, device="cuda", max_pinned_bytes=0))
     for (ph, ih, mh), (pd, idv, md) in zip(host, ring):

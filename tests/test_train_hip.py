@@ -578,3 +578,79 @@ def test_grad_scaler_branch_of_the_reference_trainer():
     # Adam divides by sqrt(v): an element whose gradient is ~0 can step +-lr on fp32 noise, so the bound on any single
     # element is steps * lr; the bulk must agree closely
     assert float(diff.max()) <= 3.1e-3 and float(diff.median()) <= 1e-6 and float((diff > 1e-4).float().mean()) <= 0.01
+
+
+@pytest.mark.parametrize("p,batch", [(0.0, 8), (0.1, 8), (0.0, 128)])
+def test_fused_forward_chain_reproduces_the_launch_sequence_tape(monkeypatch, p, batch):
+    """the tight A/B that backs the training path's golden tolerances.  The fused row-local forward
+    (chain_fwd_train_kernel: out_proj + LN1 + FFN + LN2, tape written from its epilogues) against the launch sequence it
+    replaced (AFT_TRAIN_UNFUSED_FWD, read per call), same layer, same inputs, same dropout seed: the layer output and EVERY
+    tape tensor within 1e-6 of the tensor's max (5e-7 observed: Chan-merged vs two-pass LayerNorm partials, other
+    summation orders) -- the masks are the same function of (seed, row, column), so dropout changes nothing here."""
+    import ctypes as C
+    from adafortitran_amd import _lib
+    from adafortitran_amd.training import _layer_struct, layer_params
+    lib = _lib.load()
+    d, heads = 128, 4
+    cfg = _cfg(d, heads)
+    layer = _layer(d, heads, "gelu", p).train()
+    params = [q.detach().contiguous() for q in layer_params(layer)]
+    planes = 2 * batch
+    rows = planes * cfg.tokens
+    torch.manual_seed(2)
+    x = torch.randn(planes, cfg.tokens, d, device="cuda")
+    nt, nscr = lib.aft_encoder_tape_bytes(C.byref(cfg), batch), lib.aft_encoder_train_scratch_bytes(C.byref(cfg), batch)
+    w = _layer_struct(_abi.AftLayerWeights, params)
+    al = lambda n: (n + 63) // 64 * 64  # noqa: E731
+    layout = (("qkv", rows * 3 * d), ("attn", rows * d), ("lse", rows * heads), ("s1", rows * d), ("st1", rows * 2), ("x1", rows * d),
+              ("a", rows * 2 * d), ("hd", rows * 2 * d), ("s2", rows * d), ("st2", rows * 2))
+    res = {}
+    for mode in ("fused", "unfused"):
+        if mode == "unfused":
+            monkeypatch.setenv("AFT_TRAIN_UNFUSED_FWD", "1")
+        else:
+            monkeypatch.delenv("AFT_TRAIN_UNFUSED_FWD", raising=False)
+        tape = torch.zeros(nt, dtype=torch.uint8, device="cuda")
+        scr = torch.zeros(nscr, dtype=torch.uint8, device="cuda")
+        out = torch.empty_like(x)
+        _lib.check(lib.aft_encoder_layer_fwd_train_f32(C.byref(cfg), C.byref(w), x.data_ptr(), out.data_ptr(), tape.data_ptr(), nt,
+                                                       scr.data_ptr(), nscr, batch, p, 5, _lib.current_stream_ptr(x.device)))
+        torch.cuda.synchronize()
+        f, off, segs = tape.view(torch.float32), 0, {}
+        for name, n in layout:
+            segs[name] = f[off:off + n].clone()
+            off += al(n)
+        segs["out"] = out.view(-1).clone()
+        res[mode] = segs
+    monkeypatch.delenv("AFT_TRAIN_UNFUSED_FWD", raising=False)
+    for k in res["fused"]:
+        assert _rel(res["fused"][k], res["unfused"][k]) <= 1e-6, k
+
+
+@pytest.mark.parametrize("grid,planes,p", [((24, 14), 2, 0.0), ((120, 14), 2, 0.1), ((120, 14), 16, 0.1)])
+def test_fused_backward_chain_reproduces_the_launch_sequence_gradients(monkeypatch, grid, planes, p):
+    """... and the fused row-local backward (chain_bwd_kernel) against the five launches it replaced
+    (AFT_TRAIN_UNFUSED_BWD): dx and every parameter gradient within 2e-6 of the tensor's max, with and without dropout."""
+    from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
+    d, heads = 128, 4
+    cfg = _cfg(d, heads, grid)
+    layer = _layer(d, heads, "gelu", p).train()
+    torch.manual_seed(4)
+    x0 = torch.randn(planes, cfg.tokens, d, device="cuda")
+    gout = torch.randn_like(x0)
+
+    def run(unfused):
+        if unfused:
+            monkeypatch.setenv("AFT_TRAIN_UNFUSED_BWD", "1")
+        else:
+            monkeypatch.delenv("AFT_TRAIN_UNFUSED_BWD", raising=False)
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        out = HipEncoderLayerFunction.apply(x, cfg, p, 5, *layer_params(layer))
+        out.backward(gout)
+        return [x.grad.clone()] + [q.grad.clone() for q in layer_params(layer)]
+
+    fused, unfused = run(False), run(True)
+    monkeypatch.delenv("AFT_TRAIN_UNFUSED_BWD", raising=False)
+    for name, u, v in zip(["dx", *_abi.LAYER_PARAM_NAMES], fused, unfused):
+        assert _rel(u, v) <= 2e-6, name
