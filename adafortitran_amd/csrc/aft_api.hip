@@ -247,14 +247,15 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
                 workspace_bytes, ws.total_floats * sizeof(float));
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *base = static_cast<float *>(workspace);
-    // prologue: the channel adapter and -- unless the caller owns a packed image -- the re-lay of the encoder weights into
-    // fragment order, in ONE launch (neither depends on anything the forward computes)
+    // prologue: the channel adapter, -- unless the caller owns a packed image -- the re-lay of the encoder weights into fragment
+    // order, and the pilot_upsampler product over all planes, in ONE launch (none depends on anything the forward computes).
+    // The activation buffer x is idle until the first encoder launch: it lends the upsampler its plane scratch when it is large enough
     float *wpack = prepacked != nullptr ? nullptr : base + ws.wpack;
-    hipError_t e = launch_prologue(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, wpack, st);
-    if (e != hipSuccess) return hip_fail("prologue(adapter + pack_weights)", e);
-    // the activation buffer x is idle until the first encoder launch: it lends the upsampler its plane scratch when it is large enough
     const size_t x_floats = (size_t)ws.planes * ws.tokens * cfg->model_dim, up_floats = (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
-    e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr);
+    float *up_planes = x_floats >= up_floats && prologue_upsample_ok(*cfg, *w) ? base + ws.x : nullptr;
+    hipError_t e = launch_prologue(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, wpack, pilots, up_planes, st);
+    if (e != hipSuccess) return hip_fail("prologue(adapter + pack_weights + upsampler product)", e);
+    e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr, up_planes != nullptr);
     if (e != hipSuccess) return hip_fail("upsample", e);
     // patch embedding + linear_1 + positions run inside the first chain launch, linear_2 inside the last one
     rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st, true, prepacked != nullptr ? prepacked : wpack);
@@ -410,8 +411,11 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
         switch (which) {
             case AFT_KERNEL_UPSAMPLE:
                 AFT_REQUIRE(out != nullptr, "upsample profile needs the pilots pointer in `out`");
-                e = launch_upsample(*cfg, *w, out, base + ws.conv_enhanced, batch, st,   // as the forward: x lends the plane scratch
-                                    (size_t)ws.planes * ws.tokens * cfg->model_dim >= (size_t)ws.planes * cfg->num_scs * cfg->num_symbols ? x : nullptr);
+                // as the forward: the planes of the pilot_upsampler product lie in x (computed by the prologue launch in the forward;
+                // here whatever x holds -- the conv stack's time does not depend on its data)
+                e = launch_upsample(*cfg, *w, out, base + ws.conv_enhanced, batch, st,
+                                    (size_t)ws.planes * ws.tokens * cfg->model_dim >= (size_t)ws.planes * cfg->num_scs * cfg->num_symbols ? x : nullptr,
+                                    prologue_upsample_ok(*cfg, *w));
                 break;
             case AFT_KERNEL_EMBED:
                 e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, x, batch, st);

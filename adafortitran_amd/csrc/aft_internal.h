@@ -166,13 +166,16 @@ hipError_t ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, size_t by
 // ---- kernel launchers (each enqueues on `st`, returns hipError_t of the launch) ----
 // scratch_planes (optional, 2 B * S * T floats, free to overwrite): grids other than the default one compute the upsampler as one
 // product over all planes into it and the conv head reads the planes; NULL = inside the conv head
+// planes_ready: scratch_planes already holds the upsampled planes (the forward's prologue launch computed them)
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots,
-                           float *conv_enhanced, int batch, hipStream_t st, float *scratch_planes = nullptr);
+                           float *conv_enhanced, int batch, hipStream_t st, float *scratch_planes = nullptr, bool planes_ready = false);
 hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
                           const float *dop, float *tokens6, int batch, hipStream_t st);
-// Whole forward: adapter (if c.adaptive) and the weight re-pack (if packed != NULL, all layers) as ONE launch (k_misc.hip)
+// Whole forward: adapter (if c.adaptive), the weight re-pack (if packed != NULL, all layers) and the pilot_upsampler product over all
+// planes (if up_planes != NULL and prologue_upsample_ok: [2 batch][S*T] floats) as ONE launch (k_misc.hip)
+bool prologue_upsample_ok(const aft_config &c, const aft_weights &w);
 hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const float *snr, const float *ds, const float *dop,
-                           float *tokens6, int batch, float *packed, hipStream_t st);
+                           float *tokens6, int batch, float *packed, const float *pilots, float *up_planes, hipStream_t st);
 hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced,
                         const float *tokens6, float *x, int batch, hipStream_t st);
 // Row-local chain on [rows, d]: (mlp) x <- LN2(x1 + FFN(x1)), x1 = LN1(x + attn Wo^T + bo);

@@ -1,0 +1,116 @@
+// conv_device.h -- declarations shared by the two conv-stack kernels (k_conv.hip: banded, every grid, training;
+// k_conv_stream.hip: the default 120 x 14 grid as a column-streaming pipeline).
+#pragma once
+#include <cstdint>
+
+#include "aft_internal.h"
+
+namespace aft {
+
+struct ConvArgs {
+    int mode;  // 0 = head (pilots -> conv_enhanced), 1 = tail (x, conv_enhanced -> complex out), 2 = plain (training)
+    int S, T, SP, band_rows, nbands, ntiles, nseg, arena, extra;   // SP = LDS row-vector length (>= band_rows + 8)
+    int stream_ok;   // head: pf is a multiple of 8 and the streaming scratch fits the conv1 / conv3 planes
+    int xoff;   // inference: the seam exchange rows [(seam, side)][8 channels][SP] start here (floats; 0 = the dead input plane), -1 = overlapping sweeps
+    // head
+    const float *pilots, *up_w, *up_b;
+    int pf;
+    // tail
+    const float *x, *lin2_w, *lin2_b, *resid;
+    const float *lin2_out;   // tail: linear_2 already applied by the last chain launch, [rows][lin2_stride]; NULL = apply it here
+    int lin2_stride;
+    int d, tokens, p0, p1;
+    const float *cw[4], *cb[4];
+    float *out_plane;    // head / plain: [planes][S][T]
+    float *out_complex;  // tail: [B][S][T][2]
+    // training variant only (mode 2 = plain plane in, plain plane out):
+    const float *in_plane;   // [planes][S][T]
+    float *save[3];          // outputs of conv1 / conv2 / conv3 after their activation, [planes][C][T][S] (C = 8, 32, 8)
+    const float *mask[3];    // backward: activation of stage k = acc where mask[k] > 0 else 0 (instead of bias + ReLU)
+    unsigned long long *stamps;   // diagnostic build only (AFT_DIAG_STAMPS): per-workgroup s_memtime at the phase boundaries
+};
+
+#ifndef AFT_CONV_PIPE
+#define AFT_CONV_PIPE 1        // A/B knob: conv3(t) and conv2(t+1) as two interleaved MFMA chains
+#endif
+constexpr int kConvThreads = 512;
+constexpr int kConvWaves = kConvThreads / 64;
+constexpr int kTileRows = 30;   // valid conv3 rows per 32-lane tile
+constexpr int kW3Off = 72 * 33, kWStage = kW3Off + 96 * 33;   // LDS staging of the conv2 / conv3 weights (floats)
+
+// 32-bit-offset buffer accesses for the training variant's saved tensors (each < 2 GB)
+using ConvSrd = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ ConvSrd conv_srd(const float *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float conv_ld(ConvSrd r, unsigned idx) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4u, 0, 0));
+}
+__device__ __forceinline__ void conv_st(ConvSrd r, unsigned idx, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, idx * 4u, 0, 0);
+}
+
+__device__ __forceinline__ float lane_from_below(float v) {   // lane i <- lane i-1 (DPP wave_shr:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_from_above(float v) {   // lane i <- lane i+1 (DPP wave_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+
+constexpr int kUpPix = 64, kUpPlanes = 64;
+__device__ __forceinline__ void upsample_planes_body(float *ups, const float *__restrict__ up_w, const float *__restrict__ up_b,
+                                                     const float *__restrict__ pilots, float *__restrict__ planes_out, int npix,
+                                                     int pf, int nplanes, int bx, int by) {
+    const int wld = pf + 4;                       // row stride of the weight tile: 16-byte rows, conflict-free float4 reads
+    float *Ws = ups, *Ps = ups + kUpPix * wld;    // [64][pf + 4] | [64][pf]
+    const int tid = threadIdx.x, pix0 = bx * kUpPix, plane0 = by * kUpPlanes;
+    const int nq = pf >> 2;
+    for (int i = tid; i < kUpPix * nq; i += 256) {
+        const int r = i / nq, q = i - r * nq;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pix0 + r < npix) v = *reinterpret_cast<const f32x4 *>(up_w + (size_t)(pix0 + r) * pf + 4 * q);
+        *reinterpret_cast<f32x4 *>(Ws + r * wld + 4 * q) = v;
+    }
+    for (int i = tid; i < kUpPlanes * pf; i += 256) {
+        const int pl = i / pf, k = i - pl * pf, n = plane0 + pl;
+        Ps[i] = n < nplanes ? pilots[((size_t)(n >> 1) * pf + k) * 2 + (n & 1)] : 0.f;
+    }
+    __syncthreads();
+    const int px = tid & 63, g = tid >> 6;
+    const float b = pix0 + px < npix ? up_b[pix0 + px] : 0.f;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = b;
+    for (int q = 0; q < nq; ++q) {
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(Ws + px * wld + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 pv = *reinterpret_cast<const f32x4 *>(Ps + (g * 16 + i) * pf + 4 * q);   // wave-uniform address: broadcast
+            float v = acc[i];
+            v = fmaf(wv[0], pv[0], v);
+            v = fmaf(wv[1], pv[1], v);
+            v = fmaf(wv[2], pv[2], v);
+            v = fmaf(wv[3], pv[3], v);
+            acc[i] = v;
+        }
+    }
+    if (pix0 + px < npix) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = plane0 + g * 16 + i;
+            if (n < nplanes) planes_out[(size_t)n * npix + pix0 + px] = acc[i];
+        }
+    }
+}
+inline size_t upsample_planes_lds(int pf) { return sizeof(float) * ((size_t)kUpPix * (pf + 4) + (size_t)kUpPlanes * pf); }
+inline bool upsample_planes_ok(const float *up_w, int pf) {
+    return pf % 4 == 0 && upsample_planes_lds(pf) <= 48 * 1024 && (reinterpret_cast<uintptr_t>(up_w) & 15) == 0;
+}
+
+// k_conv_stream.hip: default grid, inference, head with pre-computed upsampled planes (a.in_plane) or tail on linear_2's output
+// (a.lin2_out); returns hipErrorNotSupported when the arguments need the banded kernel
+bool conv_stream_ok(const ConvArgs &a);
+hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st);
+
+}  // namespace aft

@@ -32,59 +32,9 @@
 #include <cstdlib>
 #include <vector>
 
-#include "aft_internal.h"
+#include "conv_device.h"
 
 namespace aft {
-
-struct ConvArgs {
-    int mode;  // 0 = head (pilots -> conv_enhanced), 1 = tail (x, conv_enhanced -> complex out), 2 = plain (training)
-    int S, T, SP, band_rows, nbands, ntiles, nseg, arena, extra;   // SP = LDS row-vector length (>= band_rows + 8)
-    int stream_ok;   // head: pf is a multiple of 8 and the streaming scratch fits the conv1 / conv3 planes
-    int xoff;   // inference: the seam exchange rows [(seam, side)][8 channels][SP] start here (floats; 0 = the dead input plane), -1 = overlapping sweeps
-    // head
-    const float *pilots, *up_w, *up_b;
-    int pf;
-    // tail
-    const float *x, *lin2_w, *lin2_b, *resid;
-    const float *lin2_out;   // tail: linear_2 already applied by the last chain launch, [rows][lin2_stride]; NULL = apply it here
-    int lin2_stride;
-    int d, tokens, p0, p1;
-    const float *cw[4], *cb[4];
-    float *out_plane;    // head / plain: [planes][S][T]
-    float *out_complex;  // tail: [B][S][T][2]
-    // training variant only (mode 2 = plain plane in, plain plane out):
-    const float *in_plane;   // [planes][S][T]
-    float *save[3];          // outputs of conv1 / conv2 / conv3 after their activation, [planes][C][T][S] (C = 8, 32, 8)
-    const float *mask[3];    // backward: activation of stage k = acc where mask[k] > 0 else 0 (instead of bias + ReLU)
-    unsigned long long *stamps;   // diagnostic build only (AFT_DIAG_STAMPS): per-workgroup s_memtime at the phase boundaries
-};
-
-#ifndef AFT_CONV_PIPE
-#define AFT_CONV_PIPE 1        // A/B knob: conv3(t) and conv2(t+1) as two interleaved MFMA chains
-#endif
-constexpr int kConvThreads = 512;
-constexpr int kConvWaves = kConvThreads / 64;
-constexpr int kTileRows = 30;   // valid conv3 rows per 32-lane tile
-constexpr int kW3Off = 72 * 33, kWStage = kW3Off + 96 * 33;   // LDS staging of the conv2 / conv3 weights (floats)
-
-// 32-bit-offset buffer accesses for the training variant's saved tensors (each < 2 GB)
-using ConvSrd = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ ConvSrd conv_srd(const float *p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ float conv_ld(ConvSrd r, unsigned idx) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4u, 0, 0));
-}
-__device__ __forceinline__ void conv_st(ConvSrd r, unsigned idx, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, idx * 4u, 0, 0);
-}
-
-__device__ __forceinline__ float lane_from_below(float v) {   // lane i <- lane i-1 (DPP wave_shr:1)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float lane_from_above(float v) {   // lane i <- lane i+1 (DPP wave_shl:1)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
 
 // TRAIN = false is the inference kernel.  TRAIN = true adds what the training path needs:
 // a plain-plane input mode, the stage outputs written to HBM (forward: the activations the backward
@@ -802,6 +752,9 @@ static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStre
         a.stream_ok = (a.pf % 8 == 0 && a.up_w && (reinterpret_cast<uintptr_t>(a.up_w) & 15) == 0 &&
                        (size_t)kConvWaves * 32 * (a.pf / 4 + 1) + a.SP <= (size_t)16 * (a.T + 2) * a.SP) ? 1 : 0;
     const bool fixed = a.S == 120 && a.T == 14 && a.SP == 128 && a.band_rows == 120 && a.nbands == 1 && a.ntiles == 4 && a.nseg == 2;
+    // default grid, inference, inputs as the whole forward provides them: the column-streaming pipeline (k_conv_stream.hip);
+    // AFT_CONV_BANDED=1 keeps the banded kernel (A/B runs)
+    if (!TRAIN && fixed && conv_stream_ok(a) && !getenv("AFT_CONV_BANDED")) return launch_conv_stream(a, planes, st);
     if (fixed) return launch_conv_geo<TRAIN, true>(a, planes, lds, st);
     return launch_conv_geo<TRAIN, false>(a, planes, lds, st);
 }
@@ -859,55 +812,15 @@ hipError_t launch_conv_train(const float *const w[4], const float *const b[4], c
 // up_w again -- config 5: 602 KB per workgroup, 385 MB per launch out of the L2s, 34 500 of its 147 000 cycles.
 // One workgroup = 64 pixels x 64 planes: the 64 rows of up_w (coalesced) and the 64 pilot vectors sit in LDS, thread
 // (pixel, plane group g) accumulates 16 planes; k runs 0 .. pf-1 in order with the bias first (the per-pixel loop's order).
-constexpr int kUpPix = 64, kUpPlanes = 64;
 __global__ __launch_bounds__(256) void upsample_planes_kernel(const float *__restrict__ up_w, const float *__restrict__ up_b,
                                                               const float *__restrict__ pilots, float *__restrict__ planes_out,
                                                               int npix, int pf, int nplanes) {
     extern __shared__ __attribute__((aligned(16))) float ups[];
-    const int wld = pf + 4;                       // row stride of the weight tile: 16-byte rows, conflict-free float4 reads
-    float *Ws = ups, *Ps = ups + kUpPix * wld;    // [64][pf + 4] | [64][pf]
-    const int tid = threadIdx.x, pix0 = blockIdx.x * kUpPix, plane0 = blockIdx.y * kUpPlanes;
-    const int nq = pf >> 2;
-    for (int i = tid; i < kUpPix * nq; i += 256) {
-        const int r = i / nq, q = i - r * nq;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pix0 + r < npix) v = *reinterpret_cast<const f32x4 *>(up_w + (size_t)(pix0 + r) * pf + 4 * q);
-        *reinterpret_cast<f32x4 *>(Ws + r * wld + 4 * q) = v;
-    }
-    for (int i = tid; i < kUpPlanes * pf; i += 256) {
-        const int pl = i / pf, k = i - pl * pf, n = plane0 + pl;
-        Ps[i] = n < nplanes ? pilots[((size_t)(n >> 1) * pf + k) * 2 + (n & 1)] : 0.f;
-    }
-    __syncthreads();
-    const int px = tid & 63, g = tid >> 6;
-    const float b = pix0 + px < npix ? up_b[pix0 + px] : 0.f;
-    float acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = b;
-    for (int q = 0; q < nq; ++q) {
-        const f32x4 wv = *reinterpret_cast<const f32x4 *>(Ws + px * wld + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const f32x4 pv = *reinterpret_cast<const f32x4 *>(Ps + (g * 16 + i) * pf + 4 * q);   // wave-uniform address: broadcast
-            float v = acc[i];
-            v = fmaf(wv[0], pv[0], v);
-            v = fmaf(wv[1], pv[1], v);
-            v = fmaf(wv[2], pv[2], v);
-            v = fmaf(wv[3], pv[3], v);
-            acc[i] = v;
-        }
-    }
-    if (pix0 + px < npix) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int n = plane0 + g * 16 + i;
-            if (n < nplanes) planes_out[(size_t)n * npix + pix0 + px] = acc[i];
-        }
-    }
+    upsample_planes_body(ups, up_w, up_b, pilots, planes_out, npix, pf, nplanes, blockIdx.x, blockIdx.y);
 }
 
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots, float *conv_enhanced,
-                           int batch, hipStream_t st, float *scratch_planes) {
+                           int batch, hipStream_t st, float *scratch_planes, bool planes_ready) {
     ConvArgs a{};
     a.mode = 0;
     a.S = c.num_scs; a.T = c.num_symbols;
@@ -916,14 +829,17 @@ hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const floa
     for (int i = 0; i < 4; ++i) { a.cw[i] = w.enh_w[i]; a.cb[i] = w.enh_b[i]; }
     a.out_plane = conv_enhanced;
     a.stream_ok = -1;   // decided by launch_conv once the band plan is known
-    const bool default_grid = c.num_scs == 120 && c.num_symbols == 14 && a.pf == 24;   // streams up_w inside the head (161 KB per workgroup)
-    const size_t up_lds = sizeof(float) * ((size_t)kUpPix * (a.pf + 4) + (size_t)kUpPlanes * a.pf);
-    if (scratch_planes && !default_grid && a.pf % 4 == 0 && up_lds <= 64 * 1024 && (reinterpret_cast<uintptr_t>(w.up_w) & 15) == 0) {
-        const int npix = c.num_scs * c.num_symbols, nplanes = 2 * batch;
-        hipLaunchKernelGGL(upsample_planes_kernel, dim3((npix + kUpPix - 1) / kUpPix, (nplanes + kUpPlanes - 1) / kUpPlanes), dim3(256), up_lds,
-                           st, w.up_w, w.up_b, pilots, scratch_planes, npix, a.pf, nplanes);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
+    // With a scratch buffer the pilot_upsampler is ONE product over all planes (up_w read once per launch) and the conv head reads
+    // the planes: in the forward that product rides in the prologue launch (planes_ready); here it is its own launch.  Without
+    // scratch (the per-stage entry point) the head streams up_w itself.
+    if (scratch_planes && upsample_planes_ok(w.up_w, a.pf)) {
+        if (!planes_ready) {
+            const int npix = c.num_scs * c.num_symbols, nplanes = 2 * batch;
+            hipLaunchKernelGGL(upsample_planes_kernel, dim3((npix + kUpPix - 1) / kUpPix, (nplanes + kUpPlanes - 1) / kUpPlanes), dim3(256),
+                               upsample_planes_lds(a.pf), st, w.up_w, w.up_b, pilots, scratch_planes, npix, a.pf, nplanes);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
         a.in_plane = scratch_planes;
     }
     return launch_conv<false>(a, 2 * batch, a.pf, st);

@@ -1,6 +1,9 @@
 // k_misc.hip -- the small VALU stages: channel adapter, patch embedding + linear_1 + positional
 // table, the LinearEstimator, and the MSE metric.  None of them is MFMA-shaped (K = 1..42, 12, 24).
+#include <algorithm>
+
 #include "aft_internal.h"
+#include "conv_device.h"
 #include "pack_device.h"
 
 namespace aft {
@@ -88,21 +91,34 @@ hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float
 struct PrologueArgs {
     AdapterArgs ad;
     float *packed;
-    int adapter_blocks, d, num_layers, split;
+    const float *pilots;       // upsampler product: planes[n][pix] = up_b[pix] + sum_k up_w[pix][k] pilot[n][k]
+    float *up_planes;
+    int adapter_blocks, pack_blocks, d, num_layers, split;
+    int up_bx, npix, pf, nplanes;
 };
 
 __global__ __launch_bounds__(256) void prologue_kernel(const aft_weights w, const PrologueArgs a) {
-    extern __shared__ float sm[];
-    const int blk = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    int blk = blockIdx.x;
     if (blk < a.adapter_blocks) {            // workgroup-uniform: the barriers inside are safe
         adapter_body(a.ad, blk / 3, blk % 3, sm);
         return;
     }
-    pack_weights_vec(w, a.packed, a.d, 0, a.num_layers, a.split, (size_t)(blk - a.adapter_blocks) * 256 + threadIdx.x);
+    blk -= a.adapter_blocks;
+    if (blk < a.pack_blocks) {
+        pack_weights_vec(w, a.packed, a.d, 0, a.num_layers, a.split, (size_t)blk * 256 + threadIdx.x);
+        return;
+    }
+    blk -= a.pack_blocks;
+    upsample_planes_body(sm, w.up_w, w.up_b, a.pilots, a.up_planes, a.npix, a.pf, a.nplanes, blk % a.up_bx, blk / a.up_bx);
+}
+
+bool prologue_upsample_ok(const aft_config &c, const aft_weights &w) {
+    return upsample_planes_ok(w.up_w, c.pilot_scs * c.pilot_symbols);
 }
 
 hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const float *snr, const float *ds, const float *dop,
-                           float *tokens6, int batch, float *packed, hipStream_t st) {
+                           float *tokens6, int batch, float *packed, const float *pilots, float *up_planes, hipStream_t st) {
     PrologueArgs a{};
     size_t lds = 0;
     if (c.adaptive) {
@@ -110,14 +126,22 @@ hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const floa
         a.adapter_blocks = 3 * batch;
         lds = sizeof(float) * (a.ad.h0 + a.ad.h1);
     }
-    unsigned pack_blocks = 0;
     if (packed != nullptr) {
         a.packed = packed; a.d = c.model_dim; a.num_layers = c.num_layers;
         a.split = c.precision == AFT_PRECISION_BF16X3 ? 1 : 0;
-        pack_blocks = (unsigned)((packed_layer_floats(c.model_dim) * c.num_layers / 4 + 255) / 256);
+        a.pack_blocks = (int)((packed_layer_floats(c.model_dim) * c.num_layers / 4 + 255) / 256);
     }
-    if (a.adapter_blocks + pack_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(prologue_kernel, dim3(a.adapter_blocks + pack_blocks), dim3(256), lds, st, w, a);
+    int up_blocks = 0;
+    if (up_planes != nullptr && prologue_upsample_ok(c, w)) {
+        a.pilots = pilots; a.up_planes = up_planes;
+        a.npix = c.num_scs * c.num_symbols; a.pf = c.pilot_scs * c.pilot_symbols; a.nplanes = 2 * batch;
+        a.up_bx = (a.npix + kUpPix - 1) / kUpPix;
+        up_blocks = a.up_bx * ((a.nplanes + kUpPlanes - 1) / kUpPlanes);
+        lds = std::max(lds, upsample_planes_lds(a.pf));
+    }
+    const int blocks = a.adapter_blocks + a.pack_blocks + up_blocks;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(prologue_kernel, dim3(blocks), dim3(256), lds, st, w, a);
     return hipGetLastError();
 }
 
