@@ -20,6 +20,9 @@
 // The head takes the upsampled planes from the forward's prologue launch (one product over all planes, up_w read once per launch
 // instead of 161 KB streamed through every CU's L1); callers without that scratch (the per-stage entry points) run the banded kernel.
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "conv_device.h"
 
@@ -52,6 +55,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int n = blockIdx.x, frame = n >> 1, part = n & 1;
     const bool matrix = wave < 4;
+#ifdef AFT_DIAG_STAMPS
+    // slots 0..7: matrix wave 0, 8..15: helper wave 4 (thread 256)
+#define SSTAMP(i) do { if (a.stamps && (tid == 0 || tid == 256)) a.stamps[(size_t)blockIdx.x * 16 + (tid ? 8 : 0) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+    SSTAMP(0);
 
     // ---- phase 0 (all waves): stage the conv2 / conv3 weights TRANSPOSED in the end of c3 (as k_conv.hip does in the arena:
     //      conflict-free gathers), the small tables, the flags ----
@@ -68,6 +78,56 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         if (tid >= 320 && tid < 336) flags[tid - 320] = 0;
     }
     __syncthreads();
+    SSTAMP(1);
+
+    // conv1: 1 -> 8, ReLU.  Thread = (local row lr = 32 rw + j, channel half h): 4 channels x 9 taps per column, the window slides
+    // over the columns [t0, t1).  The helper waves take columns 0..6 right behind their input pass, the matrix waves 7..13 once
+    // their fragments are gathered and the helpers have signalled the input plane.
+    auto conv1_columns = [&](int rw, int t0, int t1) {
+        const int lr = 32 * rw + j, gr = lr - 4;
+        const bool ok = lr >= 1 && lr < LR - 1 && gr >= 0 && gr < S;
+        float w[4][9], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int k9 = 0; k9 < 9; ++k9) w[k][k9] = w1s[(4 * h + k) * 9 + k9];
+            b[k] = w1s[72 + 4 * h + k];
+        }
+        const int r0 = max(lr - 1, 0), r2 = min(lr + 1, LR - 1);
+        float win[3][3];   // [ky][kx]
+#pragma unroll
+        for (int kx = 1; kx < 3; ++kx) {
+            win[0][kx] = in0[(t0 + kx - 1) * SP + r0];
+            win[1][kx] = in0[(t0 + kx - 1) * SP + lr];
+            win[2][kx] = in0[(t0 + kx - 1) * SP + r2];
+        }
+        float *dst = c1 + (4 * h) * kPlane + SP + lr;
+#pragma unroll
+        for (int u = 0; u < T / 2; ++u) {     // 7 columns per call, fully unrolled: the window slides by renaming
+            const int t = t0 + u;
+            if (t >= t1) break;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) { win[ky][0] = win[ky][1]; win[ky][1] = win[ky][2]; }
+            win[0][2] = in0[(t + 2) * SP + r0];
+            win[1][2] = in0[(t + 2) * SP + lr];
+            win[2][2] = in0[(t + 2) * SP + r2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float acc = b[k];
+#pragma unroll
+                for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[k9 / 3][k9 % 3], w[k][k9], acc);
+                dst[k * kPlane + t * SP] = ok ? fmaxf(acc, 0.f) : 0.f;
+            }
+        }
+    };
+    auto wait_count = [&](int slot, int count) {   // workgroup-scope hand-over through an LDS counter
+        while (flags[slot] < count) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto signal_count = [&](int slot) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(const_cast<int *>(flags + slot), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
     float wa2[36], wa3[48], bias3[4];
     if (matrix) {
@@ -87,8 +147,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias3[e] = a.cb[2][e + 4 * h];
+        wait_count(4, 4);                        // the helpers' input plane
+        conv1_columns(wave, T / 2, T);
     } else {
-        // ---- helper waves: borders, input plane, conv1 of every column ----
+        // ---- helper waves: borders, input plane, conv1 of the first columns ----
         const int ht = tid - 256;   // 0..255
         // zero padding of in0 and c1: LDS columns 0 and T + 1 (the symbol borders), and in0's rows outside the plane
         for (int i = ht; i < 9 * 2 * SP; i += 256) {
@@ -99,63 +161,36 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             const int t = i >> 3, q = i & 7;
             in0[(t + 1) * SP + (q < 4 ? q : 120 + q)] = 0.f;   // rows 0..3 and 124..127
         }
-        // input plane (one pixel per thread and pass, global reads coalesced)
-        for (int i = ht; i < S * T; i += 256) {
-            const int gr = i / T, t = i - gr * T;
-            float v;
-            if (MODE == 0) {
-                v = a.in_plane[(size_t)n * (S * T) + i];
-            } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
-                const int p0 = a.p0, p1 = a.p1, tpr = T / p1;
-                const int g = gr / p0, tc = t / p1, f = (gr - g * p0) * p1 + (t - tc * p1);
-                v = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] + a.resid[(size_t)n * (S * T) + i];
-            }
-            in0[(t + 1) * SP + gr + 4] = v;
-        }
-        // the four helper waves only: a named barrier would do; LDS ops of a workgroup are visible to it once complete, and the
-        // conv1 reads below need ALL helpers' input writes -> cross-wave hand-over through a counter flag
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(const_cast<int *>(flags + 4), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (flags[4] < 4) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // conv1: 1 -> 8, ReLU.  Thread = (local row lr, channel half): 4 channels x 9 taps per column, window slides over the columns
+        // input plane (one pixel per thread and pass, global reads coalesced; all 7 requests of a thread in flight together)
         {
-            const int lr = 32 * (wave - 4) + j, gr = lr - 4;
-            const bool ok = lr >= 1 && lr < LR - 1 && gr >= 0 && gr < S;
-            float w[4][9], b[4];
+            float v[7];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int k9 = 0; k9 < 9; ++k9) w[k][k9] = w1s[(4 * h + k) * 9 + k9];
-                b[k] = w1s[72 + 4 * h + k];
-            }
-            const int r0 = max(lr - 1, 0), r2 = min(lr + 1, LR - 1);
-            float win[3][3];   // [ky][kx]
-#pragma unroll
-            for (int kx = 1; kx < 3; ++kx) {
-                win[0][kx] = in0[(kx - 1) * SP + r0];
-                win[1][kx] = in0[(kx - 1) * SP + lr];
-                win[2][kx] = in0[(kx - 1) * SP + r2];
-            }
-            float *dst = c1 + (4 * h) * kPlane + SP + lr;
-#pragma unroll 2
-            for (int t = 0; t < T; ++t) {
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) { win[ky][0] = win[ky][1]; win[ky][1] = win[ky][2]; }
-                win[0][2] = in0[(t + 2) * SP + r0];
-                win[1][2] = in0[(t + 2) * SP + lr];
-                win[2][2] = in0[(t + 2) * SP + r2];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float acc = b[k];
-#pragma unroll
-                    for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[k9 / 3][k9 % 3], w[k][k9], acc);
-                    dst[k * kPlane + t * SP] = ok ? fmaxf(acc, 0.f) : 0.f;
+            for (int u = 0; u < 7; ++u) {
+                const int i = ht + 256 * u;
+                v[u] = 0.f;
+                if (i < S * T) {
+                    if (MODE == 0) {
+                        v[u] = a.in_plane[(size_t)n * (S * T) + i];
+                    } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
+                        const int gr = i / T, t = i - gr * T, p0 = a.p0, p1 = a.p1, tpr = T / p1;
+                        const int g = gr / p0, tc = t / p1, f = (gr - g * p0) * p1 + (t - tc * p1);
+                        v[u] = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] + a.resid[(size_t)n * (S * T) + i];
+                    }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int i = ht + 256 * u, gr = i / T, t = i - gr * T;
+                if (i < S * T) in0[(t + 1) * SP + gr + 4] = v[u];
+            }
         }
+        signal_count(4);
+        wait_count(4, 4);
+        conv1_columns(wave - 4, 0, T / 2);
     }
+    SSTAMP(2);
     __syncthreads();   // fragments gathered (the staging area is dead), c1 complete (in0 is dead: it becomes the output plane)
+    SSTAMP(3);
 
     if (matrix) {
         // ---- conv2 + conv3 on the matrix cores: row tile `wave`, columns 0 .. T-1 (k_conv.hip's pipelined sweep, one segment) ----
@@ -169,9 +204,14 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         f32x16 acc3;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
-        auto publish = [&](int columns_done) {   // conv3 output columns [0, columns_done) of this tile are in LDS
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // conv3 output columns [0, columns_done) of this tile are in LDS.  No s_waitcnt here: the LDS serves one wave's requests in
+        // issue order, so a reader that sees the flag finds the data stores before it already done; the compiler barrier keeps the
+        // flag store behind them in the instruction stream (a release fence would also drain this wave's pending operand reads:
+        // a stall of the MFMA chain at every column)
+        auto publish = [&](int columns_done) {
+            asm volatile("" ::: "memory");
             if (lane == 0) flags[wave] = columns_done;
+            asm volatile("" ::: "memory");
         };
         auto store_col = [&](int tout, float v0, float v1, float v2, float v3) {
             if (tout < 0 || tout >= T) return;
@@ -191,23 +231,25 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         float b[36];
 #pragma unroll
         for (int kb = 0; kb < 36; ++kb) b[kb] = b_at(kb, 0);
-        auto bias2_acc = [&]() {
-            f32x16 acc;
+        // conv2's bias in accumulator-register order, held in registers: every column's chain STARTS from it as the C operand of
+        // its first MFMA (no copy, no LDS wait at the column boundary)
+        f32x16 bias2v;
+        {
             const f32x4 *bp = reinterpret_cast<const f32x4 *>(bias2 + 16 * h);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = bp[q];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[4 * q + u] = v[u];
+                for (int u = 0; u < 4; ++u) bias2v[4 * q + u] = v[u];
             }
-            return acc;
-        };
+        }
         float x2[16];
         {   // prologue: conv2 of column 0
-            f32x16 acc2 = bias2_acc();
+            f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
+            b[0] = b_at(0, 1);
 #pragma unroll
-            for (int kb = 0; kb < 36; ++kb) {
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[kb], b[kb], acc2, 0, 0, 0);
+            for (int kb = 1; kb < 36; ++kb) {
+                acc2 = mfma_f32(wa2[kb], b[kb], acc2);
                 b[kb] = b_at(kb, 1);
             }
 #pragma unroll
@@ -217,7 +259,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             const int e = i & 15;
             const float xv = i < 16 ? x2[e] : (i < 32 ? lane_from_below(x2[e]) : lane_from_above(x2[e]));
             const int wi = i < 16 ? 16 + e : (i < 32 ? e : 32 + e);
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[wi], xv, acc3, 0, 0, 0);
+            acc3 = mfma_f32(wa3[wi], xv, acc3);
         };
         auto rotate = [&]() {
 #pragma unroll
@@ -227,25 +269,31 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
                 acc3[e] = 0.f;
             }
         };
+        constexpr int kLead = 4;   // conv2 MFMAs of the next column issued BEFORE the column hand-over (store + rotate wait for conv3's last MFMA)
 #pragma unroll 1
         for (int tcol = 0; tcol < T - 1; ++tcol) {
+            const int tnext = min(tcol + 2, T - 1);
+            f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
+            b[0] = b_at(0, tnext);
+#pragma unroll
+            for (int kb = 1; kb < kLead; ++kb) {
+                acc2 = mfma_f32(wa2[kb], b[kb], acc2);
+                b[kb] = b_at(kb, tnext);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             store_col(tcol - 2, acc3[8], acc3[9], acc3[10], acc3[11]);   // complete since the previous column's MFMAs
             rotate();
-            f32x16 acc2 = bias2_acc();
-            const int tnext = min(tcol + 2, T - 1);
-            // 48 conv3 MFMAs of column tcol interleaved with the 36 conv2 MFMAs of column tcol + 1 (4 : 3)
+            __builtin_amdgcn_sched_barrier(0);
+            // 48 conv3 MFMAs of column tcol interleaved with the remaining 32 conv2 MFMAs of column tcol + 1 (3 : 2)
 #pragma unroll
-            for (int g = 0; g < 12; ++g) {
-                conv3_step(4 * g);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[3 * g], b[3 * g], acc2, 0, 0, 0);
-                b[3 * g] = b_at(3 * g, tnext);
-                conv3_step(4 * g + 1);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[3 * g + 1], b[3 * g + 1], acc2, 0, 0, 0);
-                b[3 * g + 1] = b_at(3 * g + 1, tnext);
-                conv3_step(4 * g + 2);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[3 * g + 2], b[3 * g + 2], acc2, 0, 0, 0);
-                b[3 * g + 2] = b_at(3 * g + 2, tnext);
-                conv3_step(4 * g + 3);
+            for (int g = 0; g < 16; ++g) {
+                conv3_step(3 * g);
+                acc2 = mfma_f32(wa2[kLead + 2 * g], b[kLead + 2 * g], acc2);
+                b[kLead + 2 * g] = b_at(kLead + 2 * g, tnext);
+                conv3_step(3 * g + 1);
+                acc2 = mfma_f32(wa2[kLead + 2 * g + 1], b[kLead + 2 * g + 1], acc2);
+                b[kLead + 2 * g + 1] = b_at(kLead + 2 * g + 1, tnext);
+                conv3_step(3 * g + 2);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);
@@ -267,10 +315,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             const int pl = i / (2 * T), rem = i - pl * 2 * T, t = rem >> 1;
             c3[pl * kPlane + (t + 1) * SP + ((rem & 1) ? 124 : 3)] = 0.f;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(const_cast<int *>(flags + 5), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (flags[5] < 4) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        signal_count(5);
+        wait_count(5, 4);
         // thread = (local row lr, input-channel half): 4 channels x 9 taps, the halves meet through one lane swap
         const int lr = 32 * (wave - 4) + j;
         const bool okrow = lr >= 4 && lr < 4 + S;
@@ -291,8 +337,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         int have = 0;        // conv3 columns known to be published by all four matrix waves
         auto need = [&](int columns) {
             if (have >= columns) return;
-            for (;;) {
-                const int m = min(min(flags[0], flags[1]), min(flags[2], flags[3]));
+            for (;;) {   // one 16-byte LDS read per poll, a long sleep between polls: a polling wave costs its SIMD's matrix wave issue slots
+                using i32x4 = __attribute__((ext_vector_type(4))) int;
+                const i32x4 f = *reinterpret_cast<const volatile i32x4 *>(flags);
+                const int m = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (m >= columns) { have = m; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -315,9 +363,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) win[c][ky][1] = win[c][ky][2];
         load_col(1);
-#pragma unroll 1
-        for (int t = 0; t < T; ++t) {
-            need(min(t + 2, T));             // symbol t + 1 (LDS column t + 2; the last one is the zero border)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {        // fully unrolled: the window slides by renaming, no register moves
+            need(t + 2 < T ? t + 2 : T);     // symbol t + 1 (LDS column t + 2; the last one is the zero border)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -332,7 +380,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             if (h == 0 && okrow) obuf[(lr - 4) * T + t] = acc + b4;
         }
     }
+    SSTAMP(4);
     __syncthreads();
+    SSTAMP(5);
     // ---- the output plane leaves in one coalesced pass ----
     {
         const float *obuf = in0;
@@ -345,6 +395,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             for (int i = tid; i < S * T; i += kConvThreads) dst[2 * i] = obuf[i];
         }
     }
+    SSTAMP(6);
+#undef SSTAMP
 }
 
 bool conv_stream_ok(const ConvArgs &a) {
@@ -357,15 +409,41 @@ bool conv_stream_ok(const ConvArgs &a) {
 hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     if (!conv_stream_ok(a)) return hipErrorNotSupported;
     static PerDeviceOnce lds_head, lds_tail;
-    if (a.mode == 0) {
-        hipError_t e = ensure_dynamic_lds(lds_head, reinterpret_cast<const void *>(conv_stream_kernel<0>), kStreamLds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
-    } else {
-        hipError_t e = ensure_dynamic_lds(lds_tail, reinterpret_cast<const void *>(conv_stream_kernel<1>), kStreamLds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((conv_stream_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+    hipError_t e = a.mode == 0 ? ensure_dynamic_lds(lds_head, reinterpret_cast<const void *>(conv_stream_kernel<0>), kStreamLds)
+                               : ensure_dynamic_lds(lds_tail, reinterpret_cast<const void *>(conv_stream_kernel<1>), kStreamLds);
+    if (e != hipSuccess) return e;
+#ifdef AFT_DIAG_STAMPS
+    static unsigned long long *dbuf = nullptr;
+    const bool stamp = getenv("AFT_STAMPS") != nullptr && planes <= 4096;
+    if (stamp) {
+        if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 4096);
+        (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
+        a.stamps = dbuf;
     }
+#endif
+    if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+    else hipLaunchKernelGGL((conv_stream_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+#ifdef AFT_DIAG_STAMPS
+    if (stamp) {
+        (void)hipDeviceSynchronize();
+        static int printed = 0;
+        if (printed++ < 4) {
+            std::vector<unsigned long long> hb(16 * (size_t)planes);
+            (void)hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
+            double m[7] = {0}, hsum[7] = {0};
+            for (int b = 0; b < planes; ++b)
+                for (int i = 1; i < 7; ++i) {
+                    m[i] += (double)(hb[(size_t)b * 16 + i] - hb[(size_t)b * 16 + i - 1]);
+                    hsum[i] += (double)(hb[(size_t)b * 16 + 8 + i] - hb[(size_t)b * 16 + 8 + i - 1]);
+                }
+            printf("conv stream mode %d (mean cycles): matrix wave: stage=%.0f gather=%.0f wait=%.0f sweeps=%.0f wait=%.0f store=%.0f | "
+                   "helper wave: stage=%.0f zero+input+conv1=%.0f wait=%.0f conv4=%.0f wait=%.0f store=%.0f\n", a.mode, m[1] / planes,
+                   m[2] / planes, m[3] / planes, m[4] / planes, m[5] / planes, m[6] / planes, hsum[1] / planes, hsum[2] / planes,
+                   hsum[3] / planes, hsum[4] / planes, hsum[5] / planes, hsum[6] / planes);
+        }
+        a.stamps = nullptr;
+    }
+#endif
     return hipGetLastError();
 }
 

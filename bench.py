@@ -81,9 +81,11 @@ def algorithmic_flops(c, batch):
     pin = p0 * p1 + (6 if c["hidden"] else 0)
     emb, lin2 = 2 * rows * d * pin, 2 * rows * d * p0 * p1
     # the first chain launch also does patch embedding + linear_1, the last one linear_2 (fused since round 2)
-    fl = {"qkv": qkv + emb, "chain": proj + ffn + qkv, "chain_last": proj + ffn + lin2, "attention": attn, "upsample": conv + up,
+    # the pilot_upsampler product (`up`, 0.5 % of the stage's FLOPs) runs in the forward's prologue launch since round 4 (one product over
+    # all planes): the conv-head launch that the "upsample" class times is the initial ConvEnhancer alone
+    fl = {"qkv": qkv + emb, "chain": proj + ffn + qkv, "chain_last": proj + ffn + lin2, "attention": attn, "upsample": conv,
           "tail": conv, "encoder_total": L * (qkv + proj + ffn + attn)}
-    fl["forward_total"] = fl["upsample"] + emb + fl["encoder_total"] + lin2 + fl["tail"]
+    fl["forward_total"] = fl["upsample"] + up + emb + fl["encoder_total"] + lin2 + fl["tail"]
     return fl
 
 
