@@ -81,3 +81,29 @@ def test_max_batch_is_the_32_bit_offset_limit_of_the_largest_region():
         assert rc == _abi.AFT_ERR_ARG and b"aft_max_batch" in lib.aft_last_error()
     bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3), adaptive_hidden=None)
     assert lib.aft_max_batch(ctypes.byref(bad)) == 0 and lib.aft_packed_weights_bytes(ctypes.byref(bad)) == 0
+
+
+def test_hot_kernels_compile_without_register_spills():
+    """hipcc's own resource report for the two hot kernels that have tripped before (an innocent-looking extra instantiation of the
+    attention body's steady-state step spilled 150 VGPRs and cost 33 % of the kernel's speed, round 4): the tuned head-dim-32
+    attention kernel and both column-streaming conv kernels must not spill a single vector register; the head-dim-64 attention
+    instantiation (two blocks of q / k / v^T, two accumulators, 256 VGPRs) may spill at most a couple."""
+    import re
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adafortitran_amd", "csrc")
+    report = {}
+    for src in ("k_attn.hip", "k_conv_stream.hip"):
+        res = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/dev/null",
+                              "-Rpass-analysis=kernel-resource-usage"], cwd=csrc, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        name = None
+        for line in res.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"VGPRs Spill: (\d+)", line)
+            if m and name:
+                report[name] = int(m.group(1))
+    spills = {k: v for k, v in report.items() if "attn_kernelILi32E" in k or "attn_kernelILi16E" in k or "conv_stream_kernel" in k}
+    assert len(spills) == 4 and all(v == 0 for v in spills.values()), report
+    assert all(v <= 4 for k, v in report.items() if "attn_kernelILi64E" in k), report
