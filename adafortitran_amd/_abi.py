@@ -145,4 +145,4 @@ EXPORTED_SYMBOLS = (
 #: size queries (return size_t, not a status code)
 SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_packed_weights_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
                 "aft_conv_enhancer_scratch_bytes", "aft_dense_bwd_scratch_bytes")
-KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6, "encoder_plane": 7}
+KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6, "encoder_plane": 7, "prologue": 8}

@@ -450,6 +450,14 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                                          cfg->adaptive ? base + ws.tokens6 : nullptr, x, attn, q, k, vt, base + ws.out6,
                                          ws.planes, ws.tokens, ws.tokpad, st);
                 break;
+            case AFT_KERNEL_PROLOGUE: {
+                AFT_REQUIRE(out != nullptr, "prologue profile needs the pilots pointer in `out`");
+                const bool lend = (size_t)ws.planes * ws.tokens * cfg->model_dim >= (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
+                const float *cond = out + (size_t)batch * cfg->pilot_scs * cfg->pilot_symbols * 2;   // [snr | ds | dop] behind the pilots
+                e = launch_prologue(*cfg, *w, cond, cond + batch, cond + 2 * batch, base + ws.tokens6, batch, base + ws.wpack, out,
+                                    lend && prologue_upsample_ok(*cfg, *w) ? x : nullptr, st);
+                break;
+            }
             case AFT_KERNEL_TAIL:
                 AFT_REQUIRE(out != nullptr, "tail profile needs an output buffer");
                 e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6);

@@ -306,6 +306,8 @@ int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float 
 #define AFT_KERNEL_TAIL 5       /* fold + residual + final ConvEnhancer (linear_2 done by AFT_KERNEL_CHAIN_LAST) */
 #define AFT_KERNEL_CHAIN_LAST 6 /* chain kernel of the last layer: out-proj+LN1+FFN+LN2 + linear_2             */
 #define AFT_KERNEL_ENCODER_PLANE 7 /* plane-resident encoder: embedding + all layers + linear_2 in one launch (k_encoder.hip) */
+#define AFT_KERNEL_PROLOGUE 8   /* the forward's first launch: channel adapter + weight re-lay + pilot_upsampler product; `out` = one
+                                   buffer [pilots: batch x Ps x Pt x 2 floats | snr: batch | ds: batch | dop: batch]        */
 int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int which, float *out,
                            void *workspace, size_t workspace_bytes, int batch, int reps, void *stream);
 

@@ -7,7 +7,7 @@
 #  3. kernel trace of one training step
 # Summaries land in gpurun_out/<tag>/ ; tools/update_profiles.py copies the ones to keep into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -26,6 +26,7 @@ pmc chain chain
 pmc attention attn
 pmc upsample conv_head
 pmc tail conv_tail
+AFT_FWD=6 pmc none prologue     # the forwards' prologue launches (adapter + weight re-lay + upsampler product)
 # training step: kernel trace of the HIP path + the A/B line against PyTorch-ROCm autograd
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_trace" -- python3 "$REPO/tools/train_bench.py" --only hip --steps 10 --warmup 3 > "$OUT/train_trace.log" 2>&1
 python3 "$REPO/tools/train_bench.py" --steps 20 --warmup 5 2>/dev/null | grep "^{" | tail -1 > "$OUT/train_bench_line.json"
@@ -34,7 +35,7 @@ python3 tools/train_step_breakdown.py "$OUT/train_trace" > "$OUT/train_kernel_tr
 python3 tools/summarize_prof.py "$OUT/bench_trace" > "$OUT/kernel_trace_summary.txt" 2>&1
 python3 tools/summarize_prof.py "$OUT/plane_trace" > "$OUT/plane_kernel_trace_summary.txt" 2>&1
 python3 tools/summarize_prof.py "$OUT/split_trace" > "$OUT/split_kernel_trace_summary.txt" 2>&1
-python3 tools/summarize_prof.py "$OUT"/pmc_chain_* "$OUT"/pmc_attn_* "$OUT"/pmc_conv_head_* "$OUT"/pmc_conv_tail_* > "$OUT/pmc_summary.txt" 2>&1
+python3 tools/summarize_prof.py "$OUT"/pmc_chain_* "$OUT"/pmc_attn_* "$OUT"/pmc_conv_head_* "$OUT"/pmc_conv_tail_* "$OUT"/pmc_prologue_* > "$OUT/pmc_summary.txt" 2>&1
 cp "$OUT"/bench_trace/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
 find "$OUT" -name "*.csv" -size +1M -delete
 grep -h "^{\"metric\"" "$OUT/bench_trace.log" | tail -1 > "$OUT/bench_under_rocprof.json"
