@@ -399,413 +399,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 #undef SSTAMP
 }
 
-// =====================================================================================================================================
-// conv_pair_kernel -- second schedule of the same pipeline (round 4, late): TWO matrix waves per SIMD again, without giving the serial
-// phases back.  conv_stream_kernel's single matrix wave per SIMD keeps its pipe 0.84 busy at best; here a row tile is
-// served by a PAIR of waves on the same SIMD:
-//   wave w + 4  "conv2 wave"  conv1's planes -> 36 MFMAs per column -> ReLU -> the 32-channel column tile into an LDS ring (2 slots);
-//                             in the issue slots its shorter chain leaves, conv4 of finished columns (non-blocking: only when conv3's
-//                             columns are published), into the LDS output plane;
-//   wave w      "conv3 wave"  48 MFMAs per column whose B operands come straight from that ring -- the ky = -1 / +1 taps are LDS row
-//                             offsets, so the 32 DPP moves per column of the other kernels are gone -- and the three output columns in
-//                             flight; conv3's output lives in a 4-column ring (conv4 needs three).
-// LDS: in0 8 KB + conv1 planes 64 KB + conv3 ring 16 KB + four pair rings 34 KB + tables = 126 KB.  Hand-over by LDS flags only
-// (x2_ready / x2_done per pair, c3_done per conv3 wave, conv4_done per conv2 wave); nobody blocks on a flag whose setter can be waiting
-// for him: a conv2 wave that waits for a free ring slot keeps doing conv4 columns, which is what the conv3 waves may be waiting for.
-// =====================================================================================================================================
-namespace {
-constexpr int kXR = 34;                                   // rows of a pair-ring channel: 32 + one halo row each side
-constexpr int kX2Slot = 32 * kXR, kX2Tile = 2 * kX2Slot;  // floats per ring slot / per pair
-constexpr int kP_C3R = 9 * kPlane;                        // conv3 ring [8 ch][4 slots][SP]
-constexpr int kP_X2 = kP_C3R + 8 * 4 * SP;                // pair rings; the conv2 / conv3 weights are staged here first
-constexpr int kP_Tab = kP_X2 + 4 * kX2Tile;
-constexpr int kP_Bias2 = kP_Tab, kP_W1 = kP_Bias2 + 32, kP_W4 = kP_W1 + 80, kP_Flags = kP_W4 + 80, kPairFloats = kP_Flags + 32;
-constexpr size_t kPairLds = sizeof(float) * kPairFloats;
-static_assert(4 * kX2Tile >= kWStage, "the weight staging area lives in the pair rings");
-}  // namespace
-
-template <int MODE>
-__global__ __launch_bounds__(kConvThreads) void conv_pair_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *in0 = smem + kIn0, *c1 = smem + kC1, *c3r = smem + kP_C3R;
-    float *bias2 = smem + kP_Bias2, *w1s = smem + kP_W1, *w4s = smem + kP_W4;
-    volatile int *flags = reinterpret_cast<volatile int *>(smem + kP_Flags);
-    // flags: [0..3] c3_done (conv3 wave w: output columns in the ring)   [4] input counter   [5] border counter
-    //        [8..11] x2_ready (pair w: conv2 columns published)   [12..15] x2_done (pair w: columns consumed)   [16..19] conv4_done
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x, frame = n >> 1, part = n & 1;
-    const bool is3 = wave < 4;
-    const int w = wave & 3;                                   // row tile of the pair
-#ifdef AFT_DIAG_STAMPS
-#define PSTAMP(i) do { if (a.stamps && (tid == 0 || tid == 256)) a.stamps[(size_t)blockIdx.x * 16 + (tid ? 8 : 0) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PSTAMP(i) do { } while (0)
-#endif
-    PSTAMP(0);
-    {
-        float *stage = smem + kP_X2;
-        for (int i = tid; i < 2304; i += kConvThreads) {
-            stage[(i % 72) * 33 + i / 72] = a.cw[1][i];
-            const int rem = i % 288;   // conv3.weight [co 8][ci 32][ky 3][kx 3]
-            stage[kW3Off + (rem / 3) * 33 + (rem % 3) * 8 + i / 288] = a.cw[2][i];
-        }
-        if (tid < 32) bias2[tid] = a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
-        if (tid >= 64 && tid < 144) w1s[tid - 64] = tid < 136 ? a.cw[0][tid - 64] : a.cb[0][tid - 136];
-        if (tid >= 192 && tid < 265) w4s[tid - 192] = tid < 264 ? a.cw[3][tid - 192] : a.cb[3][0];
-        if (tid >= 320 && tid < 352) flags[tid - 320] = 0;
-    }
-    __syncthreads();
-    PSTAMP(1);
-
-    auto conv1_columns = [&](int rw, int t0, int t1) {       // as in conv_stream_kernel
-        const int lr = 32 * rw + j, gr = lr - 4;
-        const bool ok = lr >= 1 && lr < LR - 1 && gr >= 0 && gr < S;
-        float wk[4][9], b[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int k9 = 0; k9 < 9; ++k9) wk[k][k9] = w1s[(4 * h + k) * 9 + k9];
-            b[k] = w1s[72 + 4 * h + k];
-        }
-        const int r0 = max(lr - 1, 0), r2 = min(lr + 1, LR - 1);
-        float win[3][3];   // [ky][kx]
-#pragma unroll
-        for (int kx = 1; kx < 3; ++kx) {
-            win[0][kx] = in0[(t0 + kx - 1) * SP + r0];
-            win[1][kx] = in0[(t0 + kx - 1) * SP + lr];
-            win[2][kx] = in0[(t0 + kx - 1) * SP + r2];
-        }
-        float *dst = c1 + (4 * h) * kPlane + SP + lr;
-#pragma unroll
-        for (int u = 0; u < T / 2; ++u) {
-            const int t = t0 + u;
-            if (t >= t1) break;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) { win[ky][0] = win[ky][1]; win[ky][1] = win[ky][2]; }
-            win[0][2] = in0[(t + 2) * SP + r0];
-            win[1][2] = in0[(t + 2) * SP + lr];
-            win[2][2] = in0[(t + 2) * SP + r2];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float acc = b[k];
-#pragma unroll
-                for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[k9 / 3][k9 % 3], wk[k][k9], acc);
-                dst[k * kPlane + t * SP] = ok ? fmaxf(acc, 0.f) : 0.f;
-            }
-        }
-    };
-    auto wait_count = [&](int slot, int count) {
-        while (flags[slot] < count) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    auto signal_count = [&](int slot) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(const_cast<int *>(flags + slot), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto set_flag = [&](int slot, int value) {               // in-order LDS: no wait needed before a flag store (see conv_stream_kernel)
-        asm volatile("" ::: "memory");
-        if (lane == 0) flags[slot] = value;
-        asm volatile("" ::: "memory");
-    };
-    using i32x4 = __attribute__((ext_vector_type(4))) int;
-    auto min4 = [&](int first) {
-        const i32x4 f = *reinterpret_cast<const volatile i32x4 *>(flags + first);
-        return min(min(f[0], f[1]), min(f[2], f[3]));
-    };
-
-    const int r = 4 + kTileRows * w - 1 + j;                 // this lane's local row in the matrix phase
-    const int gr = r - 4;
-    const bool ok2 = gr >= 0 && gr < S;
-    float *x2w = smem + kP_X2 + w * kX2Tile;                 // the pair's ring
-
-    if (is3) {
-        // ================= conv3 wave =================
-        float wa3[48], bias3[4];
-        {
-            const float *stage = smem + kP_X2;
-            const int kx3 = min(j >> 3, 2), co3 = j & 7;     // row j = (kx, co); rows 24..31 are padding
-            const float keep = j < 24 ? 1.f : 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 48; ++kb) {
-                const int ky = kb >> 4, e = kb & 15, ci = (e & 3) + 8 * (e >> 2) + 4 * h;
-                wa3[kb] = keep * stage[kW3Off + (ci * 3 + ky) * 33 + kx3 * 8 + co3];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bias3[e] = a.cb[2][e + 4 * h];
-        }
-        wait_count(4, 4);
-        conv1_columns(w, T / 2, T);
-        PSTAMP(2);
-        __syncthreads();
-        PSTAMP(3);
-        const bool ok3 = ok2 && j >= 1 && j <= kTileRows && r < LR - 3;
-        float *dst = c3r + (4 * h) * (4 * SP) + r;           // + k * 4 SP + slot * SP
-        const float *xsrc = x2w + (4 * h) * kXR + j;          // + slot * kX2Slot + ((e&3) + 8(e>>2)) * kXR + (0 | 1 | 2 = row below | same | above)
-        f32x16 acc3;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
-        int c4seen = 0;
-#ifdef AFT_DIAG_STAMPS
-        unsigned long long waited = 0;
-#endif
-        auto store_col = [&](int tout, float v0, float v1, float v2, float v3) {
-            if (tout < 0 || tout >= T) return;
-            if (tout >= 4 && c4seen < tout - 4) {             // the ring slot still holds column tout - 4: conv4 must have taken it
-                for (;;) {
-                    c4seen = min4(16);
-                    if (c4seen >= tout - 4) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            if (ok3) {
-                float *p = dst + (tout & 3) * SP;
-                p[0] = fmaxf(v0 + bias3[0], 0.f);
-                p[4 * SP] = fmaxf(v1 + bias3[1], 0.f);
-                p[8 * SP] = fmaxf(v2 + bias3[2], 0.f);
-                p[12 * SP] = fmaxf(v3 + bias3[3], 0.f);
-            }
-            set_flag(w, tout + 1);
-        };
-        constexpr int kAhead = 8;                              // operand reads in flight ahead of their MFMA
-#pragma unroll 1
-        for (int c = 0; c < T; ++c) {
-            if (flags[8 + w] < c + 1) {
-#ifdef AFT_DIAG_STAMPS
-                const unsigned long long t0w = __builtin_amdgcn_s_memtime();
-#endif
-                while (flags[8 + w] < c + 1) __builtin_amdgcn_s_sleep(1);
-#ifdef AFT_DIAG_STAMPS
-                waited += __builtin_amdgcn_s_memtime() - t0w;
-#endif
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const float *xs = xsrc + (c & 1) * kX2Slot;
-            auto operand = [&](int i) {                        // MFMA i of the column: ky = centre (0..15), below (16..31), above (32..47)
-                const int e = i & 15;
-                return xs[((e & 3) + 8 * (e >> 2)) * kXR + (i < 16 ? 1 : (i < 32 ? 0 : 2))];
-            };
-            float xr[kAhead];
-#pragma unroll
-            for (int i = 0; i < kAhead; ++i) xr[i] = operand(i);
-            store_col(c - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc3[8 + e] = acc3[4 + e];
-                acc3[4 + e] = acc3[e];
-                acc3[e] = 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 48; ++i) {
-                const int e = i & 15;
-                const int wi = i < 16 ? 16 + e : (i < 32 ? e : 32 + e);
-                acc3 = mfma_f32(wa3[wi], xr[i % kAhead], acc3);
-                if (i + kAhead < 48) xr[i % kAhead] = operand(i + kAhead);
-            }
-            set_flag(12 + w, c + 1);                           // every operand read of this column has been ISSUED before this store: LDS order
-        }
-        store_col(T - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
-        store_col(T - 1, acc3[4], acc3[5], acc3[6], acc3[7]);
-#ifdef AFT_DIAG_STAMPS
-        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + 7] = waited;
-#endif
-    } else {
-        // ================= conv2 wave (+ borders, input plane, conv4) =================
-        const int ht = tid - 256;
-        for (int i = ht; i < 9 * 2 * SP; i += 256) {          // zero padding of in0 and c1: LDS columns 0 and T + 1
-            const int pl = i / (2 * SP), rem = i - pl * 2 * SP, col = rem < SP ? 0 : T + 1, row = rem & (SP - 1);
-            smem[pl * kPlane + col * SP + row] = 0.f;
-        }
-        for (int i = ht; i < T * 8; i += 256) {
-            const int t = i >> 3, q = i & 7;
-            in0[(t + 1) * SP + (q < 4 ? q : 120 + q)] = 0.f;   // rows 0..3 and 124..127
-        }
-        if (ht < 8 * 4 * 2) {                                  // conv3 ring: plane rows -1 and S (local 3 and 124) are never stored
-            const int ch = ht >> 3, slot = (ht >> 1) & 3;
-            c3r[ch * (4 * SP) + slot * SP + ((ht & 1) ? 124 : 3)] = 0.f;
-        }
-        {
-            float v[7];
-#pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                const int i = ht + 256 * u;
-                v[u] = 0.f;
-                if (i < S * T) {
-                    if (MODE == 0) {
-                        v[u] = a.in_plane[(size_t)n * (S * T) + i];
-                    } else {
-                        const int gri = i / T, t = i - gri * T, p0 = a.p0, p1 = a.p1, tpr = T / p1;
-                        const int g = gri / p0, tc = t / p1, f = (gri - g * p0) * p1 + (t - tc * p1);
-                        v[u] = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] + a.resid[(size_t)n * (S * T) + i];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                const int i = ht + 256 * u, gri = i / T, t = i - gri * T;
-                if (i < S * T) in0[(t + 1) * SP + gri + 4] = v[u];
-            }
-        }
-        signal_count(4);
-        float wa2[36];
-        {
-            const float *stage = smem + kP_X2;
-#pragma unroll
-            for (int kb = 0; kb < 36; ++kb) {
-                const int tap = kb >> 2, kx = tap / 3, ky = tap % 3, ci = 4 * h + (kb & 3);
-                wa2[kb] = stage[(ci * 9 + ky * 3 + kx) * 33 + j];
-            }
-        }
-        wait_count(4, 4);
-        conv1_columns(w, 0, T / 2);
-        PSTAMP(2);
-        __syncthreads();
-        PSTAMP(3);
-        // ---- conv4 state: thread = (local row lr, input-channel half h) ----
-        const int lr = 32 * w + j;
-        const bool okrow = lr >= 4 && lr < 4 + S;
-        const int q0 = max(lr - 1, 0), q2 = min(lr + 1, LR - 1);
-        float w4[4][9];
-#pragma unroll
-        for (int cch = 0; cch < 4; ++cch)
-#pragma unroll
-            for (int k9 = 0; k9 < 9; ++k9) w4[cch][k9] = w4s[(4 * h + cch) * 9 + k9];
-        const float b4 = w4s[72];
-        const float *c3src = c3r + (4 * h) * (4 * SP);
-        float win[4][3][3];                                    // [channel][ky][kx]: columns c4 - 1, c4, c4 + 1
-#pragma unroll
-        for (int cch = 0; cch < 4; ++cch)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) win[cch][ky][0] = win[cch][ky][1] = win[cch][ky][2] = 0.f;
-        float *obuf = in0;
-        int c4 = 0, have = 0;
-        auto load_col = [&](int col) {                         // window column kx = 2 <- symbol `col` (zero outside the plane)
-            if (col < T) {
-#pragma unroll
-                for (int cch = 0; cch < 4; ++cch) {
-                    const float *p = c3src + cch * (4 * SP) + (col & 3) * SP;
-                    win[cch][0][2] = p[q0];
-                    win[cch][1][2] = p[lr];
-                    win[cch][2][2] = p[q2];
-                }
-            } else {
-#pragma unroll
-                for (int cch = 0; cch < 4; ++cch) win[cch][0][2] = win[cch][1][2] = win[cch][2][2] = 0.f;
-            }
-        };
-        auto try_conv4 = [&]() {                               // one conv4 column if conv3's columns c4 - 1 .. c4 + 1 are published
-            if (c4 >= T) return false;
-            const int needc = c4 + 2 < T ? c4 + 2 : T;
-            if (have < needc) {
-                have = min4(0);
-                if (have < needc) return false;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            if (c4 == 0) load_col(0);
-#pragma unroll
-            for (int cch = 0; cch < 4; ++cch)
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) { win[cch][ky][0] = win[cch][ky][1]; win[cch][ky][1] = win[cch][ky][2]; }
-            load_col(c4 + 1);
-            float acc = 0.f;
-#pragma unroll
-            for (int cch = 0; cch < 4; ++cch)
-#pragma unroll
-                for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[cch][k9 / 3][k9 % 3], w4[cch][k9], acc);
-            acc += other_half32(acc);
-            if (h == 0 && okrow) obuf[(lr - 4) * T + c4] = acc + b4;
-            ++c4;
-            set_flag(16 + w, c4);                              // the loads of column c4 (for the NEXT conv4) are issued: its ring slot's previous tenant is free
-            return true;
-        };
-        // ---- conv2 ----
-        const float relu_hi = ok2 ? __builtin_inff() : 0.f;
-        const float *bsrc = c1 + (4 * h) * kPlane + r - 1;
-        auto b_at = [&](int kb, int tcol) {
-            const int tap = kb >> 2, kx = tap / 3, ky = tap % 3;
-            return bsrc[(kb & 3) * kPlane + (tcol + kx) * SP + ky];
-        };
-        float b[36];
-#pragma unroll
-        for (int kb = 0; kb < 36; ++kb) b[kb] = b_at(kb, 0);
-        f32x16 bias2v;
-        {
-            const f32x4 *bp = reinterpret_cast<const f32x4 *>(bias2 + 16 * h);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = bp[q];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bias2v[4 * q + u] = v[u];
-            }
-        }
-        float *xdst = x2w + (4 * h) * kXR + 1 + j;            // + slot * kX2Slot + ((e&3) + 8(e>>2)) * kXR
-#ifdef AFT_DIAG_STAMPS
-        unsigned long long slotwait = 0, burst = 0, c4time = 0;
-#endif
-#pragma unroll 1
-        for (int c = 0; c < T; ++c) {
-#ifdef AFT_DIAG_STAMPS
-            const unsigned long long t0s = __builtin_amdgcn_s_memtime();
-#endif
-            while (flags[12 + w] < c - 1) {                    // ring slot c & 1 still holds column c - 2
-                if (!try_conv4()) __builtin_amdgcn_s_sleep(1);
-            }
-#ifdef AFT_DIAG_STAMPS
-            slotwait += __builtin_amdgcn_s_memtime() - t0s;
-#endif
-            const int tnext = min(c + 1, T - 1);
-            // the producer of the pair runs AHEAD of its consumer (shorter chain, higher priority): the conv3 wave then never waits for
-            // a column, and the two chains interleave on the SIMD's matrix pipe; conv4 takes what is left
-#ifdef AFT_DIAG_STAMPS
-            const unsigned long long t0b = __builtin_amdgcn_s_memtime();
-#endif
-            __builtin_amdgcn_s_setprio(3);
-            f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
-            b[0] = b_at(0, tnext);
-#pragma unroll
-            for (int kb = 1; kb < 36; ++kb) {
-                acc2 = mfma_f32(wa2[kb], b[kb], acc2);
-                b[kb] = b_at(kb, tnext);
-            }
-            float *xd = xdst + (c & 1) * kX2Slot;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) xd[((e & 3) + 8 * (e >> 2)) * kXR] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);
-            set_flag(8 + w, c + 1);
-#ifdef AFT_DIAG_STAMPS
-            burst += __builtin_amdgcn_s_memtime() - t0b;
-#endif
-            // no conv4 here: beside a saturated MFMA stream a vector instruction waits tens of cycles for the ALU (100 of them: ~3 000
-            // cycles), which would delay the next column and leave the conv3 wave waiting.  conv4 runs only while this wave waits for a
-            // ring slot anyway (above) -- it is the faster wave of the pair, so that happens every column
-        }
-#ifdef AFT_DIAG_STAMPS
-        if (a.stamps && tid == 256) {
-            unsigned long long *xs = a.stamps + 16 * 4096 + (size_t)blockIdx.x * 4;
-            xs[0] = slotwait; xs[1] = burst; xs[2] = c4time; xs[3] = (unsigned long long)c4;
-        }
-#endif
-        while (c4 < T) {
-            if (!try_conv4()) __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    PSTAMP(4);
-    __syncthreads();
-    PSTAMP(5);
-    {
-        const float *obuf = in0;
-        if (MODE == 0) {
-            f32x4 *dstg = reinterpret_cast<f32x4 *>(a.out_plane + (size_t)n * (S * T));
-            const f32x4 *src4 = reinterpret_cast<const f32x4 *>(obuf);
-            for (int i = tid; i < S * T / 4; i += kConvThreads) dstg[i] = src4[i];
-        } else {
-            float *dstg = a.out_complex + (size_t)frame * (S * T) * 2 + part;
-            for (int i = tid; i < S * T; i += kConvThreads) dstg[2 * i] = obuf[i];
-        }
-    }
-    PSTAMP(6);
-#undef PSTAMP
-}
-
 bool conv_stream_ok(const ConvArgs &a) {
     if (a.S != S || a.T != T) return false;
     if (a.mode == 0) return a.in_plane != nullptr && (reinterpret_cast<uintptr_t>(a.out_plane) & 15) == 0;
@@ -823,20 +416,12 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     static unsigned long long *dbuf = nullptr;
     const bool stamp = getenv("AFT_STAMPS") != nullptr && planes <= 4096;
     if (stamp) {
-        if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 20 * 4096);
-        (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 20 * 4096);
+        if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 4096);
+        (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
         a.stamps = dbuf;
     }
 #endif
-    static PerDeviceOnce lds_phead, lds_ptail;
-    const bool pair = getenv("AFT_CONV_PAIR") != nullptr;   // A/B knob: the conv2-wave / conv3-wave pair schedule (measured 6 % slower)
-    if (pair) {
-        e = a.mode == 0 ? ensure_dynamic_lds(lds_phead, reinterpret_cast<const void *>(conv_pair_kernel<0>), kPairLds)
-                        : ensure_dynamic_lds(lds_ptail, reinterpret_cast<const void *>(conv_pair_kernel<1>), kPairLds);
-        if (e != hipSuccess) return e;
-        if (a.mode == 0) hipLaunchKernelGGL((conv_pair_kernel<0>), dim3(planes), dim3(kConvThreads), kPairLds, st, a);
-        else hipLaunchKernelGGL((conv_pair_kernel<1>), dim3(planes), dim3(kConvThreads), kPairLds, st, a);
-    } else if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+    if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
     else hipLaunchKernelGGL((conv_stream_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
 #ifdef AFT_DIAG_STAMPS
     if (stamp) {
@@ -851,23 +436,10 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
                     m[i] += (double)(hb[(size_t)b * 16 + i] - hb[(size_t)b * 16 + i - 1]);
                     hsum[i] += (double)(hb[(size_t)b * 16 + 8 + i] - hb[(size_t)b * 16 + 8 + i - 1]);
                 }
-            printf("conv %s mode %d (mean cycles): matrix wave: stage=%.0f gather=%.0f wait=%.0f sweeps=%.0f wait=%.0f store=%.0f | "
-                   "helper wave: stage=%.0f zero+input+conv1=%.0f wait=%.0f conv4=%.0f wait=%.0f store=%.0f\n", pair ? "pair" : "stream", a.mode, m[1] / planes,
+            printf("conv stream mode %d (mean cycles): matrix wave: stage=%.0f gather=%.0f wait=%.0f sweeps=%.0f wait=%.0f store=%.0f | "
+                   "helper wave: stage=%.0f zero+input+conv1=%.0f wait=%.0f conv4=%.0f wait=%.0f store=%.0f\n", a.mode, m[1] / planes,
                    m[2] / planes, m[3] / planes, m[4] / planes, m[5] / planes, m[6] / planes, hsum[1] / planes, hsum[2] / planes,
                    hsum[3] / planes, hsum[4] / planes, hsum[5] / planes, hsum[6] / planes);
-        }
-        if (pair && printed <= 4) {
-            std::vector<unsigned long long> hb(16 * (size_t)planes);
-            (void)hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
-            std::vector<unsigned long long> hx(4 * (size_t)planes);
-            (void)hipMemcpy(hx.data(), dbuf + 16 * 4096, hx.size() * 8, hipMemcpyDeviceToHost);
-            double w3 = 0, x[4] = {0};
-            for (int b = 0; b < planes; ++b) {
-                w3 += (double)hb[(size_t)b * 16 + 7];
-                for (int q = 0; q < 4; ++q) x[q] += (double)hx[(size_t)b * 4 + q];
-            }
-            printf("   pair: conv3 wave waited %.0f cycles for conv2 columns; conv2 wave: ring-slot waits %.0f, MFMA bursts %.0f, in-loop conv4 %.0f cycles, "
-                   "conv4 columns done at the end of its loop %.1f\n", w3 / planes, x[0] / planes, x[1] / planes, x[2] / planes, x[3] / planes);
         }
         a.stamps = nullptr;
     }
