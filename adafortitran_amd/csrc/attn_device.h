@@ -169,12 +169,26 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     };
     // padded keys of the ragged last tile: logits -> -inf (probability 0), V^T columns -> 0 (the workspace pad is
     // never trusted: 0 x NaN would poison the row)
+    // (8 | tokens, the usual case: whole 8-key groups are padding, the same registers in every lane -- a wave-uniform test per
+    // group instead of an add, a compare and a select per register and lane: 100 vector instructions per task less)
+#ifdef AFT_ATTN_OLD_MASKS
+    const bool pad8 = false;
+#else
+    const bool pad8 = (tokens & 7) == 0;
+#endif
     auto mask_logits = [&](f32x16 &sv, int kt) {
+        if (pad8) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (kt * kTile + 8 * g >= tokens) sv[4 * g] = sv[4 * g + 1] = sv[4 * g + 2] = sv[4 * g + 3] = -INFINITY;
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             if (kt * kTile + (e & 3) + 8 * (e >> 2) + 4 * h >= tokens) sv[e] = -INFINITY;
     };
     auto mask_values = [&](f32x4 (&vvb)[NB][4], int kt) {
+      if (!BS && pad8) return;    // padded 8-key groups are skipped as a whole by the O^T loop: their V^T columns are never read
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         f32x4 (&vv)[4] = vvb[b];
