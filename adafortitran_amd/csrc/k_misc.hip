@@ -373,6 +373,8 @@ __global__ __launch_bounds__(256) void pilot_gather_kernel(const float2 *__restr
             base += __popcll(m);
         }
     }
+    for (int pos = base + lane; pos < expected; pos += 64)            // fewer non-zero entries than expected: the rest reads as zero
+        pilots[(size_t)frame * expected + pos] = make_float2(0.f, 0.f);   // (the caller need not zero-fill the output: one launch less)
     if (lane == 0) counts[frame] = base;
 }
 

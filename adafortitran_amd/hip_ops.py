@@ -277,7 +277,7 @@ def pilot_gather(hzero_ls: torch.Tensor, pilot_size, return_counts: bool = False
     B, n = hzero_ls.shape[0], hzero_ls.shape[1] * hzero_ls.shape[2]
     expected = int(pilot_size[0]) * int(pilot_size[1])
     src = torch.view_as_real(hzero_ls.contiguous())
-    out = torch.zeros((B, pilot_size[0], pilot_size[1]), dtype=torch.complex64, device=hzero_ls.device)
+    out = torch.empty((B, pilot_size[0], pilot_size[1]), dtype=torch.complex64, device=hzero_ls.device)   # the kernel writes every slot
     counts = torch.empty(B, dtype=torch.int32, device=hzero_ls.device)
     _lib.check(lib.aft_pilot_gather_f32(src.data_ptr(), torch.view_as_real(out).data_ptr(), counts.data_ptr(), B, n,
                                         expected, _lib.current_stream_ptr(hzero_ls.device)))

@@ -169,7 +169,8 @@ int aft_mse_partial_f32(const float *est, const float *ref, double *sum_sq,
  * non-pilot positions; the non-zero entries (re != 0 or im != 0) of each frame are compacted in
  * row-major order into pilots complex64 [B, expected].  counts[b] (device int32) receives the number
  * of non-zero entries found, so the caller can raise the reference's ValueError when it differs from
- * `expected` (dataset.py:128-132); at most `expected` values are written per frame. */
+ * `expected` (dataset.py:128-132); exactly `expected` values are written per frame (zeros behind the
+ * entries found when there are fewer: the output needs no initialisation). */
 int aft_pilot_gather_f32(const float *hzero_ls, float *pilots, int *counts, int batch, int grid_elems,
                          int expected, void *stream);
 

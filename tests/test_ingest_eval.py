@@ -98,6 +98,18 @@ def test_pilot_gather_and_ls_mse_kernels(tmp_path):
     sparse[2, 5, 5] = 1.0
     with pytest.raises(ValueError, match=r"Expected 24 pilot values, got 25 \(frame 2\)"):
         pilot_gather(sparse, (12, 2))
+    # a frame with FEWER non-zero entries than expected: the kernel itself zero-fills the rest of that frame's output (the output
+    # tensor comes from torch.empty: poison the allocator first), and the count says 23
+    from adafortitran_amd.hip_ops import pilot_gather as pg
+    few = torch.from_numpy(np.ascontiguousarray(H[:, :, :, 1])).cuda()
+    pos = (few[1] != 0).nonzero()[-1]
+    few[1, pos[0], pos[1]] = 0
+    junk = [torch.full((n,), float("nan"), device="cuda") for n in (1 << 20, 1 << 16, 1 << 12, 1 << 10)]
+    del junk
+    got, counts = pg(few, (12, 2), return_counts=True)
+    want = I["pilots"].copy()
+    want[1].reshape(-1)[-1] = 0
+    assert np.array_equal(got.cpu().numpy(), want) and counts.cpu().tolist()[1] == 23
     from oracle import ingest_oracle as io
     ls = torch.from_numpy(np.ascontiguousarray(H[:, :, :, 2])).cuda()
     ideal = torch.from_numpy(np.ascontiguousarray(H[:, :, :, 0])).cuda()
