@@ -754,7 +754,7 @@ static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStre
     const bool fixed = a.S == 120 && a.T == 14 && a.SP == 128 && a.band_rows == 120 && a.nbands == 1 && a.ntiles == 4 && a.nseg == 2;
     // default grid, inference, inputs as the whole forward provides them: the column-streaming pipeline (k_conv_stream.hip);
     // AFT_CONV_BANDED=1 keeps the banded kernel (A/B runs)
-    if (!TRAIN && fixed && conv_stream_ok(a) && !getenv("AFT_CONV_BANDED")) return launch_conv_stream(a, planes, st);
+    if (fixed && conv_stream_ok(a) && !getenv("AFT_CONV_BANDED")) return launch_conv_stream(a, planes, st);   // (training: mode 2)
     if (fixed) return launch_conv_geo<TRAIN, true>(a, planes, lds, st);
     return launch_conv_geo<TRAIN, false>(a, planes, lds, st);
 }

@@ -45,8 +45,13 @@ __device__ __forceinline__ float other_half32(float x) {   // value held by lane
 
 }  // namespace
 
-// MODE 0 = head (a.in_plane = upsampled planes [planes][S][T], a.out_plane), 1 = tail (a.lin2_out + a.resid, a.out_complex)
-template <int MODE>
+// MODE 0 = head (a.in_plane = upsampled planes [planes][S][T], a.out_plane), 1 = tail (a.lin2_out + a.resid, a.out_complex).
+// TRAIN (MODE 0 with a.mode == 2 semantics: plain plane in, plain plane out) adds what k_conv.hip's training instantiation adds
+// (SURVEY 8f-1): the three stage outputs written to HBM in [plane][C][T][S] order (forward: the activations the backward needs;
+// backward: the pre-activation gradients the weight-gradient kernels need), a masked activation (backward: the ReLU derivative from
+// the saved forward activation instead of bias + ReLU), and NULL biases.  The backward of the stack IS this kernel on dL/dy with
+// transposed, flipped weights (conv4^T 1->8, conv3^T 8->32, conv2^T 32->8, conv1^T 8->1: the forward's stage shapes).
+template <int MODE, bool TRAIN = false>
 __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *in0 = smem + kIn0, *c1 = smem + kC1, *c3 = smem + kC3;
@@ -72,9 +77,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             const int rem = i % 288;   // conv3.weight [co 8][ci 32][ky 3][kx 3]
             stage[kW3Off + (rem / 3) * 33 + (rem % 3) * 8 + i / 288] = a.cw[2][i];
         }
-        if (tid < 32) bias2[tid] = a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
-        if (tid >= 64 && tid < 144) w1s[tid - 64] = tid < 136 ? a.cw[0][tid - 64] : a.cb[0][tid - 136];
-        if (tid >= 192 && tid < 265) w4s[tid - 192] = tid < 264 ? a.cw[3][tid - 192] : a.cb[3][0];
+        if (tid < 32) bias2[tid] = (TRAIN && !a.cb[1]) ? 0.f : a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
+        if (tid >= 64 && tid < 144) w1s[tid - 64] = tid < 136 ? a.cw[0][tid - 64] : ((TRAIN && !a.cb[0]) ? 0.f : a.cb[0][tid - 136]);
+        if (tid >= 192 && tid < 265) w4s[tid - 192] = tid < 264 ? a.cw[3][tid - 192] : ((TRAIN && !a.cb[3]) ? 0.f : a.cb[3][0]);
         if (tid >= 320 && tid < 336) flags[tid - 320] = 0;
     }
     __syncthreads();
@@ -116,7 +121,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
                 float acc = b[k];
 #pragma unroll
                 for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[k9 / 3][k9 % 3], w[k][k9], acc);
-                dst[k * kPlane + t * SP] = ok ? fmaxf(acc, 0.f) : 0.f;
+                float v = fmaxf(acc, 0.f);
+                if constexpr (TRAIN) {
+                    if (ok) {
+                        const unsigned gi = ((unsigned)(n * 8 + 4 * h + k) * T + t) * S + gr;
+                        if (a.mask[0]) v = conv_ld(conv_srd(a.mask[0]), gi) > 0.f ? acc : 0.f;
+                        if (a.save[0]) conv_st(conv_srd(a.save[0]), gi, v);
+                    }
+                }
+                dst[k * kPlane + t * SP] = ok ? v : 0.f;
             }
         }
     };
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             wa3[kb] = keep * stage[kW3Off + (ci * 3 + ky) * 33 + kx3 * 8 + co3];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bias3[e] = a.cb[2][e + 4 * h];
+        for (int e = 0; e < 4; ++e) bias3[e] = (TRAIN && !a.cb[2]) ? 0.f : a.cb[2][e + 4 * h];
         wait_count(4, 4);                        // the helpers' input plane
         conv1_columns(wave, T / 2, T);
     } else {
@@ -217,10 +230,17 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             if (tout < 0 || tout >= T) return;
             if (ok3) {
                 float *p = dst + (tout + 1) * SP;
-                p[0] = fmaxf(v0 + bias3[0], 0.f);
-                p[kPlane] = fmaxf(v1 + bias3[1], 0.f);
-                p[2 * kPlane] = fmaxf(v2 + bias3[2], 0.f);
-                p[3 * kPlane] = fmaxf(v3 + bias3[3], 0.f);
+                const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float y = fmaxf(v[k] + bias3[k], 0.f);
+                    if constexpr (TRAIN) {
+                        const unsigned gi = ((unsigned)(n * 8 + 4 * h + k) * T + tout) * S + gr;
+                        if (a.mask[2]) y = conv_ld(conv_srd(a.mask[2]), gi) > 0.f ? v[k] : 0.f;
+                        if (a.save[2]) conv_st(conv_srd(a.save[2]), gi, y);
+                    }
+                    p[k * kPlane] = y;
+                }
             }
             publish(tout + 1);
         };
@@ -244,6 +264,37 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             }
         }
         float x2[16];
+        // conv2's activation for column tcol: ReLU (or 0 outside the plane); training: masked by / saved as the stage tensor
+        // (the mask values of column tcol were requested a column earlier: m1)
+        float m1[TRAIN ? 16 : 1];
+        const bool own_row = r >= 4 && r < 4 + S;
+        auto request_mask = [&](int tcol) {
+            if constexpr (TRAIN) {
+                if (a.mask[1] && ok2) {
+                    const ConvSrd m = conv_srd(a.mask[1]);
+                    const unsigned g0 = ((unsigned)(n * 32 + 4 * h) * T + tcol) * S + gr, cstride = (unsigned)T * S;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) m1[e] = conv_ld(m, g0 + ((e & 3) + 8 * (e >> 2)) * cstride);
+                }
+            }
+        };
+        auto activate2 = [&](const f32x16 &acc2, int tcol) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);
+            if constexpr (TRAIN) {
+                if (a.mask[1]) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) x2[e] = (ok2 && m1[e] > 0.f) ? acc2[e] : 0.f;
+                }
+                if (a.save[1] && ok2 && own_row) {
+                    const ConvSrd sv = conv_srd(a.save[1]);
+                    const unsigned g0 = ((unsigned)(n * 32 + 4 * h) * T + tcol) * S + gr, cstride = (unsigned)T * S;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) conv_st(sv, g0 + ((e & 3) + 8 * (e >> 2)) * cstride, x2[e]);
+                }
+            }
+        };
+        request_mask(0);
         {   // prologue: conv2 of column 0
             f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
             b[0] = b_at(0, 1);
@@ -252,8 +303,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
                 acc2 = mfma_f32(wa2[kb], b[kb], acc2);
                 b[kb] = b_at(kb, 1);
             }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);
+            activate2(acc2, 0);
         }
         auto conv3_step = [&](int i) {   // ky = centre (16..31), below (0..15), above (32..47)
             const int e = i & 15;
@@ -273,6 +323,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 #pragma unroll 1
         for (int tcol = 0; tcol < T - 1; ++tcol) {
             const int tnext = min(tcol + 2, T - 1);
+            request_mask(tcol + 1);
             f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
             b[0] = b_at(0, tnext);
 #pragma unroll
@@ -295,8 +346,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
                 b[kLead + 2 * g + 1] = b_at(kLead + 2 * g + 1, tnext);
                 conv3_step(3 * g + 2);
             }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);
+            activate2(acc2, tcol + 1);
         }
         store_col(T - 3, acc3[8], acc3[9], acc3[10], acc3[11]);
         rotate();
@@ -401,14 +451,20 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 
 bool conv_stream_ok(const ConvArgs &a) {
     if (a.S != S || a.T != T) return false;
-    if (a.mode == 0) return a.in_plane != nullptr && (reinterpret_cast<uintptr_t>(a.out_plane) & 15) == 0;
+    if (a.mode == 0 || a.mode == 2) return a.in_plane != nullptr && (reinterpret_cast<uintptr_t>(a.out_plane) & 15) == 0;
     if (a.mode == 1) return a.lin2_out != nullptr && a.resid != nullptr && T % a.p1 == 0 && S % a.p0 == 0;
     return false;
 }
 
 hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     if (!conv_stream_ok(a)) return hipErrorNotSupported;
-    static PerDeviceOnce lds_head, lds_tail;
+    static PerDeviceOnce lds_head, lds_tail, lds_train;
+    if (a.mode == 2) {   // training path: plain plane in / out, stage tensors saved, masked activation
+        hipError_t et = ensure_dynamic_lds(lds_train, reinterpret_cast<const void *>(conv_stream_kernel<0, true>), kStreamLds);
+        if (et != hipSuccess) return et;
+        hipLaunchKernelGGL((conv_stream_kernel<0, true>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+        return hipGetLastError();
+    }
     hipError_t e = a.mode == 0 ? ensure_dynamic_lds(lds_head, reinterpret_cast<const void *>(conv_stream_kernel<0>), kStreamLds)
                                : ensure_dynamic_lds(lds_tail, reinterpret_cast<const void *>(conv_stream_kernel<1>), kStreamLds);
     if (e != hipSuccess) return e;

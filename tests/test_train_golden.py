@@ -149,8 +149,10 @@ def test_hip_full_depth_training_step_matches_float64_reference_gradients(name):
         assert tight >= 80, tight                            # the bound is tight where the problem is well-conditioned
 
 
-def _fresh_step(spec, adaptive, device, dtype, inp, sd, hip):
-    """One dropout-free training step of a model built from `spec` (float64 = the yardstick, CPU)."""
+def _fresh_step(spec, adaptive, device, dtype, inp, sd, hip, maps=None):
+    """One dropout-free training step of a model built from `spec` (float64 = the yardstick, CPU).  `maps` (a dict) receives the
+    gradients leaving the two conv stacks (dL/d input of final_refiner / initial_enhancer), where a differing ReLU decision shows as
+    an isolated 5 x 5 patch."""
     from adafortitran_amd import blocks, training
     saved = (blocks.TransformerEncoderForChannels.hip_training, blocks.ConvEnhancer.hip_training,
              blocks.ChannelAdapter.hip_training, training.HipLinear.default_hip_training)
@@ -169,6 +171,9 @@ def _fresh_step(spec, adaptive, device, dtype, inp, sd, hip):
         if dtype == torch.float64:
             model.double()
         model.train()
+        if maps is not None:
+            for name, mod in (("final", model.final_refiner), ("initial", model.initial_enhancer)):
+                mod.register_full_backward_hook(lambda _m, gin, _go, name=name: maps.setdefault(name, []).append(gin[0].detach().double().cpu().numpy()))
         cdt = torch.complex128 if dtype == torch.float64 else torch.complex64
         pil, tgt = torch.from_numpy(inp["pilots"]).to(cdt), torch.from_numpy(inp["target"]).to(cdt).to(device)
         meta = None
@@ -196,27 +201,52 @@ def test_hip_gradients_are_as_close_to_float64_as_pytorch_fp32(adaptive):
     adapter tensors by 0.3x .. 3x in either direction (tools/debug/grad_vs_fp64.py ada --small: reference CPU 1.5e-4,
     PyTorch-ROCm 1.7e-4, HIP 2.2e-4 at worst) -- so there the bound is on the worst tensor and on the typical one:
         max_n err_hip <= 2 x max_n err_torch,   median_n (err_hip / err_torch) <= 1.5,
-        per tensor err_hip <= 4 x max(err_rocm, err_cpu) + floor."""
+        per tensor err_hip <= 4 x max(err_rocm, err_cpu) + floor.
+    ReLU DECISIONS.  The two conv stacks hold 5 M ReLUs per step at this size; a pre-activation within fp32 rounding of zero is
+    decided one way by one fp32 evaluation and the other way by the next (about one such element per pair of evaluations: found
+    when the streaming conv training kernel landed -- its one differing decision happened to be the one torch's CPU kernels made
+    too, tools/debug/conv_model_ab2.py).  One flipped decision is an isolated 5 x 5 patch in the gradient that leaves the stack
+    and moves the small upstream tensors (pilot_upsampler: |g|max 1e-6) by 1e-3 of their max -- not an accuracy property of either
+    implementation.  The test therefore looks at those gradient maps first: HIP and PyTorch-ROCm must agree on them to 2e-6 of the
+    map's max (AdaFortiTran: 5e-4, above its noise) EVERYWHERE (then the per-tensor bound is checked on that input seed), or differ in isolated patches only (< 0.5 % of the
+    pixels: a differing ReLU decision -- next seed); a dense difference fails at once.  Two clean seeds are required."""
     from helpers import DEFAULT_SPEC
     spec = dict(DEFAULT_SPEC, num_layers=2)
     sd = synth.make_state_dict(**spec, adaptive_hidden=(7, 42, 560) if adaptive else None, seed=4321)
-    inp = synth.make_inputs(16, seed=4322)
-    g64 = _fresh_step(spec, adaptive, "cpu", torch.float64, inp, sd, hip=False)
-    g_cpu = _fresh_step(spec, adaptive, "cpu", torch.float32, inp, sd, hip=False)
-    g_rocm = _fresh_step(spec, adaptive, "cuda", torch.float32, inp, sd, hip=False)
-    g_hip = _fresh_step(spec, adaptive, "cuda", torch.float32, inp, sd, hip=True)
-    err = lambda g, n: float(np.abs(g[n] - g64[n]).max() / np.abs(g64[n]).max())  # noqa: E731
-    bad, ratios = [], []
-    for n in g64:
-        e_hip, e_rocm, e_cpu = err(g_hip, n), err(g_rocm, n), err(g_cpu, n)
-        ratios.append(e_hip / max(e_rocm, 1e-12))
-        limit = 2.0 * e_rocm + 1e-6 if not adaptive else 4.0 * max(e_rocm, e_cpu) + 1e-6
-        if e_hip > limit:
-            bad.append(f"{n}: hip {e_hip:.2e} rocm {e_rocm:.2e} cpu {e_cpu:.2e}")
-    assert not bad, "\n".join(bad)
-    worst = lambda g: max(err(g, n) for n in g64)  # noqa: E731
-    assert worst(g_hip) <= 2.0 * max(worst(g_rocm), worst(g_cpu)) + 1e-6, (worst(g_hip), worst(g_rocm), worst(g_cpu))
-    assert float(np.median(ratios)) <= 1.5, float(np.median(ratios))     # typically no further from the truth than torch
+    clean = 0
+    for seed in range(4322, 4334):
+        inp = synth.make_inputs(16, seed=seed)
+        m_rocm, m_hip = {}, {}
+        g_rocm = _fresh_step(spec, adaptive, "cuda", torch.float32, inp, sd, hip=False, maps=m_rocm)
+        g_hip = _fresh_step(spec, adaptive, "cuda", torch.float32, inp, sd, hip=True, maps=m_hip)
+        flipped = False
+        for name in ("final", "initial"):     # backward order: a flip in final_refiner spreads through the encoder into everything upstream
+            a, b = m_rocm[name][0], m_hip[name][0]
+            dev = np.abs(a - b) > (5e-4 if adaptive else 2e-6) * np.abs(a).max()   # (adaptive: above its ~1e-4 of chaotic noise)
+            assert dev.mean() < 5e-3, f"{name}: HIP and PyTorch-ROCm gradient maps differ in {dev.mean():.1%} of the pixels"
+            if dev.any():
+                flipped = True
+                break
+        if flipped:
+            continue          # a differing ReLU decision somewhere in a conv stack: not an accuracy statement, next seed
+        g64 = _fresh_step(spec, adaptive, "cpu", torch.float64, inp, sd, hip=False)
+        g_cpu = _fresh_step(spec, adaptive, "cpu", torch.float32, inp, sd, hip=False)
+        err = lambda g, n: float(np.abs(g[n] - g64[n]).max() / np.abs(g64[n]).max())  # noqa: E731
+        bad, ratios = [], []
+        for n in g64:
+            e_hip, e_rocm, e_cpu = err(g_hip, n), err(g_rocm, n), err(g_cpu, n)
+            ratios.append(e_hip / max(e_rocm, 1e-12))
+            limit = 2.0 * e_rocm + 1e-6 if not adaptive else 4.0 * max(e_rocm, e_cpu) + 1e-6
+            if e_hip > limit:
+                bad.append(f"{n}: hip {e_hip:.2e} rocm {e_rocm:.2e} cpu {e_cpu:.2e}")
+        assert not bad, f"seed {seed}\n" + "\n".join(bad)
+        worst = lambda g: max(err(g, n) for n in g64)  # noqa: E731
+        assert worst(g_hip) <= 2.0 * max(worst(g_rocm), worst(g_cpu)) + 1e-6, (seed, worst(g_hip), worst(g_rocm), worst(g_cpu))
+        assert float(np.median(ratios)) <= 1.5, (seed, float(np.median(ratios)))     # typically no further from the truth than torch
+        clean += 1
+        if clean == 2:
+            break
+    assert clean == 2, f"only {clean} input seeds without a differing ReLU decision between HIP and PyTorch-ROCm in 12 tries"
 
 
 @pytest.mark.parametrize("name", ["G_grad_ada", "G_grad_forti"])
