@@ -19,10 +19,13 @@ with torch.no_grad():
     torch.cuda.synchronize()
     m0 = torch.cuda.memory_allocated()
     bad = 0
-    for i in range(2000):
+    # EVERY output is compared (on the device, one scalar comes back at the end): the conv stream kernel hands data between its
+    # waves through LDS flags -- a lost hand-over would be a one-in-many-launches event
+    diff = torch.zeros((), dtype=torch.int64, device="cuda")
+    for i in range(int(os.environ.get("SOAK_N", "3000"))):
         out = model(pil, meta)
-        if i % 100 == 99:
-            bad += int(not torch.equal(torch.view_as_real(out), torch.view_as_real(ref)))
+        diff += (torch.view_as_real(out) != torch.view_as_real(ref)).any().to(torch.int64)
+    bad = int(diff.item())
     torch.cuda.synchronize()
     print("mismatching checks:", bad, "memory growth (bytes):", torch.cuda.memory_allocated() - m0)
     assert bad == 0
