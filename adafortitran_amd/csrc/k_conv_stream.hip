@@ -91,12 +91,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
     auto conv1_columns = [&](int rw, int t0, int t1) {
         const int lr = 32 * rw + j, gr = lr - 4;
         const bool ok = lr >= 1 && lr < LR - 1 && gr >= 0 && gr < S;
-        float w[4][9], b[4];
+        // two channels per v_pk_fma_f32: the phase is bound by vector-instruction issue (36 FMAs per thread and column otherwise)
+        f32x2 w[2][9], b[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
 #pragma unroll
-            for (int k9 = 0; k9 < 9; ++k9) w[k][k9] = w1s[(4 * h + k) * 9 + k9];
-            b[k] = w1s[72 + 4 * h + k];
+            for (int k9 = 0; k9 < 9; ++k9) w[k][k9] = f32x2{w1s[(4 * h + 2 * k) * 9 + k9], w1s[(4 * h + 2 * k + 1) * 9 + k9]};
+            b[k] = f32x2{w1s[72 + 4 * h + 2 * k], w1s[72 + 4 * h + 2 * k + 1]};
         }
         const int r0 = max(lr - 1, 0), r2 = min(lr + 1, LR - 1);
         float win[3][3];   // [ky][kx]
@@ -117,19 +118,26 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             win[1][2] = in0[(t + 2) * SP + lr];
             win[2][2] = in0[(t + 2) * SP + r2];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float acc = b[k];
+            for (int k = 0; k < 2; ++k) {
+                f32x2 acc2 = b[k];
 #pragma unroll
-                for (int k9 = 0; k9 < 9; ++k9) acc = fmaf(win[k9 / 3][k9 % 3], w[k][k9], acc);
-                float v = fmaxf(acc, 0.f);
-                if constexpr (TRAIN) {
-                    if (ok) {
-                        const unsigned gi = ((unsigned)(n * 8 + 4 * h + k) * T + t) * S + gr;
-                        if (a.mask[0]) v = conv_ld(conv_srd(a.mask[0]), gi) > 0.f ? acc : 0.f;
-                        if (a.save[0]) conv_st(conv_srd(a.save[0]), gi, v);
-                    }
+                for (int k9 = 0; k9 < 9; ++k9) {
+                    const float x = win[k9 / 3][k9 % 3];
+                    acc2 = __builtin_elementwise_fma(f32x2{x, x}, w[k][k9], acc2);     // per channel: the same fma chain in tap order
                 }
-                dst[k * kPlane + t * SP] = ok ? v : 0.f;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float acc = acc2[q];
+                    float v = fmaxf(acc, 0.f);
+                    if constexpr (TRAIN) {
+                        if (ok) {
+                            const unsigned gi = ((unsigned)(n * 8 + 4 * h + 2 * k + q) * T + t) * S + gr;
+                            if (a.mask[0]) v = conv_ld(conv_srd(a.mask[0]), gi) > 0.f ? acc : 0.f;
+                            if (a.save[0]) conv_st(conv_srd(a.save[0]), gi, v);
+                        }
+                    }
+                    dst[(2 * k + q) * kPlane + t * SP] = ok ? v : 0.f;
+                }
             }
         }
     };
