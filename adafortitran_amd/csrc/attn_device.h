@@ -133,10 +133,12 @@ __device__ __forceinline__ float round_to_bf16(float x) { return (float)(__bf16)
 // logits, O^T is computed for the whole block and only this head's 16 rows are stored (half the matrix work of such a task is
 // wasted: the shape is covered, not tuned).  nn.MultiheadAttention as built at reference blocks/encoders.py:44-51 accepts any
 // num_head that divides model_dim (schemas.py:124-127).
-template <bool BS = false, int HD = 32>
+// TOK > 0: the token count as a compile-time constant (the default grid's 280: nine key tiles, the last one ragged) -- the tile loop's
+// trip count, the "last two or three tiles" logic and the padding masks resolve at compile time.  TOK = 0: any count at run time.
+template <bool BS = false, int HD = 32, int TOK = 0>
 __device__ __forceinline__ void attn_body(const float *__restrict__ q, const float *__restrict__ k,
                                           const float *__restrict__ vt, const float *__restrict__ qbias,
-                                          float *__restrict__ out, int nblk, int tokens, int tokpad, int model_dim,
+                                          float *__restrict__ out, int nblk, int tokens_rt, int tokpad_rt, int model_dim,
                                           float scale_log2e, const int first_task, const int total_waves, int ntasks,
                                           unsigned long long *stamps) {
     int lane_l = threadIdx.x & 63;
@@ -146,6 +148,8 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     static_assert(HD == 16 || HD == 32 || HD == 64, "head dimension");
     static_assert(!BS || HD == 32, "the split-precision tier is instantiated for head dimension 32");
     constexpr int NB = HD == 64 ? 2 : 1;                // 32-feature blocks per head
+    const int tokens = TOK > 0 ? TOK : tokens_rt;
+    const int tokpad = TOK > 0 ? (TOK + kTile - 1) / kTile * kTile : tokpad_rt;
     const int nkt = tokpad / kTile;
     const int r = lane & 31, h = lane >> 5;
     const bool ragged = (tokens & (kTile - 1)) != 0;   // last key tile holds padded keys

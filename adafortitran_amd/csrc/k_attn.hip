@@ -10,7 +10,7 @@ namespace aft {
 
 // launch bound (256, 3): <= 168 registers keeps accumulators in VGPRs, see attn_device.h
 // HD = 32: three waves per SIMD (the tuned shape).  HD = 64 holds two blocks of q / k / v^T and two accumulators (~210 VGPRs): two.
-template <int HD>
+template <int HD, int TOK = 0>
 __global__ __launch_bounds__(256, HD == 64 ? 2 : AFT_ATTN_WAVES) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                       const float *__restrict__ vt, const float *__restrict__ qbias,
                                                       float *__restrict__ out, int nblk, int tokens, int tokpad,
@@ -22,8 +22,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : AFT_ATTN_WAVES) void attn_kerne
     // (72 KB) through ONE L2 instead of two or three.  A pure speed choice; any mapping is correct.
     int vblock = blockIdx.x;
     if ((gridDim.x & 7) == 0) vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    attn_body<false, HD>(q, k, vt, qbias, out, nblk, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, gridDim.x * 4, ntasks,
-                         stamps);
+    attn_body<false, HD, TOK>(q, k, vt, qbias, out, nblk, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, gridDim.x * 4, ntasks,
+                              stamps);
 }
 
 // split-precision tier: K / Q^T / V^T arrive as bf16 hi / lo fragments from chain_split_kernel (attn_device.h)
@@ -99,6 +99,15 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
                            scale_log2e, ntasks, no_stamps);
     else if (hd == 64)
         hipLaunchKernelGGL((attn_kernel<64>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
+                           scale_log2e, ntasks, no_stamps);
+    // the two benchmark grids with the token count at compile time (120 x 14 -> 280 tokens, 240 x 28 -> 1120): the tile loop's trip
+    // count, the last-tiles logic and the padding masks resolve in the compiler -- 125 VGPRs and no scalar spills instead of 168 and 40,
+    // -2.7 % time at 280 tokens (A/B knob: AFT_ATTN_GENERIC=1 runs the generic instantiation; same bits)
+    else if (tokens == 280 && !getenv("AFT_ATTN_GENERIC"))
+        hipLaunchKernelGGL((attn_kernel<32, 280>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
+                           scale_log2e, ntasks, no_stamps);
+    else if (tokens == 1120 && !getenv("AFT_ATTN_GENERIC"))
+        hipLaunchKernelGGL((attn_kernel<32, 1120>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
                            scale_log2e, ntasks, no_stamps);
     else
         hipLaunchKernelGGL((attn_kernel<32>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
