@@ -112,9 +112,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
     const Srd srd_w2t = make_srd(a.w2t), srd_w1t = make_srd(a.w1t), srd_wot = make_srd(a.wot);
     const Srd srd_g2 = make_srd(a.g2), srd_gff = make_srd(a.gff), srd_g2b = make_srd(a.g2b), srd_do = make_srd(a.d_o),
               srd_dx = make_srd(a.dx);
-    const unsigned w2t_off = (unsigned)(2 * w) * W * 1024 + lane * 4;    // W2^T: 2W tiles x W k-blocks (like W1 in the forward)
-    const unsigned w1t_off = (unsigned)w * (2 * W) * 1024 + lane * 4;    // W1^T: W tiles x 2W k-blocks (like W2)
-    const unsigned wot_off = (unsigned)w * W * 1024 + lane * 4;
+    // (W2^T: 2W tiles x W k-blocks like W1 in the forward, W1^T: W tiles x 2W k-blocks like W2: offsets formed inside the tile loop)
 
     for (int i = tid; i < D; i += S::THREADS) {
         par[i] = a.gam2[i];
@@ -143,6 +141,15 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
     float psum[2] = {0.f, 0.f};     // lane (r, h): column sum of feature fb + r, quantity h, for LayerNorm 2 and LayerNorm 1
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // everything derived from the lane index is recomputed per tile from a laundered copy: as loop invariants those values
+        // (row / half / fragment offsets) were two registers over the 168 the launch bound allows, spilled before the loop and
+        // reloaded from scratch inside it (a scratch reload is a VMEM load whose wait drains vmcnt; here the
+        // layer backward measured 801-805 us either way, so this is hygiene: no vector spills in any hot kernel)
+        int tid_l = threadIdx.x;
+        asm volatile("" : "+v"(tid_l));
+        const int lane = tid_l & 63, r = lane & 31, h = lane >> 5;
+        const unsigned w2t_off = (unsigned)(2 * w) * W * 1024 + lane * 4, w1t_off = (unsigned)w * (2 * W) * 1024 + lane * 4,
+                       wot_off = (unsigned)w * W * 1024 + lane * 4;
         const int row0 = tile * 32;
         const int grow = min(row0 + r, a.rows - 1);
         const bool row_ok = row0 + r < a.rows;
