@@ -27,6 +27,8 @@ if stamps: os.environ["AFT_STAMPS"] = stamps
 res = {}
 for name in which:
     io = pil if name == "upsample" else (out if name == "tail" else None)
+    if name == "prologue":   # [pilots | snr | ds | dop] as one buffer (AFT_KERNEL_PROLOGUE)
+        io = torch.cat([torch.view_as_real(pil).reshape(-1)] + [m.reshape(-1).float() for m in meta]).contiguous()
     profile_kernel(eng, name, B, 3, io); torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):
