@@ -604,6 +604,15 @@ def test_batches_above_the_offset_limit_run_in_chunks():
     assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref))
     out2 = eng.forward(pil, *meta, cache_packed=True)
     assert torch.equal(torch.view_as_real(out2), torch.view_as_real(ref))
+    # ... and with the inputs in PINNED HOST memory, read by the kernels directly (the module surface's path): chunk offsets apply
+    # to host pointers just the same
+    pil_h = torch.from_numpy(np.ascontiguousarray(g["pilots"])).pin_memory()
+    meta_h = [torch.from_numpy(np.ascontiguousarray(g[k]).reshape(-1)).pin_memory() for k in ("snr", "ds", "dop")]
+    out3 = eng.forward(pil_h, *meta_h, pinned_inputs=True)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(out3), torch.view_as_real(ref))
+    with pytest.raises(ValueError, match="pinned"):
+        eng.forward(pil_h, *meta_h)                              # CPU tensors without the promise that they are pinned
 
 
 def test_largest_accepted_batch_has_no_offset_overflow():
