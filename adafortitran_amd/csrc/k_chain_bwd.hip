@@ -52,6 +52,56 @@ struct ChainBwdShape {
     static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(S::XB + S::HB + S::ST + PAR + COLW);
 };
 
+// ---- row-major tensors leave (and enter) the two kernels below as WHOLE CACHE LINES (round 4) ----
+// A lane of the transposed products holds ONE token row: 16 bytes at (row r, feature 8 s + 4 h) per fragment s, so a wave's
+// buffer_store_b128 of fragment s touched 64 different 16-byte pieces of 32 rows (a quad of lanes = four rows), and the tape's
+// 1 408 floats per row left the forward as 44 such instructions per wave and tile.  Measured with the same bytes stored
+// lane-linear (wrong layout, timing only): 207 -> 187 us for the forward chain with the in-projection tail, 148 -> 132 without.
+// Now every 32 x 32 block takes one turn through LDS: written as the fragments it is (one 1-KB block per s, exactly the exchange
+// buffers' blocks -- x1, hd, x2, g2, gff, g2b are published there anyway), read back with eight lanes per 128-byte row piece and
+// stored as 8 rows x 128 bytes per instruction.  The block is SWIZZLED so that both accesses are conflict-free: lane (r, h) of
+// fragment s sits at 16-byte position 32 h + (r & 16) + ((r + 2 s + h) & 15) of block s (a rotation per (s, h): the operand reads
+// of the products -- one block, all lanes -- stay a permutation of the block), and a read-out instruction takes rows R, R + 8 in
+// each 16-lane group (the rotations of a row's eight pieces are consecutive, those of row R + 8 are the other eight).
+struct LineIo {
+    int pw[4];     // float offset of this lane's fragment s inside block s (the products' operand reads and the publishing writes)
+    int rd[2];     // read-out: float offset inside the block group for instruction i & 1 (instruction i adds 64 (i >> 1) floats)
+    int brow, c;   // read-out: first row of this lane (instruction i adds 4 (i & 1) + 16 (i >> 1)), 16-byte piece of the 128-byte row
+};
+__device__ __forceinline__ LineIo make_line_io(int lane) {
+    LineIo io;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) io.pw[s] = (32 * h + (r & 16) + ((r + 2 * s + h) & 15)) * 4;
+    const int rho = lane >> 3, c = lane & 7, sc = c >> 1, hh = c & 1;
+    io.brow = 8 * (rho & 1) + (rho >> 1);
+    io.c = c;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) io.rd[k] = sc * 256 + (32 * hh + ((io.brow + 4 * k + c) & 15)) * 4;
+    return io;
+}
+__device__ __forceinline__ void srd_store_c(Srd r, unsigned byte_off, unsigned const_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r,
+                                           byte_off + (const_off & 0xfffu), const_off & ~0xfffu, 0);
+}
+// this lane's fragment s of a 32 x 32 block -> its place in the four 1-KB blocks at `blk`
+__device__ __forceinline__ void line_put(float *blk, const LineIo &io, int s, f32x4 v) {
+    *reinterpret_cast<f32x4 *>(blk + s * 256 + io.pw[s]) = v;
+}
+// the 32 x 32 block at `blk` -> rows row0 .. row0 + 31, columns col .. col + 31 of a row-major [rows][LD] tensor.  gbase = the byte
+// offset of (row0 + io.brow, col + 4 io.c); rows_left = rows - row0 - io.brow (ragged last tile: rows beyond the end are not stored).
+// Same wave wrote the block: LDS serves a wave's requests in order, the wave barrier only pins the compiler's order.
+template <int LD>
+__device__ __forceinline__ void line_store(Srd dst, const float *blk, const LineIo &io, unsigned gbase, int rows_left) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(blk + io.rd[i & 1] + 64 * (i >> 1));
+        if (4 * (i & 1) + 16 * (i >> 1) < rows_left) srd_store_c(dst, gbase, (unsigned)((4 * (i & 1) + 16 * (i >> 1)) * LD * 4), v);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // LayerNorm backward on the lane's 16 features: v = upstream gradient (in: dL/dy, out: dL/ds), sfrag = the pre-norm
 // sum of the forward, (mean, rstd) of the row.  Also returns the lane's contributions to the parameter gradients.
 template <int D>
@@ -437,6 +487,12 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
         const bool row_ok = row0 + r < a.rows;
         const unsigned xrow = ((unsigned)grow * D + fb + 4 * h) * 4;
         const unsigned hrow = ((unsigned)grow * 2 * D + 2 * fb + 4 * h) * 4;
+        // whole-line stores (LineIo above): byte offsets of (row0 + brow, this wave's columns + 4 c) in the 128- / 256- / 384-wide tensors
+        const LineIo io = make_line_io(lane);
+        const unsigned g128 = ((unsigned)(row0 + io.brow) * D + fb + 4 * io.c) * 4;
+        const unsigned g256 = ((unsigned)(row0 + io.brow) * 2 * D + 2 * fb + 4 * io.c) * 4;
+        const int rows_left = a.rows - row0 - io.brow;
+        float *xw = xb + w * 1024, *hw = hb + w * 2048;     // this wave's blocks of the two exchange buffers
         unsigned lo = 0;
         asm volatile("" : "+v"(lo));
         const unsigned wo_lane = (wo_off + lo) * 4, w1_lane = (w1_off + lo) * 4, w2_lane = (w2_off + lo) * 4;
@@ -477,46 +533,52 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             f32x4 y = {acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]};
             if (drop) y = mask4(y, rw1, colw + fb + 8 * s + 4 * h);
             const f32x4 v = xres[s] + y;
-            if (TAPE && row_ok) srd_store(srd_s1, xrow + 32 * s, v);
+            if (TAPE) line_put(hw, io, s, v);    // the wave's hidden blocks are idle until this tile's hidden barrier
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
         }
+        if (TAPE) line_store<D>(srd_s1, hw, io, g128, rows_left);
         float mean, rstd;
         layernorm_rows_stats<D>(cur, stats, par + fb, srd_be1, fb, w, r, h, mean, rstd);   // -> x1
         if (row_ok && w == 0 && h == 0) *reinterpret_cast<float2 *>(a.st1 + 2 * (size_t)grow) = make_float2(mean, rstd);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const f32x4 v = {cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
-            if (TAPE && row_ok) srd_store(srd_x1, xrow + 32 * s, v);
-            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
-        }
+        for (int s = 0; s < 4; ++s)
+            line_put(xw, io, s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});   // published, and stored from there
+        if (TAPE) line_store<D>(srd_x1, xw, io, g128, rows_left);
         __syncthreads();
         TSTAMP(2);
         // ---- linear1 + bias -> a (kept), activation, dropout 2 -> hd (kept, published) ----
         gemm_run<W, 2, PFF, 1, 0>(ring_ff, srd_w1, w1_lane, acc_h, [&](int kb, int s) {
-            return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+            return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + io.pw[s]);
         });
         TSTAMP(3);
         f32x16 acc_d[1] = {bias_acc(srd_b2, fb, h)};
         gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w2, w2_lane);
+        // a (block t) takes its turn through the wave's OTHER hidden block, hd is stored from where it is published; the LDS serves
+        // the wave's requests in order, so a block is re-written right behind its read-out
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            if (TAPE) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    line_put(hw + 1024, io, s, f32x4{acc_h[t][4 * s], acc_h[t][4 * s + 1], acc_h[t][4 * s + 2], acc_h[t][4 * s + 3]});
+                line_store<2 * D>(srd_a, hw + 1024, io, g256 + 128 * t, rows_left);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const f32x4 pre = {acc_h[t][4 * s], acc_h[t][4 * s + 1], acc_h[t][4 * s + 2], acc_h[t][4 * s + 3]};
-                if (TAPE && row_ok) srd_store(srd_a, hrow + 128 * t + 32 * s, pre);
-                const f32x2 g0 = activate2<ACT>(f32x2{pre[0], pre[1]});
-                const f32x2 g1 = activate2<ACT>(f32x2{pre[2], pre[3]});
+                const f32x2 g0 = activate2<ACT>(f32x2{acc_h[t][4 * s], acc_h[t][4 * s + 1]});
+                const f32x2 g1 = activate2<ACT>(f32x2{acc_h[t][4 * s + 2], acc_h[t][4 * s + 3]});
                 f32x4 v = {g0[0], g0[1], g1[0], g1[1]};
                 if (drop) v = mask4(v, rw2, colw + D + 2 * fb + 32 * t + 8 * s + 4 * h);
-                if (TAPE && row_ok) srd_store(srd_hd, hrow + 128 * t + 32 * s, v);
-                *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = v;
+                line_put(hw + 1024 * t, io, s, v);
             }
+            if (TAPE) line_store<2 * D>(srd_hd, hw + 1024 * t, io, g256 + 128 * t, rows_left);
+        }
         __syncthreads();
         TSTAMP(4);
         // ---- linear2 + bias, dropout 3, residual (x1, registers) ----
         gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
-            return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
+            return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + io.pw[s]);
         });
         TSTAMP(5);
 #pragma unroll
@@ -526,17 +588,17 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = cur[4 * s + j] + y[j];
-            if (TAPE && row_ok) srd_store(srd_s2, xrow + 32 * s, v);
+            if (TAPE) line_put(xw, io, s, v);    // x1's readers are past the hidden barrier: the wave's x block is free
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
         }
+        if (TAPE) line_store<D>(srd_s2, xw, io, g128, rows_left);
         layernorm_rows_stats<D>(cur, stats, par + D + fb, srd_be2, fb, w, r, h, mean, rstd);   // -> x2
         if (row_ok && w == 0 && h == 0) *reinterpret_cast<float2 *>(a.st2 + 2 * (size_t)grow) = make_float2(mean, rstd);
-        if (row_ok) {
+        // x2: into the wave's x block (the in-projection tail's operand), stored from there
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                srd_store(srd_out, xrow + 32 * s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
-        }
+        for (int s = 0; s < 4; ++s) line_put(xw, io, s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
+        line_store<D>(srd_out, xw, io, g128, rows_left);
         TSTAMP(6);
         if constexpr (QKV) {
             // ---- the next layer's in-projection on x2 (the tile is still in registers): q | k | v of feature block w, bias as the
@@ -546,21 +608,18 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             WRing<3, PFQ> ring_q;
             gemm_preload<W, 3, PFQ, W>(ring_q, srd_wq, wq_lane);
             f32x16 acc_q[3] = {bias_acc(srd_bq, fb, h), bias_acc(srd_bq, D + fb, h), bias_acc(srd_bq, 2 * D + fb, h)};
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
             __syncthreads();
             gemm_run<W, 3, PFQ, W, 0>(ring_q, srd_wq, wq_lane, acc_q, [&](int kb, int s) {
-                return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4);
+                return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + io.pw[s]);
             });
-            if (row_ok) {
-                const unsigned qrow = ((unsigned)grow * 3 * D + fb + 4 * h) * 4;
+            // q, k, v of feature block w: each through one of the wave's hidden blocks (free behind the barrier above)
+            const unsigned g384 = ((unsigned)(row0 + io.brow) * 3 * D + fb + 4 * io.c) * 4;
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+            for (int t = 0; t < 3; ++t) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        srd_store(srd_qkv, qrow + (unsigned)t * D * 4 + 32 * s,
-                                  f32x4{acc_q[t][4 * s], acc_q[t][4 * s + 1], acc_q[t][4 * s + 2], acc_q[t][4 * s + 3]});
+                for (int s = 0; s < 4; ++s)
+                    line_put(hw + 1024 * (t & 1), io, s, f32x4{acc_q[t][4 * s], acc_q[t][4 * s + 1], acc_q[t][4 * s + 2], acc_q[t][4 * s + 3]});
+                line_store<3 * D>(srd_qkv, hw + 1024 * (t & 1), io, g384 + (unsigned)t * D * 4, rows_left);
             }
         }
         TSTAMP(7);
