@@ -52,32 +52,24 @@ struct ChainBwdShape {
     static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(S::XB + S::HB + S::ST + PAR + COLW);
 };
 
-// ---- row-major tensors leave (and enter) the two kernels below as WHOLE CACHE LINES (round 4) ----
+// ---- row-major tensors leave the two kernels below as WHOLE CACHE LINES (round 4) ----
 // A lane of the transposed products holds ONE token row: 16 bytes at (row r, feature 8 s + 4 h) per fragment s, so a wave's
 // buffer_store_b128 of fragment s touched 64 different 16-byte pieces of 32 rows (a quad of lanes = four rows), and the tape's
 // 1 408 floats per row left the forward as 44 such instructions per wave and tile.  Measured with the same bytes stored
 // lane-linear (wrong layout, timing only): 207 -> 187 us for the forward chain with the in-projection tail, 148 -> 132 without.
 // Now every 32 x 32 block takes one turn through LDS: written as the fragments it is (one 1-KB block per s, exactly the exchange
 // buffers' blocks -- x1, hd, x2, g2, gff, g2b are published there anyway), read back with eight lanes per 128-byte row piece and
-// stored as 8 rows x 128 bytes per instruction.  The block is SWIZZLED so that both accesses are conflict-free: lane (r, h) of
-// fragment s sits at 16-byte position 32 h + (r & 16) + ((r + 2 s + h) & 15) of block s (a rotation per (s, h): the operand reads
-// of the products -- one block, all lanes -- stay a permutation of the block), and a read-out instruction takes rows R, R + 8 in
-// each 16-lane group (the rotations of a row's eight pieces are consecutive, those of row R + 8 are the other eight).
+// stored as 8 rows x 128 bytes per instruction.  The block is SWIZZLED so that both accesses are conflict-free: lane l = r + 32 h
+// of fragment s sits at 16-byte position l ^ (2 s + h) of block s (the operand reads of the products -- one block, all lanes --
+// stay a permutation inside every 16-lane group), and a read-out instruction takes rows R, R + 8 in each 16-lane group (the eight
+// pieces of a row land on eight different 16-byte bank groups, those of row R + 8 on the other eight).
 struct LineIo {
     int pw[4];     // float offset of this lane's fragment s inside block s (the products' operand reads and the publishing writes)
-    int rd[2];     // read-out: float offset inside the block group for instruction i & 1 (instruction i adds 64 (i >> 1) floats)
-    int brow, c;   // read-out: first row of this lane (instruction i adds 4 (i & 1) + 16 (i >> 1)), 16-byte piece of the 128-byte row
 };
 __device__ __forceinline__ LineIo make_line_io(int lane) {
     LineIo io;
-    const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) io.pw[s] = (32 * h + (r & 16) + ((r + 2 * s + h) & 15)) * 4;
-    const int rho = lane >> 3, c = lane & 7, sc = c >> 1, hh = c & 1;
-    io.brow = 8 * (rho & 1) + (rho >> 1);
-    io.c = c;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) io.rd[k] = sc * 256 + (32 * hh + ((io.brow + 4 * k + c) & 15)) * 4;
+    for (int s = 0; s < 4; ++s) io.pw[s] = (lane ^ (2 * s + (lane >> 5))) * 4;
     return io;
 }
 __device__ __forceinline__ void srd_store_c(Srd r, unsigned byte_off, unsigned const_off, f32x4 v) {
@@ -88,15 +80,23 @@ __device__ __forceinline__ void srd_store_c(Srd r, unsigned byte_off, unsigned c
 __device__ __forceinline__ void line_put(float *blk, const LineIo &io, int s, f32x4 v) {
     *reinterpret_cast<f32x4 *>(blk + s * 256 + io.pw[s]) = v;
 }
-// the 32 x 32 block at `blk` -> rows row0 .. row0 + 31, columns col .. col + 31 of a row-major [rows][LD] tensor.  gbase = the byte
-// offset of (row0 + io.brow, col + 4 io.c); rows_left = rows - row0 - io.brow (ragged last tile: rows beyond the end are not stored).
-// Same wave wrote the block: LDS serves a wave's requests in order, the wave barrier only pins the compiler's order.
+// the 32 x 32 block at `blk` -> rows row0 .. row0 + 31, columns col .. col + 31 of a row-major [rows][LD] tensor: lane = (rho, c),
+// c = the 16-byte piece of the 128-byte row piece, instruction i stores row 8 (rho & 1) + (rho >> 1) + 4 (i & 1) + 16 (i >> 1); rows
+// beyond the tensor's end (ragged last tile) are not stored.  The lane's offsets are formed here, from a laundered lane index, so
+// that they are not held in registers across the products (both kernels sit at the 168 registers three waves per SIMD allow).
+// Same wave wrote the block: LDS serves a wave's requests in order, the wave barriers only pin the compiler's order.
 template <int LD>
-__device__ __forceinline__ void line_store(Srd dst, const float *blk, const LineIo &io, unsigned gbase, int rows_left) {
+__device__ __forceinline__ void line_store(Srd dst, const float *blk, int row0, int col, int rows) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int rho = lane >> 3, c = lane & 7, brow = 8 * (rho & 1) + (rho >> 1);
+    const int rd0 = (c >> 1) * 256 + ((32 * (c & 1) + brow) ^ c) * 4;
+    const unsigned gbase = ((unsigned)(row0 + brow) * LD + col + 4 * c) * 4;
+    const int rows_left = rows - row0 - brow;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(blk + io.rd[i & 1] + 64 * (i >> 1));
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(blk + (rd0 ^ (16 * (i & 1))) + 64 * (i >> 1));
         if (4 * (i & 1) + 16 * (i >> 1) < rows_left) srd_store_c(dst, gbase, (unsigned)((4 * (i & 1) + 16 * (i >> 1)) * LD * 4), v);
     }
     __builtin_amdgcn_wave_barrier();
@@ -205,6 +205,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         const bool row_ok = row0 + r < a.rows;
         const unsigned xrow = ((unsigned)grow * D + fb + 4 * h) * 4;            // 128-wide tensors: + 32 s (bytes)
         const unsigned hrow = ((unsigned)grow * 2 * D + 2 * fb + 4 * h) * 4;    // 256-wide tensors: + 128 t + 32 s
+        // swizzled fragment positions inside the exchange buffers' blocks (LineIo above)
+        const LineIo io = make_line_io(lane);
+        float *xw = xb + w * 1024, *hw = hb + w * 2048;     // this wave's blocks of the two exchange buffers
         unsigned lo = 0;
         asm volatile("" : "+v"(lo));    // keep the tile-invariant weight loads inside the loop (see chain_device.h)
         const unsigned w2t_lane = (w2t_off + lo) * 4, w1t_lane = (w1t_off + lo) * 4, wot_lane = (wot_off + lo) * 4;
@@ -267,9 +270,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         for (int s = 0; s < 4; ++s) {
             f32x4 v = {cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
             if (drop) v = mask4(v, rw3, colw + 3 * D + fb + 8 * s + 4 * h);
-            if (row_ok) srd_store(srd_g2, xrow + 32 * s, v);
-            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
+            line_put(xw, io, s, v);
         }
+        line_store<D>(srd_g2, xw, row0, fb, a.rows);
         // linear1's pre-activations of this lane's two hidden blocks: requested now, used behind the first product
         f32x4 aq[2][4];
 #pragma unroll
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
 
         // ---- (g2 W2): hidden blocks 2w, 2w+1; epilogue = dropout-2 mask and activation derivative ----
         f32x16 acc_h[2];
-        auto xb_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + lane * 4); };
+        auto xb_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + io.pw[s]); };
         gemm_run<W, 2, PFF, 1, 0, decltype(xb_frag), 0x3>(ring_ff, srd_w2t, w2t_lane, acc_h, xb_frag);
         gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w1t, w1t_lane);
         // the pre-norm sum of LayerNorm 1: requested here, used behind the second product
@@ -289,22 +292,23 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         for (int s = 0; s < 4; ++s) s1q[s] = srd_load(srd_s1, xrow + 32 * s);
         const float2 st1 = *reinterpret_cast<const float2 *>(a.st1 + 2 * (size_t)grow);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x2 d0 = activate2_grad<ACT>(f32x2{aq[t][s][0], aq[t][s][1]});
                 const f32x2 d1 = activate2_grad<ACT>(f32x2{aq[t][s][2], aq[t][s][3]});
                 f32x4 v = {acc_h[t][4 * s] * d0[0], acc_h[t][4 * s + 1] * d0[1], acc_h[t][4 * s + 2] * d1[0], acc_h[t][4 * s + 3] * d1[1]};
                 if (drop) v = mask4(v, rw2, colw + D + 2 * fb + 32 * t + 8 * s + 4 * h);
-                if (row_ok) srd_store(srd_gff, hrow + 128 * t + 32 * s, v);
-                *reinterpret_cast<f32x4 *>(hb + ((2 * w + t) * 4 + s) * 256 + lane * 4) = v;
+                line_put(hw + 1024 * t, io, s, v);
             }
+            line_store<2 * D>(srd_gff, hw + 1024 * t, row0, 2 * fb + 32 * t, a.rows);
+        }
         __syncthreads();
 
         // ---- dx1 = gff W1 + ds2 (the accumulator starts from ds2) ----
         f32x16 acc_d[1] = {ds2};
         gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w1t, w1t_lane, acc_d, [&](int kb, int s) {
-            return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + lane * 4);
+            return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + io.pw[s]);
         });
         gemm_preload<W, 1, PFD, 1>(ring_d, srd_wot, wot_lane);
         cur = acc_d[0];
@@ -319,24 +323,26 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         }
         // ds1: the residual branch of dL/dx (the in-projection's data gradient is added by the next launch);
         // g2b = drop1 (.) ds1: stored row-major, published for the last product
+        // (ds1 through the wave's hidden blocks: behind the LayerNorm barrier every wave has finished the product that read them;
+        //  g2 was consumed by the first product, so g2b takes its place in the x block)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) line_put(hw, io, s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
+        line_store<D>(srd_dx, hw, row0, fb, a.rows);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f32x4 v = {cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
-            if (row_ok) srd_store(srd_dx, xrow + 32 * s, v);
             if (drop) v = mask4(v, rw1, colw + fb + 8 * s + 4 * h);
-            if (row_ok) srd_store(srd_g2b, xrow + 32 * s, v);
-            *reinterpret_cast<f32x4 *>(xb + (w * 4 + s) * 256 + lane * 4) = v;
+            line_put(xw, io, s, v);
         }
+        line_store<D>(srd_g2b, xw, row0, fb, a.rows);
         __syncthreads();
 
         // ---- d_o = g2b Wo ----
         f32x16 acc_o[1];
         gemm_run<W, 1, PFD, 1, 0, decltype(xb_frag), 0x1>(ring_d, srd_wot, wot_lane, acc_o, xb_frag);
-        if (row_ok) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                srd_store(srd_do, xrow + 32 * s, f32x4{acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]});
-        }
+        for (int s = 0; s < 4; ++s) line_put(hw, io, s, f32x4{acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]});
+        line_store<D>(srd_do, hw, row0, fb, a.rows);
         // LDS hazards across tiles: xb is rewritten behind the next tile's LayerNorm-2 barrier, hb behind two barriers,
         // the row-sum table of LayerNorm 2 behind the xb barrier above.
     }
@@ -480,6 +486,41 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
     };
 
     const int ntiles = (a.rows + 31) / 32;
+    // The tile's two row-major inputs -- the attention output and the layer input (residual) -- arrive as whole cache lines too, a
+    // tile AHEAD: every wave fetches only ITS feature block of both (eight line loads; until round 4 every wave fetched all W blocks
+    // of the attention tile itself as 16 scattered loads into 64 registers), issued before the previous tile's last product and
+    // staged at its end -- the attention block into the wave's EVEN hidden block (the out-projection reads its operand from there,
+    // like every other product reads the exchange buffers), the residual block into the odd one.
+    float *xw = xb + w * 1024, *hw = hb + w * 2048;     // this wave's blocks of the two exchange buffers
+    f32x4 na[4], nx[4];
+    auto fetch_tile = [&](int row0n) {      // row0n >= rows: every load is out of range (zeros, no memory access)
+        int l = threadIdx.x & 63;
+        asm volatile("" : "+v"(l));
+        const int rho = l >> 3, c = l & 7, brow = 8 * (rho & 1) + (rho >> 1);
+        const unsigned gb = ((unsigned)(row0n + brow) * D + fb + 4 * c) * 4;
+        const int left = a.rows - row0n - brow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dr = 4 * (i & 1) + 16 * (i >> 1);
+            const unsigned vo = dr < left ? gb : 0x80000000u;   // beyond the resource's 2^31 - 1 bytes: reads as zero
+            na[i] = srd_load_c(srd_attn, vo, (unsigned)(dr * D * 4));
+            nx[i] = srd_load_c(srd_x, vo, (unsigned)(dr * D * 4));
+        }
+    };
+    auto stage_lines = [&](float *blk, const f32x4 (&v)[4]) {
+        int l = threadIdx.x & 63;
+        asm volatile("" : "+v"(l));
+        const int rho = l >> 3, c = l & 7, brow = 8 * (rho & 1) + (rho >> 1);
+        const int rd0 = (c >> 1) * 256 + ((32 * (c & 1) + brow) ^ c) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(blk + (rd0 ^ (16 * (i & 1))) + 64 * (i >> 1)) = v[i];
+    };
+    if ((int)blockIdx.x < ntiles) {
+        fetch_tile(blockIdx.x * 32);
+        stage_lines(hw, na);
+        stage_lines(hw + 1024, nx);
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * 32;
@@ -487,12 +528,8 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
         const bool row_ok = row0 + r < a.rows;
         const unsigned xrow = ((unsigned)grow * D + fb + 4 * h) * 4;
         const unsigned hrow = ((unsigned)grow * 2 * D + 2 * fb + 4 * h) * 4;
-        // whole-line stores (LineIo above): byte offsets of (row0 + brow, this wave's columns + 4 c) in the 128- / 256- / 384-wide tensors
+        // swizzled fragment positions inside the exchange buffers' blocks (LineIo above)
         const LineIo io = make_line_io(lane);
-        const unsigned g128 = ((unsigned)(row0 + io.brow) * D + fb + 4 * io.c) * 4;
-        const unsigned g256 = ((unsigned)(row0 + io.brow) * 2 * D + 2 * fb + 4 * io.c) * 4;
-        const int rows_left = a.rows - row0 - io.brow;
-        float *xw = xb + w * 1024, *hw = hb + w * 2048;     // this wave's blocks of the two exchange buffers
         unsigned lo = 0;
         asm volatile("" : "+v"(lo));
         const unsigned wo_lane = (wo_off + lo) * 4, w1_lane = (w1_off + lo) * 4, w2_lane = (w2_off + lo) * 4;
@@ -507,17 +544,13 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
         // ---- out-projection + bias, dropout 1, residual ----
         f32x16 acc_o[1] = {bias_acc(srd_bo, fb, h)};
         gemm_preload<W, 1, PFD, 1>(ring_d, srd_wo, wo_lane);
-        f32x4 of[W][4], xres[4];
-        {   // the attention output of the tile's rows, all W feature blocks, row-major: 16 bytes at (row, 32 kb + 8 s + 4 h)
-            const unsigned arow = ((unsigned)grow * D + 4 * h) * 4;
+        f32x4 xres[4];      // this lane's fragments of the residual block (staged by this wave at the end of the previous tile)
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int kb = 0; kb < W; ++kb)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) of[kb][s] = srd_load(srd_attn, arow + 128 * kb + 32 * s);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) xres[s] = srd_load(srd_x, xrow + 32 * s);
-        }
-        gemm_run<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) { return of[kb][s]; });
+        for (int s = 0; s < 4; ++s) xres[s] = *reinterpret_cast<const f32x4 *>(hw + 1024 + s * 256 + io.pw[s]);
+        gemm_run<W, 1, PFD, 1, 0>(ring_d, srd_wo, wo_lane, acc_o, [&](int kb, int s) {
+            return *reinterpret_cast<const f32x4 *>(hb + (2 * kb * 4 + s) * 256 + io.pw[s]);   // attention tile: the waves' even hidden blocks
+        });
         TSTAMP(1);
         f32x16 acc_h[2] = {bias_acc(srd_b1, 2 * fb, h), bias_acc(srd_b1, 2 * fb + 32, h)};
         gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w1, w1_lane);
@@ -533,18 +566,18 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             f32x4 y = {acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]};
             if (drop) y = mask4(y, rw1, colw + fb + 8 * s + 4 * h);
             const f32x4 v = xres[s] + y;
-            if (TAPE) line_put(hw, io, s, v);    // the wave's hidden blocks are idle until this tile's hidden barrier
+            if (TAPE) line_put(hw + 1024, io, s, v);    // the wave's odd hidden block: the residual fragments are out, the even one is still being read
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
         }
-        if (TAPE) line_store<D>(srd_s1, hw, io, g128, rows_left);
+        if (TAPE) line_store<D>(srd_s1, hw + 1024, row0, fb, a.rows);
         float mean, rstd;
         layernorm_rows_stats<D>(cur, stats, par + fb, srd_be1, fb, w, r, h, mean, rstd);   // -> x1
         if (row_ok && w == 0 && h == 0) *reinterpret_cast<float2 *>(a.st1 + 2 * (size_t)grow) = make_float2(mean, rstd);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             line_put(xw, io, s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});   // published, and stored from there
-        if (TAPE) line_store<D>(srd_x1, xw, io, g128, rows_left);
+        if (TAPE) line_store<D>(srd_x1, xw, row0, fb, a.rows);
         __syncthreads();
         TSTAMP(2);
         // ---- linear1 + bias -> a (kept), activation, dropout 2 -> hd (kept, published) ----
@@ -562,7 +595,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     line_put(hw + 1024, io, s, f32x4{acc_h[t][4 * s], acc_h[t][4 * s + 1], acc_h[t][4 * s + 2], acc_h[t][4 * s + 3]});
-                line_store<2 * D>(srd_a, hw + 1024, io, g256 + 128 * t, rows_left);
+                line_store<2 * D>(srd_a, hw + 1024, row0, 2 * fb + 32 * t, a.rows);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -572,10 +605,14 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
                 if (drop) v = mask4(v, rw2, colw + D + 2 * fb + 32 * t + 8 * s + 4 * h);
                 line_put(hw + 1024 * t, io, s, v);
             }
-            if (TAPE) line_store<2 * D>(srd_hd, hw + 1024 * t, io, g256 + 128 * t, rows_left);
+            if (TAPE) line_store<2 * D>(srd_hd, hw + 1024 * t, row0, 2 * fb + 32 * t, a.rows);
         }
         __syncthreads();
         TSTAMP(4);
+        {   // the next tile's attention / residual blocks: requested here, staged at the end of this tile
+            const int ntile = tile + gridDim.x;
+            fetch_tile(ntile < ntiles ? ntile * 32 : a.rows);
+        }
         // ---- linear2 + bias, dropout 3, residual (x1, registers) ----
         gemm_run<2 * W, 1, PFD, 1, 0>(ring_d, srd_w2, w2_lane, acc_d, [&](int kb, int s) {
             return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + io.pw[s]);
@@ -592,13 +629,13 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[4 * s + j] = v[j];
         }
-        if (TAPE) line_store<D>(srd_s2, xw, io, g128, rows_left);
+        if (TAPE) line_store<D>(srd_s2, xw, row0, fb, a.rows);
         layernorm_rows_stats<D>(cur, stats, par + D + fb, srd_be2, fb, w, r, h, mean, rstd);   // -> x2
         if (row_ok && w == 0 && h == 0) *reinterpret_cast<float2 *>(a.st2 + 2 * (size_t)grow) = make_float2(mean, rstd);
         // x2: into the wave's x block (the in-projection tail's operand), stored from there
 #pragma unroll
         for (int s = 0; s < 4; ++s) line_put(xw, io, s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
-        line_store<D>(srd_out, xw, io, g128, rows_left);
+        line_store<D>(srd_out, xw, row0, fb, a.rows);
         TSTAMP(6);
         if constexpr (QKV) {
             // ---- the next layer's in-projection on x2 (the tile is still in registers): q | k | v of feature block w, bias as the
@@ -612,16 +649,19 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
             gemm_run<W, 3, PFQ, W, 0>(ring_q, srd_wq, wq_lane, acc_q, [&](int kb, int s) {
                 return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + io.pw[s]);
             });
-            // q, k, v of feature block w: each through one of the wave's hidden blocks (free behind the barrier above)
-            const unsigned g384 = ((unsigned)(row0 + io.brow) * 3 * D + fb + 4 * io.c) * 4;
+            // q, k, v of feature block w: each through the wave's odd hidden block (free behind the barrier above)
+            stage_lines(hw, na);      // (the hidden blocks' readers are past the barrier above)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    line_put(hw + 1024 * (t & 1), io, s, f32x4{acc_q[t][4 * s], acc_q[t][4 * s + 1], acc_q[t][4 * s + 2], acc_q[t][4 * s + 3]});
-                line_store<3 * D>(srd_qkv, hw + 1024 * (t & 1), io, g384 + (unsigned)t * D * 4, rows_left);
+                    line_put(hw + 1024, io, s, f32x4{acc_q[t][4 * s], acc_q[t][4 * s + 1], acc_q[t][4 * s + 2], acc_q[t][4 * s + 3]});
+                line_store<3 * D>(srd_qkv, hw + 1024, row0, t * D + fb, a.rows);
             }
+        } else {
+            stage_lines(hw, na);      // (the hidden blocks' readers are past the LayerNorm-2 barrier)
         }
+        stage_lines(hw + 1024, nx);
         TSTAMP(7);
         __syncthreads();    // the next tile's LayerNorm-1 partials must not overtake this tile's LayerNorm-2 readers
         TSTAMP(8);
