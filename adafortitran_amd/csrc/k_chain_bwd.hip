@@ -189,6 +189,40 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
 
     const int ntiles = (a.rows + 31) / 32;
     float psum[2] = {0.f, 0.f};     // lane (r, h): column sum of feature fb + r, quantity h, for LayerNorm 2 and LayerNorm 1
+    // The tile's row-major inputs arrive as whole cache lines (LineIo above), one 32 x 32 block per instruction group, and reach the
+    // lanes' fragments through the wave's own blocks of the exchange buffers: g and s2 are fetched a tile AHEAD (issued before the
+    // last product of the previous tile, staged into the wave's two hidden blocks at its end), a's two blocks are requested at the
+    // tile start and staged into the hidden blocks behind the first product (where gff then replaces them), s1 is requested behind the
+    // hidden barrier and staged into the wave's x block behind the second product (g2's readers are past that barrier).
+    const Srd srd_st2 = make_srd(a.st2), srd_st1 = make_srd(a.st1);
+    auto fetch_lines = [&](Srd src, int LD, int row0n, int col, f32x4 (&v)[4]) {   // row0n >= rows: out of range (zeros, no access)
+        int l = threadIdx.x & 63;
+        asm volatile("" : "+v"(l));
+        const int rho = l >> 3, c = l & 7, brow = 8 * (rho & 1) + (rho >> 1);
+        const unsigned gb = ((unsigned)(row0n + brow) * LD + col + 4 * c) * 4;
+        const int left = a.rows - row0n - brow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dr = 4 * (i & 1) + 16 * (i >> 1);
+            v[i] = srd_load_c(src, dr < left ? gb : 0x80000000u, (unsigned)(dr * LD * 4));
+        }
+    };
+    auto stage_lines = [&](float *blk, const f32x4 (&v)[4]) {
+        int l = threadIdx.x & 63;
+        asm volatile("" : "+v"(l));
+        const int rho = l >> 3, c = l & 7, brow = 8 * (rho & 1) + (rho >> 1);
+        const int rd0 = (c >> 1) * 256 + ((32 * (c & 1) + brow) ^ c) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(blk + (rd0 ^ (16 * (i & 1))) + 64 * (i >> 1)) = v[i];
+    };
+    {
+        f32x4 ng[4], ns[4];
+        const int first = (int)blockIdx.x < ntiles ? (int)blockIdx.x * 32 : a.rows;
+        fetch_lines(srd_g, D, first, fb, ng);
+        fetch_lines(srd_s2, D, first, fb, ns);
+        stage_lines(hb + w * 2048, ng);
+        stage_lines(hb + w * 2048 + 1024, ns);
+    }
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // everything derived from the lane index is recomputed per tile from a laundered copy: as loop invariants those values
@@ -217,12 +251,17 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
 
         // ---- LayerNorm-2 backward ----
         f32x4 gq[4], sq[4];
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            gq[s] = srd_load(srd_g, xrow + 32 * s);
-            sq[s] = srd_load(srd_s2, xrow + 32 * s);
+            gq[s] = *reinterpret_cast<const f32x4 *>(hw + s * 256 + io.pw[s]);
+            sq[s] = *reinterpret_cast<const f32x4 *>(hw + 1024 + s * 256 + io.pw[s]);
         }
-        const float2 st2 = *reinterpret_cast<const float2 *>(a.st2 + 2 * (size_t)grow);
+        const f32x2 st2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_st2, (unsigned)grow * 8, 0, 0));
+        // linear1's pre-activations of this wave's two hidden blocks: requested now, staged behind the first product
+        f32x4 al[2][4];
+        fetch_lines(srd_a, 2 * D, row0, 2 * fb, al[0]);
+        fetch_lines(srd_a, 2 * D, row0, 2 * fb + 32, al[1]);
         gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w2t, w2t_lane);
         f32x16 cur, dgam;
 #pragma unroll
@@ -255,7 +294,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         };
         {
             const f32x16 dbeta = cur;
-            layernorm_bwd_rows<D>(cur, sq, st2.x, st2.y, stats, par + fb, w, r, h, dgam);
+            layernorm_bwd_rows<D>(cur, sq, st2[0], st2[1], stats, par + fb, w, r, h, dgam);
             store_param_sums(dgam, dbeta, 0);
         }
         const f32x16 ds2 = cur;     // joins dx1 behind the second product
@@ -273,12 +312,6 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
             line_put(xw, io, s, v);
         }
         line_store<D>(srd_g2, xw, row0, fb, a.rows);
-        // linear1's pre-activations of this lane's two hidden blocks: requested now, used behind the first product
-        f32x4 aq[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) aq[t][s] = srd_load(srd_a, hrow + 128 * t + 32 * s);
         __syncthreads();
 
         // ---- (g2 W2): hidden blocks 2w, 2w+1; epilogue = dropout-2 mask and activation derivative ----
@@ -286,17 +319,16 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         auto xb_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + io.pw[s]); };
         gemm_run<W, 2, PFF, 1, 0, decltype(xb_frag), 0x3>(ring_ff, srd_w2t, w2t_lane, acc_h, xb_frag);
         gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w1t, w1t_lane);
-        // the pre-norm sum of LayerNorm 1: requested here, used behind the second product
-        f32x4 s1q[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) s1q[s] = srd_load(srd_s1, xrow + 32 * s);
-        const float2 st1 = *reinterpret_cast<const float2 *>(a.st1 + 2 * (size_t)grow);
+        stage_lines(hw, al[0]);
+        stage_lines(hw + 1024, al[1]);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const f32x2 d0 = activate2_grad<ACT>(f32x2{aq[t][s][0], aq[t][s][1]});
-                const f32x2 d1 = activate2_grad<ACT>(f32x2{aq[t][s][2], aq[t][s][3]});
+                const f32x4 aq = *reinterpret_cast<const f32x4 *>(hw + 1024 * t + s * 256 + io.pw[s]);   // gff takes its place below
+                const f32x2 d0 = activate2_grad<ACT>(f32x2{aq[0], aq[1]});
+                const f32x2 d1 = activate2_grad<ACT>(f32x2{aq[2], aq[3]});
                 f32x4 v = {acc_h[t][4 * s] * d0[0], acc_h[t][4 * s + 1] * d0[1], acc_h[t][4 * s + 2] * d1[0], acc_h[t][4 * s + 3] * d1[1]};
                 if (drop) v = mask4(v, rw2, colw + D + 2 * fb + 32 * t + 8 * s + 4 * h);
                 line_put(hw + 1024 * t, io, s, v);
@@ -304,6 +336,10 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
             line_store<2 * D>(srd_gff, hw + 1024 * t, row0, 2 * fb + 32 * t, a.rows);
         }
         __syncthreads();
+        // the pre-norm sum of LayerNorm 1: requested here, staged behind the second product
+        f32x4 sl[4];
+        fetch_lines(srd_s1, D, row0, fb, sl);
+        const f32x2 st1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_st1, (unsigned)grow * 8, 0, 0));
 
         // ---- dx1 = gff W1 + ds2 (the accumulator starts from ds2) ----
         f32x16 acc_d[1] = {ds2};
@@ -311,6 +347,11 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
             return *reinterpret_cast<const f32x4 *>(hb + (kb * 4 + s) * 256 + io.pw[s]);
         });
         gemm_preload<W, 1, PFD, 1>(ring_d, srd_wot, wot_lane);
+        f32x4 s1q[4];
+        stage_lines(xw, sl);        // g2's readers are past the hidden barrier
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) s1q[s] = *reinterpret_cast<const f32x4 *>(xw + s * 256 + io.pw[s]);
         cur = acc_d[0];
         if (!row_ok) {
 #pragma unroll
@@ -318,7 +359,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         }
         {
             const f32x16 dbeta = cur;
-            layernorm_bwd_rows<D>(cur, s1q, st1.x, st1.y, stats, par + D + fb, w, r, h, dgam);
+            layernorm_bwd_rows<D>(cur, s1q, st1[0], st1[1], stats, par + D + fb, w, r, h, dgam);
             store_param_sums(dgam, dbeta, 1);
         }
         // ds1: the residual branch of dL/dx (the in-projection's data gradient is added by the next launch);
@@ -336,6 +377,13 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         }
         line_store<D>(srd_g2b, xw, row0, fb, a.rows);
         __syncthreads();
+        // the next tile's g and s2 blocks: requested here, staged at the end of this tile
+        f32x4 ng[4], ns[4];
+        {
+            const int ntile = tile + gridDim.x, row0n = ntile < ntiles ? ntile * 32 : a.rows;
+            fetch_lines(srd_g, D, row0n, fb, ng);
+            fetch_lines(srd_s2, D, row0n, fb, ns);
+        }
 
         // ---- d_o = g2b Wo ----
         f32x16 acc_o[1];
@@ -343,6 +391,8 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
 #pragma unroll
         for (int s = 0; s < 4; ++s) line_put(hw, io, s, f32x4{acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]});
         line_store<D>(srd_do, hw, row0, fb, a.rows);
+        stage_lines(hw, ng);
+        stage_lines(hw + 1024, ns);
         // LDS hazards across tiles: xb is rewritten behind the next tile's LayerNorm-2 barrier, hb behind two barriers,
         // the row-sum table of LayerNorm 2 behind the xb barrier above.
     }
