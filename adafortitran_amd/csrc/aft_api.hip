@@ -119,7 +119,7 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     size_t off = 0;
     ws.conv_enhanced = off; off += align64((size_t)ws.planes * c.num_scs * c.num_symbols);
     ws.tokens6 = off;       off += align64((size_t)batch * ws.tokens * 6);
-    ws.x = off;             off += align64(rows * c.model_dim);
+    ws.x = off;             off += align64((rows + 31) / 32 * 32 * c.model_dim);   // whole 32-row tiles (tile-blocked x)
     // attention tiles: global 32-row tiles (layer-by-layer path) or ceil(tokens/32) tiles per plane (plane-resident path)
     ws.attn = off;          off += align64(std::max((size_t)round_up((int)rows, kTile), (size_t)ws.planes * ws.tokpad) * c.model_dim);
     const size_t per_head = (size_t)ws.planes * ws.tokpad * c.model_dim;   // planes x (model_dim / 32) blocks x tokpad x 32
@@ -179,7 +179,9 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
         return e == hipSuccess ? AFT_OK : hip_fail("encoder(plane-resident)", e);
     }
     // in-projection of the first layer (QKV-only pass of the chain kernel)
-    ChainFusion first{}, last{};
+    ChainFusion first{}, last{}, middle{};
+    // whole forward: nobody but these launches reads x, so it crosses HBM in tile-blocked order (every access 1 KB contiguous)
+    first.x_blocked = last.x_blocked = middle.x_blocked = fused;
     if (fused) {
         first.conv_enhanced = base + ws.conv_enhanced;
         first.tokens6 = c.adaptive ? base + ws.tokens6 : nullptr;
@@ -195,7 +197,7 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
         const bool more = l < last_layer;
         e = launch_chain(c, &w.layers[l], wp + l * pl, more ? &w.layers[l + 1] : nullptr,
                          more ? wp + (l + 1) * pl : nullptr, attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st,
-                         fused && !more ? &last : nullptr);
+                         fused ? (more ? &middle : &last) : nullptr);
         if (e != hipSuccess) return hip_fail("chain(mlp)", e);
     }
     return AFT_OK;
@@ -425,6 +427,7 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                 f.conv_enhanced = base + ws.conv_enhanced;
                 f.tokens6 = cfg->adaptive ? base + ws.tokens6 : nullptr;
                 f.lin1_w = w->lin1_w; f.lin1_b = w->lin1_b; f.pos = w->pos;
+                f.x_blocked = true;
                 e = launch_chain(*cfg, nullptr, nullptr, &w->layers[0], base + ws.wpack, nullptr, x, q, k, vt, rows,
                                  ws.tokens, ws.tokpad, st, &f);
                 break;
@@ -432,14 +435,18 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
             case AFT_KERNEL_ATTENTION:
                 e = launch_attention(*cfg, q, k, vt, w->layers[0].in_proj_b, attn, ws.planes, ws.tokens, ws.tokpad, st);
                 break;
-            case AFT_KERNEL_CHAIN:
+            case AFT_KERNEL_CHAIN: {   // as in the forward: x in tile-blocked order
+                ChainFusion f{};
+                f.x_blocked = true;
                 e = launch_chain(*cfg, &w->layers[0], base + ws.wpack, &w->layers[1],
                                  base + ws.wpack + packed_layer_floats(cfg->model_dim), attn, x, q, k, vt, rows,
-                                 ws.tokens, ws.tokpad, st);
+                                 ws.tokens, ws.tokpad, st, &f);
                 break;
+            }
             case AFT_KERNEL_CHAIN_LAST: {   // as in the forward: linear_2 fused behind LN2, x not stored
                 ChainFusion f{};
                 f.lin2_w = w->lin2_w; f.lin2_b = w->lin2_b; f.out6 = base + ws.out6;
+                f.x_blocked = true;
                 e = launch_chain(*cfg, &w->layers[0], base + ws.wpack, nullptr, nullptr, attn, x, q, k, vt, rows,
                                  ws.tokens, ws.tokpad, st, &f);
                 break;

@@ -188,6 +188,7 @@ struct ChainFusion {
     const float *conv_enhanced = nullptr, *tokens6 = nullptr, *lin1_w = nullptr, *lin1_b = nullptr, *pos = nullptr;
     const float *lin2_w = nullptr, *lin2_b = nullptr;
     float *out6 = nullptr;
+    bool x_blocked = false;   // x between the launches in tile-blocked order (ChainArgs::x_blocked): the whole-forward sequence only
 };
 inline int out6_stride(const aft_config &c) { return c.patch_scs * c.patch_symbols <= 8 ? 8 : 16; }
 hipError_t launch_chain(const aft_config &c, const aft_layer_weights *mlp_w, const float *mlp_packed,

@@ -183,6 +183,7 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const f
     }
     a.attn = attn;
     a.x = x;
+    a.x_blocked = fuse != nullptr && fuse->x_blocked ? 1 : 0;
     if (m != nullptr) {
         a.wo = m_packed + 3 * dd; a.bo = m->out_proj_b;
         a.w1 = m_packed + 4 * dd; a.b1 = m->lin1_b;

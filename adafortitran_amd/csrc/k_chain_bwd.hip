@@ -237,8 +237,6 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         const int row0 = tile * 32;
         const int grow = min(row0 + r, a.rows - 1);
         const bool row_ok = row0 + r < a.rows;
-        const unsigned xrow = ((unsigned)grow * D + fb + 4 * h) * 4;            // 128-wide tensors: + 32 s (bytes)
-        const unsigned hrow = ((unsigned)grow * 2 * D + 2 * fb + 4 * h) * 4;    // 256-wide tensors: + 128 t + 32 s
         // swizzled fragment positions inside the exchange buffers' blocks (LineIo above)
         const LineIo io = make_line_io(lane);
         float *xw = xb + w * 1024, *hw = hb + w * 2048;     // this wave's blocks of the two exchange buffers
@@ -576,8 +574,6 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_fwd_train_kerne
         const int row0 = tile * 32;
         const int grow = min(row0 + r, a.rows - 1);
         const bool row_ok = row0 + r < a.rows;
-        const unsigned xrow = ((unsigned)grow * D + fb + 4 * h) * 4;
-        const unsigned hrow = ((unsigned)grow * 2 * D + 2 * fb + 4 * h) * 4;
         // swizzled fragment positions inside the exchange buffers' blocks (LineIo above)
         const LineIo io = make_line_io(lane);
         unsigned lo = 0;
