@@ -470,7 +470,15 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 // dQ product takes back out with its final factor) and is read in both operand forms, only V's stays in registers.
 // LDS per workgroup at 9 tiles: staging 9.2 KB (single: the step has two barriers anyway) + exchange 13.8 + K tiles 13.8 +
 // tables 3.4 = 40.3 KB, four workgroups per CU.
-__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kernel(const AttnTrainArgs a) {
+// TOK > 0: the token count (and with it the tile and pass counts) as a compile-time constant -- the default grid's 280, as in
+// attn_kernel<32, 280> (k_attn.hip): 327.6 -> 320.4 us, same bits; any other count runs the generic instantiation
+template <int TOK = 0>
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kernel(const AttnTrainArgs a_rt) {
+    AttnTrainArgs a = a_rt;
+    if constexpr (TOK > 0) {
+        a.tokens = TOK;
+        a.ntiles = (TOK + 31) / 32;
+    }
 
     __shared__ __attribute__((aligned(16))) float stage[2 * kAtTileFloats];         // Q tile | dO tile of the step
     __shared__ __attribute__((aligned(16))) float xch[kAtWaves][kAtTileFloats];     // per wave: dS transposed, then its dQ contribution
@@ -719,7 +727,10 @@ hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const fl
     const bool two_pass = getenv("AFT_TRAIN_ATTN_BWD_SPLIT") != nullptr;   // read per call: tools/debug/attn_bwd_check.py flips it
     const size_t static_lds = sizeof(float) * (2 * kAtTileFloats + 2 * kAtWaves * kAtTileFloats);
     if (!two_pass && static_lds + 3 * words_bytes <= 64 * 1024) {
-        hipLaunchKernelGGL(attn_bwd_kernel, dim3(planes * a.heads), dim3(kAtThreads), 3 * words_bytes, st, a);
+        if (tokens == 280 && !getenv("AFT_ATTN_GENERIC"))
+            hipLaunchKernelGGL(attn_bwd_kernel<280>, dim3(planes * a.heads), dim3(kAtThreads), 3 * words_bytes, st, a);
+        else
+            hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(planes * a.heads), dim3(kAtThreads), 3 * words_bytes, st, a);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(wgs), dim3(kAtThreads), words_bytes, st, a);    // also writes D_i = dO_i . O_i
