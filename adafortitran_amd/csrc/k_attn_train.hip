@@ -471,27 +471,38 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 // LDS per workgroup at 9 tiles: staging 9.2 KB (single: the step has two barriers anyway) + exchange 13.8 + K tiles 13.8 +
 // tables 3.4 = 40.3 KB, four workgroups per CU.
 // TOK > 0: the token count (and with it the tile and pass counts) as a compile-time constant -- the default grid's 280, as in
-// attn_kernel<32, 280> (k_attn.hip): 327.6 -> 320.4 us, same bits; any other count runs the generic instantiation
-template <int TOK = 0>
-__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kernel(const AttnTrainArgs a_rt) {
+// attn_kernel<32, 280> (k_attn.hip): 327.6 -> 320.4 us, same bits; any other count runs the generic instantiation.
+// GROUPS: (plane, head) problems per workgroup, each worked by its own three waves exactly as described above (own staging, own
+// exchange blocks, own tables; only the barriers are shared).  GROUPS = 4 is a TWELVE-wave workgroup, one per CU, and exists because
+// of where the hardware puts waves (tools/micro/wg_shape.hip, round 4): with registers for three waves per SIMD, four resident
+// THREE-wave workgroups per CU sustain 0.64 of the fp32 MFMA roof on a registers-only chain benchmark where four-wave, single-wave
+// and twelve-wave workgroups sustain 0.83-0.87 -- the dispatcher does not spread a three-wave workgroup's waves so that every SIMD
+// ends up with three (late-starting workgroups and an idle SIMD showed in in-kernel timestamps), and this kernel sat at 106 cycles
+// per MFMA whatever was removed from it (LDS operand reads, the vector math, the barriers, all global traffic: each <= 6 %).
+// GROUPS = 1 is the old shape, kept for token counts whose tables do not fit four times into the CU's LDS.
+constexpr int kAtBwdStatic = (2 + 2 * kAtWaves) * kAtTileFloats;   // floats per group: stage (Q | dO) + exchange blocks + K tiles
+template <int TOK = 0, int GROUPS = 1>
+__global__ __launch_bounds__(kAtThreads * GROUPS) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kernel(const AttnTrainArgs a_rt) {
     AttnTrainArgs a = a_rt;
     if constexpr (TOK > 0) {
         a.tokens = TOK;
         a.ntiles = (TOK + 31) / 32;
     }
-
-    __shared__ __attribute__((aligned(16))) float stage[2 * kAtTileFloats];         // Q tile | dO tile of the step
-    __shared__ __attribute__((aligned(16))) float xch[kAtWaves][kAtTileFloats];     // per wave: dS transposed, then its dQ contribution
-    __shared__ __attribute__((aligned(16))) float ktile[kAtWaves][kAtTileFloats];   // per wave: its own K tile x scale2
-    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] row (query) words | lse | D
+    extern __shared__ __attribute__((aligned(16))) float smem_bwd[];
     const int nrow = a.ntiles * 32;
+    const int grp = GROUPS > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / kAtThreads) : 0;
+    float *gbase = smem_bwd + (size_t)grp * (kAtBwdStatic + 3 * nrow);
+    float *stage = gbase;                                        // Q tile | dO tile of the step
+    float *xch_base = stage + 2 * kAtTileFloats;                 // per wave: dS transposed, then its dQ contribution
+    float *ktile_base = xch_base + kAtWaves * kAtTileFloats;     // per wave: its own K tile x scale2
+    uint32_t *words = reinterpret_cast<uint32_t *>(ktile_base + kAtWaves * kAtTileFloats);   // [ntiles * 32] row (query) words | lse | D
     // the two float tables behind the mask words, as LDS-address-space float pointers: float stores, float4 loads (reading them
     // back as uint32 vectors and bit-casting the elements made hipcc use element 0 for all four)
     using LdsF = __attribute__((address_space(3))) float;
     using LdsF4 = __attribute__((address_space(3))) f32x4;
     LdsF *lse_t = (LdsF *)(words + nrow), *dsum_t = lse_t + nrow;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
-    const int ph = blockIdx.x, head = ph % a.heads, plane = ph / a.heads;
+    const int tid = (int)threadIdx.x - grp * kAtThreads, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;   // within the group
+    const int ph = blockIdx.x * GROUPS + grp, head = ph % a.heads, plane = ph / a.heads;
     const int ld = 3 * a.d;
     const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * 32;
     const float *kb = qb + a.d, *vb = qb + 2 * a.d;
@@ -555,8 +566,8 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         }
     };
     const int npass = (a.ntiles + kAtWaves - 1) / kAtWaves;
-    float *T = xch[wave];
-    const float *KT = ktile[wave];
+    float *T = xch_base + wave * kAtTileFloats;
+    const float *KT = ktile_base + wave * kAtTileFloats;
     for (int pass = 0; pass < npass; ++pass) {
         const int kt = pass * kAtWaves + wave;
         const bool active = kt < a.ntiles;
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = lane + 64 * u, row = e >> 3, q4 = e & 7;
-                *reinterpret_cast<f32x4 *>(ktile[wave] + row * kAtLd + 4 * q4) = kv[u] * a.scale2;
+                *reinterpret_cast<f32x4 *>(ktile_base + wave * kAtTileFloats + row * kAtLd + 4 * q4) = kv[u] * a.scale2;
             }
         }
         f32x16 dv = zero16(), dk = zero16();
@@ -672,14 +683,14 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
             __syncthreads();
             // the waves' contributions to query tile qt, added in wave order to what the earlier passes left
             {
-                f32x4 v0 = *reinterpret_cast<const f32x4 *>(xch[0] + l0);
-                if (nact > 1) v0 += *reinterpret_cast<const f32x4 *>(xch[1] + l0);
-                if (nact > 2) v0 += *reinterpret_cast<const f32x4 *>(xch[2] + l0);
+                f32x4 v0 = *reinterpret_cast<const f32x4 *>(xch_base + l0);
+                if (nact > 1) v0 += *reinterpret_cast<const f32x4 *>(xch_base + kAtTileFloats + l0);
+                if (nact > 2) v0 += *reinterpret_cast<const f32x4 *>(xch_base + 2 * kAtTileFloats + l0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (v0 + old0) * dq_mul), dq_rs, vq0 + t_off, 0, 0);
                 if (wave == 0) {
-                    f32x4 v1 = *reinterpret_cast<const f32x4 *>(xch[0] + l1);
-                    if (nact > 1) v1 += *reinterpret_cast<const f32x4 *>(xch[1] + l1);
-                    if (nact > 2) v1 += *reinterpret_cast<const f32x4 *>(xch[2] + l1);
+                    f32x4 v1 = *reinterpret_cast<const f32x4 *>(xch_base + l1);
+                    if (nact > 1) v1 += *reinterpret_cast<const f32x4 *>(xch_base + kAtTileFloats + l1);
+                    if (nact > 2) v1 += *reinterpret_cast<const f32x4 *>(xch_base + 2 * kAtTileFloats + l1);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (v1 + old1) * dq_mul), dq_rs, vq1 + t_off, 0, 0);
                 }
             }
@@ -725,12 +736,23 @@ hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const fl
     const size_t words_bytes = (size_t)a.ntiles * 32 * sizeof(uint32_t);
     // one pass (attn_bwd_kernel) unless its three LDS tables do not fit beside the static staging, or the two-pass form is asked for (A/B)
     const bool two_pass = getenv("AFT_TRAIN_ATTN_BWD_SPLIT") != nullptr;   // read per call: tools/debug/attn_bwd_check.py flips it
-    const size_t static_lds = sizeof(float) * (2 * kAtTileFloats + 2 * kAtWaves * kAtTileFloats);
-    if (!two_pass && static_lds + 3 * words_bytes <= 64 * 1024) {
-        if (tokens == 280 && !getenv("AFT_ATTN_GENERIC"))
-            hipLaunchKernelGGL(attn_bwd_kernel<280>, dim3(planes * a.heads), dim3(kAtThreads), 3 * words_bytes, st, a);
-        else
-            hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(planes * a.heads), dim3(kAtThreads), 3 * words_bytes, st, a);
+    const size_t group_lds = sizeof(float) * kAtBwdStatic + 3 * words_bytes;
+    if (!two_pass && group_lds <= 64 * 1024) {
+        // four problems per workgroup (twelve waves, one workgroup per CU) when their LDS fits four times; else the three-wave shape
+        const bool four = 4 * group_lds <= 160 * 1024 && (planes * a.heads) % 4 == 0 && !getenv("AFT_ATTN_BWD_3WAVE");
+        const bool tok280 = tokens == 280 && !getenv("AFT_ATTN_GENERIC");
+        const void *fn = four ? (tok280 ? reinterpret_cast<const void *>(attn_bwd_kernel<280, 4>) : reinterpret_cast<const void *>(attn_bwd_kernel<0, 4>))
+                              : (tok280 ? reinterpret_cast<const void *>(attn_bwd_kernel<280, 1>) : reinterpret_cast<const void *>(attn_bwd_kernel<0, 1>));
+        static PerDeviceOnce lds_attr[4];
+        hipError_t ea = ensure_dynamic_lds(lds_attr[(four ? 2 : 0) + (tok280 ? 1 : 0)], fn, four ? 160 * 1024 : 64 * 1024);
+        if (ea != hipSuccess) return ea;
+        const int groups = four ? 4 : 1;
+        const dim3 grid(planes * a.heads / groups), block(kAtThreads * groups);
+        const size_t lds = group_lds * groups;
+        if (four && tok280) hipLaunchKernelGGL((attn_bwd_kernel<280, 4>), grid, block, lds, st, a);
+        else if (four) hipLaunchKernelGGL((attn_bwd_kernel<0, 4>), grid, block, lds, st, a);
+        else if (tok280) hipLaunchKernelGGL((attn_bwd_kernel<280, 1>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((attn_bwd_kernel<0, 1>), grid, block, lds, st, a);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(wgs), dim3(kAtThreads), words_bytes, st, a);    // also writes D_i = dO_i . O_i
