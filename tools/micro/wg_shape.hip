@@ -81,5 +81,11 @@ int main() {
     run<192, 3>(3, 1, 1, out);
     run<64, 3>(12, 1, 1, out);
     run<768, 3>(1, 1, 1, out);
+    printf("-- four waves per SIMD at most (the training attention forward's regime) --\n");
+    run<192, 1>(5, 1, 1, out);
+    run<256, 1>(4, 1, 1, out);
+    run<64, 1>(16, 1, 1, out);
+    run<960, 1>(1, 1, 1, out);
+    run<768, 1>(1, 1, 1, out);
     return 0;
 }
