@@ -105,7 +105,7 @@ __device__ __forceinline__ void upsample_planes_body(float *ups, const float *__
 }
 inline size_t upsample_planes_lds(int pf) { return sizeof(float) * ((size_t)kUpPix * (pf + 4) + (size_t)kUpPlanes * pf); }
 inline bool upsample_planes_ok(const float *up_w, int pf) {
-    return pf % 4 == 0 && upsample_planes_lds(pf) <= 48 * 1024 && (reinterpret_cast<uintptr_t>(up_w) & 15) == 0;
+    return pf % 4 == 0 && upsample_planes_lds(pf) <= 64 * 1024 && (reinterpret_cast<uintptr_t>(up_w) & 15) == 0;   // (config 5: 96 pilots = 50 176 B)
 }
 
 // k_conv_stream.hip: default grid, inference, head with pre-computed upsampled planes (a.in_plane) or tail on linear_2's output
