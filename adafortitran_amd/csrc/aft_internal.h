@@ -130,7 +130,8 @@ __device__ __forceinline__ bool dropmask_keep(uint32_t row_word, uint32_t col_wo
 // Layout in HBM (DESIGN.md "data layout"):
 //   conv_enhanced [2B][S][T]            f32  kept for the S7 residual
 //   tokens6       [B][tokens][6]        f32  adapter features (adaptive only)
-//   x             [2B*tokens][d]        f32  token activations, row-major
+//   x             [2B*tokens][d]        f32  token activations: row-major (stage entry points, plane-resident path) or, in the
+//                                            whole-forward launch sequence, tile-blocked [tile][feature block][s][lane][4] (ChainArgs::x_blocked)
 //   attn          [ceil(2B*tokens/32)][H][4 s][64 lanes][4]  f32  attention output in operand-fragment order
 //   q, k          [2B][H][tokpad/32][4 s][64 lanes][4]  f32  MFMA-fragment order: (key%32 + 32hh, d = 8s+4hh+j)
 //   vt            [2B][H][tokpad/32][4 g][64 lanes][4]  f32  fragment order: (d + 32hh, key = 32kt+8g+4hh+j)
