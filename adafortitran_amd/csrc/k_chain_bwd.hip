@@ -52,7 +52,7 @@ struct ChainBwdShape {
     static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(S::XB + S::HB + S::ST + PAR + COLW);
 };
 
-// ---- row-major tensors leave the two kernels below as WHOLE CACHE LINES (round 4) ----
+// ---- row-major tensors leave and enter the two kernels below as WHOLE CACHE LINES (round 4) ----
 // A lane of the transposed products holds ONE token row: 16 bytes at (row r, feature 8 s + 4 h) per fragment s, so a wave's
 // buffer_store_b128 of fragment s touched 64 different 16-byte pieces of 32 rows (a quad of lanes = four rows), and the tape's
 // 1 408 floats per row left the forward as 44 such instructions per wave and tile.  Measured with the same bytes stored
@@ -63,6 +63,8 @@ struct ChainBwdShape {
 // of fragment s sits at 16-byte position l ^ (2 s + h) of block s (the operand reads of the products -- one block, all lanes --
 // stay a permutation inside every 16-lane group), and a read-out instruction takes rows R, R + 8 in each 16-lane group (the eight
 // pieces of a row land on eight different 16-byte bank groups, those of row R + 8 on the other eight).
+// Row-major INPUTS take the same road the other way (fetch_lines / stage_lines inside the kernels: 8 rows x 128 bytes per load, staged
+// into a block with the read-out's offsets, fragments read with pw[]), a tile ahead where the tile's first product needs them.
 struct LineIo {
     int pw[4];     // float offset of this lane's fragment s inside block s (the products' operand reads and the publishing writes)
 };
