@@ -112,5 +112,9 @@ inline bool upsample_planes_ok(const float *up_w, int pf) {
 // (a.lin2_out); returns hipErrorNotSupported when the arguments need the banded kernel
 bool conv_stream_ok(const ConvArgs &a);
 hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st);
+// k_conv_rows.hip: inference on grids whose planes need more than one band in k_conv.hip (config 5): whole-height workgroups that
+// stream over the columns through ring buffers; returns hipErrorNotSupported when the arguments need the banded kernel
+bool conv_rows_ok(const ConvArgs &a, int planes);
+hipError_t launch_conv_rows(ConvArgs &a, int planes, hipStream_t st);
 
 }  // namespace aft

@@ -756,6 +756,9 @@ static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStre
     // AFT_CONV_BANDED=1 keeps the banded kernel (A/B runs)
     if (fixed && conv_stream_ok(a) && !getenv("AFT_CONV_BANDED")) return launch_conv_stream(a, planes, st);   // (training: mode 2)
     if (fixed) return launch_conv_geo<TRAIN, true>(a, planes, lds, st);
+    // planes that need several bands here (config 5: five bands of two row tiles): the whole-height column-streaming kernel
+    // (k_conv_rows.hip) when its shape conditions hold; AFT_CONV_BANDED=1 keeps the banded kernel (A/B runs)
+    if (!TRAIN && a.nbands > 1 && conv_rows_ok(a, planes) && !getenv("AFT_CONV_BANDED")) return launch_conv_rows(a, planes, st);
     return launch_conv_geo<TRAIN, false>(a, planes, lds, st);
 }
 

@@ -1,0 +1,336 @@
+// k_conv_rows.hip -- the two ConvEnhancer stacks for grids whose planes do not fit the LDS (config 5: 240 x 28), as WHOLE-HEIGHT
+// workgroups that stream over the symbol columns through ring buffers (late round 4).
+//
+// Reference semantics: exactly k_conv.hip's / k_conv_stream.hip's (head: reference src/models/fortitran.py:203-209 behind the
+// pilot_upsampler product; tail: fortitran.py:225-231,180 on linear_2's output; ConvEnhancer blocks/enhancers.py:12-20) -- the same
+// arithmetic per output element: conv1 / conv4 fp32 FMA chains in tap order, conv2 / conv3 the same MFMA chains.
+//
+// Why a third kernel.  The banded kernel (k_conv.hip) holds all 17 channel planes of a row band in LDS; at 240 x 28 that allows
+// bands of two 30-row tiles only: five bands per plane (300 tile rows for 240), 640 workgroups on 256 CUs = three rounds, every
+// band with its own serial phases -- 0.34 of the fp32 roof.  Here a workgroup takes ALL rows of the plane (up to
+// eight row tiles of 30 rows, one per wave, two waves per SIMD: no bands, no halo rows) and a range of columns, and keeps only what
+// the column pipeline needs: the input columns of its range, FOUR columns of conv1's output, FOUR columns of conv3's output (ring
+// buffers indexed by symbol & 3) and its own output columns -- 100 KB for config 5.  Planes are split into column ranges when there are
+// fewer planes than CUs (config 5 at 64 frames per GPU: 128 planes x 2 halves = 256 workgroups, ONE round); a range recomputes the
+// two conv2 and the one conv3 column on either side that its outputs need (16 + 15 column sweeps for 14 columns).
+//
+// Every wave does the same thing (no helper waves as in k_conv_stream.hip: all eight are needed as matrix waves), one column per
+// iteration, one workgroup barrier per iteration:
+//     conv1 of symbol t + 4            (VALU; lane = (local row 32 w + j, channel half h))          -> c1 ring
+//     conv2 of symbol t + 1 || conv3's share of conv2 column t, as two interleaved MFMA chains exactly as in k_conv_stream.hip
+//       (conv2's B operands from the c1 ring, conv3's from registers / DPP); conv3's output column t - 2 -> c3 ring
+//     conv4 of symbol t - 4            (VALU)                                                       -> the output columns in LDS
+// The stages of one iteration read what earlier iterations wrote and write ring slots nobody reads in this iteration, so the
+// barrier at its end is the only synchronisation.
+#include <cstdint>
+#include <cstdlib>
+
+#include "conv_device.h"
+
+namespace aft {
+
+namespace {
+
+constexpr int kRowsSP = 256;        // local rows per column vector: local row lr <-> plane row lr - 4; eight waves x 32 rows
+constexpr int kRing = 4;            // columns held of conv1's / conv3's outputs
+constexpr int kRingPlane = kRing * kRowsSP;   // floats per channel of a ring
+
+__device__ __forceinline__ float rows_other_half32(float x) {   // value held by lane (l ^ 32): v_permlane32_swap
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+}  // namespace
+
+// LDS (floats): in0 [wmax][SP] | c1 [8][4][SP] | c3 [8][4][SP] (its start stages the conv2 / conv3 weights first) | obuf [S][wcols] |
+// bias2 [32] | w1s [80] | w4s [80]
+__host__ __device__ inline size_t conv_rows_lds_floats(int S, int wcols) {
+    return (size_t)(wcols + 8) * kRowsSP + 2 * (size_t)8 * kRingPlane + (size_t)S * wcols + 32 + 80 + 80;
+}
+
+// MODE 0 = head (a.in_plane = upsampled planes [planes][S][T] -> a.out_plane), 1 = tail (a.lin2_out + a.resid -> a.out_complex)
+template <int MODE>
+__global__ __launch_bounds__(kConvThreads) void conv_rows_kernel(const ConvArgs a, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SP = kRowsSP;
+    const int S = a.S, T = a.T, LR = S + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x / nsplit, part_c = blockIdx.x - n * nsplit, frame = n >> 1, part = n & 1;
+    const int wcols = (T + nsplit - 1) / nsplit;
+    const int ta = part_c * wcols, tb = min(T, ta + wcols);          // output columns of this workgroup
+    const int cb = max(ta - 2, 0), ce = min(tb + 2, T);                // conv2 columns swept: [cb, ce)
+    const int ci0 = cb - 2, win = ce + 2 - ci0;                        // input columns held: symbols ci0 .. ce + 1
+    const int ntiles = (S + kTileRows - 1) / kTileRows;                // row tiles = matrix waves (<= 8)
+    float *in0 = smem;
+    float *c1 = in0 + (size_t)(wcols + 8) * SP;
+    float *c3 = c1 + 8 * kRingPlane;
+    float *obuf = c3 + 8 * kRingPlane;
+    float *bias2 = obuf + (size_t)S * wcols, *w1s = bias2 + 32, *w4s = w1s + 80;
+
+    // ---- phase 0: conv2 / conv3 weights transposed into c3 (conflict-free gathers, as k_conv_stream.hip), tables, the input columns ----
+    {
+        float *stage = c3;
+        for (int i = tid; i < 2304; i += kConvThreads) {
+            stage[(i % 72) * 33 + i / 72] = a.cw[1][i];
+            const int rem = i % 288;   // conv3.weight [co 8][ci 32][ky 3][kx 3]
+            stage[kW3Off + (rem / 3) * 33 + (rem % 3) * 8 + i / 288] = a.cw[2][i];
+        }
+        if (tid < 32) bias2[tid] = a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
+        if (tid >= 64 && tid < 144) w1s[tid - 64] = tid < 136 ? a.cw[0][tid - 64] : a.cb[0][tid - 136];
+        if (tid >= 192 && tid < 265) w4s[tid - 192] = tid < 264 ? a.cw[3][tid - 192] : a.cb[3][0];
+        // input: element (local row lr, held column c) <- plane pixel (lr - 4, ci0 + c), zero outside the plane; the column index runs
+        // fastest so that the global reads of a row are contiguous
+        for (int i = tid; i < win * SP; i += kConvThreads) {
+            const int lr = i / win, c = i - lr * win, gr = lr - 4, t = ci0 + c;
+            float v = 0.f;
+            if (gr >= 0 && gr < S && t >= 0 && t < T) {
+                const int pix = gr * T + t;
+                if (MODE == 0) {
+                    v = a.in_plane[(size_t)n * (S * T) + pix];
+                } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
+                    const int p0 = a.p0, p1 = a.p1, tpr = T / p1;
+                    const int g = gr / p0, tc = t / p1, f = (gr - g * p0) * p1 + (t - tc * p1);
+                    v = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] + a.resid[(size_t)n * (S * T) + pix];
+                }
+            }
+            in0[c * SP + lr] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: the MFMA A fragments (84 registers, kept for the whole kernel) ----
+    const bool matrix = wave < ntiles;
+    float wa2[36], wa3[48], bias3[4];
+    {
+        const float *stage = c3;
+#pragma unroll
+        for (int kb = 0; kb < 36; ++kb) {        // k slot (kb, h): tap = kb>>2 = kx*3+ky, ci = 4h + (kb&3); row = co = j
+            const int tap = kb >> 2, kx = tap / 3, ky = tap % 3, ci = 4 * h + (kb & 3);
+            wa2[kb] = stage[(ci * 9 + ky * 3 + kx) * 33 + j];
+        }
+        const int kx3 = min(j >> 3, 2), co3 = j & 7;   // row j = (kx, co); rows 24..31 are padding
+        const float keep = j < 24 ? 1.f : 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 48; ++kb) {        // k slot (kb, h): ky = kb>>4, ci = C-layout row of register kb&15
+            const int ky = kb >> 4, e = kb & 15, ci = (e & 3) + 8 * (e >> 2) + 4 * h;
+            wa3[kb] = keep * stage[kW3Off + (ci * 3 + ky) * 33 + kx3 * 8 + co3];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias3[e] = a.cb[2][e + 4 * h];
+    }
+    __syncthreads();   // the staging area is dead: c3 becomes the ring
+
+    // conv1 of symbol `sym` (1 -> 8, ReLU; zero outside the plane): lane = (local row lr = 32 wave + j, channel half h)
+    auto conv1_col = [&](int sym) {
+        const int lr = 32 * wave + j, gr = lr - 4;
+        const bool ok = gr >= 0 && gr < S && sym >= 0 && sym < T;
+        const int r0 = max(lr - 1, 0), r2 = min(lr + 1, SP - 1);
+        const float *src = in0 + (sym - ci0 - 1) * SP;
+        float win9[3][3];   // [ky][kx]
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            win9[0][kx] = src[kx * SP + r0];
+            win9[1][kx] = src[kx * SP + lr];
+            win9[2][kx] = src[kx * SP + r2];
+        }
+        float *dst = c1 + ((4 * h) * kRing + (sym & 3)) * SP + lr;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {      // two channels per v_pk_fma_f32, the same fma chain per channel in tap order
+            f32x2 acc2 = f32x2{w1s[72 + 4 * h + 2 * k], w1s[72 + 4 * h + 2 * k + 1]};
+#pragma unroll
+            for (int k9 = 0; k9 < 9; ++k9) {
+                const float x = win9[k9 / 3][k9 % 3];
+                acc2 = __builtin_elementwise_fma(f32x2{x, x}, f32x2{w1s[(4 * h + 2 * k) * 9 + k9], w1s[(4 * h + 2 * k + 1) * 9 + k9]}, acc2);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) dst[(2 * k + q) * kRingPlane] = ok ? fmaxf(acc2[q], 0.f) : 0.f;
+        }
+    };
+    // conv4 of symbol `sym` (8 -> 1): lane = (local row, input-channel half), the halves meet through one lane swap
+    auto conv4_col = [&](int sym) {
+        const int lr = 32 * wave + j;
+        const bool okrow = lr >= 4 && lr < 4 + S;
+        const int r0 = max(lr - 1, 0), r2 = min(lr + 1, SP - 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float *p = c3 + ((4 * h + c) * kRing) * SP;
+#pragma unroll
+            for (int k9 = 0; k9 < 9; ++k9) {
+                const int ky = k9 / 3, kx = k9 % 3;
+                const float x = p[((sym + kx - 1) & 3) * SP + (ky == 0 ? r0 : ky == 1 ? lr : r2)];
+                acc = fmaf(x, w4s[(4 * h + c) * 9 + k9], acc);
+            }
+        }
+        acc += rows_other_half32(acc);
+        if (h == 0 && okrow) obuf[(lr - 4) * wcols + (sym - ta)] = acc + w4s[72];
+    };
+
+    // ---- matrix-wave state (row tile `wave`): as k_conv_stream.hip, the LDS columns replaced by ring slots ----
+    const int r = 4 + kTileRows * wave - 1 + j;                       // this lane's local row
+    const int gr = r - 4;
+    const bool ok2 = matrix && gr >= 0 && gr < S;                     // conv2 output inside the plane (else zero padding)
+    const float relu_hi = ok2 ? __builtin_inff() : 0.f;
+    const bool ok3 = ok2 && j >= 1 && j <= kTileRows && r < LR - 3;
+    const float *bsrc = c1 + (4 * h) * kRingPlane + min(r, SP - 1) - 1;     // + c*kRingPlane + slot*SP + ky
+    float *dst3 = c3 + (4 * h) * kRingPlane + min(r, SP - 1);
+    f32x16 acc3;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
+    auto store_col = [&](int tout, float v0, float v1, float v2, float v3) {   // conv3's output column `tout` (zeros outside the plane)
+        if (!ok3) return;
+        float *p = dst3 + (tout & 3) * SP;
+        const bool inr = tout >= 0 && tout < T;
+        const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k * kRingPlane] = inr ? fmaxf(v[k] + bias3[k], 0.f) : 0.f;
+    };
+    auto b_at = [&](int kb, int tcol) {      // B operand slot kb of conv2 column tcol: channel 4h + (kb&3), tap (kx, ky)
+        const int tap = kb >> 2, kx = tap / 3, ky = tap % 3;
+        return bsrc[(kb & 3) * kRingPlane + ((tcol + kx - 1) & 3) * SP + ky];
+    };
+    float b[36];
+    f32x16 bias2v;
+    {
+        const f32x4 *bp = reinterpret_cast<const f32x4 *>(bias2 + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = bp[q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bias2v[4 * q + u] = v[u];
+        }
+    }
+    float x2[16];
+    auto activate2 = [&](const f32x16 &acc2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x2[e] = __builtin_amdgcn_fmed3f(acc2[e], 0.f, relu_hi);
+    };
+    auto conv3_step = [&](int i) {   // ky = centre (16..31), below (0..15), above (32..47)
+        const int e = i & 15;
+        const float xv = i < 16 ? x2[e] : (i < 32 ? lane_from_below(x2[e]) : lane_from_above(x2[e]));
+        const int wi = i < 16 ? 16 + e : (i < 32 ? e : 32 + e);
+        acc3 = mfma_f32(wa3[wi], xv, acc3);
+    };
+    auto rotate = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc3[8 + e] = acc3[4 + e];
+            acc3[4 + e] = acc3[e];
+            acc3[e] = 0.f;
+        }
+    };
+
+    // ---- prologue: c3's rows outside the tiles' stores stay zero for the whole kernel; conv1 of the first four symbols ----
+    for (int i = tid; i < 8 * kRingPlane; i += kConvThreads) c3[i] = 0.f;
+#pragma unroll 1
+    for (int sym = cb - 1; sym <= cb + 2; ++sym) conv1_col(sym);
+    __syncthreads();
+    if (matrix) {      // conv2 of column cb; the operands of column cb + 1 requested behind it
+#pragma unroll
+        for (int kb = 0; kb < 36; ++kb) b[kb] = b_at(kb, cb);
+        f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
+        b[0] = b_at(0, cb + 1);
+#pragma unroll
+        for (int kb = 1; kb < 36; ++kb) {
+            acc2 = mfma_f32(wa2[kb], b[kb], acc2);
+            b[kb] = b_at(kb, cb + 1);
+        }
+        activate2(acc2);
+    }
+    __syncthreads();
+    conv1_col(cb + 3);
+    __syncthreads();
+
+    constexpr int kLead = 4;   // conv2 MFMAs of the next column issued BEFORE the column hand-over (store + rotate wait for conv3's last MFMA)
+#pragma unroll 1
+    for (int tcol = cb; tcol <= tb + 3; ++tcol) {
+        if (tcol + 4 <= ce) conv1_col(tcol + 4);
+        if (matrix) {
+            if (tcol + 1 < ce) {           // conv3's share of conv2 column tcol || conv2 of column tcol + 1
+                const int tnext = tcol + 2;
+                f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
+                b[0] = b_at(0, tnext);
+#pragma unroll
+                for (int kb = 1; kb < kLead; ++kb) {
+                    acc2 = mfma_f32(wa2[kb], b[kb], acc2);
+                    b[kb] = b_at(kb, tnext);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                store_col(tcol - 2, acc3[8], acc3[9], acc3[10], acc3[11]);   // complete since the previous column's MFMAs
+                rotate();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {      // 48 conv3 MFMAs interleaved with the remaining 32 conv2 MFMAs (3 : 2)
+                    conv3_step(3 * g);
+                    acc2 = mfma_f32(wa2[kLead + 2 * g], b[kLead + 2 * g], acc2);
+                    b[kLead + 2 * g] = b_at(kLead + 2 * g, tnext);
+                    conv3_step(3 * g + 1);
+                    acc2 = mfma_f32(wa2[kLead + 2 * g + 1], b[kLead + 2 * g + 1], acc2);
+                    b[kLead + 2 * g + 1] = b_at(kLead + 2 * g + 1, tnext);
+                    conv3_step(3 * g + 2);
+                }
+                activate2(acc2);
+            } else {
+                store_col(tcol - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
+                rotate();
+                if (tcol < ce) {           // conv3's share of the last conv2 column
+#pragma unroll
+                    for (int i = 0; i < 48; ++i) conv3_step(i);
+                }
+            }
+        }
+        if (tcol - 4 >= ta && tcol - 4 < tb) conv4_col(tcol - 4);
+        __syncthreads();
+    }
+
+    // ---- the output columns leave: rows of (tb - ta) contiguous floats ----
+    {
+        const int wout = tb - ta;
+        if (MODE == 0) {
+            float *dst = a.out_plane + (size_t)n * (S * T) + ta;
+            for (int i = tid; i < S * wout; i += kConvThreads) {
+                const int row = i / wout, c = i - row * wout;
+                dst[(size_t)row * T + c] = obuf[row * wcols + c];
+            }
+        } else {   // interleave this plane into the complex64 output (the frame's other plane is another workgroup's)
+            float *dst = a.out_complex + ((size_t)frame * (S * T) + ta) * 2 + part;
+            for (int i = tid; i < S * wout; i += kConvThreads) {
+                const int row = i / wout, c = i - row * wout;
+                dst[((size_t)row * T + c) * 2] = obuf[row * wcols + c];
+            }
+        }
+    }
+}
+
+// The shapes this kernel takes: inference, the plane's rows as at most eight 30-row tiles, inputs as the whole forward provides them
+// (head: upsampled planes; tail: linear_2's output), and an LDS footprint that fits -- everything else stays with k_conv.hip.
+static int conv_rows_split(const ConvArgs &a, int planes) {
+    const int cus = current_device_cus();
+    int nsplit = 1;
+    while (planes * nsplit < cus && a.T / (nsplit * 2) >= 8) nsplit *= 2;     // column ranges of at least 8 columns
+    return nsplit;
+}
+bool conv_rows_ok(const ConvArgs &a, int planes) {
+    if (a.S + 8 > kRowsSP || (a.S + kTileRows - 1) / kTileRows > kConvWaves || a.T < 8) return false;
+    if (a.mode == 0 && a.in_plane == nullptr) return false;
+    if (a.mode == 1 && (a.lin2_out == nullptr || a.resid == nullptr || a.T % a.p1 != 0 || a.S % a.p0 != 0)) return false;
+    if (a.mode != 0 && a.mode != 1) return false;
+    const int nsplit = conv_rows_split(a, planes), wcols = (a.T + nsplit - 1) / nsplit;
+    return sizeof(float) * conv_rows_lds_floats(a.S, wcols) <= 160 * 1024;
+}
+
+hipError_t launch_conv_rows(ConvArgs &a, int planes, hipStream_t st) {
+    if (!conv_rows_ok(a, planes)) return hipErrorNotSupported;
+    const int nsplit = conv_rows_split(a, planes), wcols = (a.T + nsplit - 1) / nsplit;
+    const size_t lds = sizeof(float) * conv_rows_lds_floats(a.S, wcols);
+    static PerDeviceOnce lds_head, lds_tail;
+    hipError_t e = a.mode == 0 ? ensure_dynamic_lds(lds_head, reinterpret_cast<const void *>(conv_rows_kernel<0>), 160 * 1024)
+                               : ensure_dynamic_lds(lds_tail, reinterpret_cast<const void *>(conv_rows_kernel<1>), 160 * 1024);
+    if (e != hipSuccess) return e;
+    if (a.mode == 0) hipLaunchKernelGGL((conv_rows_kernel<0>), dim3(planes * nsplit), dim3(kConvThreads), lds, st, a, nsplit);
+    else hipLaunchKernelGGL((conv_rows_kernel<1>), dim3(planes * nsplit), dim3(kConvThreads), lds, st, a, nsplit);
+    return hipGetLastError();
+}
+
+}  // namespace aft

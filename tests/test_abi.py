@@ -92,7 +92,7 @@ def test_hot_kernels_compile_without_register_spills():
     import subprocess
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adafortitran_amd", "csrc")
     report = {}
-    for src in ("k_attn.hip", "k_conv_stream.hip", "k_chain_bwd.hip"):
+    for src in ("k_attn.hip", "k_conv_stream.hip", "k_conv_rows.hip", "k_chain_bwd.hip"):
         res = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/dev/null",
                               "-Rpass-analysis=kernel-resource-usage"], cwd=csrc, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
@@ -112,3 +112,5 @@ def test_hot_kernels_compile_without_register_spills():
     # 168 registers three waves per SIMD allow: a scratch reload is a VMEM load whose wait drains vmcnt
     chain = {k: v for k, v in report.items() if "chain_fwd_train_kernel" in k or "chain_bwd_kernel" in k}
     assert len(chain) == 6 and all(v == 0 for v in chain.values()), report
+    rows = {k: v for k, v in report.items() if "conv_rows_kernel" in k}      # head / tail of the row-streaming conv kernel (226 VGPRs)
+    assert len(rows) == 2 and all(v == 0 for v in rows.values()), report

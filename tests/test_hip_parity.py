@@ -198,6 +198,52 @@ def test_other_grid_geometries_match_oracle(oracle_lib, ofdm, pilot, patch, adap
     assert np.abs(out - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("ofdm,pilot,patch,adaptive,batch", [((240, 28), (24, 4), (3, 2), True, 3), ((180, 20), (12, 4), (3, 2), False, 1),
+                                                              ((96, 40), (8, 5), (3, 2), True, 2), ((100, 36), (10, 4), (2, 2), False, 5)])
+def test_tall_planes_run_the_row_streaming_conv_kernel(oracle_lib, monkeypatch, ofdm, pilot, patch, adaptive, batch):
+    """Planes that need several bands in the banded conv kernel (17 channel planes > 160 KB of LDS) run k_conv_rows.hip in the whole
+    forward: all rows per workgroup, four-column rings, column ranges with recomputed halo columns (2 or 4 ranges at these batches;
+    8 / 6 / 4 row tiles, the last tile of the 100-row grid partly outside the plane).  Against the oracle, and against the banded
+    kernel on the same inputs (AFT_CONV_BANDED is read per launch): the two differ by conv4's summation order only."""
+    tokens = (ofdm[0] // patch[0]) * (ofdm[1] // patch[1])
+    spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=2, model_dim=128, num_head=4)
+    hid = (5, 9, 2 * tokens) if adaptive else None
+    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, max_seq_len=max(512, tokens), seed=77)
+    cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(batch, ofdm=ofdm, pilot=pilot, seed=33)
+    meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+    pil = _t(inp["pilots"])
+    out = eng.forward(pil, *meta).clone()
+    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3))
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+    eng.workspace(batch).view(torch.float32).fill_(float("nan"))           # stale workspace: same bits
+    assert torch.equal(torch.view_as_real(eng.forward(pil, *meta)), torch.view_as_real(out))
+    monkeypatch.setenv("AFT_CONV_BANDED", "1")
+    banded = eng.forward(pil, *meta).clone()
+    monkeypatch.delenv("AFT_CONV_BANDED")
+    assert float((banded - out).abs().max()) <= 2e-6 * float(out.abs().max())
+
+
+def test_row_streaming_conv_does_not_depend_on_the_column_split():
+    """k_conv_rows.hip splits a plane into column ranges when there are fewer planes than CUs; every output element is computed by the
+    same instruction sequence whatever the range (the halo columns are recomputed, not exchanged), so the first frames of a batch
+    large enough for ONE range per plane (130 frames = 260 planes) carry the same bits as the same frames alone (two ranges)."""
+    ofdm, pilot, patch = (180, 20), (12, 4), (3, 2)
+    spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=1, model_dim=128, num_head=4)
+    sd = synth.make_state_dict(**spec, adaptive_hidden=None, max_seq_len=600, seed=78)
+    cfg = _abi.make_config(**spec, adaptive_hidden=None)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(130, ofdm=ofdm, pilot=pilot, seed=34)
+    pil = _t(inp["pilots"])
+    big = eng.forward(pil, None, None, None).clone()
+    small = eng.forward(pil[:4].contiguous(), None, None, None).clone()
+    assert torch.isfinite(torch.view_as_real(big)).all()
+    assert torch.equal(torch.view_as_real(big[:4]), torch.view_as_real(small))
+
+
 @pytest.mark.parametrize("adaptive", [False, True])
 @pytest.mark.parametrize("d,heads", [(64, 2), (192, 6),                    # head dim 32: two / six waves per chain workgroup
                                      (128, 8), (64, 4), (192, 12), (256, 16),   # head dim 16: two heads per 32-feature block
