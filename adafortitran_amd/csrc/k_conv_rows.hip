@@ -79,22 +79,37 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows_kernel(const ConvArgs 
         if (tid < 32) bias2[tid] = a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
         if (tid >= 64 && tid < 144) w1s[tid - 64] = tid < 136 ? a.cw[0][tid - 64] : a.cb[0][tid - 136];
         if (tid >= 192 && tid < 265) w4s[tid - 192] = tid < 264 ? a.cw[3][tid - 192] : a.cb[3][0];
-        // input: element (local row lr, held column c) <- plane pixel (lr - 4, ci0 + c), zero outside the plane; the column index runs
-        // fastest so that the global reads of a row are contiguous
-        for (int i = tid; i < win * SP; i += kConvThreads) {
-            const int lr = i / win, c = i - lr * win, gr = lr - 4, t = ci0 + c;
-            float v = 0.f;
-            if (gr >= 0 && gr < S && t >= 0 && t < T) {
-                const int pix = gr * T + t;
-                if (MODE == 0) {
-                    v = a.in_plane[(size_t)n * (S * T) + pix];
-                } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
-                    const int p0 = a.p0, p1 = a.p1, tpr = T / p1;
-                    const int g = gr / p0, tc = t / p1, f = (gr - g * p0) * p1 + (t - tc * p1);
-                    v = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] + a.resid[(size_t)n * (S * T) + pix];
+        // input: element (local row lr, held column c) <- plane pixel (lr - 4, ci0 + c), zero outside the plane.  Thread = (column
+        // c = tid & 31, row tid >> 5 + 16 pass): the column runs fastest so that the global reads of a row are contiguous, and what
+        // depends on the column alone (the patch column of the tail's inverse patch map) is formed once (the flat-index form with its
+        // divisions per element was 14 000 of the workgroup's 257 000 cycles)
+        for (int c0 = 0; c0 < win; c0 += 32) {
+            const int c = c0 + (tid & 31), t = ci0 + c;
+            const bool cok = c < win && t >= 0 && t < T;
+            const int p0 = MODE == 1 ? a.p0 : 1, p1 = MODE == 1 ? a.p1 : 1, tpr = T / p1;
+            const int tc = cok ? t / p1 : 0, ft = t - tc * p1;
+            constexpr int kPasses = SP / (kConvThreads / 32);      // 16 rows per pass: all of a thread's requests in flight together
+            float v[kPasses], v2[kPasses];
+#pragma unroll
+            for (int u = 0; u < kPasses; ++u) {
+                const int lr = (tid >> 5) + (kConvThreads / 32) * u, gr = lr - 4;
+                v[u] = 0.f;
+                v2[u] = 0.f;
+                if (cok && gr >= 0 && gr < S) {
+                    const int pix = gr * T + t;
+                    if (MODE == 0) {
+                        v[u] = a.in_plane[(size_t)n * (S * T) + pix];
+                    } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
+                        const int g = gr / p0, f = (gr - g * p0) * p1 + ft;
+                        v[u] = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f];
+                        v2[u] = a.resid[(size_t)n * (S * T) + pix];
+                    }
                 }
             }
-            in0[c * SP + lr] = v;
+            if (c < win) {
+#pragma unroll
+                for (int u = 0; u < kPasses; ++u) in0[c * SP + (tid >> 5) + (kConvThreads / 32) * u] = v[u] + v2[u];
+            }
         }
     }
     __syncthreads();
@@ -222,7 +237,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows_kernel(const ConvArgs 
     };
 
     // ---- prologue: c3's rows outside the tiles' stores stay zero for the whole kernel; conv1 of the first four symbols ----
-    for (int i = tid; i < 8 * kRingPlane; i += kConvThreads) c3[i] = 0.f;
+    for (int i = tid; i < 8 * kRingPlane; i += kConvThreads) {
+        const int row = i & (SP - 1);
+        if (row < 4 || row >= 4 + S) c3[i] = 0.f;      // (rows 4 .. S + 3 of a slot are stored before they are read)
+    }
 #pragma unroll 1
     for (int sym = cb - 1; sym <= cb + 2; ++sym) conv1_col(sym);
     __syncthreads();
