@@ -104,6 +104,53 @@ __device__ __forceinline__ void line_store(Srd dst, const float *blk, int row0, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same with the lane's part of the offsets held in three registers for the whole tile (chain_bwd_kernel has them to spare, the
+// forward kernels do not): the per-call address arithmetic of line_store / fetch_lines / stage_lines was ~35 vector instructions, 13
+// calls per tile = 30 % of the backward kernel's vector instructions.  (The tile's origin is ADDED to the lane offset, one instruction
+// per call: with it in the scalar-offset operand the gff stores of tiles beyond a workgroup's first came out wrong at B = 128 --
+// dW1 / db1 5e-2 off, everything else exact -- for a reason not found; only compile-time constants ride in the scalar offset.)
+struct LineLane {
+    int rd0;            // read-out / staging float offset of instruction 0 (instruction i: (rd0 ^ 16 (i & 1)) + 64 (i >> 1))
+    unsigned p128;      // byte offset of (this lane's first row, its 16-byte piece) in a 128-wide tensor: brow x 512 + c x 16
+};
+__device__ __forceinline__ LineLane make_line_lane(int lane) {
+    const int rho = lane >> 3, c = lane & 7, brow = 8 * (rho & 1) + (rho >> 1);
+    return LineLane{(c >> 1) * 256 + ((32 * (c & 1) + brow) ^ c) * 4, (unsigned)brow * 512u + (unsigned)c * 16u};
+}
+template <int LD>
+__device__ __forceinline__ unsigned line_lane_off(const LineLane &ll) { return ll.p128 + (ll.p128 & ~127u) * (LD / 128 - 1); }
+// RAGGED = the row count is not a multiple of 32 (the last tile is partial): per-row guards; else only "no such tile" (row0 >= rows)
+template <int LD, bool RAGGED>
+__device__ __forceinline__ void line_store_c(Srd dst, const float *blk, const LineLane &ll, int row0, int col, int rows) {
+    const unsigned vo = line_lane_off<LD>(ll), so = ((unsigned)row0 * LD + col) * 4;
+    const int rows_left = RAGGED ? rows - row0 - (int)(ll.p128 >> 9) : 32;      // rows beyond the end: lane offset beyond the resource (dropped)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int dr = 4 * (i & 1) + 16 * (i >> 1);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(blk + (ll.rd0 ^ (16 * (i & 1))) + 64 * (i >> 1));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(dst, 0, 0, 0)), v), dst,
+                                               (!RAGGED || dr < rows_left) ? vo + so : 0x80000000u, (unsigned)(dr * LD * 4), 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// rows of [row0n, row0n + 32) beyond `rows` read as zero (lane offset beyond the resource: no memory access)
+template <int LD, bool RAGGED>
+__device__ __forceinline__ void fetch_lines_c(Srd src, const LineLane &ll, int row0n, int col, int rows, f32x4 (&v)[4]) {
+    const unsigned so = ((unsigned)min(row0n, rows) * LD + col) * 4;
+    const unsigned vo = row0n < rows ? line_lane_off<LD>(ll) + so : 0x80000000u;       // (wave-uniform) no such tile
+    const int left = RAGGED ? rows - row0n - (int)(ll.p128 >> 9) : 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int dr = 4 * (i & 1) + 16 * (i >> 1);
+        v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, (!RAGGED || dr < left) ? vo : 0x80000000u, (unsigned)(dr * LD * 4), 0));
+    }
+}
+__device__ __forceinline__ void stage_lines_c(float *blk, const LineLane &ll, const f32x4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(blk + (ll.rd0 ^ (16 * (i & 1))) + 64 * (i >> 1)) = v[i];
+}
+
 // LayerNorm backward on the lane's 16 features: v = upstream gradient (in: dL/dy, out: dL/ds), sfrag = the pre-norm
 // sum of the forward, (mean, rstd) of the row.  Also returns the lane's contributions to the parameter gradients.
 template <int D>
@@ -142,7 +189,7 @@ __device__ __forceinline__ void layernorm_bwd_rows(f32x16 &v, const f32x4 (&sfra
     for (int e = 0; e < 16; ++e) v[e] = rstd * (v[e] - a - xh[e] * b);
 }
 
-template <int D, int ACT>
+template <int D, int ACT, bool RAGGED>
 __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(const ChainBwdArgs a) {
     using S = ChainShape<D>;
     using B = ChainBwdShape<D>;
@@ -197,33 +244,14 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
     // tile start and staged into the hidden blocks behind the first product (where gff then replaces them), s1 is requested behind the
     // hidden barrier and staged into the wave's x block behind the second product (g2's readers are past that barrier).
     const Srd srd_st2 = make_srd(a.st2), srd_st1 = make_srd(a.st1);
-    auto fetch_lines = [&](Srd src, int LD, int row0n, int col, f32x4 (&v)[4]) {   // row0n >= rows: out of range (zeros, no access)
-        int l = threadIdx.x & 63;
-        asm volatile("" : "+v"(l));
-        const int rho = l >> 3, c = l & 7, brow = 8 * (rho & 1) + (rho >> 1);
-        const unsigned gb = ((unsigned)(row0n + brow) * LD + col + 4 * c) * 4;
-        const int left = a.rows - row0n - brow;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int dr = 4 * (i & 1) + 16 * (i >> 1);
-            v[i] = srd_load_c(src, dr < left ? gb : 0x80000000u, (unsigned)(dr * LD * 4));
-        }
-    };
-    auto stage_lines = [&](float *blk, const f32x4 (&v)[4]) {
-        int l = threadIdx.x & 63;
-        asm volatile("" : "+v"(l));
-        const int rho = l >> 3, c = l & 7, brow = 8 * (rho & 1) + (rho >> 1);
-        const int rd0 = (c >> 1) * 256 + ((32 * (c & 1) + brow) ^ c) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(blk + (rd0 ^ (16 * (i & 1))) + 64 * (i >> 1)) = v[i];
-    };
     {
         f32x4 ng[4], ns[4];
         const int first = (int)blockIdx.x < ntiles ? (int)blockIdx.x * 32 : a.rows;
-        fetch_lines(srd_g, D, first, fb, ng);
-        fetch_lines(srd_s2, D, first, fb, ns);
-        stage_lines(hb + w * 2048, ng);
-        stage_lines(hb + w * 2048 + 1024, ns);
+        const LineLane ll0 = make_line_lane(threadIdx.x & 63);
+        fetch_lines_c<D, RAGGED>(srd_g, ll0, first, fb, a.rows, ng);
+        fetch_lines_c<D, RAGGED>(srd_s2, ll0, first, fb, a.rows, ns);
+        stage_lines_c(hb + w * 2048, ll0, ng);
+        stage_lines_c(hb + w * 2048 + 1024, ll0, ns);
     }
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -241,6 +269,17 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         const bool row_ok = row0 + r < a.rows;
         // swizzled fragment positions inside the exchange buffers' blocks (LineIo above)
         const LineIo io = make_line_io(lane);
+        const LineLane ll_tile = make_line_lane(lane);
+        // the partial-last-tile instantiation needs its registers for the per-row guards: it re-forms the two offsets at each use
+        auto line_lane = [&]() -> LineLane {
+            if constexpr (RAGGED) {
+                int l = threadIdx.x & 63;
+                asm volatile("" : "+v"(l));
+                return make_line_lane(l);
+            } else {
+                return ll_tile;
+            }
+        };
         float *xw = xb + w * 1024, *hw = hb + w * 2048;     // this wave's blocks of the two exchange buffers
         unsigned lo = 0;
         asm volatile("" : "+v"(lo));    // keep the tile-invariant weight loads inside the loop (see chain_device.h)
@@ -260,8 +299,8 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         const f32x2 st2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_st2, (unsigned)grow * 8, 0, 0));
         // linear1's pre-activations of this wave's two hidden blocks: requested now, staged behind the first product
         f32x4 al[2][4];
-        fetch_lines(srd_a, 2 * D, row0, 2 * fb, al[0]);
-        fetch_lines(srd_a, 2 * D, row0, 2 * fb + 32, al[1]);
+        fetch_lines_c<2 * D, RAGGED>(srd_a, line_lane(), row0, 2 * fb, a.rows, al[0]);
+        fetch_lines_c<2 * D, RAGGED>(srd_a, line_lane(), row0, 2 * fb + 32, a.rows, al[1]);
         gemm_preload<W, 2, PFF, 1>(ring_ff, srd_w2t, w2t_lane);
         f32x16 cur, dgam;
 #pragma unroll
@@ -311,7 +350,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
             if (drop) v = mask4(v, rw3, colw + 3 * D + fb + 8 * s + 4 * h);
             line_put(xw, io, s, v);
         }
-        line_store<D>(srd_g2, xw, row0, fb, a.rows);
+        line_store_c<D, RAGGED>(srd_g2, xw, line_lane(), row0, fb, a.rows);
         __syncthreads();
 
         // ---- (g2 W2): hidden blocks 2w, 2w+1; epilogue = dropout-2 mask and activation derivative ----
@@ -319,8 +358,8 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         auto xb_frag = [&](int kb, int s) { return *reinterpret_cast<const f32x4 *>(xb + (kb * 4 + s) * 256 + io.pw[s]); };
         gemm_run<W, 2, PFF, 1, 0, decltype(xb_frag), 0x3>(ring_ff, srd_w2t, w2t_lane, acc_h, xb_frag);
         gemm_preload<2 * W, 1, PFD, 1>(ring_d, srd_w1t, w1t_lane);
-        stage_lines(hw, al[0]);
-        stage_lines(hw + 1024, al[1]);
+        stage_lines_c(hw, line_lane(), al[0]);
+        stage_lines_c(hw + 1024, line_lane(), al[1]);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -333,12 +372,12 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
                 if (drop) v = mask4(v, rw2, colw + D + 2 * fb + 32 * t + 8 * s + 4 * h);
                 line_put(hw + 1024 * t, io, s, v);
             }
-            line_store<2 * D>(srd_gff, hw + 1024 * t, row0, 2 * fb + 32 * t, a.rows);
+            line_store_c<2 * D, RAGGED>(srd_gff, hw + 1024 * t, line_lane(), row0, 2 * fb + 32 * t, a.rows);
         }
         __syncthreads();
         // the pre-norm sum of LayerNorm 1: requested here, staged behind the second product
         f32x4 sl[4];
-        fetch_lines(srd_s1, D, row0, fb, sl);
+        fetch_lines_c<D, RAGGED>(srd_s1, line_lane(), row0, fb, a.rows, sl);
         const f32x2 st1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(srd_st1, (unsigned)grow * 8, 0, 0));
 
         // ---- dx1 = gff W1 + ds2 (the accumulator starts from ds2) ----
@@ -348,7 +387,7 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         });
         gemm_preload<W, 1, PFD, 1>(ring_d, srd_wot, wot_lane);
         f32x4 s1q[4];
-        stage_lines(xw, sl);        // g2's readers are past the hidden barrier
+        stage_lines_c(xw, line_lane(), sl);        // g2's readers are past the hidden barrier
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < 4; ++s) s1q[s] = *reinterpret_cast<const f32x4 *>(xw + s * 256 + io.pw[s]);
@@ -368,21 +407,21 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         //  g2 was consumed by the first product, so g2b takes its place in the x block)
 #pragma unroll
         for (int s = 0; s < 4; ++s) line_put(hw, io, s, f32x4{cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]});
-        line_store<D>(srd_dx, hw, row0, fb, a.rows);
+        line_store_c<D, RAGGED>(srd_dx, hw, line_lane(), row0, fb, a.rows);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f32x4 v = {cur[4 * s], cur[4 * s + 1], cur[4 * s + 2], cur[4 * s + 3]};
             if (drop) v = mask4(v, rw1, colw + fb + 8 * s + 4 * h);
             line_put(xw, io, s, v);
         }
-        line_store<D>(srd_g2b, xw, row0, fb, a.rows);
+        line_store_c<D, RAGGED>(srd_g2b, xw, line_lane(), row0, fb, a.rows);
         __syncthreads();
         // the next tile's g and s2 blocks: requested here, staged at the end of this tile
         f32x4 ng[4], ns[4];
         {
             const int ntile = tile + gridDim.x, row0n = ntile < ntiles ? ntile * 32 : a.rows;
-            fetch_lines(srd_g, D, row0n, fb, ng);
-            fetch_lines(srd_s2, D, row0n, fb, ns);
+            fetch_lines_c<D, RAGGED>(srd_g, line_lane(), row0n, fb, a.rows, ng);
+            fetch_lines_c<D, RAGGED>(srd_s2, line_lane(), row0n, fb, a.rows, ns);
         }
 
         // ---- d_o = g2b Wo ----
@@ -390,9 +429,9 @@ __global__ __launch_bounds__(D * 2, D <= 128 ? 3 : 2) void chain_bwd_kernel(cons
         gemm_run<W, 1, PFD, 1, 0, decltype(xb_frag), 0x1>(ring_d, srd_wot, wot_lane, acc_o, xb_frag);
 #pragma unroll
         for (int s = 0; s < 4; ++s) line_put(hw, io, s, f32x4{acc_o[0][4 * s], acc_o[0][4 * s + 1], acc_o[0][4 * s + 2], acc_o[0][4 * s + 3]});
-        line_store<D>(srd_do, hw, row0, fb, a.rows);
-        stage_lines(hw, ng);
-        stage_lines(hw + 1024, ns);
+        line_store_c<D, RAGGED>(srd_do, hw, line_lane(), row0, fb, a.rows);
+        stage_lines_c(hw, line_lane(), ng);
+        stage_lines_c(hw + 1024, line_lane(), ns);
         // LDS hazards across tiles: xb is rewritten behind the next tile's LayerNorm-2 barrier, hb behind two barriers,
         // the row-sum table of LayerNorm 2 behind the xb barrier above.
     }
@@ -833,11 +872,14 @@ template <int ACT>
 static hipError_t launch_chain_bwd_t(const ChainBwdArgs &args, hipStream_t st) {
     constexpr int D = 128;
     using B = ChainBwdShape<D>;
-    static PerDeviceOnce lds_attr;
-    hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_bwd_kernel<D, ACT>), B::LDS_BYTES);
+    static PerDeviceOnce lds_attr[2];
+    const bool ragged = (args.rows & 31) != 0 || getenv("AFT_CHAIN_BWD_RAGGED") != nullptr;      // a partial last tile: the instantiation with per-row guards (the variable forces it: A/B)
+    hipError_t ea = ragged ? ensure_dynamic_lds(lds_attr[1], reinterpret_cast<const void *>(chain_bwd_kernel<D, ACT, true>), B::LDS_BYTES)
+                           : ensure_dynamic_lds(lds_attr[0], reinterpret_cast<const void *>(chain_bwd_kernel<D, ACT, false>), B::LDS_BYTES);
     if (ea != hipSuccess) return ea;
     const int blocks = chain_bwd_blocks(args.rows);
-    hipLaunchKernelGGL((chain_bwd_kernel<D, ACT>), dim3(blocks), dim3(ChainShape<D>::THREADS), B::LDS_BYTES, st, args);
+    if (ragged) hipLaunchKernelGGL((chain_bwd_kernel<D, ACT, true>), dim3(blocks), dim3(ChainShape<D>::THREADS), B::LDS_BYTES, st, args);
+    else hipLaunchKernelGGL((chain_bwd_kernel<D, ACT, false>), dim3(blocks), dim3(ChainShape<D>::THREADS), B::LDS_BYTES, st, args);
     return hipGetLastError();
 }
 

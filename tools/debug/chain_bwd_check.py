@@ -17,7 +17,7 @@ def run(layer, cfg, x0, gout, p, seed, unfused):
     return [x.grad.clone()] + [q.grad.clone() for q in layer_params(layer)]
 
 names = ["dx"] + list(_abi.LAYER_PARAM_NAMES)
-for grid, planes in (((24, 14), 2), ((120, 14), 2), ((120, 14), 16)):
+for grid, planes in [((120, 14), int(x)) for x in os.environ.get("AFT_CHECK_PLANES", "2,16").split(",")]:
     for p in (0.0, 0.1):
         d, heads = 128, 4
         cfg = _abi.make_config(ofdm=grid, pilot=(12, 2), patch=(3, 2), num_layers=1, model_dim=d, num_head=heads)
