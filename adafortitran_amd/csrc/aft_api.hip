@@ -225,6 +225,26 @@ size_t aft_workspace_bytes(const aft_config *cfg, int batch) {
     return plan_workspace(*cfg, batch).total_floats * sizeof(float);
 }
 
+int aft_workspace_region(const aft_config *cfg, int batch, int region, size_t *offset_bytes, size_t *size_bytes) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    if (batch <= 0 || !offset_bytes || !size_bytes) {
+        set_error("aft_workspace_region: bad batch or NULL result pointer");
+        return AFT_ERR_ARG;
+    }
+    const Workspace ws = plan_workspace(*cfg, batch);
+    size_t off = 0, n = 0;
+    switch (region) {
+        case AFT_REGION_CONV_ENHANCED: off = ws.conv_enhanced; n = (size_t)ws.planes * cfg->num_scs * cfg->num_symbols; break;
+        case AFT_REGION_TOKENS6: off = ws.tokens6; n = cfg->adaptive ? (size_t)batch * ws.tokens * 6 : 0; break;
+        case AFT_REGION_ENC_OUT: off = ws.out6; n = (size_t)ws.planes * ws.tokens * out6_stride(*cfg); break;
+        default: set_error("aft_workspace_region: unknown region %d", region); return AFT_ERR_ARG;
+    }
+    *offset_bytes = off * sizeof(float);
+    *size_bytes = n * sizeof(float);
+    return AFT_OK;
+}
+
 #define AFT_REQUIRE(cond, ...)        \
     do {                              \
         if (!(cond)) {                \

@@ -43,6 +43,21 @@ __device__ __forceinline__ float other_half32(float x) {   // value held by lane
     return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
+// v_mfma_f32_16x16x4_f32: A[i = lane % 16][k = lane / 16], B[k = lane / 16][j = lane % 16], D[i = 4 (lane / 16) + v][j = lane % 16]
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AFT_M16_SPACER)
+    asm volatile("s_nop 0" : "+v"(c));
+#endif
+    return c;
+}
+__device__ __forceinline__ float row16_from_below(float v) {   // lane i <- lane i-1 inside each 16-lane row, 0 into lane 0 (DPP row_shr:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_from_above(float v) {   // lane i <- lane i+1 inside each 16-lane row, 0 into lane 15 (DPP row_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+
 }  // namespace
 
 // MODE 0 = head (a.in_plane = upsampled planes [planes][S][T], a.out_plane), 1 = tail (a.lin2_out + a.resid, a.out_complex).
@@ -51,12 +66,17 @@ __device__ __forceinline__ float other_half32(float x) {   // value held by lane
 // backward: the pre-activation gradients the weight-gradient kernels need), a masked activation (backward: the ReLU derivative from
 // the saved forward activation instead of bias + ReLU), and NULL biases.  The backward of the stack IS this kernel on dL/dy with
 // transposed, flipped weights (conv4^T 1->8, conv3^T 8->32, conv2^T 32->8, conv1^T 8->1: the forward's stage shapes).
-template <int MODE, bool TRAIN = false>
+template <int MODE, bool TRAIN = false, bool M16 = false>
 __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArgs a) {
+    static_assert(!(M16 && TRAIN), "the 16x16x4 matrix phase is the inference instantiation only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *in0 = smem + kIn0, *c1 = smem + kC1, *c3 = smem + kC3;
     float *bias2 = smem + kBias2, *w1s = smem + kW1, *w4s = smem + kW4;
-    volatile int *flags = reinterpret_cast<volatile int *>(smem + kFlags);   // [0..3]: conv3 columns published by matrix wave w
+    // [0..3]: conv3 columns published by matrix wave w.  An address_space(3) pointer: volatile accesses through a GENERIC pointer are not
+    // rewritten to LDS instructions -- they were flat_load / flat_store with sc0 sc1 and an s_waitcnt vmcnt(0) behind every
+    // publication, i.e. the matrix wave stalled once per column on a flat round trip (round 5, found in the disassembly)
+    using lds_int = __attribute__((address_space(3))) int;
+    volatile lds_int *flags = (volatile lds_int *)(smem + kFlags);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int n = blockIdx.x, frame = n >> 1, part = n & 1;
     const bool matrix = wave < 4;
@@ -77,7 +97,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             const int rem = i % 288;   // conv3.weight [co 8][ci 32][ky 3][kx 3]
             stage[kW3Off + (rem / 3) * 33 + (rem % 3) * 8 + i / 288] = a.cw[2][i];
         }
-        if (tid < 32) bias2[tid] = (TRAIN && !a.cb[1]) ? 0.f : a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
+        if (tid < 32) bias2[tid] = (TRAIN && !a.cb[1]) ? 0.f : a.cb[1][M16 ? tid : (tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
         if (tid >= 64 && tid < 144) w1s[tid - 64] = tid < 136 ? a.cw[0][tid - 64] : ((TRAIN && !a.cb[0]) ? 0.f : a.cb[0][tid - 136]);
         if (tid >= 192 && tid < 265) w4s[tid - 192] = tid < 264 ? a.cw[3][tid - 192] : ((TRAIN && !a.cb[3]) ? 0.f : a.cb[3][0]);
         if (tid >= 320 && tid < 336) flags[tid - 320] = 0;
@@ -147,13 +167,39 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
     };
     auto signal_count = [&](int slot) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(const_cast<int *>(flags + slot), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_add(const_cast<lds_int *>(flags + slot), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     float wa2[36], wa3[48], bias3[4];
     if (matrix) {
         // ---- matrix waves: gather the MFMA A fragments (84 registers, kept for the whole kernel) ----
         const float *stage = smem + kStage;
+        if constexpr (M16) {
+            // 16x16x4 fragments (see the matrix phase below).  conv2: tile mt = output channels 16 mt + (lane % 16), k-step
+            // ks2 = (tap = kx*3+ky, ci half): k = lane / 16 <-> ci = 4 cih + k.
+            const int li = lane & 15, gk = lane >> 4;
+#pragma unroll
+            for (int f = 0; f < 36; ++f) {
+                const int mt = f / 18, ks2 = f % 18, tap = ks2 >> 1, cih = ks2 & 1, kx = tap / 3, ky = tap % 3;
+                wa2[f] = stage[((4 * cih + gk) * 9 + ky * 3 + kx) * 33 + 16 * mt + li];
+            }
+            // conv3: product row 16 rt + 4 g' + v' is accumulator register q = 4 rt + v' of lane group g' = output channel low
+            // bits; q = 0, 1 idle (zero weights), q - 2 = 6 kx + 2 ky + cohi, co = 4 cohi + g'.  k-step ks = (mt, v): ci = 16 mt + 4 k + v
+            // -- exactly the channel register v of conv2's tile mt holds in lane group k.
+            const int vq = li & 3, colow = li >> 2;
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt) {
+                const int q = 4 * rt + vq, qq = max(q - 2, 0), kx = qq / 6, rem = qq - 6 * kx, ky = rem >> 1, cohi = rem & 1;
+                const float *src = stage + kW3Off + (12 * gk + ky) * 33 + kx * 8 + 4 * cohi + colow;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const float wv = src[(16 * (ks >> 2) + (ks & 3)) * 99];
+                    wa3[rt * 8 + ks] = q >= 2 ? wv : 0.f;
+                }
+            }
+            bias3[0] = a.cb[2][gk];
+            bias3[1] = a.cb[2][4 + gk];
+        } else {
 #pragma unroll
         for (int kb = 0; kb < 36; ++kb) {        // k slot (kb, h): tap = kb>>2 = kx*3+ky, ci = 4h + (kb&3); row = co = j
             const int tap = kb >> 2, kx = tap / 3, ky = tap % 3, ci = 4 * h + (kb & 3);
@@ -168,6 +214,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias3[e] = (TRAIN && !a.cb[2]) ? 0.f : a.cb[2][e + 4 * h];
+        }
         wait_count(4, 4);                        // the helpers' input plane
         conv1_columns(wave, T / 2, T);
     } else {
@@ -213,7 +260,156 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
     __syncthreads();   // fragments gathered (the staging area is dead), c1 complete (in0 is dead: it becomes the output plane)
     SSTAMP(3);
 
-    if (matrix) {
+    if (matrix && M16) {
+        // ---- conv2 + conv3 as v_mfma_f32_16x16x4_f32 chains (round 5).  The 32x32x2 form below spends 48 MFMAs of 64 cycles per
+        // column on conv3 with 24 of 32 product rows used (row = (kx, co)); here ALL 72 (ky, kx, co) products of an input pixel are
+        // rows of ONE operand -- 4.5 tiles of 16 rows -> 5 tiles x 2 pixel tiles x 8 k-steps = 80 MFMAs of 32 cycles (2 560 instead
+        // of 3 072 cycles), and conv2 is 2 x 2 tiles x 18 k-steps = 72 MFMAs (2 304 cycles, as before).  What makes it work:
+        //  * pixel tile pt of a wave's 32 rows = the rows of parity pt (row j = 2 p + pt, p = lane % 16): the ky = -1 / +1 products
+        //    are needed one row further down / up, i.e. in the OTHER pixel tile's register at the same lane or one lane along the
+        //    16-lane DPP row -- no carries between tiles, and conv2's accumulators are conv3's B operands unshifted (the 32 DPP
+        //    moves per column of the 32x32 form are gone; the ky sums are 8 adds per output column instead);
+        //  * accumulator register q = 4 rt + v of a pixel tile: q = 0, 1 idle, then 6 registers (ky, co half) per kx.  The kx
+        //    products of input column t belong to output column t + 1 - kx, so "rotate by 6 registers" between columns sums them;
+        //    the rotation is the C operand of each tile's FIRST MFMA of a column (registers 4 rt - 6 .. 4 rt - 3 of the previous
+        //    column: contiguous because the idle pair sits in front; zero for tiles 0 and 1).
+        const int p = lane & 15, g = lane >> 4;
+        const int r0 = 4 + kTileRows * wave - 1 + 2 * p;                 // local row of this lane's pixel in tile pt = 0 (pt = 1: r0 + 1)
+        bool ok3[2];
+        float relu_hi[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int jj = 2 * p + pt, r = r0 + pt, gr = r - 4;
+            const bool ok2 = gr >= 0 && gr < S;                          // conv2 output inside the plane (else zero padding)
+            relu_hi[pt] = ok2 ? __builtin_inff() : 0.f;
+            ok3[pt] = ok2 && jj >= 1 && jj <= kTileRows && r < LR - 3;
+        }
+        // conv2's B operands: for (kx, ci half) the four rows r0 - 1 .. r0 + 2 of conv1's column t' + kx serve both pixel tiles and
+        // the three ky (row r0 + pt + ky - 1): 24 registers per column, two 8-byte LDS reads per (kx, ci half)
+        const float *bsrc = c1 + g * kPlane + r0 - 1;                    // + 4 cih planes + (t' + kx) SP
+        // stores of finished conv3 columns: halo lanes (row j = 0 / 31 of the tile; with 4 x 30 = 120 rows these are the only
+        // invalid ones) write to row 0 of the plane instead, which nobody reads into a stored result
+        float *dst[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) dst[pt] = c3 + g * kPlane + (ok3[pt] ? r0 + pt : 0);   // + 4 cohi planes + (t + 1) SP
+        float *const dump = c3 + g * kPlane;
+        auto publish = [&](int columns_done) {                           // (see the 32x32 form below)
+            asm volatile("" ::: "memory");
+            if (lane == 0) flags[wave] = columns_done;
+            asm volatile("" ::: "memory");
+        };
+        float bv[3][2][4];
+        auto load_b = [&](int kx, int cih, int tcol) {
+            const float *q = bsrc + 4 * cih * kPlane + (tcol + kx) * SP;
+            const f32x2 lo = *reinterpret_cast<const f32x2 *>(q), hi = *reinterpret_cast<const f32x2 *>(q + 2);
+            bv[kx][cih][0] = lo[0]; bv[kx][cih][1] = lo[1]; bv[kx][cih][2] = hi[0]; bv[kx][cih][3] = hi[1];
+        };
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi) load_b(gi >> 1, gi & 1, 0);
+        f32x4 bias2v[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) bias2v[mt] = *reinterpret_cast<const f32x4 *>(bias2 + 16 * mt + 4 * g);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 a3[2][5];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = zero4;
+        f32x4 x2[2][2];   // [pt][mt]: conv2's activation of the current column = conv3's B operands
+        f32x4 acc2[2][2];
+        auto relu2 = [&]() {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) x2[pt][mt][v] = __builtin_amdgcn_fmed3f(acc2[pt][mt][v], 0.f, relu_hi[pt]);
+        };
+        // conv2 MFMA u (0..11) of group gi = (kx, ci half): ky = u / 4, pixel tile (u / 2) % 2, channel tile u % 2
+        auto conv2_step = [&](int gi, int u) {
+            const int kx = gi >> 1, cih = gi & 1, ky = u >> 2, pt = (u >> 1) & 1, mt = u & 1, ks2 = 2 * (kx * 3 + ky) + cih;
+            acc2[pt][mt] = mfma16(wa2[mt * 18 + ks2], bv[kx][cih][ky + pt], (gi == 0 && ky == 0) ? bias2v[mt] : acc2[pt][mt]);
+        };
+        // the C operand that rotates the previous column's registers by six (tile rt of pixel tile pt)
+        auto rotated = [&](int pt, int rt) -> f32x4 {
+            if (rt < 2) return zero4;
+            const f32x4 lo = a3[pt][rt - 2], hi = a3[pt][rt - 1];
+            return f32x4{lo[2], lo[3], hi[0], hi[1]};
+        };
+        f32x4 n3[2][5];
+        // conv3 MFMA m (0..79): k-step m / 10, tiles in descending order (the finished registers sit in tiles 3, 4)
+        auto conv3_step = [&](int m) {
+            const int ks = m / 10, i = m % 10, rt = 4 - (i >> 1), pt = i & 1;
+            n3[pt][rt] = mfma16(wa3[rt * 8 + ks], x2[pt][ks >> 2][ks & 3], ks == 0 ? rotated(pt, rt) : n3[pt][rt]);
+        };
+        // conv3's output column `tout` from the six finished registers (ky, co half) of both pixel tiles
+        auto store_col = [&](int tout, const float (&Y)[2][6]) {
+            float *p0 = tout < 0 ? dump : dst[0], *p1 = tout < 0 ? dump : dst[1];
+#pragma unroll
+            for (int cohi = 0; cohi < 2; ++cohi) {
+                // row j = 2p (pt 0): ky = 0 from row j - 1 = (pt 1, lane p - 1), ky = 2 from row j + 1 = (pt 1, lane p)
+                // row j = 2p + 1 (pt 1): ky = 0 from (pt 0, lane p), ky = 2 from (pt 0, lane p + 1)
+                float o0 = Y[0][2 + cohi] + row16_from_below(Y[1][cohi]) + Y[1][4 + cohi];
+                float o1 = Y[1][2 + cohi] + Y[0][cohi] + row16_from_above(Y[0][4 + cohi]);
+                o0 = fmaxf(o0 + bias3[cohi], 0.f);
+                o1 = fmaxf(o1 + bias3[cohi], 0.f);
+                p0[4 * cohi * kPlane + (tout + 1) * SP] = o0;
+                p1[4 * cohi * kPlane + (tout + 1) * SP] = o1;
+            }
+            publish(tout + 1);     // (-1: column 0 of the flags' count, a no-op)
+        };
+        // prologue: conv2 of column 0
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi) {
+#pragma unroll
+            for (int u = 0; u < 12; ++u) conv2_step(gi, u);
+            load_b(gi >> 1, gi & 1, 1);
+        }
+        relu2();
+#pragma unroll 1
+        for (int tcol = 0; tcol < T - 1; ++tcol) {
+            const int tnext = min(tcol + 2, T - 1);
+            // 80 conv3 MFMAs of column tcol merged with the 72 conv2 MFMAs of column tcol + 1; the B operands of conv2's group are
+            // re-requested for column tcol + 2 right behind their last use (pinned: the compiler otherwise sinks all reads to the
+            // end of the column and the next column starts with an LDS round trip)
+#pragma unroll
+            for (int gi = 0; gi < 6; ++gi) {
+                const int m0 = 80 * gi / 6, m1 = 80 * (gi + 1) / 6;
+#pragma unroll
+                for (int u = 0; u < 14; ++u) {
+                    if (m0 + u < m1) conv3_step(m0 + u);
+                    if (u < 12) conv2_step(gi, u);
+                }
+                load_b(gi >> 1, gi & 1, tnext);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float Y[2][6];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                Y[pt][0] = n3[pt][3][2]; Y[pt][1] = n3[pt][3][3];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Y[pt][2 + v] = n3[pt][4][v];
+#pragma unroll
+                for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = n3[pt][rt];
+            }
+            store_col(tcol - 1, Y);
+            relu2();
+        }
+        {   // conv3 of the last column; its kx = 1 registers are output column T - 1 (column T is zero padding)
+#pragma unroll
+            for (int m = 0; m < 80; ++m) conv3_step(m);
+            float Y[2][6], Z[2][6];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                Y[pt][0] = n3[pt][3][2]; Y[pt][1] = n3[pt][3][3];
+                Z[pt][4] = n3[pt][3][0]; Z[pt][5] = n3[pt][3][1];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { Y[pt][2 + v] = n3[pt][4][v]; Z[pt][v] = n3[pt][2][v]; }
+            }
+            store_col(T - 2, Y);
+            store_col(T - 1, Z);
+        }
+    } else if (matrix) {
         // ---- conv2 + conv3 on the matrix cores: row tile `wave`, columns 0 .. T-1 (k_conv.hip's pipelined sweep, one segment) ----
         const int r = 4 + kTileRows * wave - 1 + j;                       // this lane's local row
         const int gr = r - 4;
@@ -397,7 +593,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             if (have >= columns) return;
             for (;;) {   // one 16-byte LDS read per poll, a long sleep between polls: a polling wave costs its SIMD's matrix wave issue slots
                 using i32x4 = __attribute__((ext_vector_type(4))) int;
-                const i32x4 f = *reinterpret_cast<const volatile i32x4 *>(flags);
+                using lds_i32x4 = __attribute__((address_space(3))) i32x4;
+                const i32x4 f = *(const volatile lds_i32x4 *)(flags);
                 const int m = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (m >= columns) { have = m; break; }
                 __builtin_amdgcn_s_sleep(8);
@@ -473,8 +670,16 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
         hipLaunchKernelGGL((conv_stream_kernel<0, true>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
         return hipGetLastError();
     }
-    hipError_t e = a.mode == 0 ? ensure_dynamic_lds(lds_head, reinterpret_cast<const void *>(conv_stream_kernel<0>), kStreamLds)
-                               : ensure_dynamic_lds(lds_tail, reinterpret_cast<const void *>(conv_stream_kernel<1>), kStreamLds);
+    // AFT_CONV_MFMA32=1 keeps the 32x32x2 matrix phase (A/B runs); the default is the 16x16x4 form
+    const bool m16 = getenv("AFT_CONV_MFMA32") == nullptr;
+    static PerDeviceOnce lds_head16, lds_tail16;
+    hipError_t e;
+    if (m16)
+        e = a.mode == 0 ? ensure_dynamic_lds(lds_head16, reinterpret_cast<const void *>(conv_stream_kernel<0, false, true>), kStreamLds)
+                        : ensure_dynamic_lds(lds_tail16, reinterpret_cast<const void *>(conv_stream_kernel<1, false, true>), kStreamLds);
+    else
+        e = a.mode == 0 ? ensure_dynamic_lds(lds_head, reinterpret_cast<const void *>(conv_stream_kernel<0>), kStreamLds)
+                        : ensure_dynamic_lds(lds_tail, reinterpret_cast<const void *>(conv_stream_kernel<1>), kStreamLds);
     if (e != hipSuccess) return e;
 #ifdef AFT_DIAG_STAMPS
     static unsigned long long *dbuf = nullptr;
@@ -485,7 +690,10 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
         a.stamps = dbuf;
     }
 #endif
-    if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+    if (m16) {
+        if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0, false, true>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+        else hipLaunchKernelGGL((conv_stream_kernel<1, false, true>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+    } else if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
     else hipLaunchKernelGGL((conv_stream_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
 #ifdef AFT_DIAG_STAMPS
     if (stamp) {

@@ -176,6 +176,19 @@ class HipEngine:
             _lib.check(rc)
         return out
 
+    def forward_region(self, name: str, batch: int) -> torch.Tensor:
+        """What the last ``forward`` of ``batch`` frames on the current stream left in the workspace (``aft_workspace_region``):
+        'conv_enhanced' f32 [2B,S,T], 'tokens6' f32 [B,tokens,6], 'enc_out' f32 [2B,tokens,8|16] -- the production kernels'
+        intermediates, for known-answer tests.  A copy, valid whatever runs next."""
+        c = self.cfg
+        off, size = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.aft_workspace_region(C.byref(c), batch, _abi.REGION_IDS[name], C.byref(off), C.byref(size)))
+        ws = self._ws[self._stream()]
+        flat = ws[off.value:off.value + size.value].view(torch.float32).clone()
+        shape = {"conv_enhanced": (2 * batch, c.num_scs, c.num_symbols), "tokens6": (batch, self.tokens, 6),
+                 "enc_out": (2 * batch, self.tokens, -1)}[name]
+        return flat.view(*shape)
+
     # -- per-stage entry points (tests) ----------------------------------------------------
     def stage_upsample(self, pilots: torch.Tensor) -> torch.Tensor:
         B = pilots.shape[0]

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AFT_ABI_VERSION 4   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
+#define AFT_ABI_VERSION 5   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
 #define AFT_MAX_LAYERS 32
 
 #define AFT_OK 0
@@ -118,6 +118,19 @@ int aft_max_batch(const aft_config *cfg);
 
 /* Bytes of scratch aft_forward_f32 needs for `batch` frames (0 on a bad config). */
 size_t aft_workspace_bytes(const aft_config *cfg, int batch);
+
+/* Where aft_forward_f32 LEAVES its intermediates in `workspace` (no reference counterpart; known-answer tests use it to pin
+ * the kernels the forward itself launches -- the per-stage entry points further down do not always run the same kernels):
+ * byte offset and byte size of one region for `batch` frames.  Regions stay valid until the next call on that workspace.
+ *   AFT_REGION_CONV_ENHANCED  f32 [2B,S,T]            output of S1+S2 (fortitran.py:203-209), kept for the S7 residual
+ *   AFT_REGION_TOKENS6        f32 [B,tokens,6]        ChannelAdapter output (channel_adaptivity.py:59-63); adaptive configs
+ *   AFT_REGION_ENC_OUT        f32 [2B*tokens,stride]  linear_2's output (encoders.py:70), `stride` = 8 for patches of up to
+ *                                                     8 elements, else 16; columns [0, patch elements) are valid
+ * Returns AFT_OK, or AFT_ERR_ARG / AFT_ERR_SHAPE (bad region, batch or config). */
+#define AFT_REGION_CONV_ENHANCED 0
+#define AFT_REGION_TOKENS6 1
+#define AFT_REGION_ENC_OUT 2
+int aft_workspace_region(const aft_config *cfg, int batch, int region, size_t *offset_bytes, size_t *size_bytes);
 
 /* Replaces BaseFortiTranEstimator.forward (reference src/models/fortitran.py:145-182):
  * pilots complex64 [B,Ps,Pt] -> out complex64 [B,S,T].  snr/ds/dop are float32 [B]
@@ -272,7 +285,12 @@ int aft_adapter_bwd_f32(const float *const conditions[3], const float *const wei
 int aft_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, float grad_scale, int step, void *stream);
 
-/* ---- per-stage entry points (known-answer tests; same kernels as aft_forward_f32) ---- */
+/* ---- per-stage entry points (known-answer tests) ----
+ * Same arithmetic as aft_forward_f32 stage by stage, but NOT always the same kernels: these calls own no scratch, so on the default
+ * 120 x 14 grid S1+S2 and the tail run the banded conv kernel with the pilot_upsampler product inside it (k_conv.hip), while the
+ * forward runs the product in its prologue launch and the column-streaming conv kernel (k_conv_stream.hip); the embedding stage is
+ * its own kernel here and part of the first chain launch there.  The kernels the forward launches are pinned through
+ * aft_workspace_region (tests/test_hip_parity.py::test_forward_intermediates_match_golden). */
 
 /* S1+S2 (fortitran.py:203-209): pilots complex64 [B,Ps,Pt] -> conv_enhanced f32 [2B,S,T]. */
 int aft_stage_upsample_f32(const aft_config *cfg, const aft_weights *w, const float *pilots,
@@ -298,7 +316,8 @@ int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float 
  * Launch ONE kernel class `reps` times back to back on `stream`, on the activations a previous
  * aft_forward_f32 of the same (cfg, batch) left in `workspace`, so the caller can bracket it with
  * events on that stream.  Same kernels, grids and arguments as inside aft_forward_f32. */
-#define AFT_KERNEL_UPSAMPLE 0   /* fused pilot-linear + initial ConvEnhancer                 */
+#define AFT_KERNEL_UPSAMPLE 0   /* initial ConvEnhancer as the forward launches it (on the planes of the prologue's
+                                   pilot_upsampler product where the forward does that; else product + ConvEnhancer fused) */
 #define AFT_KERNEL_EMBED 1      /* patch gather + adapter concat + linear_1 + pos as its own kernel (the stage entry
                                    point's; aft_forward_f32 runs it inside AFT_KERNEL_QKV)                     */
 #define AFT_KERNEL_QKV 2        /* chain kernel: embedding + in-projection of layer 0        */

@@ -85,6 +85,29 @@ def test_stages_match_golden_and_oracle(oracle_lib, name):
     assert np.abs(out - g["out"]).max() <= TOL_HIP_OUT * np.abs(g["out"]).max()
 
 
+@pytest.mark.parametrize("name", ["D_forti", "A_ada", "DH_forti_hot", "AH_ada_mid"])
+def test_forward_intermediates_match_golden(name):
+    """The kernels aft_forward_f32 itself launches, pinned stage by stage on the reference's own intermediates: on the default grid
+    the forward runs the pilot_upsampler product in its prologue launch and the column-streaming conv kernels, which the per-stage
+    entry points (no scratch of their own) do not -- so the regions the forward leaves in its workspace are compared directly:
+    conv_enhanced (S1+S2, fortitran.py:203-209), the adapter tokens (channel_adaptivity.py:59-63) and linear_2's output
+    (encoders.py:70); the tail's residual + refinement is then pinned by `out` given a pinned enc_out and conv_enhanced."""
+    g = Golden(name)
+    eng = _engine(g)
+    B = g["pilots"].shape[0]
+    out = eng.forward(_t(g["pilots"]), *_meta(g)).cpu().numpy()
+    ce = eng.forward_region("conv_enhanced", B).cpu().numpy()
+    assert max_rel(ce, g["conv_enhanced"]) <= TOL_HIP_OUT
+    if g.adaptive and "tokens6" in g:
+        assert max_rel(eng.forward_region("tokens6", B).cpu().numpy(), g["tokens6"]) <= TOL_HIP_OUT
+    enc = eng.forward_region("enc_out", B).cpu().numpy()[:, :, :g["enc_out"].shape[2]]
+    assert max_rel(enc, g["enc_out"]) <= 4 * TOL_HIP_OUT       # six layers deep: the stated bound of the layer-chain test above
+    assert np.abs(out - g["out"]).max() <= TOL_HIP_OUT * np.abs(g["out"]).max()
+    # and the conv kernels of the forward against the stage entry points' (banded) ones on the same inputs: same arithmetic
+    ce_stage = eng.stage_upsample(_t(g["pilots"])).cpu().numpy()
+    assert max_rel(ce, ce_stage) <= 2e-6
+
+
 @pytest.mark.parametrize("adaptive", [False, True])
 @pytest.mark.parametrize("batch", [1, 3, 37])
 def test_ragged_batches_match_oracle(oracle_lib, adaptive, batch):
@@ -138,6 +161,26 @@ def _poison_allocator(value):
     """Leave the caching allocator's pool full of `value`: the next torch.empty (workspaces, outputs) gets that memory."""
     blocks = [torch.full((n,), value, device=DEV) for n in (1 << 26, 1 << 25, 1 << 24, 1 << 22, 1 << 20, 1 << 18) for _ in range(3)]
     del blocks
+
+
+def test_conv_stream_hand_over_soak():
+    """The column-streaming conv kernel hands conv1 / conv3 columns between its waves through LDS flags (k_conv_stream.hip); a lost
+    hand-over would be a one-in-many-launches event.  600 forwards of the benchmark batch, EVERY output compared on the device with
+    the first one's bits (was tools/debug/soak_forward.py)."""
+    hid = (7, 42, 560)
+    sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=20251114)
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(128, seed=3)
+    pil, meta = _t(inp["pilots"]), [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    ref = eng.forward(pil, *meta).clone()
+    out = torch.empty_like(ref)
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    for _ in range(600):
+        eng.forward(pil, *meta, out=out)
+        bad += (torch.view_as_real(out) != torch.view_as_real(ref)).any().to(torch.int64)
+    assert int(bad.item()) == 0
 
 
 @pytest.mark.parametrize("value", [float("nan"), 1e30, -3e38, float("inf")])
