@@ -128,6 +128,7 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     ws.vt = off;            off += align64(per_head);
     ws.wpack = off;         off += align64(packed_layer_floats(c.model_dim) * c.num_layers);
     ws.out6 = off;          off += align64(rows * out6_stride(c));
+    ws.convfrag = off;      off += align64(2 * kConvFragFloats);
     ws.total_floats = off;
     return ws;
 }
@@ -275,14 +276,15 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
     float *wpack = prepacked != nullptr ? nullptr : base + ws.wpack;
     const size_t x_floats = (size_t)ws.planes * ws.tokens * cfg->model_dim, up_floats = (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
     float *up_planes = x_floats >= up_floats && prologue_upsample_ok(*cfg, *w) ? base + ws.x : nullptr;
-    hipError_t e = launch_prologue(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, wpack, pilots, up_planes, st);
+    hipError_t e = launch_prologue(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, wpack, pilots, up_planes, st, base + ws.convfrag);
     if (e != hipSuccess) return hip_fail("prologue(adapter + pack_weights + upsampler product)", e);
-    e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr, up_planes != nullptr);
+    e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr, up_planes != nullptr,
+                        base + ws.convfrag);
     if (e != hipSuccess) return hip_fail("upsample", e);
     // patch embedding + linear_1 + positions run inside the first chain launch, linear_2 inside the last one
     rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st, true, prepacked != nullptr ? prepacked : wpack);
     if (rc != AFT_OK) return rc;
-    e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6);
+    e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6, base + ws.convfrag + kConvFragFloats);
     if (e != hipSuccess) return hip_fail("tail", e);
     return AFT_OK;
 }
@@ -437,7 +439,7 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                 // here whatever x holds -- the conv stack's time does not depend on its data)
                 e = launch_upsample(*cfg, *w, out, base + ws.conv_enhanced, batch, st,
                                     (size_t)ws.planes * ws.tokens * cfg->model_dim >= (size_t)ws.planes * cfg->num_scs * cfg->num_symbols ? x : nullptr,
-                                    prologue_upsample_ok(*cfg, *w));
+                                    prologue_upsample_ok(*cfg, *w), base + ws.convfrag);
                 break;
             case AFT_KERNEL_EMBED:
                 e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, x, batch, st);
@@ -482,12 +484,12 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                 const bool lend = (size_t)ws.planes * ws.tokens * cfg->model_dim >= (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
                 const float *cond = out + (size_t)batch * cfg->pilot_scs * cfg->pilot_symbols * 2;   // [snr | ds | dop] behind the pilots
                 e = launch_prologue(*cfg, *w, cond, cond + batch, cond + 2 * batch, base + ws.tokens6, batch, base + ws.wpack, out,
-                                    lend && prologue_upsample_ok(*cfg, *w) ? x : nullptr, st);
+                                    lend && prologue_upsample_ok(*cfg, *w) ? x : nullptr, st, base + ws.convfrag);
                 break;
             }
             case AFT_KERNEL_TAIL:
                 AFT_REQUIRE(out != nullptr, "tail profile needs an output buffer");
-                e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6);
+                e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6, base + ws.convfrag + kConvFragFloats);
                 break;
             default:
                 set_error("unknown kernel id %d", which);

@@ -137,8 +137,10 @@ __device__ __forceinline__ bool dropmask_keep(uint32_t row_word, uint32_t col_wo
 //   vt            [2B][H][tokpad/32][4 g][64 lanes][4]  f32  fragment order: (d + 32hh, key = 32kt+8g+4hh+j)
 //   wpack         [L][8*d*d]            f32  encoder GEMM weights in MFMA-fragment order (rebuilt per call)
 //   out6          [2B*tokens][8 | 16]   f32  linear_2 output of the last chain launch (input of the conv tail)
+//   convfrag      [2][22][64][4]        f32  conv2 / conv3 weights of the initial enhancer | the final refiner as 16x16x4 MFMA
+//                                            operand fragments (conv_device.h: conv_frag16_entry; rebuilt per call by the prologue)
 struct Workspace {
-    size_t conv_enhanced, tokens6, x, attn, q, k, vt, wpack, out6, total_floats;
+    size_t conv_enhanced, tokens6, x, attn, q, k, vt, wpack, out6, convfrag, total_floats;
     int tokens, tokpad, planes;
 };
 
@@ -168,15 +170,20 @@ hipError_t ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, size_t by
 // scratch_planes (optional, 2 B * S * T floats, free to overwrite): grids other than the default one compute the upsampler as one
 // product over all planes into it and the conv head reads the planes; NULL = inside the conv head
 // planes_ready: scratch_planes already holds the upsampled planes (the forward's prologue launch computed them)
+// conv_frag: this stack's fragment image (kConvFragFloats floats, written by launch_prologue) or NULL
+constexpr size_t kConvFragFloats = 22 * 64 * 4;   // = conv_device.h kFragFloats, per ConvEnhancer
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots,
-                           float *conv_enhanced, int batch, hipStream_t st, float *scratch_planes = nullptr, bool planes_ready = false);
+                           float *conv_enhanced, int batch, hipStream_t st, float *scratch_planes = nullptr, bool planes_ready = false,
+                           const float *conv_frag = nullptr);
 hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
                           const float *dop, float *tokens6, int batch, hipStream_t st);
 // Whole forward: adapter (if c.adaptive), the weight re-pack (if packed != NULL, all layers) and the pilot_upsampler product over all
 // planes (if up_planes != NULL and prologue_upsample_ok: [2 batch][S*T] floats) as ONE launch (k_misc.hip)
 bool prologue_upsample_ok(const aft_config &c, const aft_weights &w);
+// conv_frag != NULL: + both ConvEnhancers' conv2 / conv3 weights as 16x16x4 operand fragments (2 x kConvFragFloats floats)
 hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const float *snr, const float *ds, const float *dop,
-                           float *tokens6, int batch, float *packed, const float *pilots, float *up_planes, hipStream_t st);
+                           float *tokens6, int batch, float *packed, const float *pilots, float *up_planes, hipStream_t st,
+                           float *conv_frag = nullptr);
 hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced,
                         const float *tokens6, float *x, int batch, hipStream_t st);
 // Row-local chain on [rows, d]: (mlp) x <- LN2(x1 + FFN(x1)), x1 = LN1(x + attn Wo^T + bo);
@@ -213,7 +220,7 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
 bool conv_plan_ok(int S, int T, int extra_floats);
 // x = encoder output [rows][d] (linear_2 applied here), or NULL with out6 = linear_2 output [rows][out6_stride(c)]
 hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
-                       float *out, int batch, hipStream_t st, const float *out6 = nullptr);
+                       float *out, int batch, hipStream_t st, const float *out6 = nullptr, const float *conv_frag = nullptr);
 hipError_t launch_linear(const float *weight, const float *bias, const float *pilots, float *out, int batch,
                          int in_features, int out_features, hipStream_t st);
 hipError_t launch_pilot_gather(const float *hzero_ls, float *pilots, int *counts, int batch, int grid_elems,

@@ -28,7 +28,35 @@ struct ConvArgs {
     float *save[3];          // outputs of conv1 / conv2 / conv3 after their activation, [planes][C][T][S] (C = 8, 32, 8)
     const float *mask[3];    // backward: activation of stage k = acc where mask[k] > 0 else 0 (instead of bias + ReLU)
     unsigned long long *stamps;   // diagnostic build only (AFT_DIAG_STAMPS): per-workgroup s_memtime at the phase boundaries
+    const float *wfrag;           // conv_stream16_kernel: this stack's conv2 / conv3 weights as 16x16x4 operand fragments (conv_frag16_entry)
 };
+
+// ---- conv2 / conv3 weights of one ConvEnhancer as v_mfma_f32_16x16x4_f32 A-operand fragments, packed by the forward's prologue launch
+// (k_misc.hip) and read by conv_stream16_kernel's matrix waves with 22 lane-linear 16-byte loads: [22 quads][64 lanes][4] floats.
+// Entry e = 4 quad + j of lane l (li = l % 16: the operand's row, gk = l / 16: its k index):
+//   0 .. 35   conv2, e = 18 mt + ks2: output channel 16 mt + li, k-step ks2 = 2 (kx*3 + ky) + ci half, input channel 4 (ci half) + gk
+//   36 .. 75  conv3, e - 36 = 8 rt + ks: product row 16 rt + li = accumulator register q = 4 rt + li % 4 of lane group li / 4;
+//             q = 0, 1 idle (zero), q - 2 = 6 kx + 2 ky + co half, output channel 4 (co half) + li / 4; input channel 16 (ks / 4) + 4 gk + ks % 4
+//   76, 77    conv3.bias[4 (co half) + gk]        78, 79  unused
+//   80 .. 87  conv2.bias[16 mt + 4 gk + v], e - 80 = 4 mt + v
+constexpr int kFragQuads = 22, kFragFloats = kFragQuads * 64 * 4;
+__device__ __forceinline__ float conv_frag16_entry(const float *__restrict__ w2, const float *__restrict__ b2, const float *__restrict__ w3,
+                                                   const float *__restrict__ b3, int e, int lane) {
+    const int li = lane & 15, gk = lane >> 4;
+    if (e < 36) {
+        const int mt = e / 18, ks2 = e - 18 * mt, tap = ks2 >> 1, cih = ks2 & 1, kx = tap / 3, ky = tap - 3 * kx;
+        return w2[(16 * mt + li) * 72 + (4 * cih + gk) * 9 + ky * 3 + kx];
+    }
+    if (e < 76) {
+        const int i = e - 36, rt = i >> 3, ks = i & 7, q = 4 * rt + (li & 3);
+        if (q < 2) return 0.f;
+        const int qq = q - 2, kx = qq / 6, rem = qq - 6 * kx, ky = rem >> 1, cohi = rem & 1;
+        return w3[(4 * cohi + (li >> 2)) * 288 + (16 * (ks >> 2) + 4 * gk + (ks & 3)) * 9 + ky * 3 + kx];
+    }
+    if (e < 78) return b3[4 * (e - 76) + gk];
+    if (e < 80) return 0.f;
+    return b2[16 * ((e - 80) >> 2) + 4 * gk + ((e - 80) & 3)];
+}
 
 #ifndef AFT_CONV_PIPE
 #define AFT_CONV_PIPE 1        // A/B knob: conv3(t) and conv2(t+1) as two interleaved MFMA chains

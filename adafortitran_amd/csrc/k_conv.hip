@@ -823,9 +823,11 @@ __global__ __launch_bounds__(256) void upsample_planes_kernel(const float *__res
 }
 
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots, float *conv_enhanced,
-                           int batch, hipStream_t st, float *scratch_planes, bool planes_ready) {
+                           int batch, hipStream_t st, float *scratch_planes, bool planes_ready, const float *conv_frag) {
+    static_assert(kConvFragFloats == (size_t)kFragFloats, "fragment image size");
     ConvArgs a{};
     a.mode = 0;
+    a.wfrag = conv_frag;
     a.S = c.num_scs; a.T = c.num_symbols;
     a.pilots = pilots; a.up_w = w.up_w; a.up_b = w.up_b;
     a.pf = c.pilot_scs * c.pilot_symbols;
@@ -849,9 +851,10 @@ hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const floa
 }
 
 hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
-                       float *out, int batch, hipStream_t st, const float *out6) {
+                       float *out, int batch, hipStream_t st, const float *out6, const float *conv_frag) {
     ConvArgs a{};
     a.mode = 1;
+    a.wfrag = conv_frag;
     a.lin2_out = out6;
     a.lin2_stride = out6_stride(c);
     a.S = c.num_scs; a.T = c.num_symbols;

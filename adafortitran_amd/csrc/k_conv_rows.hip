@@ -327,7 +327,10 @@ static int conv_rows_split(const ConvArgs &a, int planes) {
     const int cus = current_device_cus();
     int nsplit = 1;
     while (planes * nsplit < cus && a.T / (nsplit * 2) >= 8) nsplit *= 2;     // column ranges of at least 8 columns
-    return nsplit;
+    // ranges are ceil(T / nsplit) columns wide: drop the ranges that would start behind the last column (T = 129, 16 ranges of 9
+    // columns: the 16th would start at column 135 -- ADVICE r4), so that every workgroup of the launch owns at least one column
+    const int wcols = (a.T + nsplit - 1) / nsplit;
+    return (a.T + wcols - 1) / wcols;
 }
 bool conv_rows_ok(const ConvArgs &a, int planes) {
     if (a.S + 8 > kRowsSP || (a.S + kTileRows - 1) / kTileRows > kConvWaves || a.T < 8) return false;

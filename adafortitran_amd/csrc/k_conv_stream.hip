@@ -37,6 +37,10 @@ constexpr int kStage = kArena - kWStage;             // conv2 / conv3 weights st
 constexpr int kBias2 = kArena, kW1 = kBias2 + 32, kW4 = kW1 + 80, kFlags = kW4 + 80, kStreamFloats = kFlags + 16;
 constexpr size_t kStreamLds = sizeof(float) * kStreamFloats;   // 140 352 B: one workgroup per CU, as before
 
+using lds_int = __attribute__((address_space(3))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using lds_i32x4 = __attribute__((address_space(3))) i32x4;
+
 __device__ __forceinline__ float other_half32(float x) {   // value held by lane (l ^ 32): v_permlane32_swap
     const unsigned u = __builtin_bit_cast(unsigned, x);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -57,6 +61,18 @@ __device__ __forceinline__ float row16_from_below(float v) {   // lane i <- lane
 __device__ __forceinline__ float row16_from_above(float v) {   // lane i <- lane i+1 inside each 16-lane row, 0 into lane 15 (DPP row_shl:1)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
 }
+// conv3's 80 MFMAs of a column over the six conv2 groups (12 MFMAs each): the last group takes more of conv3, so conv2's last MFMA --
+// whose result the next column's first MFMAs wait for -- issues well before the column ends
+#ifndef AFT_POLL_SLEEP
+#define AFT_POLL_SLEEP 24
+#endif
+#ifndef AFT_HELPER_PRIO
+#define AFT_HELPER_PRIO 3
+#endif
+#ifndef AFT_C3_SPLIT
+#define AFT_C3_SPLIT {0, 12, 24, 36, 48, 60, 80}
+#endif
+__device__ constexpr int kC3Split[7] = AFT_C3_SPLIT;
 
 }  // namespace
 
@@ -66,16 +82,14 @@ __device__ __forceinline__ float row16_from_above(float v) {   // lane i <- lane
 // backward: the pre-activation gradients the weight-gradient kernels need), a masked activation (backward: the ReLU derivative from
 // the saved forward activation instead of bias + ReLU), and NULL biases.  The backward of the stack IS this kernel on dL/dy with
 // transposed, flipped weights (conv4^T 1->8, conv3^T 8->32, conv2^T 32->8, conv1^T 8->1: the forward's stage shapes).
-template <int MODE, bool TRAIN = false, bool M16 = false>
+template <int MODE, bool TRAIN = false>
 __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArgs a) {
-    static_assert(!(M16 && TRAIN), "the 16x16x4 matrix phase is the inference instantiation only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *in0 = smem + kIn0, *c1 = smem + kC1, *c3 = smem + kC3;
     float *bias2 = smem + kBias2, *w1s = smem + kW1, *w4s = smem + kW4;
-    // [0..3]: conv3 columns published by matrix wave w.  An address_space(3) pointer: volatile accesses through a GENERIC pointer are not
-    // rewritten to LDS instructions -- they were flat_load / flat_store with sc0 sc1 and an s_waitcnt vmcnt(0) behind every
-    // publication, i.e. the matrix wave stalled once per column on a flat round trip (round 5, found in the disassembly)
-    using lds_int = __attribute__((address_space(3))) int;
+    // [0..3]: conv3 columns published by matrix wave w.  An address_space(3) pointer: volatile accesses through a GENERIC pointer are
+    // not rewritten to LDS instructions -- they were flat_load / flat_store with sc0 sc1 and an s_waitcnt vmcnt(0) behind every
+    // publication (round 5, found in the disassembly)
     volatile lds_int *flags = (volatile lds_int *)(smem + kFlags);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int n = blockIdx.x, frame = n >> 1, part = n & 1;
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             const int rem = i % 288;   // conv3.weight [co 8][ci 32][ky 3][kx 3]
             stage[kW3Off + (rem / 3) * 33 + (rem % 3) * 8 + i / 288] = a.cw[2][i];
         }
-        if (tid < 32) bias2[tid] = (TRAIN && !a.cb[1]) ? 0.f : a.cb[1][M16 ? tid : (tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
+        if (tid < 32) bias2[tid] = (TRAIN && !a.cb[1]) ? 0.f : a.cb[1][(tid & 3) + 8 * ((tid & 15) >> 2) + 4 * (tid >> 4)];
         if (tid >= 64 && tid < 144) w1s[tid - 64] = tid < 136 ? a.cw[0][tid - 64] : ((TRAIN && !a.cb[0]) ? 0.f : a.cb[0][tid - 136]);
         if (tid >= 192 && tid < 265) w4s[tid - 192] = tid < 264 ? a.cw[3][tid - 192] : ((TRAIN && !a.cb[3]) ? 0.f : a.cb[3][0]);
         if (tid >= 320 && tid < 336) flags[tid - 320] = 0;
@@ -174,32 +188,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
     if (matrix) {
         // ---- matrix waves: gather the MFMA A fragments (84 registers, kept for the whole kernel) ----
         const float *stage = smem + kStage;
-        if constexpr (M16) {
-            // 16x16x4 fragments (see the matrix phase below).  conv2: tile mt = output channels 16 mt + (lane % 16), k-step
-            // ks2 = (tap = kx*3+ky, ci half): k = lane / 16 <-> ci = 4 cih + k.
-            const int li = lane & 15, gk = lane >> 4;
-#pragma unroll
-            for (int f = 0; f < 36; ++f) {
-                const int mt = f / 18, ks2 = f % 18, tap = ks2 >> 1, cih = ks2 & 1, kx = tap / 3, ky = tap % 3;
-                wa2[f] = stage[((4 * cih + gk) * 9 + ky * 3 + kx) * 33 + 16 * mt + li];
-            }
-            // conv3: product row 16 rt + 4 g' + v' is accumulator register q = 4 rt + v' of lane group g' = output channel low
-            // bits; q = 0, 1 idle (zero weights), q - 2 = 6 kx + 2 ky + cohi, co = 4 cohi + g'.  k-step ks = (mt, v): ci = 16 mt + 4 k + v
-            // -- exactly the channel register v of conv2's tile mt holds in lane group k.
-            const int vq = li & 3, colow = li >> 2;
-#pragma unroll
-            for (int rt = 0; rt < 5; ++rt) {
-                const int q = 4 * rt + vq, qq = max(q - 2, 0), kx = qq / 6, rem = qq - 6 * kx, ky = rem >> 1, cohi = rem & 1;
-                const float *src = stage + kW3Off + (12 * gk + ky) * 33 + kx * 8 + 4 * cohi + colow;
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const float wv = src[(16 * (ks >> 2) + (ks & 3)) * 99];
-                    wa3[rt * 8 + ks] = q >= 2 ? wv : 0.f;
-                }
-            }
-            bias3[0] = a.cb[2][gk];
-            bias3[1] = a.cb[2][4 + gk];
-        } else {
 #pragma unroll
         for (int kb = 0; kb < 36; ++kb) {        // k slot (kb, h): tap = kb>>2 = kx*3+ky, ci = 4h + (kb&3); row = co = j
             const int tap = kb >> 2, kx = tap / 3, ky = tap % 3, ci = 4 * h + (kb & 3);
@@ -214,7 +202,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias3[e] = (TRAIN && !a.cb[2]) ? 0.f : a.cb[2][e + 4 * h];
-        }
         wait_count(4, 4);                        // the helpers' input plane
         conv1_columns(wave, T / 2, T);
     } else {
@@ -260,156 +247,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
     __syncthreads();   // fragments gathered (the staging area is dead), c1 complete (in0 is dead: it becomes the output plane)
     SSTAMP(3);
 
-    if (matrix && M16) {
-        // ---- conv2 + conv3 as v_mfma_f32_16x16x4_f32 chains (round 5).  The 32x32x2 form below spends 48 MFMAs of 64 cycles per
-        // column on conv3 with 24 of 32 product rows used (row = (kx, co)); here ALL 72 (ky, kx, co) products of an input pixel are
-        // rows of ONE operand -- 4.5 tiles of 16 rows -> 5 tiles x 2 pixel tiles x 8 k-steps = 80 MFMAs of 32 cycles (2 560 instead
-        // of 3 072 cycles), and conv2 is 2 x 2 tiles x 18 k-steps = 72 MFMAs (2 304 cycles, as before).  What makes it work:
-        //  * pixel tile pt of a wave's 32 rows = the rows of parity pt (row j = 2 p + pt, p = lane % 16): the ky = -1 / +1 products
-        //    are needed one row further down / up, i.e. in the OTHER pixel tile's register at the same lane or one lane along the
-        //    16-lane DPP row -- no carries between tiles, and conv2's accumulators are conv3's B operands unshifted (the 32 DPP
-        //    moves per column of the 32x32 form are gone; the ky sums are 8 adds per output column instead);
-        //  * accumulator register q = 4 rt + v of a pixel tile: q = 0, 1 idle, then 6 registers (ky, co half) per kx.  The kx
-        //    products of input column t belong to output column t + 1 - kx, so "rotate by 6 registers" between columns sums them;
-        //    the rotation is the C operand of each tile's FIRST MFMA of a column (registers 4 rt - 6 .. 4 rt - 3 of the previous
-        //    column: contiguous because the idle pair sits in front; zero for tiles 0 and 1).
-        const int p = lane & 15, g = lane >> 4;
-        const int r0 = 4 + kTileRows * wave - 1 + 2 * p;                 // local row of this lane's pixel in tile pt = 0 (pt = 1: r0 + 1)
-        bool ok3[2];
-        float relu_hi[2];
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const int jj = 2 * p + pt, r = r0 + pt, gr = r - 4;
-            const bool ok2 = gr >= 0 && gr < S;                          // conv2 output inside the plane (else zero padding)
-            relu_hi[pt] = ok2 ? __builtin_inff() : 0.f;
-            ok3[pt] = ok2 && jj >= 1 && jj <= kTileRows && r < LR - 3;
-        }
-        // conv2's B operands: for (kx, ci half) the four rows r0 - 1 .. r0 + 2 of conv1's column t' + kx serve both pixel tiles and
-        // the three ky (row r0 + pt + ky - 1): 24 registers per column, two 8-byte LDS reads per (kx, ci half)
-        const float *bsrc = c1 + g * kPlane + r0 - 1;                    // + 4 cih planes + (t' + kx) SP
-        // stores of finished conv3 columns: halo lanes (row j = 0 / 31 of the tile; with 4 x 30 = 120 rows these are the only
-        // invalid ones) write to row 0 of the plane instead, which nobody reads into a stored result
-        float *dst[2];
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) dst[pt] = c3 + g * kPlane + (ok3[pt] ? r0 + pt : 0);   // + 4 cohi planes + (t + 1) SP
-        float *const dump = c3 + g * kPlane;
-        auto publish = [&](int columns_done) {                           // (see the 32x32 form below)
-            asm volatile("" ::: "memory");
-            if (lane == 0) flags[wave] = columns_done;
-            asm volatile("" ::: "memory");
-        };
-        float bv[3][2][4];
-        auto load_b = [&](int kx, int cih, int tcol) {
-            const float *q = bsrc + 4 * cih * kPlane + (tcol + kx) * SP;
-            const f32x2 lo = *reinterpret_cast<const f32x2 *>(q), hi = *reinterpret_cast<const f32x2 *>(q + 2);
-            bv[kx][cih][0] = lo[0]; bv[kx][cih][1] = lo[1]; bv[kx][cih][2] = hi[0]; bv[kx][cih][3] = hi[1];
-        };
-#pragma unroll
-        for (int gi = 0; gi < 6; ++gi) load_b(gi >> 1, gi & 1, 0);
-        f32x4 bias2v[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) bias2v[mt] = *reinterpret_cast<const f32x4 *>(bias2 + 16 * mt + 4 * g);
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 a3[2][5];
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = zero4;
-        f32x4 x2[2][2];   // [pt][mt]: conv2's activation of the current column = conv3's B operands
-        f32x4 acc2[2][2];
-        auto relu2 = [&]() {
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) x2[pt][mt][v] = __builtin_amdgcn_fmed3f(acc2[pt][mt][v], 0.f, relu_hi[pt]);
-        };
-        // conv2 MFMA u (0..11) of group gi = (kx, ci half): ky = u / 4, pixel tile (u / 2) % 2, channel tile u % 2
-        auto conv2_step = [&](int gi, int u) {
-            const int kx = gi >> 1, cih = gi & 1, ky = u >> 2, pt = (u >> 1) & 1, mt = u & 1, ks2 = 2 * (kx * 3 + ky) + cih;
-            acc2[pt][mt] = mfma16(wa2[mt * 18 + ks2], bv[kx][cih][ky + pt], (gi == 0 && ky == 0) ? bias2v[mt] : acc2[pt][mt]);
-        };
-        // the C operand that rotates the previous column's registers by six (tile rt of pixel tile pt)
-        auto rotated = [&](int pt, int rt) -> f32x4 {
-            if (rt < 2) return zero4;
-            const f32x4 lo = a3[pt][rt - 2], hi = a3[pt][rt - 1];
-            return f32x4{lo[2], lo[3], hi[0], hi[1]};
-        };
-        f32x4 n3[2][5];
-        // conv3 MFMA m (0..79): k-step m / 10, tiles in descending order (the finished registers sit in tiles 3, 4)
-        auto conv3_step = [&](int m) {
-            const int ks = m / 10, i = m % 10, rt = 4 - (i >> 1), pt = i & 1;
-            n3[pt][rt] = mfma16(wa3[rt * 8 + ks], x2[pt][ks >> 2][ks & 3], ks == 0 ? rotated(pt, rt) : n3[pt][rt]);
-        };
-        // conv3's output column `tout` from the six finished registers (ky, co half) of both pixel tiles
-        auto store_col = [&](int tout, const float (&Y)[2][6]) {
-            float *p0 = tout < 0 ? dump : dst[0], *p1 = tout < 0 ? dump : dst[1];
-#pragma unroll
-            for (int cohi = 0; cohi < 2; ++cohi) {
-                // row j = 2p (pt 0): ky = 0 from row j - 1 = (pt 1, lane p - 1), ky = 2 from row j + 1 = (pt 1, lane p)
-                // row j = 2p + 1 (pt 1): ky = 0 from (pt 0, lane p), ky = 2 from (pt 0, lane p + 1)
-                float o0 = Y[0][2 + cohi] + row16_from_below(Y[1][cohi]) + Y[1][4 + cohi];
-                float o1 = Y[1][2 + cohi] + Y[0][cohi] + row16_from_above(Y[0][4 + cohi]);
-                o0 = fmaxf(o0 + bias3[cohi], 0.f);
-                o1 = fmaxf(o1 + bias3[cohi], 0.f);
-                p0[4 * cohi * kPlane + (tout + 1) * SP] = o0;
-                p1[4 * cohi * kPlane + (tout + 1) * SP] = o1;
-            }
-            publish(tout + 1);     // (-1: column 0 of the flags' count, a no-op)
-        };
-        // prologue: conv2 of column 0
-#pragma unroll
-        for (int gi = 0; gi < 6; ++gi) {
-#pragma unroll
-            for (int u = 0; u < 12; ++u) conv2_step(gi, u);
-            load_b(gi >> 1, gi & 1, 1);
-        }
-        relu2();
-#pragma unroll 1
-        for (int tcol = 0; tcol < T - 1; ++tcol) {
-            const int tnext = min(tcol + 2, T - 1);
-            // 80 conv3 MFMAs of column tcol merged with the 72 conv2 MFMAs of column tcol + 1; the B operands of conv2's group are
-            // re-requested for column tcol + 2 right behind their last use (pinned: the compiler otherwise sinks all reads to the
-            // end of the column and the next column starts with an LDS round trip)
-#pragma unroll
-            for (int gi = 0; gi < 6; ++gi) {
-                const int m0 = 80 * gi / 6, m1 = 80 * (gi + 1) / 6;
-#pragma unroll
-                for (int u = 0; u < 14; ++u) {
-                    if (m0 + u < m1) conv3_step(m0 + u);
-                    if (u < 12) conv2_step(gi, u);
-                }
-                load_b(gi >> 1, gi & 1, tnext);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            float Y[2][6];
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                Y[pt][0] = n3[pt][3][2]; Y[pt][1] = n3[pt][3][3];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) Y[pt][2 + v] = n3[pt][4][v];
-#pragma unroll
-                for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = n3[pt][rt];
-            }
-            store_col(tcol - 1, Y);
-            relu2();
-        }
-        {   // conv3 of the last column; its kx = 1 registers are output column T - 1 (column T is zero padding)
-#pragma unroll
-            for (int m = 0; m < 80; ++m) conv3_step(m);
-            float Y[2][6], Z[2][6];
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                Y[pt][0] = n3[pt][3][2]; Y[pt][1] = n3[pt][3][3];
-                Z[pt][4] = n3[pt][3][0]; Z[pt][5] = n3[pt][3][1];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { Y[pt][2 + v] = n3[pt][4][v]; Z[pt][v] = n3[pt][2][v]; }
-            }
-            store_col(T - 2, Y);
-            store_col(T - 1, Z);
-        }
-    } else if (matrix) {
+    if (matrix) {
         // ---- conv2 + conv3 on the matrix cores: row tile `wave`, columns 0 .. T-1 (k_conv.hip's pipelined sweep, one segment) ----
         const int r = 4 + kTileRows * wave - 1 + j;                       // this lane's local row
         const int gr = r - 4;
@@ -592,8 +430,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         auto need = [&](int columns) {
             if (have >= columns) return;
             for (;;) {   // one 16-byte LDS read per poll, a long sleep between polls: a polling wave costs its SIMD's matrix wave issue slots
-                using i32x4 = __attribute__((ext_vector_type(4))) int;
-                using lds_i32x4 = __attribute__((address_space(3))) i32x4;
                 const i32x4 f = *(const volatile lds_i32x4 *)(flags);
                 const int m = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (m >= columns) { have = m; break; }
@@ -654,6 +490,427 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 #undef SSTAMP
 }
 
+
+// =====================================================================================================================================
+// conv_stream16_kernel (round 5): the same pipeline with conv2 / conv3 as v_mfma_f32_16x16x4_f32 chains and no staging phase.
+//
+// Matrix phase.  The 32x32x2 form above spends 48 MFMAs of 64 cycles per column on conv3 with 24 of 32 product rows used (row =
+// (kx, co)).  Here ALL 72 (ky, kx, co) products of an input pixel are rows of ONE operand -- 4.5 tiles of 16 rows -> 5 tiles x 2 pixel
+// tiles x 8 k-steps = 80 MFMAs of 32 cycles (2 560 instead of 3 072 cycles per column); conv2 is 2 x 2 tiles x 18 k-steps = 72 MFMAs
+// (2 304 cycles, as before).  What makes it work:
+//  * pixel tile pt of a wave's 32 rows = the rows of parity pt (row j = 2 p + pt, p = lane % 16).  The ky = -1 / +1 products are
+//    needed one row further down / up, i.e. in the OTHER pixel tile's register at the same lane or one lane along the 16-lane DPP row
+//    -- no carries between tiles, and conv2's accumulators are conv3's B operands unshifted (the 32 DPP moves per column of the 32x32
+//    form are gone; the ky sums are 8 adds per output column);
+//  * accumulator register q = 4 rt + v of a pixel tile: q = 0, 1 idle, then 6 registers (ky, co half) per kx.  The kx products of
+//    input column t belong to output column t + 1 - kx, so "rotate by 6 registers" between columns sums them; the rotation is the C
+//    operand of each tile's FIRST MFMA of a column (registers 4 rt - 6 .. 4 rt - 3 of the previous column: contiguous because the
+//    idle pair sits in front; zero for tiles 0 and 1).
+// Staging.  The forward's prologue launch leaves both stacks' weights as operand fragments in the workspace (conv_frag16_entry): a
+// matrix wave fetches its 76 fragment registers with 22 lane-linear 16-byte loads and starts sweeping as soon as the helper waves
+// have published conv1's first two columns -- no transposed LDS staging, no gather, no workgroup barrier before the sweeps (the
+// 32x32 kernel: 1 950 + 5 300 + 1 050 cycles before its first MFMA).  The helper waves run conv1 of ALL columns (one LDS flag per
+// helper wave and column), in the shadow of the first sweeps.
+// =====================================================================================================================================
+template <int MODE>
+__global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *in0 = smem + kIn0, *c1 = smem + kC1, *c3 = smem + kC3;
+    // flags [0..3]: conv3 columns published by matrix wave w; [4], [5]: helper-only counters; [8..11]: conv1 columns published by helper wave
+    volatile lds_int *flags = (volatile lds_int *)(smem + kFlags);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x, frame = n >> 1, part = n & 1;
+    const bool matrix = wave < 4;
+#ifdef AFT_DIAG_STAMPS
+#define SSTAMP(i) do { if (a.stamps && (tid == 0 || tid == 256)) a.stamps[(size_t)blockIdx.x * 16 + (tid ? 8 : 0) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+    SSTAMP(0);
+    if (tid < 16) flags[tid] = 0;
+    __syncthreads();   // (all waves are at the kernel's start: this costs an arrival, not a phase)
+    SSTAMP(1);
+    auto wait_count = [&](int slot, int count) {   // workgroup-scope hand-over through an LDS counter
+        while (flags[slot] < count) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto signal_count = [&](int slot) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(const_cast<lds_int *>(flags + slot), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    if (matrix) {
+        // ---- operand fragments straight from the packed image ----
+        float wa2[36], wa3[40], bias3[2];
+        f32x4 bias2v[2];
+        {
+            const f32x4 *fp = reinterpret_cast<const f32x4 *>(a.wfrag) + lane;
+            f32x4 fq[kFragQuads];
+#pragma unroll
+            for (int q = 0; q < kFragQuads; ++q) fq[q] = fp[q * 64];
+#pragma unroll
+            for (int f = 0; f < 36; ++f) wa2[f] = fq[f >> 2][f & 3];
+#pragma unroll
+            for (int f = 0; f < 40; ++f) wa3[f] = fq[9 + (f >> 2)][f & 3];
+            bias3[0] = fq[19][0]; bias3[1] = fq[19][1];
+            bias2v[0] = fq[20]; bias2v[1] = fq[21];
+        }
+        const int p = lane & 15, g = lane >> 4;
+        const int r0 = 4 + kTileRows * wave - 1 + 2 * p;                 // local row of this lane's pixel in tile pt = 0 (pt = 1: r0 + 1)
+        bool ok3[2];
+        float relu_hi[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int jj = 2 * p + pt, r = r0 + pt, gr = r - 4;
+            const bool ok2 = gr >= 0 && gr < S;                          // conv2 output inside the plane (else zero padding)
+            relu_hi[pt] = ok2 ? __builtin_inff() : 0.f;
+            ok3[pt] = ok2 && jj >= 1 && jj <= kTileRows && r < LR - 3;
+        }
+        // conv2's B operands: for (kx, ci half) the four rows r0 - 1 .. r0 + 2 of conv1's column t' + kx serve both pixel tiles and
+        // the three ky (row r0 + pt + ky - 1): 24 registers per column, two 8-byte LDS reads per (kx, ci half)
+        const float *bsrc = c1 + g * kPlane + r0 - 1;                    // + 4 cih planes + (t' + kx) SP
+        // stores of finished conv3 columns: halo lanes (row j = 0 / 31 of the tile; with 4 x 30 = 120 rows these are the only
+        // invalid ones) write to row 0 of the plane instead, which nobody reads into a stored result
+        float *dst[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) dst[pt] = c3 + g * kPlane + (ok3[pt] ? r0 + pt : 0);   // + 4 cohi planes + (t + 1) SP
+        float *const dump = c3 + g * kPlane;
+        // conv3 output columns [0, columns_done) of this tile are in LDS.  No s_waitcnt: the LDS serves one wave's requests in issue
+        // order, so a reader that sees the flag finds the data stores before it already done; the compiler barriers keep the flag
+        // store behind them in the instruction stream (a release fence would drain this wave's pending operand reads)
+        auto publish = [&](int columns_done) {
+            asm volatile("" ::: "memory");
+            if (lane == 0) flags[wave] = columns_done;
+            asm volatile("" ::: "memory");
+        };
+        int have1 = 0;   // conv1 columns known to be published by all four helper waves (wave-uniform)
+        auto need_c1 = [&](int columns) {
+            if (have1 >= columns) return;
+            for (;;) {
+                const i32x4 f = *(const volatile lds_i32x4 *)(flags + 8);
+                const int m = __builtin_amdgcn_readfirstlane(min(min(f[0], f[1]), min(f[2], f[3])));
+                if (m >= columns) { have1 = m; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        float bv[3][2][4];
+        auto load_b = [&](int kx, int cih, int tcol) {
+            const float *q = bsrc + 4 * cih * kPlane + (tcol + kx) * SP;
+            const f32x2 lo = *reinterpret_cast<const f32x2 *>(q), hi = *reinterpret_cast<const f32x2 *>(q + 2);
+            bv[kx][cih][0] = lo[0]; bv[kx][cih][1] = lo[1]; bv[kx][cih][2] = hi[0]; bv[kx][cih][3] = hi[1];
+        };
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 a3[2][5];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = zero4;
+        f32x4 x2[2][2];   // [pt][mt]: conv2's activation of the current column = conv3's B operands
+        f32x4 acc2[2][2];
+        auto relu2 = [&]() {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) x2[pt][mt][v] = __builtin_amdgcn_fmed3f(acc2[pt][mt][v], 0.f, relu_hi[pt]);
+        };
+        // conv2 MFMA u (0..11) of group gi = (kx, ci half): ky = u / 4, pixel tile (u / 2) % 2, channel tile u % 2
+        auto conv2_step = [&](int gi, int u) {
+            const int kx = gi >> 1, cih = gi & 1, ky = u >> 2, pt = (u >> 1) & 1, mt = u & 1, ks2 = 2 * (kx * 3 + ky) + cih;
+            acc2[pt][mt] = mfma16(wa2[mt * 18 + ks2], bv[kx][cih][ky + pt], (gi == 0 && ky == 0) ? bias2v[mt] : acc2[pt][mt]);
+        };
+        // the C operand that rotates the previous column's registers by six (tile rt of pixel tile pt)
+        auto rotated = [&](int pt, int rt) -> f32x4 {
+            if (rt < 2) return zero4;
+            const f32x4 lo = a3[pt][rt - 2], hi = a3[pt][rt - 1];
+            return f32x4{lo[2], lo[3], hi[0], hi[1]};
+        };
+        f32x4 n3[2][5];
+        // conv3 MFMA m (0..79): k-step m / 10, tiles in descending order (the finished registers sit in tiles 3, 4)
+        auto conv3_step = [&](int m) {
+            const int ks = m / 10, i = m % 10, rt = 4 - (i >> 1), pt = i & 1;
+            n3[pt][rt] = mfma16(wa3[rt * 8 + ks], x2[pt][ks >> 2][ks & 3], ks == 0 ? rotated(pt, rt) : n3[pt][rt]);
+        };
+        // conv3's output column `tout` from six finished registers (ky, co half) of both pixel tiles
+        auto store_col = [&](int tout, const float (&Y)[2][6]) {
+            float *p0 = tout < 0 ? dump : dst[0], *p1 = tout < 0 ? dump : dst[1];
+#pragma unroll
+            for (int cohi = 0; cohi < 2; ++cohi) {
+                // row j = 2p (pt 0): ky = 0 from row j - 1 = (pt 1, lane p - 1), ky = 2 from row j + 1 = (pt 1, lane p)
+                // row j = 2p + 1 (pt 1): ky = 0 from (pt 0, lane p), ky = 2 from (pt 0, lane p + 1)
+                float o0 = Y[0][2 + cohi] + row16_from_below(Y[1][cohi]) + Y[1][4 + cohi];
+                float o1 = Y[1][2 + cohi] + Y[0][cohi] + row16_from_above(Y[0][4 + cohi]);
+                o0 = fmaxf(o0 + bias3[cohi], 0.f);
+                o1 = fmaxf(o1 + bias3[cohi], 0.f);
+                p0[4 * cohi * kPlane + (tout + 1) * SP] = o0;
+                p1[4 * cohi * kPlane + (tout + 1) * SP] = o1;
+            }
+            publish(tout + 1);     // (tout < 0: the dump slot and a count of 0 -- both no-ops)
+        };
+        // the registers of `acc` that hold output column (input column - 1): the kx = 2 set, registers 14 .. 19
+        auto finished = [&](const f32x4 (&acc)[2][5], float (&Y)[2][6]) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                Y[pt][0] = acc[pt][3][2]; Y[pt][1] = acc[pt][3][3];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Y[pt][2 + v] = acc[pt][4][v];
+            }
+        };
+        SSTAMP(2);
+        need_c1(2);
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi) load_b(gi >> 1, gi & 1, 0);
+        need_c1(3);
+        SSTAMP(3);
+        // prologue: conv2 of column 0
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi) {
+#pragma unroll
+            for (int u = 0; u < 12; ++u) conv2_step(gi, u);
+            load_b(gi >> 1, gi & 1, 1);
+        }
+        relu2();
+#pragma unroll 1
+        for (int tcol = 0; tcol < T - 1; ++tcol) {
+            const int tnext = min(tcol + 2, T - 1);
+            need_c1(min(tnext + 2, T));
+            // 80 conv3 MFMAs of column tcol merged with the 72 conv2 MFMAs of column tcol + 1; the B operands of a conv2 group are
+            // re-requested for column tcol + 2 right behind their last use (pinned: the compiler otherwise sinks all reads to the end
+            // of the column and the next column starts with an LDS round trip).  Output column tcol - 2 -- finished by the PREVIOUS
+            // iteration -- is combined and stored behind the first group, when its registers have long left the matrix pipe.
+#pragma unroll
+            for (int gi = 0; gi < 6; ++gi) {
+                const int m0 = kC3Split[gi], m1 = kC3Split[gi + 1];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    conv3_step(m0 + u);
+                    conv2_step(gi, u);
+                }
+                load_b(gi >> 1, gi & 1, tnext);
+                if (m1 - m0 > 12) {   // the tail of conv3 behind conv2's last MFMA (pinned: the compiler otherwise moves conv2's MFMAs to the end)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 12; u < 20; ++u)
+                        if (m0 + u < m1) conv3_step(m0 + u);
+                }
+                if (gi == 0) {
+                    float Y[2][6];
+                    finished(a3, Y);
+                    store_col(tcol - 2, Y);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            relu2();
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = n3[pt][rt];
+        }
+        {   // output column T - 3, then conv3 of the last column: its kx = 2 registers are column T - 2, its kx = 1 registers column
+            // T - 1 (column T is zero padding)
+            float Y[2][6], Z[2][6];
+            finished(a3, Y);
+            store_col(T - 3, Y);
+#pragma unroll
+            for (int m = 0; m < 80; ++m)
+                if (m % 10 < 6) conv3_step(m);     // tiles 4, 3, 2 only: tiles 1, 0 hold the kx = 0 registers = output column T (padding)
+            finished(n3, Y);
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                Z[pt][4] = n3[pt][3][0]; Z[pt][5] = n3[pt][3][1];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Z[pt][v] = n3[pt][2][v];
+            }
+            store_col(T - 2, Y);
+            store_col(T - 1, Z);
+        }
+    } else {
+        // ---- helper waves: input plane, borders, conv1 of all columns (published column by column), conv4 behind the matrix waves ----
+        // Priority: a SIMD's issue arbiter serves the OLDER wave first at equal priority, and the matrix wave always has an independent
+        // MFMA ready -- at equal priority the helper got one issue slot per ~70 cycles (conv1 of 14 columns: 45 700 cycles of wall time
+        // for ~3 000 cycles of vector work, conv4 then finished 5 500 cycles behind the last sweep; stamps, round 5).  The helpers'
+        // vector work is on the matrix waves' critical path either way (they consume conv1's columns), so it goes first.
+        __builtin_amdgcn_s_setprio(AFT_HELPER_PRIO);
+        const int ht = tid - 256, hw = wave - 4;
+        float v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {      // one pixel per thread and pass, global reads coalesced; all 7 requests in flight together
+            const int i = ht + 256 * u;
+            v[u] = 0.f;
+            if (i < S * T) {
+                if (MODE == 0) {
+                    v[u] = a.in_plane[(size_t)n * (S * T) + i];
+                } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
+                    const int gr = i / T, t = i - gr * T, p0 = a.p0, p1 = a.p1, tpr = T / p1;
+                    const int g = gr / p0, tc = t / p1, f = (gr - g * p0) * p1 + (t - tc * p1);
+                    v[u] = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] + a.resid[(size_t)n * (S * T) + i];
+                }
+            }
+        }
+        // conv1's weights: thread = (local row lr = 32 hw + j, channel half h), two channels per v_pk_fma_f32
+        f32x2 w[2][9], b[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int k9 = 0; k9 < 9; ++k9) w[k][k9] = f32x2{a.cw[0][(4 * h + 2 * k) * 9 + k9], a.cw[0][(4 * h + 2 * k + 1) * 9 + k9]};
+            b[k] = f32x2{a.cb[0][4 * h + 2 * k], a.cb[0][4 * h + 2 * k + 1]};
+        }
+        // zero padding of in0 and c1: LDS columns 0 and T + 1 (the symbol borders), and in0's rows outside the plane
+        for (int i = ht; i < 9 * 2 * SP; i += 256) {
+            const int pl = i / (2 * SP), rem = i - pl * 2 * SP, col = rem < SP ? 0 : T + 1, row = rem & (SP - 1);
+            smem[pl * kPlane + col * SP + row] = 0.f;   // planes 0..8 = in0, c1[0..7]
+        }
+        for (int i = ht; i < T * 8; i += 256) {
+            const int t = i >> 3, q = i & 7;
+            in0[(t + 1) * SP + (q < 4 ? q : 120 + q)] = 0.f;   // rows 0..3 and 124..127
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int i = ht + 256 * u, gr = i / T, t = i - gr * T;
+            if (i < S * T) in0[(t + 1) * SP + gr + 4] = v[u];
+        }
+        SSTAMP(7);    // (helper slot 7: the input plane has arrived and is in LDS)
+        signal_count(4);
+        wait_count(4, 4);
+        SSTAMP(2);
+        {   // conv1: 1 -> 8, ReLU, all T columns; the window slides by renaming (fully unrolled)
+            const int lr = 32 * hw + j, gr = lr - 4;
+            const bool ok = lr >= 1 && lr < LR - 1 && gr >= 0 && gr < S;
+            const int r0 = max(lr - 1, 0), r2 = min(lr + 1, LR - 1);
+            float win[3][3];   // [ky][kx]
+#pragma unroll
+            for (int kx = 1; kx < 3; ++kx) {
+                win[0][kx] = in0[(kx - 1) * SP + r0];
+                win[1][kx] = in0[(kx - 1) * SP + lr];
+                win[2][kx] = in0[(kx - 1) * SP + r2];
+            }
+            float *dst = c1 + (4 * h) * kPlane + SP + lr;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) { win[ky][0] = win[ky][1]; win[ky][1] = win[ky][2]; }
+                win[0][2] = in0[(t + 2) * SP + r0];
+                win[1][2] = in0[(t + 2) * SP + lr];
+                win[2][2] = in0[(t + 2) * SP + r2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    f32x2 acc2 = b[k];
+#pragma unroll
+                    for (int k9 = 0; k9 < 9; ++k9) {
+                        const float x = win[k9 / 3][k9 % 3];
+                        acc2 = __builtin_elementwise_fma(f32x2{x, x}, w[k][k9], acc2);     // per channel: the same fma chain in tap order
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) dst[(2 * k + q) * kPlane + t * SP] = ok ? fmaxf(acc2[q], 0.f) : 0.f;
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) flags[8 + hw] = t + 1;     // LDS order: the column's stores are done when a reader sees the count
+                asm volatile("" ::: "memory");
+            }
+        }
+        SSTAMP(3);
+        // conv3's zero borders, then conv4 (8 -> 1) column by column behind the matrix waves
+        for (int i = ht; i < 8 * 2 * SP; i += 256) {
+            const int pl = i / (2 * SP), rem = i - pl * 2 * SP, col = rem < SP ? 0 : T + 1, row = rem & (SP - 1);
+            c3[pl * kPlane + col * SP + row] = 0.f;
+        }
+        for (int i = ht; i < 8 * T * 2; i += 256) {   // rows 3 and 124: plane rows -1 and S (never stored by conv3)
+            const int pl = i / (2 * T), rem = i - pl * 2 * T, t = rem >> 1;
+            c3[pl * kPlane + (t + 1) * SP + ((rem & 1) ? 124 : 3)] = 0.f;
+        }
+        signal_count(5);        // every helper is through conv1 (in0 is dead: it becomes the output plane) and the borders
+        wait_count(5, 4);
+        // thread = (local row lr, input-channel half): 4 channels x 9 taps, the halves meet through one lane swap
+        const int lr = 32 * hw + j;
+        const bool okrow = lr >= 4 && lr < 4 + S;
+        const int r0 = max(lr - 1, 0), r2 = min(lr + 1, LR - 1);
+        float w4[4][9];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k9 = 0; k9 < 9; ++k9) w4[c][k9] = a.cw[3][(4 * h + c) * 9 + k9];
+        const float b4 = a.cb[3][0];
+        const float *src = c3 + (4 * h) * kPlane;
+        float win[4][3][3];   // [channel][ky][kx]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) win[c][ky][1] = win[c][ky][2] = 0.f;
+        float *obuf = in0;   // output plane [S][T] row-major
+        int have = 0;        // conv3 columns known to be published by all four matrix waves
+        auto need = [&](int columns) {
+            if (have >= columns) return;
+            for (;;) {   // one 16-byte LDS read per poll, a long sleep between polls: a polling wave costs its SIMD's matrix wave issue slots
+                const i32x4 f = *(const volatile lds_i32x4 *)(flags);
+                const int m = min(min(f[0], f[1]), min(f[2], f[3]));
+                if (m >= columns) { have = m; break; }
+                // a poll is ~6 instructions on the SIMD the matrix wave needs: a column takes ~5 000 cycles, so sleep long while
+                // columns are far apart and short only for the last ones, whose conv4 is the kernel's tail
+                if (columns >= T - 1) __builtin_amdgcn_s_sleep(2);
+                else __builtin_amdgcn_s_sleep(AFT_POLL_SLEEP);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        auto load_col = [&](int ldscol) {   // window column kx = 2 <- LDS column `ldscol`
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float *pc = src + c * kPlane + ldscol * SP;
+                win[c][0][2] = pc[r0];
+                win[c][1][2] = pc[lr];
+                win[c][2][2] = pc[r2];
+            }
+        };
+        // window before the loop: kx = 1 <- LDS column 0 (zero border), kx = 2 <- LDS column 1 (symbol 0)
+        need(1);
+        load_col(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) win[c][ky][1] = win[c][ky][2];
+        load_col(1);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {        // fully unrolled: the window slides by renaming, no register moves
+            need(t + 2 < T ? t + 2 : T);     // symbol t + 1 (LDS column t + 2; the last one is the zero border)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) { win[c][ky][0] = win[c][ky][1]; win[c][ky][1] = win[c][ky][2]; }
+            load_col(t + 2);
+            // two channels per v_pk_fma_f32 (the helpers' vector work costs the SIMD's matrix wave ALU time: 36 -> 18 issue slots)
+            f32x2 acc2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+                for (int k9 = 0; k9 < 9; ++k9)
+                    acc2[cp] = __builtin_elementwise_fma(f32x2{win[2 * cp][k9 / 3][k9 % 3], win[2 * cp + 1][k9 / 3][k9 % 3]},
+                                                         f32x2{w4[2 * cp][k9], w4[2 * cp + 1][k9]}, acc2[cp]);
+            const f32x2 s2 = acc2[0] + acc2[1];
+            float acc = s2[0] + s2[1];
+            acc += other_half32(acc);
+            if (h == 0 && okrow) obuf[(lr - 4) * T + t] = acc + b4;
+        }
+    }
+    SSTAMP(4);
+    __syncthreads();
+    SSTAMP(5);
+    // ---- the output plane leaves in one coalesced pass ----
+    {
+        const float *obuf = in0;
+        if (MODE == 0) {
+            f32x4 *dstp = reinterpret_cast<f32x4 *>(a.out_plane + (size_t)n * (S * T));
+            const f32x4 *src4 = reinterpret_cast<const f32x4 *>(obuf);
+            for (int i = tid; i < S * T / 4; i += kConvThreads) dstp[i] = src4[i];
+        } else {   // interleave this plane into the complex64 output (the frame's other plane is another workgroup's)
+            float *dstp = a.out_complex + (size_t)frame * (S * T) * 2 + part;
+            for (int i = tid; i < S * T; i += kConvThreads) dstp[2 * i] = obuf[i];
+        }
+    }
+    SSTAMP(6);
+#undef SSTAMP
+}
+
 bool conv_stream_ok(const ConvArgs &a) {
     if (a.S != S || a.T != T) return false;
     if (a.mode == 0 || a.mode == 2) return a.in_plane != nullptr && (reinterpret_cast<uintptr_t>(a.out_plane) & 15) == 0;
@@ -670,13 +927,13 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
         hipLaunchKernelGGL((conv_stream_kernel<0, true>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
         return hipGetLastError();
     }
-    // AFT_CONV_MFMA32=1 keeps the 32x32x2 matrix phase (A/B runs); the default is the 16x16x4 form
-    const bool m16 = getenv("AFT_CONV_MFMA32") == nullptr;
+    // the 16x16x4 kernel needs the fragment image of the forward's prologue launch; AFT_CONV_MFMA32=1 keeps the 32x32x2 kernel (A/B runs)
+    const bool m16 = a.wfrag != nullptr && getenv("AFT_CONV_MFMA32") == nullptr;
     static PerDeviceOnce lds_head16, lds_tail16;
     hipError_t e;
     if (m16)
-        e = a.mode == 0 ? ensure_dynamic_lds(lds_head16, reinterpret_cast<const void *>(conv_stream_kernel<0, false, true>), kStreamLds)
-                        : ensure_dynamic_lds(lds_tail16, reinterpret_cast<const void *>(conv_stream_kernel<1, false, true>), kStreamLds);
+        e = a.mode == 0 ? ensure_dynamic_lds(lds_head16, reinterpret_cast<const void *>(conv_stream16_kernel<0>), kStreamLds)
+                        : ensure_dynamic_lds(lds_tail16, reinterpret_cast<const void *>(conv_stream16_kernel<1>), kStreamLds);
     else
         e = a.mode == 0 ? ensure_dynamic_lds(lds_head, reinterpret_cast<const void *>(conv_stream_kernel<0>), kStreamLds)
                         : ensure_dynamic_lds(lds_tail, reinterpret_cast<const void *>(conv_stream_kernel<1>), kStreamLds);
@@ -691,8 +948,8 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     }
 #endif
     if (m16) {
-        if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0, false, true>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
-        else hipLaunchKernelGGL((conv_stream_kernel<1, false, true>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+        if (a.mode == 0) hipLaunchKernelGGL((conv_stream16_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+        else hipLaunchKernelGGL((conv_stream16_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
     } else if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
     else hipLaunchKernelGGL((conv_stream_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
 #ifdef AFT_DIAG_STAMPS
@@ -708,6 +965,9 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
                     m[i] += (double)(hb[(size_t)b * 16 + i] - hb[(size_t)b * 16 + i - 1]);
                     hsum[i] += (double)(hb[(size_t)b * 16 + 8 + i] - hb[(size_t)b * 16 + 8 + i - 1]);
                 }
+            double in_lds = 0;
+            for (int b = 0; b < planes; ++b) in_lds += (double)(hb[(size_t)b * 16 + 15] - hb[(size_t)b * 16 + 8]);
+            if (m16) printf("conv stream16: input plane in LDS %.0f cycles after the kernel's start (helper wave)\n", in_lds / planes);
             printf("conv stream mode %d (mean cycles): matrix wave: stage=%.0f gather=%.0f wait=%.0f sweeps=%.0f wait=%.0f store=%.0f | "
                    "helper wave: stage=%.0f zero+input+conv1=%.0f wait=%.0f conv4=%.0f wait=%.0f store=%.0f\n", a.mode, m[1] / planes,
                    m[2] / planes, m[3] / planes, m[4] / planes, m[5] / planes, m[6] / planes, hsum[1] / planes, hsum[2] / planes,

@@ -127,6 +127,8 @@ struct PrologueArgs {
     float *up_planes;
     int adapter_blocks, pack_blocks, d, num_layers, split;
     int up_bx, npix, pf, nplanes;
+    float *conv_frag;          // [2 stacks][22 quads][64 lanes][4]: conv2 / conv3 weights as 16x16x4 operand fragments (conv_device.h)
+    int frag_blocks;
 };
 
 __global__ __launch_bounds__(256) void prologue_kernel(const aft_weights w, const PrologueArgs a) {
@@ -142,6 +144,20 @@ __global__ __launch_bounds__(256) void prologue_kernel(const aft_weights w, cons
         return;
     }
     blk -= a.pack_blocks;
+    if (blk < a.frag_blocks) {               // thread = (stack, quad, lane): one 16-byte piece of the image
+        const int v = blk * 256 + threadIdx.x;
+        if (v < 2 * kFragQuads * 64) {
+            const int stack = v / (kFragQuads * 64), rem = v - stack * (kFragQuads * 64), quad = rem >> 6, lane = rem & 63;
+            const float *const *cw = stack ? w.ref_w : w.enh_w;
+            const float *const *cb = stack ? w.ref_b : w.enh_b;
+            f32x4 o;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) o[jj] = conv_frag16_entry(cw[1], cb[1], cw[2], cb[2], 4 * quad + jj, lane);
+            *reinterpret_cast<f32x4 *>(a.conv_frag + (size_t)v * 4) = o;
+        }
+        return;
+    }
+    blk -= a.frag_blocks;
     upsample_planes_body(sm, w.up_w, w.up_b, a.pilots, a.up_planes, a.npix, a.pf, a.nplanes, blk % a.up_bx, blk / a.up_bx);
 }
 
@@ -150,8 +166,13 @@ bool prologue_upsample_ok(const aft_config &c, const aft_weights &w) {
 }
 
 hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const float *snr, const float *ds, const float *dop,
-                           float *tokens6, int batch, float *packed, const float *pilots, float *up_planes, hipStream_t st) {
+                           float *tokens6, int batch, float *packed, const float *pilots, float *up_planes, hipStream_t st,
+                           float *conv_frag) {
     PrologueArgs a{};
+    if (conv_frag != nullptr) {
+        a.conv_frag = conv_frag;
+        a.frag_blocks = (2 * kFragQuads * 64 + 255) / 256;
+    }
     size_t lds = 0;
     if (c.adaptive) {
         a.ad = adapter_args(c, w, snr, ds, dop, tokens6);
@@ -171,7 +192,7 @@ hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const floa
         up_blocks = a.up_bx * ((a.nplanes + kUpPlanes - 1) / kUpPlanes);
         lds = std::max(lds, upsample_planes_lds(a.pf));
     }
-    const int blocks = a.adapter_blocks + a.pack_blocks + up_blocks;
+    const int blocks = a.adapter_blocks + a.pack_blocks + a.frag_blocks + up_blocks;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(prologue_kernel, dim3(blocks), dim3(256), lds, st, w, a);
     return hipGetLastError();

@@ -76,7 +76,7 @@ class HipEngine:
         self._packed: Dict[int, torch.Tensor] = {}
         self._packed_key: Dict[int, tuple] = {}
 
-    MAX_STREAMS = 8      # scratch buffers kept (one per stream that ran a forward); the oldest is dropped beyond that
+    MAX_STREAMS = 8      # scratch buffers kept (one per stream that ran a forward); the least recently used is dropped beyond that
 
     # -- helpers ---------------------------------------------------------------------------
     @property
@@ -90,6 +90,10 @@ class HipEngine:
         """The calling stream's scratch buffer (grown on demand)."""
         stream = self._stream()
         ws = self._ws.get(stream)
+        if ws is not None:   # least-recently-used order: the entry in use moves to the end (eviction below drops the front)
+            for table in (self._ws, self._ws_batch, self._packed, self._packed_key):
+                if stream in table:
+                    table[stream] = table.pop(stream)
         if ws is None or batch > self._ws_batch[stream]:
             nbytes = self.lib.aft_workspace_bytes(C.byref(self.cfg), batch)
             if nbytes == 0:
@@ -145,12 +149,17 @@ class HipEngine:
         B = pilots.shape[0]
         if pilots.device.type == "cpu" and not pinned_inputs:
             raise ValueError("pilot_symbols must be on the engine's device (or pinned, with pinned_inputs=True)")
+        if pilots.device.type == "cpu" and not (pilots.is_pinned() and pilots.is_contiguous()):
+            # a pageable (or silently re-copied non-contiguous) host pointer would be a GPU page fault that aborts the process
+            raise ValueError("pinned_inputs=True needs contiguous pinned host tensors (pilot_symbols is not)")
         pil = torch.view_as_real(pilots.contiguous())
         metas = [None, None, None]
         if c.adaptive:
             if snr is None or ds is None or dop is None:
                 raise ValueError("meta_data is required when channel adaptation is enabled")
-            metas = [m.reshape(-1) if (pinned_inputs and m.device.type == "cpu" and m.dtype == torch.float32 and m.is_contiguous())
+            # host conditions are read in place only when they are pinned, contiguous float32; anything else is copied to the device
+            metas = [m.reshape(-1) if (pinned_inputs and m.device.type == "cpu" and m.dtype == torch.float32 and m.is_contiguous()
+                                       and m.is_pinned())
                      else _dev_f32(m.reshape(-1), self.device) for m in (snr, ds, dop)]
             if any(m.numel() != B for m in metas):
                 raise ValueError("meta_data tensors must have one value per frame")

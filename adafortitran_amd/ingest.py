@@ -11,6 +11,7 @@ reference's ``DataLoader`` yields: ``(pilots cfloat[B,Ps,Pt], H cfloat[B,S,T], m
 """
 from __future__ import annotations
 
+import logging
 import os
 import re
 from pathlib import Path
@@ -84,10 +85,11 @@ class PackedLoader:
     dataset.py:254-260) and yields reference-format batches.  On a HIP device the pilots are gathered
     by the GPU kernel and both pilots and targets stay on the device.  There the reference's "Expected 24 pilot values,
     got 25" ValueError (dataset.py:128-132) is raised ONE BATCH LATE (the counts come back asynchronously): when the
-    next batch is requested, when the iterator is exhausted, or when it is CLOSED.  A consumer that leaves the loop early
-    with ``break`` should close the iterator (``with contextlib.closing(iter(loader)) as it:`` or ``it.close()``): left to
-    the garbage collector, an error raised while the generator is finalised is only printed ("Exception ignored in
-    generator"), not raised.  An exception from the consumer's own loop body propagates unchanged."""
+    next batch is requested, when the iterator is exhausted, or when it is CLOSED (``it.close()``,
+    ``contextlib.closing(iter(loader))``).  A consumer that simply leaves the loop (``break``, or an exception of its own,
+    which propagates unchanged) abandons the sweep with one check outstanding: that check is still settled when the
+    iterator is finalised, a failure is LOGGED as an error (never an "Exception ignored in generator" on stderr that nobody
+    reads) and kept on the loader, where ``raise_pending()`` -- or leaving a ``with loader:`` block -- raises it."""
 
     def __init__(self, packed: Union[str, Path, Dict[str, np.ndarray]], pilot_size: Tuple[int, int], batch_size: int,
                  device: Union[str, torch.device] = "cpu", pin_memory: bool = True,
@@ -123,7 +125,27 @@ class PackedLoader:
     def __len__(self) -> int:
         return (self.n + self.batch_size - 1) // self.batch_size
 
+    # -- deferred pilot-count errors of abandoned sweeps ---------------------------------------------------------------
+    def raise_pending(self) -> None:
+        """Raise (once) the count error of a sweep that was abandoned before its last check could be delivered."""
+        err, self._pending_error = getattr(self, "_pending_error", None), None
+        if err is not None:
+            raise err
+
+    def __enter__(self) -> "PackedLoader":
+        return self
+
+    def __exit__(self, exc_type, exc, tb) -> bool:
+        if exc_type is None:
+            self.raise_pending()
+        return False
+
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, tuple]]:
+        if self.device.type != "cuda":
+            return self._batches()
+        return _Sweep(self, self._batches())
+
+    def _batches(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, tuple]]:
         if self.device.type != "cuda":
             for lo in range(0, self.n, self.batch_size):
                 hi = min(lo + self.batch_size, self.n)
@@ -196,12 +218,15 @@ class PackedLoader:
                 prev = (done, host_counts, lo)
                 yield pilots, ideal, self._meta(lo, hi)
         except GeneratorExit:
-            # the consumer stopped early and CLOSED the iterator (``it.close()``, ``contextlib.closing``, or -- with the
-            # caveat in the class docstring -- garbage collection after ``break``): the last yielded batch's count check is
-            # settled before the generator goes away; a ValueError raised here propagates out of close()
+            # the consumer stopped early: the last yielded batch's count check is settled before the generator goes away.  A
+            # failure is handed to the loader, not raised here -- raised inside a generator that the garbage collector is
+            # finalising it would only be printed; _Sweep.close() raises it, _Sweep.__del__ logs it
             if prev is not None:
                 pending, prev = prev, None
-                settle(pending)
+                try:
+                    settle(pending)
+                except ValueError as err:
+                    self._pending_error = err
             raise
         # normal exhaustion: the count check of the last batch.  (An exception thrown by the consumer's loop body is NOT
         # intercepted: it propagates unchanged, and the pending check is dropped with the failed sweep.)
@@ -212,6 +237,35 @@ class PackedLoader:
         m = torch.from_numpy(self.p["meta"][lo:hi])
         return (m[:, 0:1], m[:, 1:2], m[:, 2:3], m[:, 3:4], m[:, 4:5],
                 [tuple(str(c) for c in self.p["channel_type"][lo:hi])])
+
+
+class _Sweep:
+    """One pass over a PackedLoader on the HIP device: the batch generator plus what happens to the count check that is
+    still outstanding when the consumer stops early (PackedLoader docstring)."""
+
+    def __init__(self, loader: "PackedLoader", gen) -> None:
+        self._loader, self._gen = loader, gen
+
+    def __iter__(self) -> "_Sweep":
+        return self
+
+    def __next__(self):
+        return next(self._gen)
+
+    def close(self) -> None:
+        """Settle the outstanding check and RAISE its error (explicit close: ``it.close()`` / ``contextlib.closing``)."""
+        self._gen.close()
+        self._loader.raise_pending()
+
+    def __del__(self) -> None:
+        try:
+            self._gen.close()
+        except Exception:      # nothing may escape a finaliser
+            return
+        err = getattr(self._loader, "_pending_error", None)
+        if err is not None:
+            logging.getLogger(__name__).error(
+                "PackedLoader: %s -- found while settling an abandoned sweep; loader.raise_pending() (or `with loader:`) raises it", err)
 
 
 def ls_mse_db_per_frame(h_ls_full: torch.Tensor, h_ideal: torch.Tensor) -> torch.Tensor:

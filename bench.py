@@ -235,8 +235,9 @@ def rank_identity(rank, local_rank, device, args):
         return ident
     props = torch.cuda.get_device_properties(device)
     dom, bus, dev = (getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-    pci = f"{dom:04x}:{bus:02x}:{dev:02x}" if None not in (dom, bus, dev) else str(getattr(props, "uuid", f"index{device.index}"))
-    ident.update({"device": device.index, "pci": pci, "name": props.name,
+    uuid = getattr(props, "uuid", None)
+    pci = f"{dom:04x}:{bus:02x}:{dev:02x}" if None not in (dom, bus, dev) else (str(uuid) if uuid is not None else f"index{device.index}")
+    ident.update({"device": device.index, "pci": pci, "pci_known": None not in (dom, bus, dev) or uuid is not None, "name": props.name,
                   "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))})
     return ident
 
@@ -689,10 +690,15 @@ def main() -> int:
         per_rank["device_names"] = sorted({r.get("name", "cpu") for r in ranks})
         per_rank["hosts"] = sorted({r["host"] for r in ranks})
         per_rank["pids"] = len({(r["host"], r["pid"]) for r in ranks})
-        bus = [r["pci"] for r in ranks]
+        # a device is (host, PCI id): equal PCI ids on different hosts are different GPUs; without a PCI id or uuid from torch the
+        # (host, device index) fallback only says what LOCAL_RANK selected, so the check then warns instead of failing
+        bus = [(r["host"], r["pci"]) for r in ranks]
         per_rank["distinct_devices"] = len(set(bus))
-        if not (args.stub or args.share_gpu) and len(set(bus)) != world:
-            print(f"bench.py: {world} ranks but only {len(set(bus))} distinct PCI devices: {bus}", file=sys.stderr)
+        known = all(r.get("pci_known", True) for r in ranks)
+        if not (args.stub or args.share_gpu) and len(set(bus)) != world and not known:
+            print(f"bench.py: warning: device identities unavailable from torch (index fallback): {bus}", file=sys.stderr)
+        if not (args.stub or args.share_gpu) and len(set(bus)) != world and known:
+            print(f"bench.py: {world} ranks but only {len(set(bus))} distinct (host, PCI) devices: {bus}", file=sys.stderr)
             dist.barrier()
             dist.destroy_process_group()
             return 4

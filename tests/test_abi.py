@@ -41,8 +41,8 @@ def test_loader_checks_version_and_host_only_calls():
     # + linear_2 output of the last chain launch (rows x 8)
     # (the attention tiles are sized for per-plane row tiles, planes x tokpad rows: the plane-resident encoder's layout)
     expect = 4 * (planes * 1680 + 128 * tokens * 6 + planes * tokens * d + planes * tokpad * d + 3 * planes * 4 * tokpad * 32
-                  + 6 * 8 * d * d + planes * tokens * 8)
-    assert expect <= nbytes <= expect + 8 * 256
+                  + 6 * 8 * d * d + planes * tokens * 8 + 2 * 22 * 64 * 4)   # + both conv stacks' 16x16x4 operand fragments
+    assert expect <= nbytes <= expect + 10 * 256
     bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3))
     assert lib.aft_workspace_bytes(ctypes.byref(bad), 8) == 0
     assert b"model_dim" in lib.aft_last_error()

@@ -181,6 +181,16 @@ def test_packed_loader_on_device_matches_host_and_raises_late():
     with pytest.raises(Boom):
         for _ in ingest.PackedLoader(broken, (12, 2), 8, device="cuda"):
             raise Boom()
+    # that abandoned sweep's outstanding count error is not lost in an "Exception ignored in generator": it is
+    # logged when the iterator is finalised and kept on the loader
+    import gc
+    loader = ingest.PackedLoader(broken, (12, 2), 8, device="cuda")
+    with pytest.raises(ValueError, match=r"Expected 24 pilot values, got 25 \(frame 2\)"):
+        with loader:
+            for _ in loader:
+                break
+            gc.collect()
+    loader.raise_pending()                                 # delivered once
     # packs above max_pinned_bytes go through the pinned ring instead of pinning the whole pack: same batches
     ring = list(ingest.PackedLoader(packed, (12, 2), 8, device="cuda", max_pinned_bytes=0))
     for (ph, ih, mh), (pd, idv, md) in zip(host, ring):
