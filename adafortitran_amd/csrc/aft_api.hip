@@ -3,6 +3,7 @@
 // thread-local error string the only things cached are per-device facts (CU count, LDS function
 // attribute) in tables indexed by device ordinal (hipGraph-capturable, re-entrant per stream).
 #include <algorithm>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -483,8 +484,11 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                 AFT_REQUIRE(out != nullptr, "prologue profile needs the pilots pointer in `out`");
                 const bool lend = (size_t)ws.planes * ws.tokens * cfg->model_dim >= (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
                 const float *cond = out + (size_t)batch * cfg->pilot_scs * cfg->pilot_symbols * 2;   // [snr | ds | dop] behind the pilots
+                // AFT_PROLOGUE_NO_UP=1 (measurement only): the launch without the pilot_upsampler product -- bench.py charges the
+                // difference to the upsampler stage (the stage is K0 + K1 + K2)
                 e = launch_prologue(*cfg, *w, cond, cond + batch, cond + 2 * batch, base + ws.tokens6, batch, base + ws.wpack, out,
-                                    lend && prologue_upsample_ok(*cfg, *w) ? x : nullptr, st, base + ws.convfrag);
+                                    lend && prologue_upsample_ok(*cfg, *w) && !getenv("AFT_PROLOGUE_NO_UP") ? x : nullptr, st,
+                                    base + ws.convfrag);
                 break;
             }
             case AFT_KERNEL_TAIL:

@@ -137,7 +137,7 @@ __device__ __forceinline__ bool dropmask_keep(uint32_t row_word, uint32_t col_wo
 //   vt            [2B][H][tokpad/32][4 g][64 lanes][4]  f32  fragment order: (d + 32hh, key = 32kt+8g+4hh+j)
 //   wpack         [L][8*d*d]            f32  encoder GEMM weights in MFMA-fragment order (rebuilt per call)
 //   out6          [2B*tokens][8 | 16]   f32  linear_2 output of the last chain launch (input of the conv tail)
-//   convfrag      [2][22][64][4]        f32  conv2 / conv3 weights of the initial enhancer | the final refiner as 16x16x4 MFMA
+//   convfrag      [2][22*64*4 + 160]    f32  conv2 / conv3 weights of the initial enhancer | the final refiner as 16x16x4 MFMA
 //                                            operand fragments (conv_device.h: conv_frag16_entry; rebuilt per call by the prologue)
 struct Workspace {
     size_t conv_enhanced, tokens6, x, attn, q, k, vt, wpack, out6, convfrag, total_floats;
@@ -171,7 +171,7 @@ hipError_t ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, size_t by
 // product over all planes into it and the conv head reads the planes; NULL = inside the conv head
 // planes_ready: scratch_planes already holds the upsampled planes (the forward's prologue launch computed them)
 // conv_frag: this stack's fragment image (kConvFragFloats floats, written by launch_prologue) or NULL
-constexpr size_t kConvFragFloats = 22 * 64 * 4;   // = conv_device.h kFragFloats, per ConvEnhancer
+constexpr size_t kConvFragFloats = 22 * 64 * 4 + 160;   // = conv_device.h kFragFloats, per ConvEnhancer (16-byte multiple)
 hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots,
                            float *conv_enhanced, int batch, hipStream_t st, float *scratch_planes = nullptr, bool planes_ready = false,
                            const float *conv_frag = nullptr);

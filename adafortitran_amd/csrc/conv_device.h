@@ -35,11 +35,24 @@ struct ConvArgs {
 // (k_misc.hip) and read by conv_stream16_kernel's matrix waves with 22 lane-linear 16-byte loads: [22 quads][64 lanes][4] floats.
 // Entry e = 4 quad + j of lane l (li = l % 16: the operand's row, gk = l / 16: its k index):
 //   0 .. 35   conv2, e = 18 mt + ks2: output channel 16 mt + li, k-step ks2 = 2 (kx*3 + ky) + ci half, input channel 4 (ci half) + gk
-//   36 .. 75  conv3, e - 36 = 8 rt + ks: product row 16 rt + li = accumulator register q = 4 rt + li % 4 of lane group li / 4;
-//             q = 0, 1 idle (zero), q - 2 = 6 kx + 2 ky + co half, output channel 4 (co half) + li / 4; input channel 16 (ks / 4) + 4 gk + ks % 4
+//   36 .. 75  conv3, e - 36 = 8 rt + ks: product row 16 rt + li = accumulator register v = li % 4 of tile rt, lane group li / 4 = output
+//             channel low bits (co = 4 (co half) + li / 4).  Tiles 0, 1, 2 = kx 0, 1, 2 with v = 2 ky + (co half), ky = 0, 1; tile 3 =
+//             [idle, idle, (kx 0, ky 2, co half 0 / 1)]; tile 4 = [(kx 1, ky 2, co half 0 / 1), (kx 2, ky 2, co half 0 / 1)]
+//             (conv3_row16).  Input channel 16 (ks / 4) + 4 gk + ks % 4.
 //   76, 77    conv3.bias[4 (co half) + gk]        78, 79  unused
 //   80 .. 87  conv2.bias[16 mt + 4 gk + v], e - 80 = 4 mt + v
-constexpr int kFragQuads = 22, kFragFloats = kFragQuads * 64 * 4;
+// Behind the 22 x 64 quads: the helper waves' tables, [channel half h][80]: conv1 as v_pk_fma operands -- pair k (channels 4h + 2k,
+// 4h + 2k + 1), tap k9: floats 2 (9 k + k9) + {0, 1}; their biases at 36 + 2k + {0, 1} -- and conv4 at 40 ..: input-channel pair cp
+// (channels 4h + 2cp, + 1), tap k9: 40 + 2 (9 cp + k9) + {0, 1}; conv4's bias at 76 (conv_helper_entry).  Lanes of one half read the
+// same addresses: 20 broadcast 16-byte loads per helper wave instead of 77 dword loads with two addresses each.
+constexpr int kFragQuads = 22, kHelperFloats = 2 * 80, kFragFloats = kFragQuads * 64 * 4 + kHelperFloats;
+__device__ __forceinline__ float conv_helper_entry(const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w4,
+                                                   const float *__restrict__ b4, int h, int i) {
+    if (i < 36) { const int pr = i >> 1, k = pr / 9, k9 = pr - 9 * k; return w1[(4 * h + 2 * k + (i & 1)) * 9 + k9]; }
+    if (i < 40) return b1[4 * h + (i - 36)];
+    if (i < 76) { const int pr = (i - 40) >> 1, cp = pr / 9, k9 = pr - 9 * cp; return w4[(4 * h + 2 * cp + (i & 1)) * 9 + k9]; }
+    return i == 76 ? b4[0] : 0.f;
+}
 __device__ __forceinline__ float conv_frag16_entry(const float *__restrict__ w2, const float *__restrict__ b2, const float *__restrict__ w3,
                                                    const float *__restrict__ b3, int e, int lane) {
     const int li = lane & 15, gk = lane >> 4;
@@ -48,9 +61,11 @@ __device__ __forceinline__ float conv_frag16_entry(const float *__restrict__ w2,
         return w2[(16 * mt + li) * 72 + (4 * cih + gk) * 9 + ky * 3 + kx];
     }
     if (e < 76) {
-        const int i = e - 36, rt = i >> 3, ks = i & 7, q = 4 * rt + (li & 3);
-        if (q < 2) return 0.f;
-        const int qq = q - 2, kx = qq / 6, rem = qq - 6 * kx, ky = rem >> 1, cohi = rem & 1;
+        const int i = e - 36, rt = i >> 3, ks = i & 7, v = li & 3, cohi = v & 1;
+        int kx, ky;
+        if (rt < 3) { kx = rt; ky = v >> 1; }
+        else if (rt == 3) { if (v < 2) return 0.f; kx = 0; ky = 2; }
+        else { kx = 1 + (v >> 1); ky = 2; }
         return w3[(4 * cohi + (li >> 2)) * 288 + (16 * (ks >> 2) + 4 * gk + (ks & 3)) * 9 + ky * 3 + kx];
     }
     if (e < 78) return b3[4 * (e - 76) + gk];

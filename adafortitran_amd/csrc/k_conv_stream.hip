@@ -502,10 +502,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 //    needed one row further down / up, i.e. in the OTHER pixel tile's register at the same lane or one lane along the 16-lane DPP row
 //    -- no carries between tiles, and conv2's accumulators are conv3's B operands unshifted (the 32 DPP moves per column of the 32x32
 //    form are gone; the ky sums are 8 adds per output column);
-//  * accumulator register q = 4 rt + v of a pixel tile: q = 0, 1 idle, then 6 registers (ky, co half) per kx.  The kx products of
-//    input column t belong to output column t + 1 - kx, so "rotate by 6 registers" between columns sums them; the rotation is the C
-//    operand of each tile's FIRST MFMA of a column (registers 4 rt - 6 .. 4 rt - 3 of the previous column: contiguous because the
-//    idle pair sits in front; zero for tiles 0 and 1).
+//  * the kx products of input column t belong to output column t + 1 - kx, so the six (ky, co half) registers of tap column kx
+//    become those of kx + 1 one column later: the rotation that sums the kx taps is the C operand of each tile's FIRST MFMA of a
+//    column.  Tiles 0, 1, 2 hold (ky 0 / 1, co half) of kx = 0, 1, 2 -- their rotation is a whole tuple, no copies -- and the ky = 2
+//    pairs share tiles 3 = [idle, idle, kx 0] and 4 = [kx 1, kx 2]: 4 register copies per pixel tile and column (a layout with six
+//    consecutive registers per kx needed 12); conv3's bias is the initial value of the fresh kx = 0 centre-row registers.
 // Staging.  The forward's prologue launch leaves both stacks' weights as operand fragments in the workspace (conv_frag16_entry): a
 // matrix wave fetches its 76 fragment registers with 22 lane-linear 16-byte loads and starts sweeping as soon as the helper waves
 // have published conv1's first two columns -- no transposed LDS staging, no gather, no workgroup barrier before the sweeps (the
@@ -527,9 +528,38 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
 #define SSTAMP(i) do { } while (0)
 #endif
     SSTAMP(0);
+    // the kernel's first instructions are its global requests: the matrix waves' operand fragments, the helpers' input plane (one pixel
+    // per thread and pass, coalesced; all 7 requests of a thread in flight together) -- the input's trip from the previous launch's
+    // output (another XCD's L2 or the memory side) is the one latency nothing in this kernel can hide
+    f32x4 fq[kFragQuads];
+    float vin[7];
+    if (!matrix) {
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int i = tid - 256 + 256 * u;
+            vin[u] = 0.f;
+            if (i < S * T) {
+                if (MODE == 0) {
+                    vin[u] = a.in_plane[(size_t)n * (S * T) + i];
+                } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
+                    const int gr = i / T, t = i - gr * T, p0 = a.p0, p1 = a.p1, tpr = T / p1;
+                    const int g = gr / p0, tc = t / p1, f = (gr - g * p0) * p1 + (t - tc * p1);
+                    vin[u] = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] + a.resid[(size_t)n * (S * T) + i];
+                }
+            }
+        }
+    }
     if (tid < 16) flags[tid] = 0;
-    __syncthreads();   // (all waves are at the kernel's start: this costs an arrival, not a phase)
+    // a bare barrier behind the LDS stores: __syncthreads() would also wait for the global requests just issued (vmcnt(0)), i.e. every
+    // wave would sit here until the slowest wave's data had arrived (2 000 cycles, stamps)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     SSTAMP(1);
+    if (matrix) {   // behind the helpers' requests: 88 KB of fragments per workgroup would otherwise queue in front of the input plane
+        __builtin_amdgcn_s_sleep(3);
+        const f32x4 *fp = reinterpret_cast<const f32x4 *>(a.wfrag) + lane;
+#pragma unroll
+        for (int q = 0; q < kFragQuads; ++q) fq[q] = fp[q * 64];
+    }
     auto wait_count = [&](int slot, int count) {   // workgroup-scope hand-over through an LDS counter
         while (flags[slot] < count) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -544,10 +574,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         float wa2[36], wa3[40], bias3[2];
         f32x4 bias2v[2];
         {
-            const f32x4 *fp = reinterpret_cast<const f32x4 *>(a.wfrag) + lane;
-            f32x4 fq[kFragQuads];
-#pragma unroll
-            for (int q = 0; q < kFragQuads; ++q) fq[q] = fp[q * 64];
 #pragma unroll
             for (int f = 0; f < 36; ++f) wa2[f] = fq[f >> 2][f & 3];
 #pragma unroll
@@ -574,7 +600,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         float *dst[2];
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) dst[pt] = c3 + g * kPlane + (ok3[pt] ? r0 + pt : 0);   // + 4 cohi planes + (t + 1) SP
-        float *const dump = c3 + g * kPlane;
         // conv3 output columns [0, columns_done) of this tile are in LDS.  No s_waitcnt: the LDS serves one wave's requests in issue
         // order, so a reader that sees the flag finds the data stores before it already done; the compiler barriers keep the flag
         // store behind them in the instruction stream (a release fence would drain this wave's pending operand reads)
@@ -601,11 +626,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             bv[kx][cih][0] = lo[0]; bv[kx][cih][1] = lo[1]; bv[kx][cih][2] = hi[0]; bv[kx][cih][3] = hi[1];
         };
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 bias3v = {0.f, 0.f, bias3[0], bias3[1]};        // tile 0 = fresh kx 0 registers [(ky 0, c), (ky 1 = centre row, c)]
         f32x4 a3[2][5];
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-            for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = zero4;
+            for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = rt == 0 ? bias3v : zero4;   // as if the zero column -1 had been swept: output column 0's bias
         f32x4 x2[2][2];   // [pt][mt]: conv2's activation of the current column = conv3's B operands
         f32x4 acc2[2][2];
         auto relu2 = [&]() {
@@ -614,61 +640,72 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
+#ifdef AFT_T_NORELU
+                    for (int v = 0; v < 4; ++v) x2[pt][mt][v] = acc2[pt][mt][v];
+#else
                     for (int v = 0; v < 4; ++v) x2[pt][mt][v] = __builtin_amdgcn_fmed3f(acc2[pt][mt][v], 0.f, relu_hi[pt]);
+#endif
         };
         // conv2 MFMA u (0..11) of group gi = (kx, ci half): ky = u / 4, pixel tile (u / 2) % 2, channel tile u % 2
         auto conv2_step = [&](int gi, int u) {
             const int kx = gi >> 1, cih = gi & 1, ky = u >> 2, pt = (u >> 1) & 1, mt = u & 1, ks2 = 2 * (kx * 3 + ky) + cih;
             acc2[pt][mt] = mfma16(wa2[mt * 18 + ks2], bv[kx][cih][ky + pt], (gi == 0 && ky == 0) ? bias2v[mt] : acc2[pt][mt]);
         };
-        // the C operand that rotates the previous column's registers by six (tile rt of pixel tile pt)
+        // the C operand of tile rt's first MFMA of a column: the previous column's registers one kx further (header comment)
         auto rotated = [&](int pt, int rt) -> f32x4 {
-            if (rt < 2) return zero4;
-            const f32x4 lo = a3[pt][rt - 2], hi = a3[pt][rt - 1];
-            return f32x4{lo[2], lo[3], hi[0], hi[1]};
+            if (rt == 0) return bias3v;
+            if (rt < 3) return a3[pt][rt - 1];
+            if (rt == 3) return zero4;
+            return f32x4{a3[pt][3][2], a3[pt][3][3], a3[pt][4][0], a3[pt][4][1]};
         };
         f32x4 n3[2][5];
-        // conv3 MFMA m (0..79): k-step m / 10, tiles in descending order (the finished registers sit in tiles 3, 4)
+        // conv3 MFMA m (0..79): k-step m / 10; the tiles whose registers finish a column (2 and 4) first
         auto conv3_step = [&](int m) {
-            const int ks = m / 10, i = m % 10, rt = 4 - (i >> 1), pt = i & 1;
+            constexpr int kOrder[5] = {2, 4, 1, 0, 3};
+            const int ks = m / 10, i = m % 10, rt = kOrder[i >> 1], pt = i & 1;
             n3[pt][rt] = mfma16(wa3[rt * 8 + ks], x2[pt][ks >> 2][ks & 3], ks == 0 ? rotated(pt, rt) : n3[pt][rt]);
         };
         // conv3's output column `tout` from six finished registers (ky, co half) of both pixel tiles
         auto store_col = [&](int tout, const float (&Y)[2][6]) {
-            float *p0 = tout < 0 ? dump : dst[0], *p1 = tout < 0 ? dump : dst[1];
+            if (tout < 0) return;          // (wave-uniform: a scalar branch)
+            float *p0 = dst[0], *p1 = dst[1];
 #pragma unroll
             for (int cohi = 0; cohi < 2; ++cohi) {
                 // row j = 2p (pt 0): ky = 0 from row j - 1 = (pt 1, lane p - 1), ky = 2 from row j + 1 = (pt 1, lane p)
                 // row j = 2p + 1 (pt 1): ky = 0 from (pt 0, lane p), ky = 2 from (pt 0, lane p + 1)
+#ifdef AFT_T_NOOUT
+                float o0 = Y[0][2 + cohi] + Y[1][cohi], o1 = Y[1][2 + cohi] + Y[0][4 + cohi];
+#else
                 float o0 = Y[0][2 + cohi] + row16_from_below(Y[1][cohi]) + Y[1][4 + cohi];
                 float o1 = Y[1][2 + cohi] + Y[0][cohi] + row16_from_above(Y[0][4 + cohi]);
-                o0 = fmaxf(o0 + bias3[cohi], 0.f);
-                o1 = fmaxf(o1 + bias3[cohi], 0.f);
+                o0 = fmaxf(o0, 0.f);       // (the bias rode in as the accumulator's initial value)
+                o1 = fmaxf(o1, 0.f);
+#endif
                 p0[4 * cohi * kPlane + (tout + 1) * SP] = o0;
                 p1[4 * cohi * kPlane + (tout + 1) * SP] = o1;
             }
-            publish(tout + 1);     // (tout < 0: the dump slot and a count of 0 -- both no-ops)
+            publish(tout + 1);
         };
-        // the registers of `acc` that hold output column (input column - 1): the kx = 2 set, registers 14 .. 19
+        // the registers of `acc` that hold output column (input column - 1): the kx = 2 set, Y[pt][2 ky + co half]
         auto finished = [&](const f32x4 (&acc)[2][5], float (&Y)[2][6]) {
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
-                Y[pt][0] = acc[pt][3][2]; Y[pt][1] = acc[pt][3][3];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) Y[pt][2 + v] = acc[pt][4][v];
+                for (int v = 0; v < 4; ++v) Y[pt][v] = acc[pt][2][v];
+                Y[pt][4] = acc[pt][4][2]; Y[pt][5] = acc[pt][4][3];
             }
         };
         SSTAMP(2);
         need_c1(2);
 #pragma unroll
         for (int gi = 0; gi < 6; ++gi) load_b(gi >> 1, gi & 1, 0);
-        need_c1(3);
         SSTAMP(3);
-        // prologue: conv2 of column 0
+        // prologue: conv2 of column 0 (conv1's third column is only needed behind the first group: the sweeps start a column earlier)
 #pragma unroll
         for (int gi = 0; gi < 6; ++gi) {
 #pragma unroll
             for (int u = 0; u < 12; ++u) conv2_step(gi, u);
+            if (gi == 0) need_c1(3);
             load_b(gi >> 1, gi & 1, 1);
         }
         relu2();
@@ -715,13 +752,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             store_col(T - 3, Y);
 #pragma unroll
             for (int m = 0; m < 80; ++m)
-                if (m % 10 < 6) conv3_step(m);     // tiles 4, 3, 2 only: tiles 1, 0 hold the kx = 0 registers = output column T (padding)
+                if (m % 10 < 6) conv3_step(m);     // tiles 2, 4, 1 only: tiles 0, 3 hold the kx = 0 registers = output column T (padding)
             finished(n3, Y);
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
-                Z[pt][4] = n3[pt][3][0]; Z[pt][5] = n3[pt][3][1];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) Z[pt][v] = n3[pt][2][v];
+                for (int v = 0; v < 4; ++v) Z[pt][v] = n3[pt][1][v];
+                Z[pt][4] = n3[pt][4][0]; Z[pt][5] = n3[pt][4][1];
             }
             store_col(T - 2, Y);
             store_col(T - 1, Z);
@@ -734,28 +771,22 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         // vector work is on the matrix waves' critical path either way (they consume conv1's columns), so it goes first.
         __builtin_amdgcn_s_setprio(AFT_HELPER_PRIO);
         const int ht = tid - 256, hw = wave - 4;
-        float v[7];
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {      // one pixel per thread and pass, global reads coalesced; all 7 requests in flight together
-            const int i = ht + 256 * u;
-            v[u] = 0.f;
-            if (i < S * T) {
-                if (MODE == 0) {
-                    v[u] = a.in_plane[(size_t)n * (S * T) + i];
-                } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
-                    const int gr = i / T, t = i - gr * T, p0 = a.p0, p1 = a.p1, tpr = T / p1;
-                    const int g = gr / p0, tc = t / p1, f = (gr - g * p0) * p1 + (t - tc * p1);
-                    v[u] = a.lin2_out[((size_t)n * a.tokens + g * tpr + tc) * a.lin2_stride + f] + a.resid[(size_t)n * (S * T) + i];
-                }
-            }
-        }
         // conv1's weights: thread = (local row lr = 32 hw + j, channel half h), two channels per v_pk_fma_f32
         f32x2 w[2][9], b[2];
+        f32x4 hq[20];   // this channel half's tables (conv_helper_entry): conv1 in quads 0..9, conv4 in 10..19
+        {
+            const f32x4 *hp = reinterpret_cast<const f32x4 *>(a.wfrag + kFragQuads * 64 * 4 + 80 * h);
+#pragma unroll
+            for (int q = 0; q < 20; ++q) hq[q] = hp[q];
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
 #pragma unroll
-            for (int k9 = 0; k9 < 9; ++k9) w[k][k9] = f32x2{a.cw[0][(4 * h + 2 * k) * 9 + k9], a.cw[0][(4 * h + 2 * k + 1) * 9 + k9]};
-            b[k] = f32x2{a.cb[0][4 * h + 2 * k], a.cb[0][4 * h + 2 * k + 1]};
+            for (int k9 = 0; k9 < 9; ++k9) {
+                const int i = 2 * (9 * k + k9);
+                w[k][k9] = f32x2{hq[i >> 2][i & 3], hq[i >> 2][(i & 3) + 1]};
+            }
+            b[k] = f32x2{hq[9][2 * k], hq[9][2 * k + 1]};
         }
         // zero padding of in0 and c1: LDS columns 0 and T + 1 (the symbol borders), and in0's rows outside the plane
         for (int i = ht; i < 9 * 2 * SP; i += 256) {
@@ -769,7 +800,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const int i = ht + 256 * u, gr = i / T, t = i - gr * T;
-            if (i < S * T) in0[(t + 1) * SP + gr + 4] = v[u];
+            if (i < S * T) in0[(t + 1) * SP + gr + 4] = vin[u];
         }
         SSTAMP(7);    // (helper slot 7: the input plane has arrived and is in LDS)
         signal_count(4);
@@ -826,12 +857,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         const int lr = 32 * hw + j;
         const bool okrow = lr >= 4 && lr < 4 + S;
         const int r0 = max(lr - 1, 0), r2 = min(lr + 1, LR - 1);
-        float w4[4][9];
+        f32x2 w4[2][9];   // [input-channel pair][tap]
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
-            for (int k9 = 0; k9 < 9; ++k9) w4[c][k9] = a.cw[3][(4 * h + c) * 9 + k9];
-        const float b4 = a.cb[3][0];
+            for (int k9 = 0; k9 < 9; ++k9) {
+                const int i = 40 + 2 * (9 * cp + k9);
+                w4[cp][k9] = f32x2{hq[i >> 2][i & 3], hq[i >> 2][(i & 3) + 1]};
+            }
+        const float b4 = hq[19][0];
         const float *src = c3 + (4 * h) * kPlane;
         float win[4][3][3];   // [channel][ky][kx]
 #pragma unroll
@@ -870,6 +904,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) win[c][ky][1] = win[c][ky][2];
         load_col(1);
+#ifdef AFT_T_NOCONV4
+        need(T);
+#else
 #pragma unroll
         for (int t = 0; t < T; ++t) {        // fully unrolled: the window slides by renaming, no register moves
             need(t + 2 < T ? t + 2 : T);     // symbol t + 1 (LDS column t + 2; the last one is the zero border)
@@ -884,13 +921,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             for (int cp = 0; cp < 2; ++cp)
 #pragma unroll
                 for (int k9 = 0; k9 < 9; ++k9)
-                    acc2[cp] = __builtin_elementwise_fma(f32x2{win[2 * cp][k9 / 3][k9 % 3], win[2 * cp + 1][k9 / 3][k9 % 3]},
-                                                         f32x2{w4[2 * cp][k9], w4[2 * cp + 1][k9]}, acc2[cp]);
+                    acc2[cp] = __builtin_elementwise_fma(f32x2{win[2 * cp][k9 / 3][k9 % 3], win[2 * cp + 1][k9 / 3][k9 % 3]}, w4[cp][k9], acc2[cp]);
             const f32x2 s2 = acc2[0] + acc2[1];
             float acc = s2[0] + s2[1];
             acc += other_half32(acc);
             if (h == 0 && okrow) obuf[(lr - 4) * T + t] = acc + b4;
         }
+#endif
     }
     SSTAMP(4);
     __syncthreads();

@@ -146,13 +146,21 @@ __global__ __launch_bounds__(256) void prologue_kernel(const aft_weights w, cons
     blk -= a.pack_blocks;
     if (blk < a.frag_blocks) {               // thread = (stack, quad, lane): one 16-byte piece of the image
         const int v = blk * 256 + threadIdx.x;
-        if (v < 2 * kFragQuads * 64) {
-            const int stack = v / (kFragQuads * 64), rem = v - stack * (kFragQuads * 64), quad = rem >> 6, lane = rem & 63;
+        constexpr int kPerStack = kFragFloats / 4;      // 16-byte pieces per stack: 22 x 64 operand quads + 40 of helper tables
+        if (v < 2 * kPerStack) {
+            const int stack = v / kPerStack, rem = v - stack * kPerStack;
             const float *const *cw = stack ? w.ref_w : w.enh_w;
             const float *const *cb = stack ? w.ref_b : w.enh_b;
             f32x4 o;
+            if (rem < kFragQuads * 64) {
+                const int quad = rem >> 6, lane = rem & 63;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) o[jj] = conv_frag16_entry(cw[1], cb[1], cw[2], cb[2], 4 * quad + jj, lane);
+                for (int jj = 0; jj < 4; ++jj) o[jj] = conv_frag16_entry(cw[1], cb[1], cw[2], cb[2], 4 * quad + jj, lane);
+            } else {
+                const int i0 = 4 * (rem - kFragQuads * 64), h = i0 / 80;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) o[jj] = conv_helper_entry(cw[0], cb[0], cw[3], cb[3], h, i0 - 80 * h + jj);
+            }
             *reinterpret_cast<f32x4 *>(a.conv_frag + (size_t)v * 4) = o;
         }
         return;
@@ -171,7 +179,7 @@ hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const floa
     PrologueArgs a{};
     if (conv_frag != nullptr) {
         a.conv_frag = conv_frag;
-        a.frag_blocks = (2 * kFragQuads * 64 + 255) / 256;
+        a.frag_blocks = (2 * (kFragFloats / 4) + 255) / 256;
     }
     size_t lds = 0;
     if (c.adaptive) {

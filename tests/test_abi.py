@@ -41,7 +41,7 @@ def test_loader_checks_version_and_host_only_calls():
     # + linear_2 output of the last chain launch (rows x 8)
     # (the attention tiles are sized for per-plane row tiles, planes x tokpad rows: the plane-resident encoder's layout)
     expect = 4 * (planes * 1680 + 128 * tokens * 6 + planes * tokens * d + planes * tokpad * d + 3 * planes * 4 * tokpad * 32
-                  + 6 * 8 * d * d + planes * tokens * 8 + 2 * 22 * 64 * 4)   # + both conv stacks' 16x16x4 operand fragments
+                  + 6 * 8 * d * d + planes * tokens * 8 + 2 * (22 * 64 * 4 + 160))   # + both conv stacks' 16x16x4 operand fragments and helper tables
     assert expect <= nbytes <= expect + 10 * 256
     bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3))
     assert lib.aft_workspace_bytes(ctypes.byref(bad), 8) == 0
@@ -121,8 +121,8 @@ def test_hot_kernels_compile_without_register_spills():
             m = re.search(r"VGPRs Spill: (\d+)", line)
             if m and name:
                 report[name] = int(m.group(1))
-    spills = {k: v for k, v in report.items() if "attn_kernelILi32E" in k or "attn_kernelILi16E" in k or "conv_stream_kernel" in k}
-    # attention HD 32 (generic, 280 tokens, 1120 tokens) / 16, conv stream head / tail (16x16x4 and 32x32x2 matrix phases) / training
+    spills = {k: v for k, v in report.items() if "attn_kernelILi32E" in k or "attn_kernelILi16E" in k or "conv_stream_kernel" in k or "conv_stream16_kernel" in k}
+    # attention HD 32 (generic, 280 tokens, 1120 tokens) / 16, conv stream head / tail (conv_stream16_kernel and the 32x32x2 kernel) / training
     assert len(spills) == 9 and all(v == 0 for v in spills.values()), report
     assert all(v <= 4 for k, v in report.items() if "attn_kernelILi64E" in k), report
     # the row-local training kernels (forward chain with / without the in-projection tail, backward chain; gelu and relu) sit at the
