@@ -63,12 +63,18 @@ int check_config(const aft_config *c) {
         set_error("bad pilot grid or layer count (layers=%d, max %d)", c->num_layers, AFT_MAX_LAYERS);
         return AFT_ERR_SHAPE;
     }
-    if (c->model_dim != 64 && c->model_dim != 128 && c->model_dim != 192 && c->model_dim != 256) {
-        set_error("model_dim %d not covered by the gfx950 kernels (64, 128, 192 or 256)", c->model_dim);
+    // The row-local chain kernel gives every wave one 32-feature block of every activation and keeps a 32-row tile's whole hidden
+    // layer (2 x model_dim wide) in the registers of its model_dim / 32 waves: any multiple of 32 up to 256 is an instantiation of
+    // the same body (251 VGPRs at 256); wider models would need a second kernel that tiles the feature dimension through LDS.
+    if (c->model_dim < 32 || c->model_dim > 256 || c->model_dim % 32 != 0) {
+        set_error("model_dim %d not covered by the gfx950 kernels (multiples of 32 up to 256: the row-local chain keeps a row tile's "
+                  "hidden layer in the registers of model_dim / 32 waves)", c->model_dim);
         return AFT_ERR_SHAPE;
     }
     // nn.MultiheadAttention takes any num_head that divides model_dim (reference blocks/encoders.py:44-51, schemas.py:124-127);
-    // the attention kernel is instantiated for head dimensions 16, 32 (the tuned shape) and 64
+    // the attention kernel is instantiated for head dimensions 16, 32 (the tuned shape) and 64: q / k / v^T live in 32-feature blocks
+    // and a 32x32x2 MFMA contracts 32 features at a time -- head dim 8 would spend 3/4 of every product on masked features, head dim
+    // 128 needs four output accumulators per query tile (> 256 VGPRs); both are refused rather than run at a fraction of the rate
     const int hd = c->num_head > 0 && c->model_dim % c->num_head == 0 ? c->model_dim / c->num_head : 0;
     if (hd != 16 && hd != 32 && hd != 64) {
         set_error("head dim must be 16, 32 or 64 (model_dim=%d, num_head=%d)", c->model_dim, c->num_head);

@@ -299,11 +299,13 @@ hipError_t launch_chain_fwd_train(const aft_config &c, const aft_layer_weights &
                                   int rows, uint32_t seed1, uint32_t seed2, uint32_t seed3, uint32_t threshold, float keep_scale,
                                   hipStream_t st, const float *next_in_proj_w = nullptr, const float *next_in_proj_b = nullptr,
                                   float *next_qkv = nullptr);   // all three set: + the next layer's in-projection, row-major [rows][3 d]
+// pad: attn_train_pad_floats(c, rows) floats of scratch (head dim 16: the operands re-laid with every head padded to 32 features), else NULL
+size_t attn_train_pad_floats(const aft_config &c, size_t rows);
 hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o, float *lse, int planes, int tokens,
-                                 float dropout_p, uint32_t seed, hipStream_t st);
+                                 float dropout_p, uint32_t seed, hipStream_t st, float *pad = nullptr);
 hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const float *o, const float *d_o, const float *lse,
                                  float *dsum, float *dqkv, int planes, int tokens, float dropout_p, uint32_t seed,
-                                 hipStream_t st);
+                                 hipStream_t st, float *pad = nullptr);
 hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamma, const float *beta, float *s_out,
                              float *stats, float *out, int rows, int n, float eps, float dropout_p, uint32_t seed,
                              hipStream_t st);

@@ -21,7 +21,7 @@ struct Tape {   // offsets in floats
     size_t qkv, attn, lse, s1, st1, x1, a, hd, s2, st2, total;
 };
 struct Scratch {
-    size_t g1, g2, g2b, gff, dqkv, dsum, slices, packed_t, lnp, total;
+    size_t g1, g2, g2b, gff, dqkv, dsum, slices, packed_t, lnp, attn_pad, total;
 };
 
 int tokens_of_cfg(const aft_config &c) { return (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols); }
@@ -63,6 +63,7 @@ Scratch plan_scratch(const aft_config &c, int batch) {
     // fused row-local backward (k_chain_bwd.hip): transposed fragment-packed weights, per-tile LayerNorm parameter sums
     s.packed_t = off; off += al64(std::max(chain_bwd_packed_floats((int)d), packed_layer_floats((int)d)));   // also the forward chain's fp32 image
     s.lnp = off;      off += al64(chain_bwd_lnp_floats(r, (int)d));
+    s.attn_pad = off; off += al64(attn_train_pad_floats(c, rows));    // head dim 16: padded-head images of qkv, o, d_o, dqkv
     s.total = off;
     return s;
 }
@@ -93,9 +94,16 @@ int check_train(const aft_config *cfg, int batch, float dropout_p) {
         set_error("bad batch %d or dropout %g", batch, (double)dropout_p);
         return AFT_ERR_ARG;
     }
-    if (cfg->model_dim / cfg->num_head != kHeadDim || tokens_of_cfg(*cfg) < kTile) {
-        set_error("the training kernels cover head dim %d and >= %d tokens (model_dim=%d, num_head=%d, tokens=%d)", kHeadDim, kTile,
-                  cfg->model_dim, cfg->num_head, tokens_of_cfg(*cfg));
+    // head dim 32 is the kernels' own shape, 16 runs as zero-padded 32-feature heads (k_attn_train.hip); head dim 64 -- two 32-feature
+    // blocks under one softmax -- has no training attention kernel yet: such a model's encoder is differentiated by PyTorch-ROCm
+    // autograd (blocks.py logs it), the inference path covers it
+    if (cfg->model_dim % 64 != 0) {
+        set_error("the row-wise training kernels are instantiated for model_dim 64, 128, 192 and 256 (got %d)", cfg->model_dim);
+        return AFT_ERR_SHAPE;
+    }
+    const int hd = cfg->model_dim / cfg->num_head;
+    if (hd != kHeadDim && hd != 16) {
+        set_error("the training attention kernels cover head dims 32 and 16 (model_dim=%d, num_head=%d)", cfg->model_dim, cfg->num_head);
         return AFT_ERR_SHAPE;
     }
     if ((size_t)2 * batch * tokens_of_cfg(*cfg) * 3 * cfg->model_dim >= ((size_t)1 << 32)) {
@@ -149,7 +157,7 @@ int aft_encoder_layer_fwd_train_chained_f32(const aft_config *cfg, const aft_lay
     if (!qkv_ready)   // (else the previous layer's row-local kernel already left this layer's in-projection in the tape)
         STEP("qkv", launch_gemm(0, x_in, w->in_proj_w, tp + t.qkv, w->in_proj_b, rows, 3 * d, d, d, d, 3 * d, false, st));
     STEP("attention", launch_attn_train_fwd(*cfg, tp + t.qkv, tp + t.attn, tp + t.lse, planes, tokens, dropout_p,
-                                            site_seed(seed, 0), st));
+                                            site_seed(seed, 0), st, sc + s.attn_pad));
     const uint32_t drop_th = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
     const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     // the NEXT layer's in-projection as the tail of this layer's row-local kernel (same tape layout: the layers share cfg and batch)
@@ -243,7 +251,7 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
         STEP("norm2 parameter gradients", launch_reduce_slices3(lnp, g->norm2_w, g->norm2_b, nullptr, d, 2, ntl, (size_t)4 * d, acc, st));
         STEP("norm1 parameter gradients", launch_reduce_slices3(lnp + 2 * d, g->norm1_w, g->norm1_b, nullptr, d, 2, ntl, (size_t)4 * d, acc, st));
         STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,
-                                                    dropout_p, site_seed(seed, 0), st));
+                                                    dropout_p, site_seed(seed, 0), st, sc + s.attn_pad));
         STEP("in_proj dgrad", launch_gemm(1, dqkv, w->in_proj_w, dx_in, nullptr, rows, d, 3 * d, 3 * d, d, d, true, st));
         {   // the four weight gradients and all four bias gradients (column sums of the A operands) in one launch
             const float *A[4] = {g2, gff, g2b, dqkv}, *B[4] = {hd, tp + t.x1, tp + t.attn, x_in};
@@ -276,7 +284,7 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
                                     rows, d, dropout_p, site_seed(seed, 1), acc, st));
     STEP("out_proj dgrad", launch_gemm(1, g2b, w->out_proj_w, g1, nullptr, rows, d, d, d, d, d, false, st));
     STEP("attention bwd", launch_attn_train_bwd(*cfg, tp + t.qkv, tp + t.attn, g1, tp + t.lse, sc + s.dsum, dqkv, planes, tokens,
-                                                dropout_p, site_seed(seed, 0), st));
+                                                dropout_p, site_seed(seed, 0), st, sc + s.attn_pad));
     STEP("in_proj dgrad", launch_gemm(1, dqkv, w->in_proj_w, dx_in, nullptr, rows, d, 3 * d, 3 * d, d, d, true, st));
     {   // the layer's four weight gradients in one launch: dW2 = g2^T hd, dW1 = gff^T x1, dWo = g2b^T attn, dWqkv = dqkv^T x_in
         const float *A[4] = {g2, gff, g2b, dqkv}, *B[4] = {hd, tp + t.x1, tp + t.attn, x_in};

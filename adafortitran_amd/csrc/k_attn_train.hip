@@ -704,9 +704,46 @@ __global__ __launch_bounds__(kAtThreads * GROUPS) __attribute__((amdgpu_waves_pe
     }
 }
 
+// ---- head dimension 16 (round 5): the kernels above contract 32 features per head.  A 16-feature head is run as a 32-feature head
+// whose upper half is zero: q | k | v are re-laid with every head's 16 features padded to 32 (the zeros add nothing to Q K^T, the
+// padded half of O / dV / dQ / dK comes out zero and is dropped), the softmax scale stays 1 / sqrt(16).  Twice the matrix work of a
+// tuned kernel and four re-lay passes per layer -- covered, not tuned -- but every gradient comes from this library's kernels
+// (reference blocks/encoders.py:44-51 builds whatever num_head the YAML says; trainer.py:195-233 trains it).
+// pad: dst [rows][nseg][heads][32] <- src [rows][nseg][heads][16]; unpad: the reverse.  One 16-byte piece per thread.
+__global__ __launch_bounds__(256) void pad_heads16_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t pieces, int nh) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // piece of dst: (row, seg*heads + head, j4 in 0..7)
+    if (v >= pieces) return;
+    const int j4 = (int)(v & 7);
+    const size_t rh = v >> 3;                                      // row * nh + (seg, head)
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (j4 < 4) o = *reinterpret_cast<const f32x4 *>(src + rh * 16 + 4 * j4);
+    *reinterpret_cast<f32x4 *>(dst + v * 4) = o;
+    (void)nh;
+}
+__global__ __launch_bounds__(256) void unpad_heads16_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t pieces) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // piece of dst: (row * nh + (seg, head), j4 in 0..3)
+    if (v >= pieces) return;
+    const size_t rh = v >> 2;
+    *reinterpret_cast<f32x4 *>(dst + v * 4) = *reinterpret_cast<const f32x4 *>(src + rh * 32 + 4 * (v & 3));
+}
+static hipError_t pad16(const float *src, float *dst, size_t rows, int nseg, int heads, hipStream_t st) {
+    const size_t pieces = rows * nseg * heads * 8;
+    hipLaunchKernelGGL(pad_heads16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, src, dst, pieces, nseg * heads);
+    return hipGetLastError();
+}
+static hipError_t unpad16(const float *src, float *dst, size_t rows, int nseg, int heads, hipStream_t st) {
+    const size_t pieces = rows * nseg * heads * 4;
+    hipLaunchKernelGGL(unpad_heads16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, src, dst, pieces);
+    return hipGetLastError();
+}
+size_t attn_train_pad_floats(const aft_config &c, size_t rows) {   // scratch the head-dim-16 path needs: qkv, o, d_o, dqkv padded
+    return c.num_head > 0 && c.model_dim / c.num_head == 16 ? rows * (size_t)c.num_head * 32 * 8 : 0;
+}
+
 static AttnTrainArgs make_args(const aft_config &c, int planes, int tokens, float dropout_p, uint32_t seed) {
     AttnTrainArgs a{};
     a.planes = planes; a.tokens = tokens; a.heads = c.num_head; a.d = c.model_dim;
+    if (c.model_dim / c.num_head == 16) a.d = 32 * c.num_head;    // padded heads (the launchers re-lay the operands)
     a.ntiles = (tokens + 31) / 32;
     const float inv = 1.f / sqrtf((float)(c.model_dim / c.num_head));
     a.scale = inv;
@@ -719,19 +756,55 @@ static AttnTrainArgs make_args(const aft_config &c, int planes, int tokens, floa
 }
 
 hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o, float *lse, int planes, int tokens,
-                                 float dropout_p, uint32_t seed, hipStream_t st) {
+                                 float dropout_p, uint32_t seed, hipStream_t st, float *pad) {
     AttnTrainArgs a = make_args(c, planes, tokens, dropout_p, seed);
     a.qkv = qkv; a.out = o; a.lse = lse;
+    const bool hd16 = c.model_dim / c.num_head == 16;
+    const size_t rows = (size_t)planes * tokens;
+    if (hd16) {
+        if (pad == nullptr) return hipErrorInvalidValue;
+        float *qkv_p = pad, *o_p = pad + rows * 3 * a.d;
+        hipError_t e = pad16(qkv, qkv_p, rows, 3, c.num_head, st);
+        if (e != hipSuccess) return e;
+        a.qkv = qkv_p; a.out = o_p;
+    }
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
     hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && hd16) e = unpad16(a.out, o, rows, 1, c.num_head, st);
+    return e;
 }
+
+static hipError_t launch_attn_train_bwd_padded(const aft_config &c, AttnTrainArgs a, const float *qkv, const float *o, const float *d_o,
+                                               float *dqkv, int planes, int tokens, hipStream_t st);
 
 hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const float *o, const float *d_o, const float *lse,
                                  float *dsum, float *dqkv, int planes, int tokens, float dropout_p, uint32_t seed,
-                                 hipStream_t st) {
+                                 hipStream_t st, float *pad) {
     AttnTrainArgs a = make_args(c, planes, tokens, dropout_p, seed);
     a.qkv = qkv; a.o = o; a.d_o = d_o; a.lse = const_cast<float *>(lse); a.dsum = dsum; a.out = dqkv;
+    if (c.model_dim / c.num_head == 16) {   // padded heads: re-lay the three operands, run on the padded image, drop the padding of dqkv
+        if (pad == nullptr) return hipErrorInvalidValue;
+        const size_t rows = (size_t)planes * tokens;
+        float *qkv_p = pad, *o_p = qkv_p + rows * 3 * a.d, *do_p = o_p + rows * a.d, *dqkv_p = do_p + rows * a.d;
+        hipError_t e = pad16(qkv, qkv_p, rows, 3, c.num_head, st);
+        if (e == hipSuccess) e = pad16(o, o_p, rows, 1, c.num_head, st);
+        if (e == hipSuccess) e = pad16(d_o, do_p, rows, 1, c.num_head, st);
+        if (e != hipSuccess) return e;
+        aft_config c32 = c;
+        c32.model_dim = a.d;                 // 32 features per head: the plain path below, scales already set from the true head dim
+        AttnTrainArgs keep = a;
+        e = launch_attn_train_bwd_padded(c32, keep, qkv_p, o_p, do_p, dqkv_p, planes, tokens, st);
+        if (e == hipSuccess) e = unpad16(dqkv_p, dqkv, rows, 3, c.num_head, st);
+        return e;
+    }
+    return launch_attn_train_bwd_padded(c, a, qkv, o, d_o, dqkv, planes, tokens, st);
+}
+
+static hipError_t launch_attn_train_bwd_padded(const aft_config &c, AttnTrainArgs a, const float *qkv, const float *o, const float *d_o,
+                                               float *dqkv, int planes, int tokens, hipStream_t st) {
+    a.qkv = qkv; a.o = o; a.d_o = d_o; a.out = dqkv;
+    (void)c;
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
     const size_t words_bytes = (size_t)a.ntiles * 32 * sizeof(uint32_t);
     // one pass (attn_bwd_kernel) unless its three LDS tables do not fit beside the static staging, or the two-pass form is asked for (A/B)

@@ -207,6 +207,12 @@ hipError_t launch_chain(const aft_config &c, const aft_layer_weights *m, const f
             return gelu ? launch_chain_split_t<256, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_split_t<256, AFT_ACT_RELU>(a, mlp, qkv, st);
         return hipErrorInvalidValue;    // refused earlier by check_config
     }
+    // every multiple of 32 up to 256 (round 5: the body is generic in D = 32 x waves; 128 and 256 are the tuned shapes, the others are
+    // covered -- odd wave counts leave SIMDs unevenly filled)
+#define AFT_CHAIN_DIM(DD) \
+    if (c.model_dim == DD) return gelu ? launch_chain_t<DD, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<DD, AFT_ACT_RELU>(a, mlp, qkv, st);
+    AFT_CHAIN_DIM(32) AFT_CHAIN_DIM(96) AFT_CHAIN_DIM(160) AFT_CHAIN_DIM(224)
+#undef AFT_CHAIN_DIM
     if (c.model_dim == 64)
         return gelu ? launch_chain_t<64, AFT_ACT_GELU>(a, mlp, qkv, st) : launch_chain_t<64, AFT_ACT_RELU>(a, mlp, qkv, st);
     if (c.model_dim == 192)

@@ -320,7 +320,15 @@ hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *
         if (small) hipLaunchKernelGGL((embed_kernel<D_, A_, 6>), dim3(blocks), dim3(256), lds, st, a); \
         else hipLaunchKernelGGL((embed_kernel<D_, A_, kMaxPatchFeatures>), dim3(blocks), dim3(256), lds, st, a); \
     } while (0)
-    if (c.model_dim == 64 && c.adaptive) AFT_EMBED(64, true);
+    if (c.model_dim == 32 && c.adaptive) AFT_EMBED(32, true);
+    else if (c.model_dim == 32) AFT_EMBED(32, false);
+    else if (c.model_dim == 96 && c.adaptive) AFT_EMBED(96, true);
+    else if (c.model_dim == 96) AFT_EMBED(96, false);
+    else if (c.model_dim == 160 && c.adaptive) AFT_EMBED(160, true);
+    else if (c.model_dim == 160) AFT_EMBED(160, false);
+    else if (c.model_dim == 224 && c.adaptive) AFT_EMBED(224, true);
+    else if (c.model_dim == 224) AFT_EMBED(224, false);
+    else if (c.model_dim == 64 && c.adaptive) AFT_EMBED(64, true);
     else if (c.model_dim == 64) AFT_EMBED(64, false);
     else if (c.model_dim == 128 && c.adaptive) AFT_EMBED(128, true);
     else if (c.model_dim == 128) AFT_EMBED(128, false);

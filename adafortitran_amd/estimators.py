@@ -17,11 +17,13 @@ Execution paths of ``forward``:
   * ``device: cpu`` -> the same composite on ATen's CPU kernels (what the reference itself runs).
 
 Coverage is ONE predicate, asked once at construction (``aft_check_config``): a configuration the
-reference accepts but the gfx950 kernels do not cover (model_dim outside {64,128,192,256}, head dim
-!= 32, < 32 tokens, patch > 16 elements, a grid with no LDS band plan) is refused with a ``ValueError``
-when the model is built on a HIP device -- before any training -- instead of training through
-per-block PyTorch fallbacks and failing in the first ``eval()`` forward.  ``AFT_ALLOW_COMPOSITE=1`` in
-the environment opts into running such a model entirely on the PyTorch-ROCm composite (logged).
+reference accepts but the gfx950 kernels do not cover (model_dim not a multiple of 32 up to 256, head dim
+other than 16 / 32 / 64, patch > 16 elements, a grid with no LDS band plan) is refused with a ``ValueError``
+when the model is built on a HIP device -- before any training -- instead of failing in the first ``eval()``
+forward.  ``AFT_ALLOW_COMPOSITE=1`` in the environment opts into running such a model entirely on the
+PyTorch-ROCm composite (logged).  The TRAINING kernels cover a subset of what inference covers (head dims 32
+and 16, not 64): where a block of an accepted model is differentiated by PyTorch-ROCm autograd instead, the
+constructor logs a warning naming the block and the reason, and ``training_backends()`` returns the same.
 """
 from __future__ import annotations
 
@@ -196,6 +198,11 @@ class BaseFortiTranEstimator(nn.Module):
         reason = config_coverage(cfg)
         if reason is None:
             self._hip_covered = True
+            # what loss.backward() runs on (no silent per-block fallback): logged once, also in training_backends()
+            for block, gap in self.training_backends().items():
+                if gap is not None:
+                    self.logger.warning("training: %s is differentiated by PyTorch-ROCm autograd, not by the library's kernels (%s); "
+                                        "inference (eval() + no_grad) runs the HIP engine either way", block, gap)
             return
         if os.environ.get("AFT_ALLOW_COMPOSITE") == "1":
             self.logger.warning("configuration not covered by the gfx950 kernels (%s): AFT_ALLOW_COMPOSITE=1, "
@@ -203,6 +210,15 @@ class BaseFortiTranEstimator(nn.Module):
             return
         raise ValueError(f"configuration not covered by the gfx950 kernels: {reason}. Build the model with "
                          "device='cpu', or set AFT_ALLOW_COMPOSITE=1 to run the PyTorch-ROCm composite instead.")
+
+    def training_backends(self) -> dict:
+        """{block: None | reason}: None = ``loss.backward()`` through that block runs this library's hand-written kernels on a HIP
+        device; a string = it is differentiated by PyTorch-ROCm autograd and why (reference trainer.py:195-233 trains
+        whatever encoders.py:44-51 builds).  The dense layers, the adapter MLPs and the loss glue are not listed: always HIP / torch."""
+        from .hip_ops import conv_enhancer_covered
+        conv_gap = None if conv_enhancer_covered(*self.ofdm_size) else f"no LDS band plan of the fused conv-stack kernel for a {self.ofdm_size} grid"
+        return {"transformer_encoder": self.transformer_encoder.hip_train_gap(),
+                "initial_enhancer / final_refiner": conv_gap}
 
     def _apply(self, fn, *args, **kwargs):  # .to()/.cuda()/.float() re-allocate parameters
         self._engine = None

@@ -376,11 +376,20 @@ if __name__ == "__main__":
         run_grad("G_grad_forti_full", dict(DEFAULT, dropout=0.0, seed=779), 128, store_inputs=False)
     if not only or "G_grad_ada_full" in only:
         run_grad("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128, store_inputs=False)
+    # round 5: the training kernels' new shapes pinned on the reference's own gradients -- head dim 16 (8 heads at
+    # model_dim 128, as `num_head: 8` in the YAML) and a 28-token grid (12 x 14, patch 3 x 2: one masked key tile)
+    H16 = dict(DEFAULT, num_layers=2, num_head=8, dropout=0.0, seed=781, attn_gain=8.0)
+    S28 = dict(DEFAULT, ofdm=(12, 14), pilot=(4, 2), num_layers=2, dropout=0.0, seed=782, attn_gain=8.0)
+    if not only or "G_grad_forti_h16" in only:
+        run_grad("G_grad_forti_h16", H16, 3)
+    if not only or "G_grad_forti_s28" in only:
+        run_grad("G_grad_forti_s28", S28, 5)
     # float64 runs of the reference on the same steps: the yardstick for the fp32 gradient tolerances
     GRAD64 = {"G_grad64_forti": ("G_grad_forti", dict(DEFAULT, num_layers=2, dropout=0.0, activation="relu", seed=778), 2),
               "G_grad64_ada": ("G_grad_ada", dict(DEFAULT, num_layers=2, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=777), 3),
               "G_grad64_forti_full": ("G_grad_forti_full", dict(DEFAULT, dropout=0.0, seed=779), 128),
-              "G_grad64_ada_full": ("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128)}
+              "G_grad64_ada_full": ("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128),
+              "G_grad64_forti_h16": ("G_grad_forti_h16", H16, 3), "G_grad64_forti_s28": ("G_grad_forti_s28", S28, 5)}
     for nm, (_f32, spec, batch) in GRAD64.items():
         if not only or nm in only:
             run_grad64(nm, spec, batch)

@@ -43,7 +43,7 @@ def test_loader_checks_version_and_host_only_calls():
     expect = 4 * (planes * 1680 + 128 * tokens * 6 + planes * tokens * d + planes * tokpad * d + 3 * planes * 4 * tokpad * 32
                   + 6 * 8 * d * d + planes * tokens * 8 + 2 * (22 * 64 * 4 + 160))   # + both conv stacks' 16x16x4 operand fragments and helper tables
     assert expect <= nbytes <= expect + 10 * 256
-    bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3))
+    bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=80, num_head=5))
     assert lib.aft_workspace_bytes(ctypes.byref(bad), 8) == 0
     assert b"model_dim" in lib.aft_last_error()
 
@@ -96,7 +96,7 @@ def test_max_batch_is_the_32_bit_offset_limit_of_the_largest_region():
         ptr = ctypes.addressof(one)                       # non-NULL dummies: the call must fail before touching them
         rc = lib.aft_forward_f32(ctypes.byref(cfg), ctypes.byref(w), ptr, ptr, ptr, ptr, ptr, ptr, 1 << 40, mb + 1, None)
         assert rc == _abi.AFT_ERR_ARG and b"aft_max_batch" in lib.aft_last_error()
-    bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=96, num_head=3), adaptive_hidden=None)
+    bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=320, num_head=10), adaptive_hidden=None)
     assert lib.aft_max_batch(ctypes.byref(bad)) == 0 and lib.aft_packed_weights_bytes(ctypes.byref(bad)) == 0
 
 

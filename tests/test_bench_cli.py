@@ -91,13 +91,17 @@ def test_bench_full_line_on_gpu(tmp_path):
     res = _run(["--steps", "10", "--warmup", "3", "--verbose-json", str(tmp_path / "v.json")])
     assert res.returncode == 0, res.stderr[-3000:]
     raw = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-    assert len(raw) < 5000, len(raw)
+    assert len(raw) < 6500, len(raw)
     line = json.loads(raw)
     for key in ("roofline", "cpu_baseline", "kernels", "upsampler", "parity", "configs", "next_rows", "module_surface",
-                "value_h2d_inclusive", "split_precision"):
+                "value_h2d_inclusive", "split_precision", "batch_sweep"):
         assert key in line, key
     assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "mfma"
     assert set(line["configs"]) == {"C1", "C2", "C3", "C5"}
+    bs = line["batch_sweep"]["C3"]
+    assert bs["batch"] == [16, 32, 64, 96, 128, 129, 192, 256, 512] and len(bs["value"]) == 9 and bs["rel"][4] == 1.0
+    ups = line["upsampler"]                                   # the stage counted whole: conv head + the product's share of the prologue
+    assert ups["stage_ms"] >= ups["conv_head_ms"] and 0 < ups["frac"] <= ups["conv_only_frac"] < 1
     assert "error" not in line["next_rows"], line["next_rows"]
     assert line["next_rows"]["f1_train_step_ms"] > 0 and 0 < line["next_rows"]["f1_frac_of_fp32_roof"] < 1
     assert line["parity"]["max_abs"] <= 5e-5 * line["parity"]["ymax"] and line["parity"]["rel_dMSE"] <= 1e-4

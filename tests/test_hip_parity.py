@@ -290,7 +290,8 @@ def test_row_streaming_conv_does_not_depend_on_the_column_split():
 @pytest.mark.parametrize("adaptive", [False, True])
 @pytest.mark.parametrize("d,heads", [(64, 2), (192, 6),                    # head dim 32: two / six waves per chain workgroup
                                      (128, 8), (64, 4), (192, 12), (256, 16),   # head dim 16: two heads per 32-feature block
-                                     (128, 2), (64, 1), (192, 3), (256, 4)])    # head dim 64: a head spans two blocks
+                                     (128, 2), (64, 1), (192, 3), (256, 4),     # head dim 64: a head spans two blocks
+                                     (32, 1), (32, 2), (96, 3), (96, 6), (160, 5), (160, 10), (224, 7), (224, 14)])   # round 5: every multiple of 32
 def test_other_model_dims_match_oracle(oracle_lib, adaptive, d, heads):
     """Every (model_dim, num_head) the kernels cover besides the default: nn.MultiheadAttention takes any num_head that divides
     model_dim (reference blocks/encoders.py:44-51).  Non-uniform softmax (attn_gain), 9 frames = ragged row tiles, run-to-run
@@ -448,9 +449,9 @@ def test_uncovered_configuration_is_refused_at_construction(monkeypatch):
     """One coverage predicate, asked at construction on the HIP device: a shape the reference accepts but
     the kernels do not cover raises a ValueError before any training, unless the caller opts
     into the PyTorch-ROCm composite."""
-    # model_dim 96 (3 heads of 32): accepted by the reference's schema, not by the kernels
+    # model_dim 80 (5 heads of 16): accepted by the reference's schema, not by the kernels (multiples of 32 up to 256)
     sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
-    kw = dict(model_type="fortitran", patch_size=(3, 2), num_layers=2, model_dim=96, num_head=3)
+    kw = dict(model_type="fortitran", patch_size=(3, 2), num_layers=2, model_dim=80, num_head=5)
     assert A.FortiTranEstimator(sc, A.ModelConfig(device="cpu", **kw)) is not None      # CPU: the reference's own path
     monkeypatch.delenv("AFT_ALLOW_COMPOSITE", raising=False)
     with pytest.raises(ValueError, match="not covered by the gfx950 kernels"):
@@ -466,9 +467,10 @@ def test_uncovered_configuration_is_refused_at_construction(monkeypatch):
 @pytest.mark.parametrize("name", ["H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28"])
 def test_module_surface_with_other_head_dims_and_small_grids(name):
     """`num_head: 8` at `model_dim: 128` (head dim 16), `num_head: 2` (head dim 64) and a 28-token grid through the MODULE, as the
-    reference's YAML would configure them: eval() runs the HIP engine (golden parity, CPU inputs), train() differentiates -- the
-    encoder through PyTorch-ROCm autograd there (the training kernels cover head dim 32 and >= 32 tokens), everything else through
-    the library -- and the gradients agree with the CPU composite."""
+    reference's YAML would configure them: eval() runs the HIP engine (golden parity, CPU inputs), train() differentiates -- head dim
+    16 and the 28-token grid through the library's training kernels since round 5, the head-dim-64 encoder through PyTorch-ROCm
+    autograd (said so by training_backends() and a construction-time warning, not silently) -- and the gradients agree with the
+    CPU composite."""
     from test_estimators_cpu import _configs, golden_meta
     g = Golden(name)
     sc, mc = _configs(g.spec, device="cuda")
@@ -482,6 +484,8 @@ def test_module_surface_with_other_head_dims_and_small_grids(name):
         out = model(pil, meta) if g.adaptive else model(pil)
     assert model._engine is not None                                     # the C-ABI engine ran
     assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_HIP_OUT * np.abs(g["out"]).max()
+    gap = model.training_backends()["transformer_encoder"]
+    assert (gap is None) == (name != "H64_forti_heads2") and (gap is None or "head dim 64" in gap)
     # one training step on the GPU against the same step on the CPU composite
     sc_c, mc_c = _configs(dict(g.spec, dropout=0.0), device="cpu")
     sc_g, mc_g = _configs(dict(g.spec, dropout=0.0), device="cuda")
@@ -576,7 +580,8 @@ def test_linear_and_mse_kernels(oracle_lib):
 
 def _random_specs(n, seed):
     """Random valid configurations: any grid the patch divides (token counts from 1 to 512, below one MFMA tile included), patches of
-    <= 16 elements, model_dim in {64, 128, 192, 256} with head dim 16 / 32 / 64, 1-3 layers, both activations / positional encodings."""
+    <= 16 elements, model_dim any multiple of 32 up to 256 with head dim 16 / 32 / 64 (64 where it divides), 1-3 layers, both activations /
+    positional encodings."""
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
@@ -587,8 +592,8 @@ def _random_specs(n, seed):
         gs, gt = (int(rng.integers(1, 8)), int(rng.integers(1, 5))) if small else (int(rng.integers(4, 30)), int(rng.integers(2, 9)))
         if (not small and gs * gt < 32) or (small and gs * gt >= 32) or gs * gt > 512 or gs * p0 > 160 or gt * p1 > 28:
             continue
-        d = int(rng.choice([64, 128, 192, 256]))
-        hd = int(rng.choice([16, 32, 64]))
+        d = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256]))
+        hd = int(rng.choice([16, 32, 64] if d % 64 == 0 else [16, 32]))
         ps, pt = int(rng.integers(2, 13)), int(rng.integers(1, 4))
         out.append(dict(ofdm=(gs * p0, gt * p1), pilot=(ps, pt), patch=(p0, p1), num_layers=int(rng.integers(1, 4)),
                         model_dim=d, num_head=d // hd, activation=str(rng.choice(["gelu", "relu"])),
@@ -597,7 +602,7 @@ def _random_specs(n, seed):
     return out
 
 
-@pytest.mark.parametrize("spec", _random_specs(28, 2026), ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['model_dim']}h{s['num_head']}{'a' if s['adaptive'] else 'f'}")
+@pytest.mark.parametrize("spec", _random_specs(40, 2027), ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['model_dim']}h{s['num_head']}{'a' if s['adaptive'] else 'f'}")
 def test_random_configurations_match_oracle(oracle_lib, spec):
     tokens = (spec["ofdm"][0] // spec["patch"][0]) * (spec["ofdm"][1] // spec["patch"][1])
     base = dict(ofdm=spec["ofdm"], pilot=spec["pilot"], patch=spec["patch"], num_layers=spec["num_layers"],

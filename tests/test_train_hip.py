@@ -33,7 +33,12 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("d,heads,ofdm,planes,act", [(128, 4, (120, 14), 6, "gelu"), (128, 4, (24, 14), 2, "relu"),
-                                                     (256, 8, (48, 14), 4, "gelu"), (64, 2, (48, 14), 4, "gelu"), (192, 6, (48, 14), 2, "relu")])
+                                                     (256, 8, (48, 14), 4, "gelu"), (64, 2, (48, 14), 4, "gelu"), (192, 6, (48, 14), 2, "relu"),
+                                                     # round 5: head dim 16 (zero-padded 32-feature heads), grids below 32
+                                                     # tokens (one masked key tile)
+                                                     (128, 8, (120, 14), 6, "gelu"), (256, 16, (48, 14), 2, "relu"), (64, 4, (24, 14), 4, "gelu"),
+                                                     (128, 4, (12, 14), 6, "gelu"), (128, 8, (12, 14), 2, "relu"), (128, 4, (3, 14), 4, "gelu"),
+                                                     (128, 4, (3, 2), 8, "gelu"), (192, 12, (24, 14), 2, "relu")])
 def test_layer_forward_backward_matches_autograd(d, heads, ofdm, planes, act):
     from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
     cfg = _cfg(d, heads, ofdm, act)
@@ -460,11 +465,15 @@ def _random_train_specs(n, seed):
         d = int(rng.choice([64, 128, 192, 256]))
         out.append(dict(ofdm=(gs * p0, gt * p1), pilot=(int(rng.integers(2, 9)), int(rng.integers(1, 3))), patch=(p0, p1),
                         d=d, act=str(rng.choice(["gelu", "relu"])), adaptive=bool(rng.integers(0, 2)), batch=int(rng.integers(1, 4))))
+    # round 5: head dim 16, a 28-token grid and a model_dim off the tuned set, through the whole model
+    out.append(dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), d=128, hd=16, act="gelu", adaptive=True, batch=2))
+    out.append(dict(ofdm=(12, 14), pilot=(4, 2), patch=(3, 2), d=128, hd=32, act="gelu", adaptive=True, batch=3))
+    out.append(dict(ofdm=(48, 14), pilot=(6, 2), patch=(3, 2), d=192, hd=16, act="relu", adaptive=False, batch=2))
     return out
 
 
 @pytest.mark.parametrize("spec", _random_train_specs(8, 77),
-                         ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['d']}{'a' if s['adaptive'] else 'f'}")
+                         ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['d']}hd{s.get('hd', 32)}{'a' if s['adaptive'] else 'f'}")
 def test_random_configurations_training_step_matches_autograd(spec):
     """Whole-model loss.backward() on random valid configurations: HIP training kernels (encoder, conv stacks,
     dense layers) against PyTorch-ROCm autograd on the same module, dropout 0."""
@@ -474,12 +483,13 @@ def test_random_configurations_training_step_matches_autograd(spec):
     sc = A.SystemConfig(ofdm=dict(num_scs=spec["ofdm"][0], num_symbols=spec["ofdm"][1]),
                         pilot=dict(num_scs=spec["pilot"][0], num_symbols=spec["pilot"][1]))
     kw = dict(model_type="adafortitran" if spec["adaptive"] else "fortitran", patch_size=spec["patch"], num_layers=2,
-              model_dim=spec["d"], num_head=spec["d"] // 32, activation=spec["act"], max_seq_len=512,
+              model_dim=spec["d"], num_head=spec["d"] // spec.get("hd", 32), activation=spec["act"], max_seq_len=512,
               pos_encoding_type="learnable", device="cuda", dropout=0.0)
     if spec["adaptive"]:
         kw.update(channel_adaptivity_hidden_sizes=[5, 9, 2 * tokens], adaptive_token_length=6)
     torch.manual_seed(0)
     model = (A.AdaFortiTranEstimator if spec["adaptive"] else A.FortiTranEstimator)(sc, A.ModelConfig(**kw)).train()
+    assert all(v is None for v in model.training_backends().values()), model.training_backends()    # every block on the library's kernels
     B = spec["batch"]
     inp = synth.make_inputs(B, ofdm=spec["ofdm"], pilot=spec["pilot"], seed=9)
     pil, tgt = torch.from_numpy(inp["pilots"]).cuda(), torch.from_numpy(inp["target"]).cuda()

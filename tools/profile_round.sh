@@ -7,7 +7,7 @@
 #  3. kernel trace of one training step
 # Summaries land in gpurun_out/<tag>/ ; tools/update_profiles.py copies the ones to keep into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"

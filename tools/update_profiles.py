@@ -86,14 +86,19 @@ if plane:
 # round 4: the default grid runs the column-streaming kernels (k_conv_stream.hip) -- conv_stream_kernel<0> = head, <1> = tail, distinct
 # symbols -- and the pilot_upsampler product sits in the prologue launch: the head LAUNCH reads the upsampled planes (13,440 B per frame)
 # instead of pilots + up_w; the stage's compulsory bytes are unchanged, 13,632 B per frame.
-head = block("conv_head", "conv_stream_kernel<0", 1, frames * (13440 + 13440) + 19 * 1024,
+# round 5: conv_stream16_kernel<0> / <1> (16x16x4 matrix phase; 23 KB of operand fragments + tables per launch instead of 19 KB of weights)
+head = block("conv_head", "conv_stream16_kernel<0", 1, frames * (13440 + 13440) + 23 * 1024,
+             "conv_stream16_kernel<0> HEAD (upsampled planes in, 4 convs, conv_enhanced out), B=128") or \
+       block("conv_head", "conv_stream_kernel<0", 1, frames * (13440 + 13440) + 19 * 1024,
              "conv_stream_kernel<0, false> HEAD (upsampled planes in, 4 convs, conv_enhanced out), B=128") or \
        block("conv_head", "conv_stack_kernel", 2, frames * 13632 + 187 * 1024, "conv_stack_kernel<false,true> HEAD (pilot split + Linear 24->1680 + 4 convs), B=128")
-tail = block("conv_tail", "conv_stream_kernel<1", 1, frames * (13440 + 17920 + 13440) + 19 * 1024,
+tail = block("conv_tail", "conv_stream16_kernel<1", 1, frames * (13440 + 17920 + 13440) + 23 * 1024,
+             "conv_stream16_kernel<1> TAIL (fold + residual + 4 convs + complex store), B=128") or \
+       block("conv_tail", "conv_stream_kernel<1", 1, frames * (13440 + 17920 + 13440) + 19 * 1024,
              "conv_stream_kernel<1, false> TAIL (fold + residual + 4 convs + complex store), B=128") or \
        block("conv_tail", "conv_stack_kernel", 2, frames * (13440 + 17920 + 13440) + 19 * 1024, "conv_stack_kernel<false,true> TAIL (fold + residual + 4 convs + complex store), B=128")
-prol = block("prologue", "prologue_kernel", 0, 3 * 128 * 4 + 128 * 192 + 2 * 3_145_728 + 168_000 + 128 * (13440 + 6720),
-             "prologue_kernel: channel adapter + weight re-lay (3 MB in, 3 MB out) + pilot_upsampler product over all planes, B=128")
+prol = block("prologue", "prologue_kernel", 0, 3 * 128 * 4 + 128 * 192 + 2 * 3_145_728 + 168_000 + 128 * (13440 + 6720) + 2 * 23 * 1024 + 2 * 19 * 1024,
+             "prologue_kernel: channel adapter + weight re-lay (3 MB in, 3 MB out) + pilot_upsampler product over all planes + conv operand fragments, B=128")
 if prol:
     out["prologue"] = prol
 if head:
