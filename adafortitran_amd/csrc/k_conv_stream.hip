@@ -512,15 +512,30 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 // have published conv1's first two columns -- no transposed LDS staging, no gather, no workgroup barrier before the sweeps (the
 // 32x32 kernel: 1 950 + 5 300 + 1 050 cycles before its first MFMA).  The helper waves run conv1 of ALL columns (one LDS flag per
 // helper wave and column), in the shadow of the first sweeps.
+// Column ranges (NSPLIT = 2, 4).  With fewer planes than half the CUs (batches of 64 frames and fewer -- the reference's default
+// batch is 64, parser.py:81) a plane is worked by NSPLIT workgroups, each producing the output columns [ta, tb) of its range.  What a
+// range needs of the earlier stages reaches one column further per stage -- conv3 [ta-1, tb+1), conv2 [ta-2, tb+2), conv1
+// [ta-3, tb+3), input [ta-4, tb+4), clipped to the grid -- and is RECOMPUTED, not exchanged (7 output columns cost 9 conv2 and 8
+// conv3 sweeps: 0.6 of a whole plane).  The LDS planes keep their whole-grid layout and absolute column numbers; the loops run over
+// the range, the hand-over counters stay absolute.  Every output element goes through the same instruction sequence whatever the
+// split, so a batch of 16 frames (four ranges per plane) reproduces the same frames inside a batch of 128 bit for bit.
 // =====================================================================================================================================
-template <int MODE>
+template <int MODE, int NSPLIT = 1>
 __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *in0 = smem + kIn0, *c1 = smem + kC1, *c3 = smem + kC3;
     // flags [0..3]: conv3 columns published by matrix wave w; [4], [5]: helper-only counters; [8..11]: conv1 columns published by helper wave
     volatile lds_int *flags = (volatile lds_int *)(smem + kFlags);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x, frame = n >> 1, part = n & 1;
+    const int n = NSPLIT == 1 ? blockIdx.x : blockIdx.x / NSPLIT, frame = n >> 1, part = n & 1;
+    // this workgroup's output columns [ta, tb) and what it computes of each earlier stage (compile-time constants for NSPLIT = 1)
+    const int range = NSPLIT == 1 ? 0 : blockIdx.x - n * NSPLIT;
+    const int ta = NSPLIT == 1 ? 0 : (NSPLIT == 2 ? 7 * range : (range < 2 ? 4 * range : 8 + 3 * (range - 2)));
+    const int tb = NSPLIT == 1 ? T : (NSPLIT == 2 ? ta + 7 : (range < 2 ? ta + 4 : ta + 3));
+    const int c2lo = max(ta - 2, 0), c2hi = min(tb + 2, T);      // conv2 columns swept
+    const int c1lo = max(ta - 3, 0), c1hi = min(tb + 3, T);      // conv1 columns computed
+    const int inlo = max(ta - 4, 0), inhi = min(tb + 4, T);      // input columns fetched
+    const int c3first = c2lo == 0 ? 0 : c2lo + 1;                // first conv3 column with all three kx taps inside the sweep (= ta - 1)
     const bool matrix = wave < 4;
 #ifdef AFT_DIAG_STAMPS
 #define SSTAMP(i) do { if (a.stamps && (tid == 0 || tid == 256)) a.stamps[(size_t)blockIdx.x * 16 + (tid ? 8 : 0) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         for (int u = 0; u < 7; ++u) {
             const int i = tid - 256 + 256 * u;
             vin[u] = 0.f;
-            if (i < S * T) {
+            if (i < S * T && (NSPLIT == 1 || (i % T >= inlo && i % T < inhi))) {
                 if (MODE == 0) {
                     vin[u] = a.in_plane[(size_t)n * (S * T) + i];
                 } else {   // inverse patch map + conv_enhanced residual: feature f of token (g, tc) is pixel (g*p0 + f/p1, tc*p1 + f%p1)
@@ -640,11 +655,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-#ifdef AFT_T_NORELU
-                    for (int v = 0; v < 4; ++v) x2[pt][mt][v] = acc2[pt][mt][v];
-#else
                     for (int v = 0; v < 4; ++v) x2[pt][mt][v] = __builtin_amdgcn_fmed3f(acc2[pt][mt][v], 0.f, relu_hi[pt]);
-#endif
         };
         // conv2 MFMA u (0..11) of group gi = (kx, ci half): ky = u / 4, pixel tile (u / 2) % 2, channel tile u % 2
         auto conv2_step = [&](int gi, int u) {
@@ -667,20 +678,16 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         };
         // conv3's output column `tout` from six finished registers (ky, co half) of both pixel tiles
         auto store_col = [&](int tout, const float (&Y)[2][6]) {
-            if (tout < 0) return;          // (wave-uniform: a scalar branch)
+            if (tout < c3first) return;    // (wave-uniform: a scalar branch) columns before the sweep's first complete one
             float *p0 = dst[0], *p1 = dst[1];
 #pragma unroll
             for (int cohi = 0; cohi < 2; ++cohi) {
                 // row j = 2p (pt 0): ky = 0 from row j - 1 = (pt 1, lane p - 1), ky = 2 from row j + 1 = (pt 1, lane p)
                 // row j = 2p + 1 (pt 1): ky = 0 from (pt 0, lane p), ky = 2 from (pt 0, lane p + 1)
-#ifdef AFT_T_NOOUT
-                float o0 = Y[0][2 + cohi] + Y[1][cohi], o1 = Y[1][2 + cohi] + Y[0][4 + cohi];
-#else
                 float o0 = Y[0][2 + cohi] + row16_from_below(Y[1][cohi]) + Y[1][4 + cohi];
                 float o1 = Y[1][2 + cohi] + Y[0][cohi] + row16_from_above(Y[0][4 + cohi]);
                 o0 = fmaxf(o0, 0.f);       // (the bias rode in as the accumulator's initial value)
                 o1 = fmaxf(o1, 0.f);
-#endif
                 p0[4 * cohi * kPlane + (tout + 1) * SP] = o0;
                 p1[4 * cohi * kPlane + (tout + 1) * SP] = o1;
             }
@@ -696,22 +703,22 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             }
         };
         SSTAMP(2);
-        need_c1(2);
+        need_c1(min(c2lo + 2, T));
 #pragma unroll
-        for (int gi = 0; gi < 6; ++gi) load_b(gi >> 1, gi & 1, 0);
+        for (int gi = 0; gi < 6; ++gi) load_b(gi >> 1, gi & 1, c2lo);
         SSTAMP(3);
-        // prologue: conv2 of column 0 (conv1's third column is only needed behind the first group: the sweeps start a column earlier)
+        // prologue: conv2 of the first column (conv1's third column is only needed behind the first group: the sweeps start a column earlier)
 #pragma unroll
         for (int gi = 0; gi < 6; ++gi) {
 #pragma unroll
             for (int u = 0; u < 12; ++u) conv2_step(gi, u);
-            if (gi == 0) need_c1(3);
-            load_b(gi >> 1, gi & 1, 1);
+            if (gi == 0) need_c1(min(c2lo + 3, T));
+            load_b(gi >> 1, gi & 1, c2lo + 1);
         }
         relu2();
 #pragma unroll 1
-        for (int tcol = 0; tcol < T - 1; ++tcol) {
-            const int tnext = min(tcol + 2, T - 1);
+        for (int tcol = c2lo; tcol < c2hi - 1; ++tcol) {
+            const int tnext = min(tcol + 2, c2hi - 1);
             need_c1(min(tnext + 2, T));
             // 80 conv3 MFMAs of column tcol merged with the 72 conv2 MFMAs of column tcol + 1; the B operands of a conv2 group are
             // re-requested for column tcol + 2 right behind their last use (pinned: the compiler otherwise sinks all reads to the end
@@ -745,11 +752,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
 #pragma unroll
                 for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = n3[pt][rt];
         }
-        {   // output column T - 3, then conv3 of the last column: its kx = 2 registers are column T - 2, its kx = 1 registers column
-            // T - 1 (column T is zero padding)
+        {   // output column c2hi - 3, then conv3 of the last swept column: its kx = 2 registers are column c2hi - 2, its kx = 1 registers
+            // column c2hi - 1 -- complete only at the grid's edge (column T is zero padding), not needed inside it
             float Y[2][6], Z[2][6];
             finished(a3, Y);
-            store_col(T - 3, Y);
+            store_col(c2hi - 3, Y);
 #pragma unroll
             for (int m = 0; m < 80; ++m)
                 if (m % 10 < 6) conv3_step(m);     // tiles 2, 4, 1 only: tiles 0, 3 hold the kx = 0 registers = output column T (padding)
@@ -760,8 +767,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                 for (int v = 0; v < 4; ++v) Z[pt][v] = n3[pt][1][v];
                 Z[pt][4] = n3[pt][4][0]; Z[pt][5] = n3[pt][4][1];
             }
-            store_col(T - 2, Y);
-            store_col(T - 1, Z);
+            store_col(c2hi - 2, Y);
+            if (NSPLIT == 1 || c2hi == T) store_col(T - 1, Z);
         }
     } else {
         // ---- helper waves: input plane, borders, conv1 of all columns (published column by column), conv4 behind the matrix waves ----
@@ -825,16 +832,18 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                 win[0][2] = in0[(t + 2) * SP + r0];
                 win[1][2] = in0[(t + 2) * SP + lr];
                 win[2][2] = in0[(t + 2) * SP + r2];
+                if (NSPLIT == 1 || (t >= c1lo && t < c1hi)) {      // (wave-uniform) the window slides over every column, the work is the range's
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    f32x2 acc2 = b[k];
+                    for (int k = 0; k < 2; ++k) {
+                        f32x2 acc2 = b[k];
 #pragma unroll
-                    for (int k9 = 0; k9 < 9; ++k9) {
-                        const float x = win[k9 / 3][k9 % 3];
-                        acc2 = __builtin_elementwise_fma(f32x2{x, x}, w[k][k9], acc2);     // per channel: the same fma chain in tap order
+                        for (int k9 = 0; k9 < 9; ++k9) {
+                            const float x = win[k9 / 3][k9 % 3];
+                            acc2 = __builtin_elementwise_fma(f32x2{x, x}, w[k][k9], acc2);     // per channel: the same fma chain in tap order
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) dst[(2 * k + q) * kPlane + t * SP] = ok ? fmaxf(acc2[q], 0.f) : 0.f;
                     }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) dst[(2 * k + q) * kPlane + t * SP] = ok ? fmaxf(acc2[q], 0.f) : 0.f;
                 }
                 asm volatile("" ::: "memory");
                 if (lane == 0) flags[8 + hw] = t + 1;     // LDS order: the column's stores are done when a reader sees the count
@@ -896,19 +905,23 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                 win[c][2][2] = pc[r2];
             }
         };
-        // window before the loop: kx = 1 <- LDS column 0 (zero border), kx = 2 <- LDS column 1 (symbol 0)
-        need(1);
-        load_col(0);
+        // window before the first output column ta: kx = 1 <- LDS column ta (symbol ta - 1; the zero border for ta = 0), kx = 2 <- symbol ta
+        auto start_window = [&](int t0) {
+            need(t0 + 1);
+            load_col(t0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) win[c][ky][1] = win[c][ky][2];
-        load_col(1);
-#ifdef AFT_T_NOCONV4
-        need(T);
-#else
+                for (int ky = 0; ky < 3; ++ky) win[c][ky][1] = win[c][ky][2];
+            load_col(t0 + 1);
+        };
+        if (NSPLIT == 1) start_window(0);
 #pragma unroll
         for (int t = 0; t < T; ++t) {        // fully unrolled: the window slides by renaming, no register moves
+            if (NSPLIT != 1) {               // (wave-uniform) this range's columns only
+                if (t < ta || t >= tb) continue;
+                if (t == ta) start_window(t);
+            }
             need(t + 2 < T ? t + 2 : T);     // symbol t + 1 (LDS column t + 2; the last one is the zero border)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -927,7 +940,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             acc += other_half32(acc);
             if (h == 0 && okrow) obuf[(lr - 4) * T + t] = acc + b4;
         }
-#endif
     }
     SSTAMP(4);
     __syncthreads();
@@ -935,7 +947,14 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
     // ---- the output plane leaves in one coalesced pass ----
     {
         const float *obuf = in0;
-        if (MODE == 0) {
+        if (NSPLIT != 1) {   // this range's columns of the plane
+            const int wc = tb - ta;
+            for (int i = tid; i < S * wc; i += kConvThreads) {
+                const int e = (i / wc) * T + ta + i % wc;
+                if (MODE == 0) a.out_plane[(size_t)n * (S * T) + e] = obuf[e];
+                else a.out_complex[((size_t)frame * (S * T) + e) * 2 + part] = obuf[e];
+            }
+        } else if (MODE == 0) {
             f32x4 *dstp = reinterpret_cast<f32x4 *>(a.out_plane + (size_t)n * (S * T));
             const f32x4 *src4 = reinterpret_cast<const f32x4 *>(obuf);
             for (int i = tid; i < S * T / 4; i += kConvThreads) dstp[i] = src4[i];
@@ -966,11 +985,23 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     }
     // the 16x16x4 kernel needs the fragment image of the forward's prologue launch; AFT_CONV_MFMA32=1 keeps the 32x32x2 kernel (A/B runs)
     const bool m16 = a.wfrag != nullptr && getenv("AFT_CONV_MFMA32") == nullptr;
-    static PerDeviceOnce lds_head16, lds_tail16;
     hipError_t e;
+    // column ranges when the planes would leave half (three quarters) of the CUs idle; AFT_CONV_NSPLIT=1|2|4 forces a split (tests, A/B)
+    int nsplit = 1;
+    if (m16) {
+        const int cus = current_device_cus();
+        nsplit = 4 * planes <= cus ? 4 : (2 * planes <= cus ? 2 : 1);
+        if (const char *f = getenv("AFT_CONV_NSPLIT")) nsplit = atoi(f) == 4 ? 4 : (atoi(f) == 2 ? 2 : 1);
+    }
+    const void *fn16 = a.mode == 0 ? (nsplit == 4 ? reinterpret_cast<const void *>(conv_stream16_kernel<0, 4>)
+                                                  : nsplit == 2 ? reinterpret_cast<const void *>(conv_stream16_kernel<0, 2>)
+                                                                : reinterpret_cast<const void *>(conv_stream16_kernel<0, 1>))
+                                   : (nsplit == 4 ? reinterpret_cast<const void *>(conv_stream16_kernel<1, 4>)
+                                                  : nsplit == 2 ? reinterpret_cast<const void *>(conv_stream16_kernel<1, 2>)
+                                                                : reinterpret_cast<const void *>(conv_stream16_kernel<1, 1>));
+    static PerDeviceOnce lds16[6];
     if (m16)
-        e = a.mode == 0 ? ensure_dynamic_lds(lds_head16, reinterpret_cast<const void *>(conv_stream16_kernel<0>), kStreamLds)
-                        : ensure_dynamic_lds(lds_tail16, reinterpret_cast<const void *>(conv_stream16_kernel<1>), kStreamLds);
+        e = ensure_dynamic_lds(lds16[(a.mode == 0 ? 0 : 3) + (nsplit == 4 ? 2 : nsplit == 2 ? 1 : 0)], fn16, kStreamLds);
     else
         e = a.mode == 0 ? ensure_dynamic_lds(lds_head, reinterpret_cast<const void *>(conv_stream_kernel<0>), kStreamLds)
                         : ensure_dynamic_lds(lds_tail, reinterpret_cast<const void *>(conv_stream_kernel<1>), kStreamLds);
@@ -985,8 +1016,16 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     }
 #endif
     if (m16) {
-        if (a.mode == 0) hipLaunchKernelGGL((conv_stream16_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
-        else hipLaunchKernelGGL((conv_stream16_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+        const dim3 grid(planes * nsplit), block(kConvThreads);
+        if (a.mode == 0) {
+            if (nsplit == 4) hipLaunchKernelGGL((conv_stream16_kernel<0, 4>), grid, block, kStreamLds, st, a);
+            else if (nsplit == 2) hipLaunchKernelGGL((conv_stream16_kernel<0, 2>), grid, block, kStreamLds, st, a);
+            else hipLaunchKernelGGL((conv_stream16_kernel<0, 1>), grid, block, kStreamLds, st, a);
+        } else {
+            if (nsplit == 4) hipLaunchKernelGGL((conv_stream16_kernel<1, 4>), grid, block, kStreamLds, st, a);
+            else if (nsplit == 2) hipLaunchKernelGGL((conv_stream16_kernel<1, 2>), grid, block, kStreamLds, st, a);
+            else hipLaunchKernelGGL((conv_stream16_kernel<1, 1>), grid, block, kStreamLds, st, a);
+        }
     } else if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
     else hipLaunchKernelGGL((conv_stream_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
 #ifdef AFT_DIAG_STAMPS

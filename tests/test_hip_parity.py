@@ -163,6 +163,31 @@ def _poison_allocator(value):
     del blocks
 
 
+@pytest.mark.parametrize("batch", [3, 40, 64])
+def test_conv_stream_column_ranges_reproduce_whole_planes(monkeypatch, batch):
+    """Small batches split every plane of the default grid into 2 or 4 column ranges (k_conv_stream.hip, NSPLIT): the ranges recompute
+    what they need of their neighbours' columns and every output element goes through the same instruction sequence, so the forward's
+    conv_enhanced and output carry the same BITS whatever the split -- and match the oracle."""
+    hid = (7, 42, 560)
+    sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=91, head_gain=2.0)
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(batch, seed=92)
+    pil, meta = _t(inp["pilots"]), [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    outs = {}
+    for ns in ("1", "2", "4"):
+        monkeypatch.setenv("AFT_CONV_NSPLIT", ns)
+        outs[ns] = (eng.forward(pil, *meta).clone(), eng.forward_region("conv_enhanced", batch))
+    monkeypatch.delenv("AFT_CONV_NSPLIT")
+    auto = eng.forward(pil, *meta).clone()
+    for ns in ("2", "4"):
+        assert torch.equal(outs[ns][1], outs["1"][1]), f"conv_enhanced differs at NSPLIT={ns}"
+        assert torch.equal(torch.view_as_real(outs[ns][0]), torch.view_as_real(outs["1"][0])), f"output differs at NSPLIT={ns}"
+    assert torch.equal(torch.view_as_real(auto), torch.view_as_real(outs["1"][0]))
+    assert torch.isfinite(torch.view_as_real(auto)).all()
+
+
 def test_conv_stream_hand_over_soak():
     """The column-streaming conv kernel hands conv1 / conv3 columns between its waves through LDS flags (k_conv_stream.hip); a lost
     hand-over would be a one-in-many-launches event.  600 forwards of the benchmark batch, EVERY output compared on the device with
