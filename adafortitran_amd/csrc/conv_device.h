@@ -28,6 +28,7 @@ struct ConvArgs {
     float *save[3];          // outputs of conv1 / conv2 / conv3 after their activation, [planes][C][T][S] (C = 8, 32, 8)
     const float *mask[3];    // backward: activation of stage k = acc where mask[k] > 0 else 0 (instead of bias + ReLU)
     unsigned long long *stamps;   // diagnostic build only (AFT_DIAG_STAMPS): per-workgroup s_memtime at the phase boundaries
+    int plane0;                   // conv_stream16_kernel: first plane of this launch (a forward may launch its planes in two parts)
     const float *wfrag;           // conv_stream16_kernel: this stack's conv2 / conv3 weights as 16x16x4 operand fragments (conv_frag16_entry)
 };
 

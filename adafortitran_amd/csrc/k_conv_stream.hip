@@ -527,9 +527,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
     // flags [0..3]: conv3 columns published by matrix wave w; [4], [5]: helper-only counters; [8..11]: conv1 columns published by helper wave
     volatile lds_int *flags = (volatile lds_int *)(smem + kFlags);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int n = NSPLIT == 1 ? blockIdx.x : blockIdx.x / NSPLIT, frame = n >> 1, part = n & 1;
+    const int n = a.plane0 + (NSPLIT == 1 ? blockIdx.x : blockIdx.x / NSPLIT), frame = n >> 1, part = n & 1;
     // this workgroup's output columns [ta, tb) and what it computes of each earlier stage (compile-time constants for NSPLIT = 1)
-    const int range = NSPLIT == 1 ? 0 : blockIdx.x - n * NSPLIT;
+    const int range = NSPLIT == 1 ? 0 : blockIdx.x % NSPLIT;
     const int ta = NSPLIT == 1 ? 0 : (NSPLIT == 2 ? 7 * range : (range < 2 ? 4 * range : 8 + 3 * (range - 2)));
     const int tb = NSPLIT == 1 ? T : (NSPLIT == 2 ? ta + 7 : (range < 2 ? ta + 4 : ta + 3));
     const int c2lo = max(ta - 2, 0), c2hi = min(tb + 2, T);      // conv2 columns swept
@@ -1016,16 +1016,38 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     }
 #endif
     if (m16) {
-        const dim3 grid(planes * nsplit), block(kConvThreads);
-        if (a.mode == 0) {
-            if (nsplit == 4) hipLaunchKernelGGL((conv_stream16_kernel<0, 4>), grid, block, kStreamLds, st, a);
-            else if (nsplit == 2) hipLaunchKernelGGL((conv_stream16_kernel<0, 2>), grid, block, kStreamLds, st, a);
-            else hipLaunchKernelGGL((conv_stream16_kernel<0, 1>), grid, block, kStreamLds, st, a);
+        auto go = [&](int ns, int first, int count) {
+            a.plane0 = first;
+            const dim3 grid(count * ns), block(kConvThreads);
+            if (a.mode == 0) {
+                if (ns == 4) hipLaunchKernelGGL((conv_stream16_kernel<0, 4>), grid, block, kStreamLds, st, a);
+                else if (ns == 2) hipLaunchKernelGGL((conv_stream16_kernel<0, 2>), grid, block, kStreamLds, st, a);
+                else hipLaunchKernelGGL((conv_stream16_kernel<0, 1>), grid, block, kStreamLds, st, a);
+            } else {
+                if (ns == 4) hipLaunchKernelGGL((conv_stream16_kernel<1, 4>), grid, block, kStreamLds, st, a);
+                else if (ns == 2) hipLaunchKernelGGL((conv_stream16_kernel<1, 2>), grid, block, kStreamLds, st, a);
+                else hipLaunchKernelGGL((conv_stream16_kernel<1, 1>), grid, block, kStreamLds, st, a);
+            }
+        };
+        // One plane per CU (the LDS): planes beyond a whole number of rounds would cost a full round for a few workgroups (258 planes
+        // on 256 CUs: the 128 -> 129 frames step).  When that remainder fits the chip as column ranges it is a second launch of
+        // ranges -- 0.42 (four ranges) or 0.62 (two) of a round instead of 1.0.  Same bits (ranges reproduce whole planes).
+        const int cus = current_device_cus();
+        const int rem = planes % cus, whole = planes - rem;
+        const bool forced = getenv("AFT_CONV_NSPLIT") != nullptr;
+        if (!forced && nsplit == 1 && whole > 0 && rem > 0 && 2 * rem <= cus) {
+            const int ns2 = 4 * rem <= cus ? 4 : 2;
+            hipError_t ea = ensure_dynamic_lds(lds16[(a.mode == 0 ? 0 : 3) + (ns2 == 4 ? 2 : 1)],
+                                               a.mode == 0 ? (ns2 == 4 ? reinterpret_cast<const void *>(conv_stream16_kernel<0, 4>) : reinterpret_cast<const void *>(conv_stream16_kernel<0, 2>))
+                                                           : (ns2 == 4 ? reinterpret_cast<const void *>(conv_stream16_kernel<1, 4>) : reinterpret_cast<const void *>(conv_stream16_kernel<1, 2>)),
+                                               kStreamLds);
+            if (ea != hipSuccess) return ea;
+            go(1, 0, whole);
+            go(ns2, whole, rem);
         } else {
-            if (nsplit == 4) hipLaunchKernelGGL((conv_stream16_kernel<1, 4>), grid, block, kStreamLds, st, a);
-            else if (nsplit == 2) hipLaunchKernelGGL((conv_stream16_kernel<1, 2>), grid, block, kStreamLds, st, a);
-            else hipLaunchKernelGGL((conv_stream16_kernel<1, 1>), grid, block, kStreamLds, st, a);
+            go(nsplit, 0, planes);
         }
+        a.plane0 = 0;
     } else if (a.mode == 0) hipLaunchKernelGGL((conv_stream_kernel<0>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
     else hipLaunchKernelGGL((conv_stream_kernel<1>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
 #ifdef AFT_DIAG_STAMPS

@@ -163,11 +163,12 @@ def _poison_allocator(value):
     del blocks
 
 
-@pytest.mark.parametrize("batch", [3, 40, 64])
+@pytest.mark.parametrize("batch", [3, 40, 64, 130, 170])
 def test_conv_stream_column_ranges_reproduce_whole_planes(monkeypatch, batch):
-    """Small batches split every plane of the default grid into 2 or 4 column ranges (k_conv_stream.hip, NSPLIT): the ranges recompute
-    what they need of their neighbours' columns and every output element goes through the same instruction sequence, so the forward's
-    conv_enhanced and output carry the same BITS whatever the split -- and match the oracle."""
+    """Small batches split every plane of the default grid into 2 or 4 column ranges (k_conv_stream.hip, NSPLIT), and the planes
+    beyond a whole number of one-plane-per-CU rounds (130 frames = 260 planes: 4; 170 frames: 84) run as a second launch of ranges:
+    the ranges recompute what they need of their neighbours' columns and every output element goes through the same instruction
+    sequence, so the forward's conv_enhanced and output carry the same BITS whatever the split."""
     hid = (7, 42, 560)
     sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=91, head_gain=2.0)
     cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
