@@ -26,6 +26,15 @@
 
 #include "conv_device.h"
 
+// The wave-to-wave hand-overs of both kernels in this file publish a column count with a plain LDS store behind the column's data
+// stores and NO release fence (a fence would drain the publishing wave's pending operand reads and stall its MFMA chain once per
+// column): correct because gfx950's LDS serves one wave's requests in issue order, so a reader that sees the count finds the data.
+// That is a property of this target, not of the memory model -- refuse to build for anything else; the every-output
+// comparison that guards it is tests/test_hip_parity.py::test_conv_stream_hand_over_soak.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_conv_stream.hip relies on gfx950's in-order LDS service for its flag hand-overs"
+#endif
+
 namespace aft {
 
 namespace {

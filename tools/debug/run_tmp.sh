@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r5; L=gpurun_out/r5/t11.log; : > $L
-python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "column_ranges or golden or full_size or chunks" 2>&1 | tail -5 >> $L
-for b in 129 160; do for ns in 1 0; do if [ $ns = 1 ]; then export AFT_CONV_NSPLIT=1; else unset AFT_CONV_NSPLIT; fi; echo "B=$b forced_nsplit1=$ns" >> $L; AFT_BATCH=$b python tools/time_kernels.py upsample tail 2>&1 | grep -v amdgpu >> $L; done; done
+mkdir -p gpurun_out/r5; L=gpurun_out/r5/full2.log; : > $L
+python -m pytest tests -x -q -m gpu 2>&1 | tail -6 >> $L
+python bench.py --verbose-json gpurun_out/r5/bench_verbose2.json > gpurun_out/r5/bench2.json 2> gpurun_out/r5/bench2.err; tail -c 400 gpurun_out/r5/bench2.err >> $L
 cat $L
