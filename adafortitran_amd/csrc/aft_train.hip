@@ -94,16 +94,15 @@ int check_train(const aft_config *cfg, int batch, float dropout_p) {
         set_error("bad batch %d or dropout %g", batch, (double)dropout_p);
         return AFT_ERR_ARG;
     }
-    // head dim 32 is the kernels' own shape, 16 runs as zero-padded 32-feature heads (k_attn_train.hip); head dim 64 -- two 32-feature
-    // blocks under one softmax -- has no training attention kernel yet: such a model's encoder is differentiated by PyTorch-ROCm
-    // autograd (blocks.py logs it), the inference path covers it
+    // head dim 32 is the kernels' own shape, 16 runs as zero-padded 32-feature heads, 64 as two 32-feature blocks under one softmax
+    // (forward + the two-pass backward instantiated for two blocks: k_attn_train.hip)
     if (cfg->model_dim % 64 != 0) {
         set_error("the row-wise training kernels are instantiated for model_dim 64, 128, 192 and 256 (got %d)", cfg->model_dim);
         return AFT_ERR_SHAPE;
     }
     const int hd = cfg->model_dim / cfg->num_head;
-    if (hd != kHeadDim && hd != 16) {
-        set_error("the training attention kernels cover head dims 32 and 16 (model_dim=%d, num_head=%d)", cfg->model_dim, cfg->num_head);
+    if (hd != kHeadDim && hd != 16 && hd != 64) {
+        set_error("the training attention kernels cover head dims 16, 32 and 64 (model_dim=%d, num_head=%d)", cfg->model_dim, cfg->num_head);
         return AFT_ERR_SHAPE;
     }
     if ((size_t)2 * batch * tokens_of_cfg(*cfg) * 3 * cfg->model_dim >= ((size_t)1 << 32)) {

@@ -224,39 +224,53 @@ __device__ __forceinline__ void lds_rowwords(const uint32_t *__restrict__ s, int
 }
 
 // ---- forward: own = query tile, walks the key tiles (staged: K, V) ----
-__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_train_fwd_kernel(const AttnTrainArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
-    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] column (key) words of the dropout mask
+// NB = 32-feature blocks per head: 1 (head dim 32, the tuned shape; head dim 16 runs here as zero-padded heads) or 2 (head dim 64,
+// round 5: S sums both blocks' products, O is one accumulator per block; covered, not tuned).
+template <int NB>
+__device__ __forceinline__ void attn_train_fwd_body(const AttnTrainArgs &a, float (*lds)[NB * kAtBufFloats], uint32_t *words) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
     const int ph = blockIdx.x / groups, qt = (blockIdx.x % groups) * kAtWaves + wave;
     const int head = ph % a.heads, plane = ph / a.heads;
     const bool active = qt < a.ntiles;
     const int ld = 3 * a.d;
-    const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * 32;
+    const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * (32 * NB);
     const float *kb = qb + a.d, *vb = qb + 2 * a.d;
     const int query = qt * 32 + j;
 
-    float qf[16];
-    load_rowfrag(qb, ld, active ? query : 0, a.tokens, h, a.scale2, qf);
+    float qf[NB][16];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) load_rowfrag(qb + 32 * b, ld, active ? query : 0, a.tokens, h, a.scale2, qf[b]);
     float m = -__builtin_inff(), l = 0.f;
-    f32x16 o = zero16();
+    f32x16 o[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) o[b] = zero16();
     const uint32_t row_word = drop_row_word(a.seed, (uint32_t)ph * a.tokens + min(query, a.tokens - 1));
     if (a.threshold)
         for (int i = tid; i < a.ntiles * 32; i += kAtThreads) words[i] = drop_col_word(a.seed, (uint32_t)ph * a.tokens + i);
-    StageRegs sr;
-    const Stager sg = make_stager(kb, ld, vb, ld, nullptr, nullptr, a.tokens, tid);
-    stage_fetch(sr, sg, 0);
-    stage_store(sr, lds[0], tid);
+    StageRegs sr[NB];
+    Stager sg[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        sg[b] = make_stager(kb + 32 * b, ld, vb + 32 * b, ld, nullptr, nullptr, a.tokens, tid);
+        stage_fetch(sr[b], sg[b], 0);
+        stage_store(sr[b], lds[0] + b * kAtBufFloats, tid);
+    }
     __syncthreads();
     for (int kt = 0; kt < a.ntiles; ++kt) {
         const float *buf = lds[kt & 1];
-        if (kt + 1 < a.ntiles) stage_fetch(sr, sg, kt + 1);
+        if (kt + 1 < a.ntiles) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) stage_fetch(sr[b], sg[b], kt + 1);
+        }
         if (active) {
-            float kf[16], vt[16];
-            lds_rowfrag(buf, j, h, kf);
-            lds_colfrag(buf + kAtTileFloats, j, h, vt);
-            f32x16 s = mma16z(kf, qf);               // [row = key][col = query]
+            f32x16 s;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float kf[16];
+                lds_rowfrag(buf + b * kAtBufFloats, j, h, kf);
+                s = b == 0 ? mma16z(kf, qf[0]) : mma16(kf, qf[b], s);   // [row = key][col = query]
+            }
             if (kt == a.ntiles - 1) {                         // only the last key tile can be ragged
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -282,46 +296,74 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             l = l * alpha + sum;
             m = mn;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[e] *= alpha;
-            o = mma16(vt, p, o);                              // [row = feature][col = query]
+            for (int b = 0; b < NB; ++b) {
+                float vt[16];
+                lds_colfrag(buf + b * kAtBufFloats + kAtTileFloats, j, h, vt);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[b][e] *= alpha;
+                o[b] = mma16(vt, p, o[b]);                    // [row = feature][col = query]
+            }
         }
-        if (kt + 1 < a.ntiles) stage_store(sr, lds[(kt + 1) & 1], tid);
+        if (kt + 1 < a.ntiles) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) stage_store(sr[b], lds[(kt + 1) & 1] + b * kAtBufFloats, tid);
+        }
         __syncthreads();
     }
     if (!active) return;
     l += __shfl_xor(l, 32);
-    store_transposed(a.out + (size_t)plane * a.tokens * a.d + head * 32, a.d, query, a.tokens, h, o, a.keep_scale / l);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        store_transposed(a.out + (size_t)plane * a.tokens * a.d + head * (32 * NB) + 32 * b, a.d, query, a.tokens, h, o[b], a.keep_scale / l);
     if (h == 0 && query < a.tokens) a.lse[(size_t)ph * a.tokens + query] = m + log2f(l);
+}
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_train_fwd_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] column (key) words of the dropout mask
+    attn_train_fwd_body<1>(a, lds, words);
+}
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_train_fwd64_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2 * kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];
+    attn_train_fwd_body<2>(a, lds, words);
 }
 
 // ---- dK, dV: own = key tile, walks the query tiles (staged: Q, dO, lse, D) ----
-__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kv_kernel(const AttnTrainArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
-    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] row (query) words of the dropout mask
+template <int NB>
+__device__ __forceinline__ void attn_bwd_kv_body(const AttnTrainArgs &a, float (*lds)[NB * kAtBufFloats], uint32_t *words) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
     const int ph = blockIdx.x / groups, kt = (blockIdx.x % groups) * kAtWaves + wave;
     const int head = ph % a.heads, plane = ph / a.heads;
     const bool active = kt < a.ntiles;
     const int ld = 3 * a.d;
-    const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * 32;
+    const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * (32 * NB);
     const float *kb = qb + a.d, *vb = qb + 2 * a.d;
-    const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * 32;
+    const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * (32 * NB);
     const float *lse = a.lse + (size_t)ph * a.tokens, *dsum = a.dsum + (size_t)ph * a.tokens;
     const int key = kt * 32 + j;
     const int keyc = min(key, a.tokens - 1);
 
-    float kf[16], vf[16];
-    load_rowfrag(kb, ld, active ? key : 0, a.tokens, h, a.scale2, kf);   // B operands: lane <-> key
-    load_rowfrag(vb, ld, active ? key : 0, a.tokens, h, 1.f, vf);
-    f32x16 dv = zero16(), dk = zero16();
+    float kf[NB][16], vf[NB][16];
+    f32x16 dv[NB], dk[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        load_rowfrag(kb + 32 * b, ld, active ? key : 0, a.tokens, h, a.scale2, kf[b]);   // B operands: lane <-> key
+        load_rowfrag(vb + 32 * b, ld, active ? key : 0, a.tokens, h, 1.f, vf[b]);
+        dv[b] = zero16();
+        dk[b] = zero16();
+    }
     const uint32_t col_word = drop_col_word(a.seed, (uint32_t)ph * a.tokens + keyc);
     if (a.threshold)
         for (int i = tid; i < a.ntiles * 32; i += kAtThreads) words[i] = drop_row_word(a.seed, (uint32_t)ph * a.tokens + min(i, a.tokens - 1));
     StageRegs sr;
-    const Stager sg = make_stager(qb, ld, dob, a.d, lse, dsum, a.tokens, tid);
-    stage_fetch(sr, sg, 0);
-    stage_store(sr, lds[0], tid);
+    Stager sg[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        sg[b] = make_stager(qb + 32 * b, ld, dob + 32 * b, a.d, lse, dsum, a.tokens, tid);
+        stage_fetch(sr, sg[b], 0);
+        stage_store(sr, lds[0] + b * kAtBufFloats, tid);
+    }
     __syncthreads();
     for (int qt = 0; qt < a.ntiles; ++qt) {
         const float *buf = lds[qt & 1];
@@ -329,15 +371,17 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
             // operands are read from LDS right before their product so that at most two 16-register
             // fragments are live next to the accumulators (3 waves per SIMD need <= 168 VGPRs)
             f32x16 s, dp;
-            {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
                 float qf[16];
-                lds_rowfrag(buf, j, h, qf);                                // A operand: lane <-> query
-                s = mma16z(qf, kf);                               // [row = query][col = key]
+                lds_rowfrag(buf + b * kAtBufFloats, j, h, qf);                       // A operand: lane <-> query
+                s = b == 0 ? mma16z(qf, kf[0]) : mma16(qf, kf[b], s);                // [row = query][col = key]
             }
-            {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
                 float dof[16];
-                lds_rowfrag(buf + kAtTileFloats, j, h, dof);
-                dp = mma16z(dof, vf);
+                lds_rowfrag(buf + b * kAtBufFloats + kAtTileFloats, j, h, dof);
+                dp = b == 0 ? mma16z(dof, vf[0]) : mma16(dof, vf[b], dp);
             }
             // No range masks: query rows beyond the plane were staged as zeros (Q, dO rows = 0, lse = D = 0), so
             // whatever finite p / ds they get meets a zero A-operand column; key lanes beyond it are never stored.
@@ -360,73 +404,107 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ds[r] = fmaf(pd[r] * dp[r], a.keep_scale, -ds[r]);   // P o (dP o mask/(1-p) - D)
             }
-            float qT[16], doT[16];
-            lds_colfrag(buf + kAtTileFloats, j, h, doT);                   // A operands: lane <-> feature
-            dv = mma16(doT, pd, dv);                                       // [row = feature][col = key]
-            lds_colfrag(buf, j, h, qT);
-            dk = mma16(qT, ds, dk);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float qT[16], doT[16];
+                lds_colfrag(buf + b * kAtBufFloats + kAtTileFloats, j, h, doT);          // A operands: lane <-> feature
+                dv[b] = mma16(doT, pd, dv[b]);                                       // [row = feature][col = key]
+                lds_colfrag(buf + b * kAtBufFloats, j, h, qT);
+                dk[b] = mma16(qT, ds, dk[b]);
+            }
         }
         if (qt + 1 < a.ntiles) {   // fetched after the products: the 18 staging registers are not live across them
-            stage_fetch(sr, sg, qt + 1);
-            stage_store(sr, lds[(qt + 1) & 1], tid);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                stage_fetch(sr, sg[b], qt + 1);
+                stage_store(sr, lds[(qt + 1) & 1] + b * kAtBufFloats, tid);
+            }
         }
         __syncthreads();
     }
     if (!active) return;
-    float *dst = a.out + (size_t)plane * a.tokens * ld + head * 32;
-    store_transposed(dst + a.d, ld, key, a.tokens, h, dk, a.scale);
-    store_transposed(dst + 2 * a.d, ld, key, a.tokens, h, dv, a.keep_scale);
+    float *dst = a.out + (size_t)plane * a.tokens * ld + head * (32 * NB);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        store_transposed(dst + a.d + 32 * b, ld, key, a.tokens, h, dk[b], a.scale);
+        store_transposed(dst + 2 * a.d + 32 * b, ld, key, a.tokens, h, dv[b], a.keep_scale);
+    }
+}
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kv_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] row (query) words of the dropout mask
+    attn_bwd_kv_body<1>(a, lds, words);
+}
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_kv64_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2 * kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];
+    attn_bwd_kv_body<2>(a, lds, words);
 }
 
 // ---- dQ: own = query tile, walks the key tiles (staged: K, V) ----
-__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_q_kernel(const AttnTrainArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
-    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] column (key) words of the dropout mask
+template <int NB>
+__device__ __forceinline__ void attn_bwd_q_body(const AttnTrainArgs &a, float (*lds)[NB * kAtBufFloats], uint32_t *words) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int groups = (a.ntiles + kAtWaves - 1) / kAtWaves;
     const int ph = blockIdx.x / groups, qt = (blockIdx.x % groups) * kAtWaves + wave;
     const int head = ph % a.heads, plane = ph / a.heads;
     const bool active = qt < a.ntiles;
     const int ld = 3 * a.d;
-    const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * 32;
+    const float *qb = a.qkv + (size_t)plane * a.tokens * ld + head * (32 * NB);
     const float *kb = qb + a.d, *vb = qb + 2 * a.d;
-    const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * 32;
+    const float *dob = a.d_o + (size_t)plane * a.tokens * a.d + head * (32 * NB);
     const int query = qt * 32 + j, qc = min(query, a.tokens - 1);
     const float lse = a.lse[(size_t)ph * a.tokens + qc];
     const uint32_t row_word = drop_row_word(a.seed, (uint32_t)ph * a.tokens + qc);
     if (a.threshold)
         for (int i = tid; i < a.ntiles * 32; i += kAtThreads) words[i] = drop_col_word(a.seed, (uint32_t)ph * a.tokens + i);
 
-    float qf[16], dof[16];
-    load_rowfrag(qb, ld, active ? query : 0, a.tokens, h, a.scale2, qf);   // B operands: lane <-> query
-    load_rowfrag(dob, a.d, active ? query : 0, a.tokens, h, 1.f, dof);
-    // D_i = dO_i . O_i of this lane's query (the two lane halves hold 16 features each); also left in a.dsum for the
+    float qf[NB][16], dof[NB][16];
+    // D_i = dO_i . O_i of this lane's query (the two lane halves hold 16 features of each block); also left in a.dsum for the
     // dK / dV pass, which runs after this one (this used to be a kernel of its own: 18 us of pure traffic per layer)
     float dsum;
     {
-        float of[16];
-        load_rowfrag(a.o + (size_t)plane * a.tokens * a.d + head * 32, a.d, active ? query : 0, a.tokens, h, 1.f, of);
         float part = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) part = fmaf(dof[e], of[e], part);
+        for (int b = 0; b < NB; ++b) {
+            load_rowfrag(qb + 32 * b, ld, active ? query : 0, a.tokens, h, a.scale2, qf[b]);   // B operands: lane <-> query
+            load_rowfrag(dob + 32 * b, a.d, active ? query : 0, a.tokens, h, 1.f, dof[b]);
+            float of[16];
+            load_rowfrag(a.o + (size_t)plane * a.tokens * a.d + head * (32 * NB) + 32 * b, a.d, active ? query : 0, a.tokens, h, 1.f, of);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part = fmaf(dof[b][e], of[e], part);
+        }
         dsum = part + __shfl_xor(part, 32);
         if (active && h == 0 && query < a.tokens) a.dsum[(size_t)ph * a.tokens + query] = dsum;
     }
-    f32x16 dq = zero16();
-    StageRegs sr;
-    const Stager sg = make_stager(kb, ld, vb, ld, nullptr, nullptr, a.tokens, tid);
-    stage_fetch(sr, sg, 0);
-    stage_store(sr, lds[0], tid);
+    f32x16 dq[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) dq[b] = zero16();
+    StageRegs sr[NB];
+    Stager sg[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        sg[b] = make_stager(kb + 32 * b, ld, vb + 32 * b, ld, nullptr, nullptr, a.tokens, tid);
+        stage_fetch(sr[b], sg[b], 0);
+        stage_store(sr[b], lds[0] + b * kAtBufFloats, tid);
+    }
     __syncthreads();
     for (int kt = 0; kt < a.ntiles; ++kt) {
         const float *buf = lds[kt & 1];
-        if (kt + 1 < a.ntiles) stage_fetch(sr, sg, kt + 1);
+        if (kt + 1 < a.ntiles) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) stage_fetch(sr[b], sg[b], kt + 1);
+        }
         if (active) {
-            float kf[16], vf[16];
-            lds_rowfrag(buf, j, h, kf);                                    // A operands: lane <-> key
-            lds_rowfrag(buf + kAtTileFloats, j, h, vf);
-            f32x16 s = mma16z(kf, qf);                            // [row = key][col = query]
-            const f32x16 dp = mma16z(vf, dof);
+            f32x16 s, dp;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float kf[16], vf[16];
+                lds_rowfrag(buf + b * kAtBufFloats, j, h, kf);                           // A operands: lane <-> key
+                lds_rowfrag(buf + b * kAtBufFloats + kAtTileFloats, j, h, vf);
+                s = b == 0 ? mma16z(kf, qf[0]) : mma16(kf, qf[b], s);                // [row = key][col = query]
+                dp = b == 0 ? mma16z(vf, dof[0]) : mma16(vf, dof[b], dp);
+            }
             // Range masks only in the (possibly ragged) last key tile, where exp2(0 - lse) of a padded key could
             // overflow and meet the zero row of K as 0 * inf; query lanes beyond the plane are never stored.
             if (kt == a.ntiles - 1) {
@@ -445,15 +523,33 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(s[r] - lse) * fmaf(dpm[r], a.keep_scale, -dsum);
-            float kT[16];
-            lds_colfrag(buf, j, h, kT);                                    // A operand: lane <-> feature
-            dq = mma16(kT, ds, dq);                                        // [row = feature][col = query]
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float kT[16];
+                lds_colfrag(buf + b * kAtBufFloats, j, h, kT);                           // A operand: lane <-> feature
+                dq[b] = mma16(kT, ds, dq[b]);                                        // [row = feature][col = query]
+            }
         }
-        if (kt + 1 < a.ntiles) stage_store(sr, lds[(kt + 1) & 1], tid);
+        if (kt + 1 < a.ntiles) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) stage_store(sr[b], lds[(kt + 1) & 1] + b * kAtBufFloats, tid);
+        }
         __syncthreads();
     }
     if (!active) return;
-    store_transposed(a.out + (size_t)plane * a.tokens * ld + head * 32, ld, query, a.tokens, h, dq, a.scale);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        store_transposed(a.out + (size_t)plane * a.tokens * ld + head * (32 * NB) + 32 * b, ld, query, a.tokens, h, dq[b], a.scale);
+}
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_q_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];   // [ntiles * 32] column (key) words of the dropout mask
+    attn_bwd_q_body<1>(a, lds, words);
+}
+__global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_q64_kernel(const AttnTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2 * kAtBufFloats];
+    extern __shared__ __attribute__((aligned(16))) uint32_t words[];
+    attn_bwd_q_body<2>(a, lds, words);
 }
 
 // ---- dQ, dK and dV in ONE pass (round 3): own = key tile, walks the query tiles (staged: Q, dO) ----
@@ -769,7 +865,10 @@ hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o
         a.qkv = qkv_p; a.out = o_p;
     }
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
-    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
+    if (c.model_dim / c.num_head == 64)      // a head = two 32-feature blocks (round 5; covered, not tuned)
+        hipLaunchKernelGGL(attn_train_fwd64_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
+    else
+        hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && hd16) e = unpad16(a.out, o, rows, 1, c.num_head, st);
     return e;
@@ -804,7 +903,13 @@ hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const fl
 static hipError_t launch_attn_train_bwd_padded(const aft_config &c, AttnTrainArgs a, const float *qkv, const float *o, const float *d_o,
                                                float *dqkv, int planes, int tokens, hipStream_t st) {
     a.qkv = qkv; a.o = o; a.d_o = d_o; a.out = dqkv;
-    (void)c;
+    if (c.model_dim / c.num_head == 64) {   // head dim 64: the two-pass form with two 32-feature blocks per head (round 5)
+        const int wgs64 = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
+        const size_t wb = (size_t)a.ntiles * 32 * sizeof(uint32_t);
+        hipLaunchKernelGGL(attn_bwd_q64_kernel, dim3(wgs64), dim3(kAtThreads), wb, st, a);     // also writes D_i = dO_i . O_i
+        hipLaunchKernelGGL(attn_bwd_kv64_kernel, dim3(wgs64), dim3(kAtThreads), wb, st, a);    // reads it
+        return hipGetLastError();
+    }
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
     const size_t words_bytes = (size_t)a.ntiles * 32 * sizeof(uint32_t);
     // one pass (attn_bwd_kernel) unless its three LDS tables do not fit beside the static staging, or the two-pass form is asked for (A/B)

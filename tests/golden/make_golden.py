@@ -380,6 +380,9 @@ if __name__ == "__main__":
     # model_dim 128, as `num_head: 8` in the YAML) and a 28-token grid (12 x 14, patch 3 x 2: one masked key tile)
     H16 = dict(DEFAULT, num_layers=2, num_head=8, dropout=0.0, seed=781, attn_gain=8.0)
     S28 = dict(DEFAULT, ofdm=(12, 14), pilot=(4, 2), num_layers=2, dropout=0.0, seed=782, attn_gain=8.0)
+    H64 = dict(DEFAULT, num_layers=2, num_head=2, dropout=0.0, seed=783, attn_gain=8.0)      # head dim 64 (`num_head: 2`)
+    if not only or "G_grad_forti_h64" in only:
+        run_grad("G_grad_forti_h64", H64, 3)
     if not only or "G_grad_forti_h16" in only:
         run_grad("G_grad_forti_h16", H16, 3)
     if not only or "G_grad_forti_s28" in only:
@@ -389,7 +392,8 @@ if __name__ == "__main__":
               "G_grad64_ada": ("G_grad_ada", dict(DEFAULT, num_layers=2, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=777), 3),
               "G_grad64_forti_full": ("G_grad_forti_full", dict(DEFAULT, dropout=0.0, seed=779), 128),
               "G_grad64_ada_full": ("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128),
-              "G_grad64_forti_h16": ("G_grad_forti_h16", H16, 3), "G_grad64_forti_s28": ("G_grad_forti_s28", S28, 5)}
+              "G_grad64_forti_h16": ("G_grad_forti_h16", H16, 3), "G_grad64_forti_s28": ("G_grad_forti_s28", S28, 5),
+              "G_grad64_forti_h64": ("G_grad_forti_h64", H64, 3)}
     for nm, (_f32, spec, batch) in GRAD64.items():
         if not only or nm in only:
             run_grad64(nm, spec, batch)

@@ -38,7 +38,10 @@ def _rel(a, b):
                                                      # tokens (one masked key tile)
                                                      (128, 8, (120, 14), 6, "gelu"), (256, 16, (48, 14), 2, "relu"), (64, 4, (24, 14), 4, "gelu"),
                                                      (128, 4, (12, 14), 6, "gelu"), (128, 8, (12, 14), 2, "relu"), (128, 4, (3, 14), 4, "gelu"),
-                                                     (128, 4, (3, 2), 8, "gelu"), (192, 12, (24, 14), 2, "relu")])
+                                                     (128, 4, (3, 2), 8, "gelu"), (192, 12, (24, 14), 2, "relu"),
+                                                     # head dim 64: two 32-feature blocks per head (forward + two-pass backward)
+                                                     (128, 2, (120, 14), 4, "gelu"), (64, 1, (48, 14), 4, "relu"), (256, 4, (24, 14), 2, "gelu"),
+                                                     (128, 2, (12, 14), 6, "gelu")])
 def test_layer_forward_backward_matches_autograd(d, heads, ofdm, planes, act):
     from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
     cfg = _cfg(d, heads, ofdm, act)
@@ -469,6 +472,8 @@ def _random_train_specs(n, seed):
     out.append(dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), d=128, hd=16, act="gelu", adaptive=True, batch=2))
     out.append(dict(ofdm=(12, 14), pilot=(4, 2), patch=(3, 2), d=128, hd=32, act="gelu", adaptive=True, batch=3))
     out.append(dict(ofdm=(48, 14), pilot=(6, 2), patch=(3, 2), d=192, hd=16, act="relu", adaptive=False, batch=2))
+    out.append(dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), d=128, hd=64, act="gelu", adaptive=True, batch=2))
+    out.append(dict(ofdm=(24, 14), pilot=(6, 2), patch=(3, 2), d=64, hd=64, act="relu", adaptive=False, batch=3))
     return out
 
 
