@@ -96,10 +96,6 @@ int check_train(const aft_config *cfg, int batch, float dropout_p) {
     }
     // head dim 32 is the kernels' own shape, 16 runs as zero-padded 32-feature heads, 64 as two 32-feature blocks under one softmax
     // (forward + the two-pass backward instantiated for two blocks: k_attn_train.hip)
-    if (cfg->model_dim % 64 != 0) {
-        set_error("the row-wise training kernels are instantiated for model_dim 64, 128, 192 and 256 (got %d)", cfg->model_dim);
-        return AFT_ERR_SHAPE;
-    }
     const int hd = cfg->model_dim / cfg->num_head;
     if (hd != kHeadDim && hd != 16 && hd != 64) {
         set_error("the training attention kernels cover head dims 16, 32 and 64 (model_dim=%d, num_head=%d)", cfg->model_dim, cfg->num_head);

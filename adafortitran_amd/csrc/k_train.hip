@@ -23,14 +23,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// s = res + drop(y);  out = LN(s) * gamma + beta;  keeps s, mean, rstd.   NPL = n / 64 floats per lane
-template <int NPL>
+// s = res + drop(y);  out = LN(s) * gamma + beta;  keeps s, mean, rstd.   NPL = ceil(n / 64) floats per lane; HALF: n = 64 NPL - 32
+// (model dims 32, 96, 160, 224: the last float of a lane exists in lanes 0..31 only)
+template <int NPL, bool HALF = false>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float *__restrict__ res, const float *__restrict__ y,
                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                                          float *__restrict__ s_out, float *__restrict__ stats,
                                                          float *__restrict__ out, int rows, float eps, uint32_t seed,
                                                          uint32_t threshold, float keep_scale) {
-    constexpr int N = NPL * 64;
+    constexpr int N = NPL * 64 - (HALF ? 32 : 0);
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     float v[NPL];
@@ -39,19 +40,24 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float *__restrict
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int col = lane + 64 * q;
-        float t = y[(size_t)row * N + col];
+        const bool ok = !HALF || q < NPL - 1 || lane < 32;
+        float t = ok ? y[(size_t)row * N + col] : 0.f;
         if (threshold) t *= tdrop(rw, dropmask_col_word(seed, (uint32_t)col), threshold, keep_scale);
-        v[q] = res[(size_t)row * N + col] + t;
+        v[q] = ok ? res[(size_t)row * N + col] + t : 0.f;
         sum += v[q];
     }
     const float mean = wave_sum(sum) * (1.f / N);
     float var = 0.f;
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) var += (v[q] - mean) * (v[q] - mean);
+    for (int q = 0; q < NPL; ++q) {
+        const bool ok = !HALF || q < NPL - 1 || lane < 32;
+        var += ok ? (v[q] - mean) * (v[q] - mean) : 0.f;
+    }
     const float rstd = rsqrtf(wave_sum(var) * (1.f / N) + eps);
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
         const int col = lane + 64 * q;
+        if (HALF && q == NPL - 1 && lane >= 32) continue;
         s_out[(size_t)row * N + col] = v[q];
         out[(size_t)row * N + col] = (v[q] - mean) * rstd * gamma[col] + beta[col];
     }
@@ -65,24 +71,26 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float *__restrict
 // dgamma = sum dy * xhat and dbeta = sum dy into slices[block][3n].  ds times the dropout factor of the
 // forward's `y` branch is the gradient of y: written to `dbranch`, its column sums (the bias gradient of
 // the linear layer that produced y) into the third n of the slice.
-template <int NPL>
+template <int NPL, bool HALF = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ s,
                                                      const float *__restrict__ stats, const float *__restrict__ gamma,
                                                      float *__restrict__ ds, float *__restrict__ dbranch,
                                                      float *__restrict__ slices, int rows, int rows_per_block, uint32_t seed,
                                                      uint32_t threshold, float keep_scale) {
-    constexpr int N = NPL * 64;
+    constexpr int N = NPL * 64 - (HALF ? 32 : 0);
     __shared__ float part[4][3 * N];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float dg[NPL], db[NPL], dbr[NPL], gm[NPL];
     uint32_t cw[NPL];
+    bool okq[NPL];      // HALF: the last column group exists in lanes 0..31 only
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
+        okq[q] = !HALF || q < NPL - 1 || lane < 32;
         dg[q] = 0.f;
         db[q] = 0.f;
         dbr[q] = 0.f;
-        gm[q] = gamma[lane + 64 * q];
+        gm[q] = okq[q] ? gamma[lane + 64 * q] : 0.f;
         cw[q] = dropmask_col_word(seed, (uint32_t)(lane + 64 * q));
     }
     for (int row = r0 + wave; row < r1; row += 4) {
@@ -92,8 +100,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             const int col = lane + 64 * q;
-            const float d = dy[(size_t)row * N + col];
-            xh[q] = (s[(size_t)row * N + col] - mean) * rstd;
+            const float d = okq[q] ? dy[(size_t)row * N + col] : 0.f;
+            xh[q] = okq[q] ? (s[(size_t)row * N + col] - mean) * rstd : 0.f;
             g[q] = d * gm[q];
             a += g[q];
             b += g[q] * xh[q];
@@ -105,6 +113,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             const int col = lane + 64 * q;
+            if (!okq[q]) continue;
             const float v = rstd * (g[q] - a - xh[q] * b);
             ds[(size_t)row * N + col] = v;
             const float vb = threshold ? v * tdrop(rw, cw[q], threshold, keep_scale) : v;
@@ -114,6 +123,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
     }
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
+        if (!okq[q]) continue;
         part[wave][lane + 64 * q] = dg[q];
         part[wave][N + lane + 64 * q] = db[q];
         part[wave][2 * N + lane + 64 * q] = dbr[q];
@@ -437,6 +447,14 @@ hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamm
         hipLaunchKernelGGL(add_ln_fwd_kernel<3>, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
     else if (n == 256)
         hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else if (n == 32)
+        hipLaunchKernelGGL((add_ln_fwd_kernel<1, true>), grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else if (n == 96)
+        hipLaunchKernelGGL((add_ln_fwd_kernel<2, true>), grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else if (n == 160)
+        hipLaunchKernelGGL((add_ln_fwd_kernel<3, true>), grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else if (n == 224)
+        hipLaunchKernelGGL((add_ln_fwd_kernel<4, true>), grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -459,6 +477,14 @@ hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, co
         hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
     else if (n == 256)
         hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else if (n == 32)
+        hipLaunchKernelGGL((ln_bwd_kernel<1, true>), dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else if (n == 96)
+        hipLaunchKernelGGL((ln_bwd_kernel<2, true>), dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else if (n == 160)
+        hipLaunchKernelGGL((ln_bwd_kernel<3, true>), dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else if (n == 224)
+        hipLaunchKernelGGL((ln_bwd_kernel<4, true>), dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
     else
         return hipErrorInvalidValue;
     // slices[b][0..n) = dgamma partials, [n..2n) = dbeta partials, [2n..3n) = branch bias gradient

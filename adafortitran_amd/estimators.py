@@ -21,8 +21,8 @@ reference accepts but the gfx950 kernels do not cover (model_dim not a multiple 
 other than 16 / 32 / 64, patch > 16 elements, a grid with no LDS band plan) is refused with a ``ValueError``
 when the model is built on a HIP device -- before any training -- instead of failing in the first ``eval()``
 forward.  ``AFT_ALLOW_COMPOSITE=1`` in the environment opts into running such a model entirely on the
-PyTorch-ROCm composite (logged).  The TRAINING kernels cover a subset of what inference covers (model_dim 64 /
-128 / 192 / 256, not 32 / 96 / 160 / 224): where a block of an accepted model is differentiated by PyTorch-ROCm autograd instead, the
+PyTorch-ROCm composite (logged).  The TRAINING kernels cover what inference covers; where a block of an accepted
+model is nevertheless differentiated by PyTorch-ROCm autograd (switched off by hand, a conv grid without a band plan), the
 constructor logs a warning naming the block and the reason, and ``training_backends()`` returns the same.
 """
 from __future__ import annotations
