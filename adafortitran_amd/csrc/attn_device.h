@@ -60,7 +60,8 @@ __device__ __forceinline__ float max16(const f32x16 &v) {   // 8 x v_max3_f32
 // S^T tile = K tile . Q^T - m_ref: 16 MFMAs on one accumulator that starts from the inline constant 0.  A non-zero
 // reference enters as ONE more MFMA of the same chain (A = 1 on the k = 0 half, B = -m_ref of the lane's query), so
 // no register tuple of initial values and no copies are needed; `zero_ref` (wave-uniform) skips it.
-template <int NB>
+// NMF = MFMAs of the chain: 16 per 32-feature block; 8 for a 16-feature head, whose operands arrive in slots 0, 1 (round 5)
+template <int NB, int NMF = 16 * NB>
 __device__ __forceinline__ f32x16 qk_tile(const f32x4 (&kreg)[NB][4], const f32x4 (&qreg)[NB][4], bool zero_ref, float a_one,
                                           float neg_m) {
     f32x16 c;
@@ -71,7 +72,7 @@ __device__ __forceinline__ f32x16 qk_tile(const f32x4 (&kreg)[NB][4], const f32x
         c = mfma_f32(kreg[0][0][0], qreg[0][0][0], c);
     }
 #pragma unroll
-    for (int i = 1; i < 16 * NB; ++i) c = mfma_f32(kreg[i >> 4][(i >> 2) & 3][i & 3], qreg[i >> 4][(i >> 2) & 3][i & 3], c);
+    for (int i = 1; i < NMF; ++i) c = mfma_f32(kreg[i >> 4][(i >> 2) & 3][i & 3], qreg[i >> 4][(i >> 2) & 3][i & 3], c);
     return c;
 }
 
@@ -129,9 +130,9 @@ __device__ __forceinline__ float round_to_bf16(float x) { return (float)(__bf16)
 // HD = head dimension.  q / k / v^T and the output are laid out per 32-FEATURE BLOCK of the model dimension (`nblk` = model_dim / 32
 // blocks per plane), whatever the head count: for HD = 32 a block is a head.  HD = 64: a head is two adjacent blocks -- S^T sums
 // both blocks' products in one 32-MFMA chain, O^T is one accumulator per block.  HD = 16: a block holds two heads -- a task takes
-// ONE of them (`sub`): the other head's query features are zeroed, so the unchanged 16-MFMA chain yields exactly this head's
-// logits, O^T is computed for the whole block and only this head's 16 rows are stored (half the matrix work of such a task is
-// wasted: the shape is covered, not tuned).  nn.MultiheadAttention as built at reference blocks/encoders.py:44-51 accepts any
+// ONE of them (`sub`): S^T is an 8-MFMA chain over this head's two 8-feature slots of Q and K (round 5; round 4 zeroed the other head's
+// query features and ran the whole 16-MFMA chain), O^T is computed for the whole block and only this head's 16 rows are stored (the
+// value product still does twice the work it needs: a 32x32 MFMA cannot take half its rows).  nn.MultiheadAttention as built at reference blocks/encoders.py:44-51 accepts any
 // num_head that divides model_dim (schemas.py:124-127).
 // TOK > 0: the token count as a compile-time constant (the default grid's 280: nine key tiles, the last one ragged) -- the tile loop's
 // trip count, the "last two or three tiles" logic and the padding masks resolve at compile time.  TOK = 0: any count at run time.
@@ -171,6 +172,17 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
 #pragma unroll
             for (int s = 0; s < 4; ++s) dst[b][s] = srd_load(src, base + b * blk_bytes + (unsigned)(kt * 1024 + s * 256) * 4);
     };
+    // HD = 16: only the head's two slots (8-feature groups 2 sub, 2 sub + 1) of a Q / K tile, into slots 0, 1
+    constexpr int NMF = HD == 16 ? 8 : 16 * NB;
+    auto load_qk = [&](Srd src, int kt, f32x4 (&dst)[NB][4], unsigned base, int sub_) {
+        if constexpr (HD == 16) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dst[0][s] = srd_load(src, base + (unsigned)(kt * 1024 + (2 * sub_ + s) * 256) * 4);
+        } else {
+            load_tile(src, kt, dst, base);
+        }
+    };
+    auto sub_of = [&](int task) { return HD == 16 ? (task / nkt) & 1 : 0; };
     // padded keys of the ragged last tile: logits -> -inf (probability 0), V^T columns -> 0 (the workspace pad is
     // never trusted: 0 x NaN would poison the row)
     // (8 | tokens, the usual case: whole 8-key groups are padding, the same registers in every lane -- a wave-uniform test per
@@ -222,8 +234,8 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
   f32x4 qreg[NB][4], kcur[NB][4], vcur[NB][4];
   if (task < ntasks) {       // operands of the first task; later ones are requested during the previous task's last tile
       const unsigned hb0 = head_base(task);
-      load_tile(qs, task % nkt, qreg, hb0);
-      load_tile(ks, 0, kcur, hb0);
+      load_qk(qs, task % nkt, qreg, hb0, sub_of(task));
+      load_qk(ks, 0, kcur, hb0, sub_of(task));
       load_tile(vs, 0, vcur, hb0);
   }
   for (; task < ntasks; task += total_waves, ++round) {
@@ -242,16 +254,12 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
     // a row constant to the logits, which softmax cancels), then everything is pre-scaled
     if constexpr (!BS) {   // (split tier: bias and scale were applied before the bf16 split, in the chain kernel's epilogue)
-        const float *bq = qbias + (pb % nblk) * kHeadDim + 4 * h;
+        const float *bq = qbias + (pb % nblk) * kHeadDim + 4 * h + (HD == 16 ? 16 * sub : 0);   // HD = 16: slots 0, 1 hold features 16 sub ..
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < (HD == 16 ? 2 : 4); ++s)
                 qreg[b][s] = (qreg[b][s] + *reinterpret_cast<const f32x4 *>(bq + 32 * b + 8 * s)) * scale_log2e;
-                if constexpr (HD == 16) {   // slots s = 2 sub, 2 sub + 1 are this head's 16 features; the other head's contribute 0
-                    if ((s >> 1) != sub) qreg[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
     }
     // Padded query lanes of the ragged last query tile read workspace nobody wrote: their results are never stored, but
     // the reference tests below are wave-wide (__any), so a large stale value there would switch the VALID lanes of the
@@ -261,15 +269,15 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) qreg[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < (HD == 16 ? 2 : 4); ++s) qreg[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // ---- key tile 0: plain logits, reference maximum ----
     AttnRow<NB> st;
     f32x16 sA, sB;
     if constexpr (BS) sA = qk_tile_bs(kcur[0], qreg[0], true, 0.f, h);
-    else sA = qk_tile<NB>(kcur, qreg, true, a_one, 0.f);
-    if (nkt > 1) load_tile(ks, 1, kcur, hb);
+    else sA = qk_tile<NB, NMF>(kcur, qreg, true, a_one, 0.f);
+    if (nkt > 1) load_qk(ks, 1, kcur, hb, sub);
     if (ragged && nkt == 1) { mask_logits(sA, 0); mask_values(vcur, 0); }
     {
         float m0 = max16(sA);
@@ -296,12 +304,12 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
         const bool more = FAST || kt + 1 < nkt;
         if (more) {
             if constexpr (BS) nxt = qk_tile_bs(kcur[0], qreg[0], st.zero_ref, -st.m_ref, h);
-            else nxt = qk_tile<NB>(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
-            if (FAST || kt + 2 < nkt) load_tile(ks, kt + 2, kcur, hb);
+            else nxt = qk_tile<NB, NMF>(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
+            if (FAST || kt + 2 < nkt) load_qk(ks, kt + 2, kcur, hb, sub);
         } else if (has_next) {      // last tile: Q and K are idle -> request the next task's
             const unsigned hbn = head_base(next_task);
-            load_tile(qs, next_task % nkt, qreg, hbn);
-            load_tile(ks, 0, kcur, hbn);
+            load_qk(qs, next_task % nkt, qreg, hbn, sub_of(next_task));
+            load_qk(ks, 0, kcur, hbn, sub_of(next_task));
         }
         // stale-reference test for THIS tile
         const float tmax = max16(cur);
