@@ -189,21 +189,23 @@ def test_conv_stream_column_ranges_reproduce_whole_planes(monkeypatch, batch):
     assert torch.isfinite(torch.view_as_real(auto)).all()
 
 
-def test_conv_stream_hand_over_soak():
+@pytest.mark.parametrize("batch,reps", [(128, 600), (64, 300), (16, 300), (130, 200)])
+def test_conv_stream_hand_over_soak(batch, reps):
     """The column-streaming conv kernel hands conv1 / conv3 columns between its waves through LDS flags (k_conv_stream.hip); a lost
-    hand-over would be a one-in-many-launches event.  600 forwards of the benchmark batch, EVERY output compared on the device with
-    the first one's bits (was tools/debug/soak_forward.py)."""
+    hand-over would be a one-in-many-launches event.  Hundreds of forwards of the benchmark batch -- and of batches that run two / four
+    column ranges per plane and a remainder launch -- EVERY output compared on the device with the first one's bits (was
+    tools/debug/soak_forward.py)."""
     hid = (7, 42, 560)
     sd = synth.make_state_dict(**DEFAULT_SPEC, adaptive_hidden=hid, seed=20251114)
     cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=hid)
     from adafortitran_amd.hip_ops import engine_from_numpy
     eng = engine_from_numpy(cfg, sd, DEV)
-    inp = synth.make_inputs(128, seed=3)
+    inp = synth.make_inputs(batch, seed=3)
     pil, meta = _t(inp["pilots"]), [_t(inp[k]) for k in ("snr", "ds", "dop")]
     ref = eng.forward(pil, *meta).clone()
     out = torch.empty_like(ref)
     bad = torch.zeros((), dtype=torch.int64, device=DEV)
-    for _ in range(600):
+    for _ in range(reps):
         eng.forward(pil, *meta, out=out)
         bad += (torch.view_as_real(out) != torch.view_as_real(ref)).any().to(torch.int64)
     assert int(bad.item()) == 0
@@ -285,8 +287,14 @@ def test_tall_planes_run_the_row_streaming_conv_kernel(oracle_lib, monkeypatch, 
     meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
     pil = _t(inp["pilots"])
     out = eng.forward(pil, *meta).clone()
-    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3))
+    ref, dump = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3), dump=True)
     assert np.abs(out.cpu().numpy() - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+    # the head stage of the kernel the forward launched (conv_rows16_kernel), straight from the workspace
+    assert max_rel(eng.forward_region("conv_enhanced", batch).cpu().numpy(), dump["conv_enhanced"]) <= TOL_HIP_OUT
+    monkeypatch.setenv("AFT_CONV_MFMA32", "1")                             # round 4's 32x32x2 row-streaming kernel: rounding-level agreement
+    mfma32 = eng.forward(pil, *meta).clone()
+    monkeypatch.delenv("AFT_CONV_MFMA32")
+    assert float((mfma32 - out).abs().max()) <= 2e-6 * float(out.abs().max())
     eng.workspace(batch).view(torch.float32).fill_(float("nan"))           # stale workspace: same bits
     assert torch.equal(torch.view_as_real(eng.forward(pil, *meta)), torch.view_as_real(out))
     monkeypatch.setenv("AFT_CONV_BANDED", "1")
