@@ -100,6 +100,9 @@ struct AttnRow {          // per-lane softmax state of the lane's query row
 //   * QK^T of tile t+1 is issued before the exponentials of tile t; two named accumulators alternate roles
 //     (the loop is unrolled by two) so neither is ever copied.
 //   * the next task's Q / K tile 0 / V tile 0 are requested during the last key tile of the current one.
+// `tail_task` (round 5): the launcher may hand the tasks beyond the last WHOLE round (ntasks then counts only the whole rounds) out
+// itself, one per wave at most, so that a partial last round is spread over all XCDs and CUs instead of filling half the chip for a
+// full round (k_attn.hip); -1 = none.  Which wave works a task never changes the task's arithmetic: same bits.
 // One WAVE walks the tasks first_task, first_task + total_waves, ... < ntasks (task = (plane * heads + head) * nkt + query
 // tile): attn_kernel (k_attn.hip) deals them over a persistent grid, the plane-resident encoder kernel (k_encoder.hip)
 // over the 12 waves of the workgroup that owns the plane.  No LDS, no barriers.
@@ -141,7 +144,7 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
                                           const float *__restrict__ vt, const float *__restrict__ qbias,
                                           float *__restrict__ out, int nblk, int tokens_rt, int tokpad_rt, int model_dim,
                                           float scale_log2e, const int first_task, const int total_waves, int ntasks,
-                                          unsigned long long *stamps) {
+                                          unsigned long long *stamps, const int tail_task = -1) {
     int lane_l = threadIdx.x & 63;
     asm volatile("" : "+v"(lane_l));   // laundered: lane-dependent offsets are recomputed per call, not hoisted out of the caller's loops
     const int lane = lane_l;
@@ -228,17 +231,17 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     };
 
   // wave priority by work left (set_progress_priority, aft_internal.h): keeps the waves of a SIMD abreast
-  const int rounds = (ntasks + total_waves - 1) / total_waves;
+  const int rounds = (ntasks + total_waves - 1) / total_waves + (tail_task >= 0 ? 1 : 0);
   int round = 0;
-  int task = first_task;
+  int task = first_task < ntasks ? first_task : tail_task;     // -1: nothing to do
   f32x4 qreg[NB][4], kcur[NB][4], vcur[NB][4];
-  if (task < ntasks) {       // operands of the first task; later ones are requested during the previous task's last tile
+  if (task >= 0) {           // operands of the first task; later ones are requested during the previous task's last tile
       const unsigned hb0 = head_base(task);
       load_qk(qs, task % nkt, qreg, hb0, sub_of(task));
       load_qk(ks, 0, kcur, hb0, sub_of(task));
       load_tile(vs, 0, vcur, hb0);
   }
-  for (; task < ntasks; task += total_waves, ++round) {
+  for (; task >= 0; ++round) {
     ASTAMP(0);
 #ifdef AFT_DIAG_STAMPS
     if (stamps && lane == 0) stamps[(size_t)task * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -247,8 +250,9 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     const int pb = first_block(task);       // plane * nblk + the head's first block
     const int sub = HD == 16 ? (task / nkt) & 1 : 0;   // HD = 16: which of the block's two heads
     const unsigned hb = head_base(task);   // byte offset of this (plane, block)
-    const int next_task = task + total_waves;
-    const bool has_next = next_task < ntasks;
+    // the strided tasks of the whole rounds, then (at most) one task of the partial round
+    const int next_task = task >= ntasks ? -1 : (task + total_waves < ntasks ? task + total_waves : tail_task);
+    const bool has_next = next_task >= 0;
 
     // B operand of S^T = K Q^T : lane (q = r, h) holds Q[q][8s + 4h + j]; the query bias of the
     // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
@@ -408,6 +412,7 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
 #ifdef AFT_DIAG_STAMPS
     if (stamps && lane == 0) stamps[(size_t)task * 8 + 5] = __builtin_amdgcn_s_memrealtime();
 #endif
+    task = next_task;
   }
 }
 

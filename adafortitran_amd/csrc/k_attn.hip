@@ -22,8 +22,24 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : AFT_ATTN_WAVES) void attn_kerne
     // (72 KB) through ONE L2 instead of two or three.  A pure speed choice; any mapping is correct.
     int vblock = blockIdx.x;
     if ((gridDim.x & 7) == 0) vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    attn_body<false, HD, TOK>(q, k, vt, qbias, out, nblk, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, gridDim.x * 4, ntasks,
-                              stamps);
+    // A partial last round (tasks beyond the last whole multiple of the wave count; none at the benchmark's batch: 9 216 tasks = 3 x
+    // 3 072 waves) is NOT left to the stride: with the XCD-contiguous order above its tasks would all land on the first XCDs -- at 64
+    // frames (4 608 tasks) XCDs 0-3 ran a second full 29-us round with three waves per SIMD while XCDs 4-7 idled: 59.6 us for 1.5
+    // rounds of work (profiles/r05_b64_kernel_trace_summary.txt).  Each XCD takes an eighth of the partial round (still a contiguous
+    // task range per XCD) on its earliest-dispatched workgroups, i.e. spread over its CUs.  Same arithmetic per task: same bits.
+    const int total_waves = gridDim.x * 4, nfull = ntasks / total_waves * total_waves, rem = ntasks - nfull;
+    int tail = -1;
+    if (rem > 0) {
+        if ((gridDim.x & 7) == 0) {
+            const int per = gridDim.x >> 3, xcd = vblock / per, jj = (vblock - xcd * per) * 4 + wave;
+            const int s0 = (xcd * rem) >> 3, s1 = ((xcd + 1) * rem) >> 3;
+            if (jj < s1 - s0) tail = nfull + s0 + jj;
+        } else if (vblock * 4 + wave < rem) {
+            tail = nfull + vblock * 4 + wave;
+        }
+    }
+    attn_body<false, HD, TOK>(q, k, vt, qbias, out, nblk, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, total_waves, nfull,
+                              stamps, tail);
 }
 
 // split-precision tier: K / Q^T / V^T arrive as bf16 hi / lo fragments from chain_split_kernel (attn_device.h)
