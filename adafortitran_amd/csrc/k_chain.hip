@@ -7,6 +7,10 @@
 #include "chain_device.h"
 #include "pack_device.h"
 
+#ifndef AFT_CHAIN_MANY_MAX_D
+#define AFT_CHAIN_MANY_MAX_D 96
+#endif
+
 namespace aft {
 
 // MLP / QKV select the three launch variants at compile time (distinct symbols in a profile), see chain_device.h
@@ -50,11 +54,12 @@ static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
     static PerDeviceOnce lds_attr;   // per instantiation x device
     hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(chain_kernel<D, ACT, MLP, QKV>), S::LDS_BYTES);
     if (ea != hipSuccess) return ea;
-    // co-resident workgroups: CUs x (3 at d = 96 / 128 | 1 above), see __launch_bounds__ / LDS.  The one- and two-wave workgroups of
-    // d = 32 / 64 would leave the SIMDs at 0.75 / 1.5 waves with three per CU: as many as give twelve waves per CU and fit the LDS
-    // (1 280-byte granules, section 4.0 fact 8) -- round 5, d = 64: 154 k -> see bench `other_shapes`
+    // co-resident workgroups: CUs x (3 at d = 128 | 1 above), see __launch_bounds__ / LDS.  The one-, two- and three-wave workgroups
+    // of d = 32 / 64 / 96 would leave the SIMDs at 0.75 / 1.5 / 2.25 waves with three per CU: as many as give twelve waves per CU and
+    // fit the LDS (1 280-byte granules, section 4.0 fact 8) -- round 5: d = 64 154 k -> 166 k frames/s, d = 96 chain 0.60 -> 0.67 of
+    // the roof (bench `other_shapes`)
     constexpr int kGranules = (int)((S::LDS_BYTES + 1279) / 1280);
-    constexpr int kPerCu = D <= 64 ? std::min(12 / S::WAVES, 128 / kGranules) : (D <= 128 ? 3 : 1);
+    constexpr int kPerCu = D <= AFT_CHAIN_MANY_MAX_D ? std::min(12 / S::WAVES, 128 / kGranules) : (D <= 128 ? 3 : 1);
     const int resident = current_device_cus() * kPerCu;
     const int blocks = std::min((args.rows + 31) / 32, resident);
     const size_t lds = S::LDS_BYTES;
