@@ -8,6 +8,18 @@
 
 namespace aft {
 
+// The task of the partial last round this wave takes (-1: none), see attn_kernel.  vblock = the XCD-contiguous workgroup index.
+__device__ __forceinline__ int partial_round_task(int vblock, int wave, int ntasks) {
+    const int total_waves = gridDim.x * 4, nfull = ntasks / total_waves * total_waves, rem = ntasks - nfull;
+    if (rem <= 0) return -1;
+    if ((gridDim.x & 7) == 0) {
+        const int per = gridDim.x >> 3, xcd = vblock / per, jj = (vblock - xcd * per) * 4 + wave;
+        const int s0 = (xcd * rem) >> 3, s1 = ((xcd + 1) * rem) >> 3;
+        return jj < s1 - s0 ? nfull + s0 + jj : -1;
+    }
+    return vblock * 4 + wave < rem ? nfull + vblock * 4 + wave : -1;
+}
+
 // launch bound (256, 3): <= 168 registers keeps accumulators in VGPRs, see attn_device.h
 // HD = 32: three waves per SIMD (the tuned shape).  HD = 64 holds two blocks of q / k / v^T and two accumulators (~210 VGPRs): two.
 template <int HD, int TOK = 0>
@@ -27,19 +39,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : AFT_ATTN_WAVES) void attn_kerne
     // frames (4 608 tasks) XCDs 0-3 ran a second full 29-us round with three waves per SIMD while XCDs 4-7 idled: 59.6 us for 1.5
     // rounds of work (profiles/r05_b64_kernel_trace_summary.txt).  Each XCD takes an eighth of the partial round (still a contiguous
     // task range per XCD) on its earliest-dispatched workgroups, i.e. spread over its CUs.  Same arithmetic per task: same bits.
-    const int total_waves = gridDim.x * 4, nfull = ntasks / total_waves * total_waves, rem = ntasks - nfull;
-    int tail = -1;
-    if (rem > 0) {
-        if ((gridDim.x & 7) == 0) {
-            const int per = gridDim.x >> 3, xcd = vblock / per, jj = (vblock - xcd * per) * 4 + wave;
-            const int s0 = (xcd * rem) >> 3, s1 = ((xcd + 1) * rem) >> 3;
-            if (jj < s1 - s0) tail = nfull + s0 + jj;
-        } else if (vblock * 4 + wave < rem) {
-            tail = nfull + vblock * 4 + wave;
-        }
-    }
+    const int total_waves = gridDim.x * 4, nfull = ntasks / total_waves * total_waves;
     attn_body<false, HD, TOK>(q, k, vt, qbias, out, nblk, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, total_waves, nfull,
-                              stamps, tail);
+                              stamps, partial_round_task(vblock, wave, ntasks));
 }
 
 // split-precision tier: K / Q^T / V^T arrive as bf16 hi / lo fragments from chain_split_kernel (attn_device.h)
@@ -49,7 +51,9 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_split_kernel(const f
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int vblock = blockIdx.x;
     if ((gridDim.x & 7) == 0) vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    attn_body<true>(q, k, vt, nullptr, out, heads, tokens, tokpad, model_dim, 0.f, vblock * 4 + wave, gridDim.x * 4, ntasks, nullptr);
+    const int total_waves = gridDim.x * 4, nfull = ntasks / total_waves * total_waves;
+    attn_body<true>(q, k, vt, nullptr, out, heads, tokens, tokpad, model_dim, 0.f, vblock * 4 + wave, total_waves, nfull, nullptr,
+                    partial_round_task(vblock, wave, ntasks));
 }
 
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
