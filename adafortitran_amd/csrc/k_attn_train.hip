@@ -917,15 +917,27 @@ static hipError_t launch_attn_train_bwd_padded(const aft_config &c, AttnTrainArg
     const size_t group_lds = sizeof(float) * kAtBwdStatic + 3 * words_bytes;
     if (!two_pass && group_lds <= 64 * 1024) {
         // four problems per workgroup (twelve waves, one workgroup per CU) when their LDS fits four times; else the three-wave shape
-        const bool four = 4 * group_lds <= 160 * 1024 && (planes * a.heads) % 4 == 0 && !getenv("AFT_ATTN_BWD_3WAVE");
+        // Problems per workgroup: 4 (twelve waves, ONE workgroup per CU, all in lock-step) is the shape of fact 10 and wins exactly when
+        // the problems fill whole rounds of it -- 128 frames: 1 024 problems = 256 twelve-wave workgroups (6.94 ms per step against 7.24
+        // with three-wave workgroups), 256 frames likewise.  Anywhere else the hardware's dispatcher does better with three-wave
+        // workgroups (measured, ms per training step, three- vs twelve-wave: 32 frames 2.93 vs 3.80, 64 frames -- the reference's
+        // default batch -- 4.30 vs 4.81: its 128 twelve-wave workgroups left half the CUs idle and the kernel took as long as at 128
+        // frames; 96: 5.71 vs 5.83, 160: 8.97 vs 9.65, 192: 10.33 vs 10.76).  (round 5)
+        const int problems = planes * a.heads, cus = current_device_cus();
+        int groups = (4 * group_lds <= 160 * 1024 && problems % (4 * cus) == 0) ? 4 : 1;
+        if (getenv("AFT_ATTN_BWD_3WAVE")) groups = 1;
+        if (const char *g = getenv("AFT_ATTN_BWD_GROUPS")) {     // A/B: force 1 or 4 where the shape allows it
+            const int want = atoi(g);
+            if ((want == 1 || want == 4) && problems % want == 0 && (size_t)want * group_lds <= 160 * 1024) groups = want;
+        }
+        const bool four = groups == 4;
         const bool tok280 = tokens == 280 && !getenv("AFT_ATTN_GENERIC");
         const void *fn = four ? (tok280 ? reinterpret_cast<const void *>(attn_bwd_kernel<280, 4>) : reinterpret_cast<const void *>(attn_bwd_kernel<0, 4>))
                               : (tok280 ? reinterpret_cast<const void *>(attn_bwd_kernel<280, 1>) : reinterpret_cast<const void *>(attn_bwd_kernel<0, 1>));
         static PerDeviceOnce lds_attr[4];
         hipError_t ea = ensure_dynamic_lds(lds_attr[(four ? 2 : 0) + (tok280 ? 1 : 0)], fn, four ? 160 * 1024 : 64 * 1024);
         if (ea != hipSuccess) return ea;
-        const int groups = four ? 4 : 1;
-        const dim3 grid(planes * a.heads / groups), block(kAtThreads * groups);
+        const dim3 grid(problems / groups), block(kAtThreads * groups);
         const size_t lds = group_lds * groups;
         if (four && tok280) hipLaunchKernelGGL((attn_bwd_kernel<280, 4>), grid, block, lds, st, a);
         else if (four) hipLaunchKernelGGL((attn_bwd_kernel<0, 4>), grid, block, lds, st, a);

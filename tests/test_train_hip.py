@@ -130,6 +130,15 @@ def test_one_pass_attention_backward_agrees_with_the_two_pass_form(ofdm, heads, 
         assert torch.equal(a, b), i
         assert _rel(a, c) <= 2e-6, (i, _rel(a, c))
     assert any(not torch.equal(a, c) for a, c in zip(one, two))   # the switch did select another kernel
+    # the launcher picks three- or twelve-wave workgroups (one or four problems each) by the problem count: same arithmetic per
+    # problem, so the same bits (2 planes x heads problems here: a multiple of four)
+    monkeypatch.delenv("AFT_TRAIN_ATTN_BWD_SPLIT")
+    monkeypatch.setenv("AFT_ATTN_BWD_GROUPS", "4")
+    four = run()
+    monkeypatch.setenv("AFT_ATTN_BWD_GROUPS", "1")
+    three = run()
+    for i, (a, b) in enumerate(zip(four, three)):
+        assert torch.equal(a, b), i
 
 
 @pytest.mark.parametrize("d,heads,ofdm", [(128, 4, (120, 14)), (128, 4, (24, 14)), (256, 8, (48, 14))])
