@@ -71,13 +71,17 @@ int check_config(const aft_config *c) {
                   "hidden layer in the registers of model_dim / 32 waves)", c->model_dim);
         return AFT_ERR_SHAPE;
     }
-    // nn.MultiheadAttention takes any num_head that divides model_dim (reference blocks/encoders.py:44-51, schemas.py:124-127);
-    // the attention kernel is instantiated for head dimensions 16, 32 (the tuned shape) and 64: q / k / v^T live in 32-feature blocks
-    // and a 32x32x2 MFMA contracts 32 features at a time -- head dim 8 would spend 3/4 of every product on masked features, head dim
-    // 128 needs four output accumulators per query tile (> 256 VGPRs); both are refused rather than run at a fraction of the rate
+    // nn.MultiheadAttention takes any num_head that divides model_dim (reference blocks/encoders.py:44-51, schemas.py:124-127).
+    // q / k / v^T live in 32-feature blocks whose fragment slots hold 8 features each; a 32x32x2 MFMA chain contracts the slots it
+    // is given.  Head dims 32 (the tuned shape), 16 and 64 have their own instantiations; every other multiple of 8 up to 48 runs
+    // the generic one (a head = a run of slots that starts anywhere in a block: exact logits work, whole-block value products).
+    // Refused: head dims that are not multiples of 8 (a head would split a fragment slot), 56 (a head can straddle THREE blocks:
+    // three O^T accumulators and three V^T tiles do not fit in 256 VGPRs beside the operands) and > 64 (four accumulators).
     const int hd = c->num_head > 0 && c->model_dim % c->num_head == 0 ? c->model_dim / c->num_head : 0;
-    if (hd != 16 && hd != 32 && hd != 64) {
-        set_error("head dim must be 16, 32 or 64 (model_dim=%d, num_head=%d)", c->model_dim, c->num_head);
+    if (hd < 8 || hd > 64 || hd % 8 != 0 || hd == 56) {
+        set_error("head dim %d not covered (model_dim=%d, num_head=%d): the attention kernels take head dims that are multiples of 8 up "
+                  "to 64, except 56 -- q / k / v^T are held in 8-feature fragment slots, and a head may straddle at most two 32-feature "
+                  "blocks", hd, c->model_dim, c->num_head);
         return AFT_ERR_SHAPE;
     }
     if (tokens_of(*c) < 1) {

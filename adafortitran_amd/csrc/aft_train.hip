@@ -94,13 +94,9 @@ int check_train(const aft_config *cfg, int batch, float dropout_p) {
         set_error("bad batch %d or dropout %g", batch, (double)dropout_p);
         return AFT_ERR_ARG;
     }
-    // head dim 32 is the kernels' own shape, 16 runs as zero-padded 32-feature heads, 64 as two 32-feature blocks under one softmax
-    // (forward + the two-pass backward instantiated for two blocks: k_attn_train.hip)
-    const int hd = cfg->model_dim / cfg->num_head;
-    if (hd != kHeadDim && hd != 16 && hd != 64) {
-        set_error("the training attention kernels cover head dims 16, 32 and 64 (model_dim=%d, num_head=%d)", cfg->model_dim, cfg->num_head);
-        return AFT_ERR_SHAPE;
-    }
+    // head dim 32 is the kernels' own shape, 64 runs as two 32-feature blocks under one softmax (forward + the two-pass backward
+    // instantiated for two blocks), every other multiple of 8 as zero-padded 32- or 64-feature heads (k_attn_train.hip); check_config
+    // above has already refused what the inference engine does not take (head dims off the multiples of 8, 56, > 64)
     if ((size_t)2 * batch * tokens_of_cfg(*cfg) * 3 * cfg->model_dim >= ((size_t)1 << 32)) {
         set_error("batch %d: dropout counters are 32-bit", batch);
         return AFT_ERR_ARG;

@@ -137,6 +137,13 @@ __device__ __forceinline__ float round_to_bf16(float x) { return (float)(__bf16)
 // query features and ran the whole 16-MFMA chain), O^T is computed for the whole block and only this head's 16 rows are stored (the
 // value product still does twice the work it needs: a 32x32 MFMA cannot take half its rows).  nn.MultiheadAttention as built at reference blocks/encoders.py:44-51 accepts any
 // num_head that divides model_dim (schemas.py:124-127).
+// Every other multiple of 8 (8, 24, 40, 48: what 4 or 8 heads give at model_dim 96 / 160 / 192, or 16 heads at 128; late round 5): a
+// head is a run of HD / 8 of the plane's 8-FEATURE GROUPS (the slots of the fragment layout) that starts wherever the heads before
+// it end -- anywhere in a block.  S^T contracts exactly the head's features: one Q / K slot per group, fetched from whichever block
+// holds it, 4 MFMAs each.  O^T is computed for the one or two whole blocks the head touches (V^T's rows cannot be picked apart in a
+// 32-row MFMA operand) and only the head's groups are stored: exact logits work, 1.3-4 x the value work -- covered, not tuned.
+// HD = 56 could straddle three blocks (three accumulators do not fit beside the operands) and head dims that are not multiples of 8
+// would split a fragment slot: refused by aft_check_config.
 // TOK > 0: the token count as a compile-time constant (the default grid's 280: nine key tiles, the last one ragged) -- the tile loop's
 // trip count, the "last two or three tiles" logic and the padding masks resolve at compile time.  TOK = 0: any count at run time.
 template <bool BS = false, int HD = 32, int TOK = 0>
@@ -149,9 +156,13 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     asm volatile("" : "+v"(lane_l));   // laundered: lane-dependent offsets are recomputed per call, not hoisted out of the caller's loops
     const int lane = lane_l;
     const Srd qs = make_srd(q), ks = make_srd(k), vs = make_srd(vt), os = make_srd(out);
-    static_assert(HD == 16 || HD == 32 || HD == 64, "head dimension");
+    static_assert(HD % 8 == 0 && HD >= 8 && HD <= 64 && HD != 56, "head dimension");
     static_assert(!BS || HD == 32, "the split-precision tier is instantiated for head dimension 32");
-    constexpr int NB = HD == 64 ? 2 : 1;                // 32-feature blocks per head
+    constexpr bool GEN = HD != 16 && HD != 32 && HD != 64;   // a head = HD / 8 feature groups starting anywhere in a block
+    constexpr int NS = HD / 8;                          // 8-feature groups (fragment slots) per head
+    constexpr int NB = GEN ? (32 % HD == 0 ? 1 : 2) : HD == 64 ? 2 : 1;   // 32-feature blocks a head touches (V^T tiles, O^T accumulators)
+    constexpr int NQ = GEN ? (NS + 3) / 4 : NB;         // Q / K operand registers, in units of four slots
+    const int heads = model_dim / HD;
     const int tokens = TOK > 0 ? TOK : tokens_rt;
     const int tokpad = TOK > 0 ? (TOK + kTile - 1) / kTile * kTile : tokpad_rt;
     const int nkt = tokpad / kTile;
@@ -166,26 +177,50 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     // q, k, vt arrive in MFMA-fragment order from k_chain.hip: [ph][tile][s or g][lane][4] -> every
     // operand load below is one fully coalesced 1-KB buffer_load_dwordx4 per wave
     // (plane, block) index of a task's first block: task / nkt is (plane, head)
-    auto first_block = [&](int task) { const int ph = task / nkt; return HD == 16 ? ph >> 1 : ph * NB; };
+    // GEN: first group of the task's head, counted over the whole launch (plane * nblk * 4 + head * NS): group G lies in (plane,
+    // block) G >> 2, slot G & 3
+    auto first_group = [&](int task) { const int ph = task / nkt, plane = ph / heads; return plane * nblk * 4 + (ph - plane * heads) * NS; };
+    auto first_block = [&](int task) {
+        if constexpr (GEN) return first_group(task) >> 2;
+        const int ph = task / nkt;
+        return HD == 16 ? ph >> 1 : ph * NB;
+    };
     auto head_base = [&](int task) { return ((unsigned)first_block(task) * tokpad * kHeadDim + lane * 4) * 4; };
     const unsigned blk_bytes = (unsigned)tokpad * kHeadDim * 4;     // one (plane, block) of q / k / v^T
-    auto load_tile = [&](Srd src, int kt, f32x4 (&dst)[NB][4], unsigned base) {
+    // GEN: a head that ends inside its first block, in the plane's last block, has no second block: the second V^T tile re-reads the
+    // first (its product is computed and dropped at the store) rather than running past the plane
+    auto second_block_bytes = [&](int task) {
+        if constexpr (GEN && NB == 2) return ((first_group(task) + NS - 1) >> 2) != first_block(task) ? blk_bytes : 0u;
+        return blk_bytes;
+    };
+    auto load_tile = [&](Srd src, int kt, f32x4 (&dst)[NB][4], unsigned base, unsigned b1_bytes) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) dst[b][s] = srd_load(src, base + b * blk_bytes + (unsigned)(kt * 1024 + s * 256) * 4);
+            for (int s = 0; s < 4; ++s) dst[b][s] = srd_load(src, base + b * b1_bytes + (unsigned)(kt * 1024 + s * 256) * 4);
     };
     // HD = 16: only the head's two slots (8-feature groups 2 sub, 2 sub + 1) of a Q / K tile, into slots 0, 1
-    constexpr int NMF = HD == 16 ? 8 : 16 * NB;
-    auto load_qk = [&](Srd src, int kt, f32x4 (&dst)[NB][4], unsigned base, int sub_) {
-        if constexpr (HD == 16) {
+    constexpr int NMF = GEN ? 4 * NS : HD == 16 ? 8 : 16 * NB;
+    // sub_: HD = 16: which of the block's two heads.  GEN: the head's first slot within its first block (first_group & 3); `base` is
+    // that block's, and slot i of the head is slot (sub_ + i) & 3 of block (sub_ + i) >> 2 from there
+    auto load_qk = [&](Srd src, int kt, f32x4 (&dst)[NQ][4], unsigned base, int sub_) {
+        if constexpr (GEN) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int sl = sub_ + i;
+                dst[i >> 2][i & 3] = srd_load(src, base + (unsigned)(sl >> 2) * blk_bytes + (unsigned)(kt * 1024 + (sl & 3) * 256) * 4);
+            }
+        } else if constexpr (HD == 16) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) dst[0][s] = srd_load(src, base + (unsigned)(kt * 1024 + (2 * sub_ + s) * 256) * 4);
         } else {
-            load_tile(src, kt, dst, base);
+            load_tile(src, kt, dst, base, blk_bytes);
         }
     };
-    auto sub_of = [&](int task) { return HD == 16 ? (task / nkt) & 1 : 0; };
+    auto sub_of = [&](int task) {
+        if constexpr (GEN) return first_group(task) & 3;
+        return HD == 16 ? (task / nkt) & 1 : 0;
+    };
     // padded keys of the ragged last tile: logits -> -inf (probability 0), V^T columns -> 0 (the workspace pad is
     // never trusted: 0 x NaN would poison the row)
     // (8 | tokens, the usual case: whole 8-key groups are padding, the same registers in every lane -- a wave-uniform test per
@@ -234,12 +269,12 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
   const int rounds = (ntasks + total_waves - 1) / total_waves + (tail_task >= 0 ? 1 : 0);
   int round = 0;
   int task = first_task < ntasks ? first_task : tail_task;     // -1: nothing to do
-  f32x4 qreg[NB][4], kcur[NB][4], vcur[NB][4];
+  f32x4 qreg[NQ][4], kcur[NQ][4], vcur[NB][4];
   if (task >= 0) {           // operands of the first task; later ones are requested during the previous task's last tile
       const unsigned hb0 = head_base(task);
       load_qk(qs, task % nkt, qreg, hb0, sub_of(task));
       load_qk(ks, 0, kcur, hb0, sub_of(task));
-      load_tile(vs, 0, vcur, hb0);
+      load_tile(vs, 0, vcur, hb0, second_block_bytes(task));
   }
   for (; task >= 0; ++round) {
     ASTAMP(0);
@@ -248,8 +283,9 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
 #endif
     const int qt = task % nkt;
     const int pb = first_block(task);       // plane * nblk + the head's first block
-    const int sub = HD == 16 ? (task / nkt) & 1 : 0;   // HD = 16: which of the block's two heads
+    const int sub = sub_of(task);           // HD = 16: which of the block's two heads; GEN: the head's first slot in its first block
     const unsigned hb = head_base(task);   // byte offset of this (plane, block)
+    const unsigned vb1 = second_block_bytes(task);
     // the strided tasks of the whole rounds, then (at most) one task of the partial round
     const int next_task = task >= ntasks ? -1 : (task + total_waves < ntasks ? task + total_waves : tail_task);
     const bool has_next = next_task >= 0;
@@ -258,12 +294,14 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     // packed in-projection is added here (k_chain.hip stores q and k without bias: K's bias only adds
     // a row constant to the logits, which softmax cancels), then everything is pre-scaled
     if constexpr (!BS) {   // (split tier: bias and scale were applied before the bf16 split, in the chain kernel's epilogue)
-        const float *bq = qbias + (pb % nblk) * kHeadDim + 4 * h + (HD == 16 ? 16 * sub : 0);   // HD = 16: slots 0, 1 hold features 16 sub ..
+        // HD = 16: slots 0, 1 hold features 16 sub ..; GEN: slot i holds the features 8 (sub + i) .. of the first block
+        const float *bq = qbias + (pb % nblk) * kHeadDim + 4 * h + (HD == 16 ? 16 * sub : GEN ? 8 * sub : 0);
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NQ; ++b)
 #pragma unroll
-            for (int s = 0; s < (HD == 16 ? 2 : 4); ++s)
-                qreg[b][s] = (qreg[b][s] + *reinterpret_cast<const f32x4 *>(bq + 32 * b + 8 * s)) * scale_log2e;
+            for (int s = 0; s < 4; ++s)
+                if (4 * b + s < (GEN ? NS : HD == 16 ? 2 : 4 * NB))
+                    qreg[b][s] = (qreg[b][s] + *reinterpret_cast<const f32x4 *>(bq + 32 * b + 8 * s)) * scale_log2e;
     }
     // Padded query lanes of the ragged last query tile read workspace nobody wrote: their results are never stored, but
     // the reference tests below are wave-wide (__any), so a large stale value there would switch the VALID lanes of the
@@ -271,16 +309,17 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
     // allocator handed out (found by a NaN / 1e30-poisoned pool, tools/debug/poison_repro.py).  Zero queries never trigger.
     if (ragged && qt == nkt - 1 && qt * kTile + r >= tokens) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NQ; ++b)
 #pragma unroll
-            for (int s = 0; s < (HD == 16 ? 2 : 4); ++s) qreg[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < 4; ++s)
+                if (4 * b + s < (GEN ? NS : HD == 16 ? 2 : 4 * NB)) qreg[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // ---- key tile 0: plain logits, reference maximum ----
     AttnRow<NB> st;
     f32x16 sA, sB;
     if constexpr (BS) sA = qk_tile_bs(kcur[0], qreg[0], true, 0.f, h);
-    else sA = qk_tile<NB, NMF>(kcur, qreg, true, a_one, 0.f);
+    else sA = qk_tile<NQ, NMF>(kcur, qreg, true, a_one, 0.f);
     if (nkt > 1) load_qk(ks, 1, kcur, hb, sub);
     if (ragged && nkt == 1) { mask_logits(sA, 0); mask_values(vcur, 0); }
     {
@@ -308,7 +347,7 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
         const bool more = FAST || kt + 1 < nkt;
         if (more) {
             if constexpr (BS) nxt = qk_tile_bs(kcur[0], qreg[0], st.zero_ref, -st.m_ref, h);
-            else nxt = qk_tile<NB, NMF>(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
+            else nxt = qk_tile<NQ, NMF>(kcur, qreg, st.zero_ref, a_one, -st.m_ref);   // independent of everything below
             if (FAST || kt + 2 < nkt) load_qk(ks, kt + 2, kcur, hb, sub);
         } else if (has_next) {      // last tile: Q and K are idle -> request the next task's
             const unsigned hbn = head_base(next_task);
@@ -367,10 +406,10 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
                 }
         }
         if (more) {
-            load_tile(vs, kt + 1, vcur, hb);
+            load_tile(vs, kt + 1, vcur, hb, vb1);
             if (!FAST && ragged && kt + 2 == nkt) mask_values(vcur, kt + 1);
         } else if (has_next) {
-            load_tile(vs, 0, vcur, head_base(next_task));
+            load_tile(vs, 0, vcur, head_base(next_task), second_block_bytes(next_task));
         }
     };
     using Fast = std::integral_constant<bool, true>;
@@ -404,6 +443,7 @@ __device__ __forceinline__ void attn_body(const float *__restrict__ q, const flo
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (HD == 16 && (g >> 1) != sub) continue;   // rows 8g .. 8g+7 of the block belong to the other head
+                if (GEN && (4 * b + g < sub || 4 * b + g >= sub + NS)) continue;   // group 4b + g of the first block onwards: not this head's
                 f32x4 o = {st.oacc[b][4 * g] * inv, st.oacc[b][4 * g + 1] * inv, st.oacc[b][4 * g + 2] * inv, st.oacc[b][4 * g + 3] * inv};
                 srd_store(os, dst + (b * 4 + g) * 1024, o);
             }

@@ -21,9 +21,11 @@ __device__ __forceinline__ int partial_round_task(int vblock, int wave, int ntas
 }
 
 // launch bound (256, 3): <= 168 registers keeps accumulators in VGPRs, see attn_device.h
-// HD = 32: three waves per SIMD (the tuned shape).  HD = 64 holds two blocks of q / k / v^T and two accumulators (~210 VGPRs): two.
+// HD = 32: three waves per SIMD (the tuned shape).  HD = 64 holds two blocks of q / k / v^T and two accumulators (~210 VGPRs): two; so do
+// the head dims whose heads straddle two blocks (24, 40, 48).
+constexpr int attn_waves_per_simd(int hd) { return hd == 64 || hd == 24 || hd == 40 || hd == 48 ? 2 : AFT_ATTN_WAVES; }
 template <int HD, int TOK = 0>
-__global__ __launch_bounds__(256, HD == 64 ? 2 : AFT_ATTN_WAVES) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
+__global__ __launch_bounds__(256, attn_waves_per_simd(HD)) void attn_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                       const float *__restrict__ vt, const float *__restrict__ qbias,
                                                       float *__restrict__ out, int nblk, int tokens, int tokpad,
                                                       int model_dim,
@@ -58,9 +60,9 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn_split_kernel(const f
 
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
                             float *attn, int planes, int tokens, int tokpad, hipStream_t st) {
-    const int hd = c.model_dim / c.num_head, nblk = c.model_dim / kHeadDim;   // head dimension 16 | 32 | 64 (check_config); 32-feature blocks
+    const int hd = c.model_dim / c.num_head, nblk = c.model_dim / kHeadDim;   // head dimension: a multiple of 8 up to 64, not 56 (check_config); 32-feature blocks
     const int ntasks = planes * c.num_head * (tokpad / kTile);
-    const int resident_blocks = (hd == 64 ? 2 : AFT_ATTN_WAVES) * current_device_cus();   // CUs x workgroups (launch bound: waves / SIMD)
+    const int resident_blocks = attn_waves_per_simd(hd) * current_device_cus();   // CUs x workgroups (launch bound: waves / SIMD)
     const int blocks = std::min((ntasks + 3) / 4, resident_blocks);
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
     if (c.precision == AFT_PRECISION_BF16X3) {
@@ -114,6 +116,15 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
     }
 #endif
     unsigned long long *no_stamps = nullptr;
+#define AFT_ATTN_HD(HD_)                                                                                                              \
+    if (hd == HD_) {                                                                                                                  \
+        hipLaunchKernelGGL((attn_kernel<HD_>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim, \
+                           scale_log2e, ntasks, no_stamps);                                                                           \
+        return hipGetLastError();                                                                                                     \
+    }
+    AFT_ATTN_HD(8) AFT_ATTN_HD(24) AFT_ATTN_HD(40) AFT_ATTN_HD(48)   // heads that start anywhere in a block (attn_device.h); covered, not tuned
+#undef AFT_ATTN_HD
+    if (hd != 16 && hd != 32 && hd != 64) return hipErrorInvalidValue;   // check_config refuses these
     if (hd == 16)
         hipLaunchKernelGGL((attn_kernel<16>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
                            scale_log2e, ntasks, no_stamps);

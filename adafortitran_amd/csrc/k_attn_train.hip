@@ -800,46 +800,51 @@ __global__ __launch_bounds__(kAtThreads * GROUPS) __attribute__((amdgpu_waves_pe
     }
 }
 
-// ---- head dimension 16 (round 5): the kernels above contract 32 features per head.  A 16-feature head is run as a 32-feature head
-// whose upper half is zero: q | k | v are re-laid with every head's 16 features padded to 32 (the zeros add nothing to Q K^T, the
-// padded half of O / dV / dQ / dK comes out zero and is dropped), the softmax scale stays 1 / sqrt(16).  Twice the matrix work of a
-// tuned kernel and four re-lay passes per layer -- covered, not tuned -- but every gradient comes from this library's kernels
+// ---- head dimensions other than 32 and 64 (round 5): the kernels above contract 32 (or, in their two-block form, 64) features per
+// head.  A head of 8 / 16 / 24 features is run as a 32-feature head, one of 40 / 48 as a 64-feature head, whose upper features are
+// zero: q | k | v are re-laid with every head padded (the zeros add nothing to Q K^T, the padded part of O / dV / dQ / dK comes out
+// zero and is dropped), the softmax scale stays 1 / sqrt(true head dim).  More matrix work than a tuned kernel would do and four
+// re-lay passes per layer -- covered, not tuned -- but every gradient comes from this library's kernels
 // (reference blocks/encoders.py:44-51 builds whatever num_head the YAML says; trainer.py:195-233 trains it).
-// pad: dst [rows][nseg][heads][32] <- src [rows][nseg][heads][16]; unpad: the reverse.  One 16-byte piece per thread.
-__global__ __launch_bounds__(256) void pad_heads16_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t pieces, int nh) {
-    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // piece of dst: (row, seg*heads + head, j4 in 0..7)
+// pad: dst [rows][nseg][heads][hp] <- src [rows][nseg][heads][hd]; unpad: the reverse.  One 16-byte piece per thread.
+static int padded_head(int hd) { return hd == 32 || hd == 64 ? hd : hd < 32 ? 32 : 64; }
+__global__ __launch_bounds__(256) void pad_heads_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t pieces, int hd4, int hp4) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // piece of dst: (row, seg * heads + head, j4 in 0 .. hp4 - 1)
     if (v >= pieces) return;
-    const int j4 = (int)(v & 7);
-    const size_t rh = v >> 3;                                      // row * nh + (seg, head)
+    const size_t rh = v / hp4;                                     // row * nseg * heads + (seg, head)
+    const int j4 = (int)(v - rh * hp4);
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    if (j4 < 4) o = *reinterpret_cast<const f32x4 *>(src + rh * 16 + 4 * j4);
+    if (j4 < hd4) o = *reinterpret_cast<const f32x4 *>(src + (rh * hd4 + j4) * 4);
     *reinterpret_cast<f32x4 *>(dst + v * 4) = o;
-    (void)nh;
 }
-__global__ __launch_bounds__(256) void unpad_heads16_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t pieces) {
-    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // piece of dst: (row * nh + (seg, head), j4 in 0..3)
+__global__ __launch_bounds__(256) void unpad_heads_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t pieces, int hd4, int hp4) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // piece of dst: (row * nseg * heads + (seg, head), j4 in 0 .. hd4 - 1)
     if (v >= pieces) return;
-    const size_t rh = v >> 2;
-    *reinterpret_cast<f32x4 *>(dst + v * 4) = *reinterpret_cast<const f32x4 *>(src + rh * 32 + 4 * (v & 3));
+    const size_t rh = v / hd4;
+    *reinterpret_cast<f32x4 *>(dst + v * 4) = *reinterpret_cast<const f32x4 *>(src + (rh * hp4 + (v - rh * hd4)) * 4);
 }
-static hipError_t pad16(const float *src, float *dst, size_t rows, int nseg, int heads, hipStream_t st) {
-    const size_t pieces = rows * nseg * heads * 8;
-    hipLaunchKernelGGL(pad_heads16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, src, dst, pieces, nseg * heads);
+static hipError_t pad_heads(const float *src, float *dst, size_t rows, int nseg, int heads, int hd, hipStream_t st) {
+    const int hp = padded_head(hd);
+    const size_t pieces = rows * nseg * heads * (hp / 4);
+    hipLaunchKernelGGL(pad_heads_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, src, dst, pieces, hd / 4, hp / 4);
     return hipGetLastError();
 }
-static hipError_t unpad16(const float *src, float *dst, size_t rows, int nseg, int heads, hipStream_t st) {
-    const size_t pieces = rows * nseg * heads * 4;
-    hipLaunchKernelGGL(unpad_heads16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, src, dst, pieces);
+static hipError_t unpad_heads(const float *src, float *dst, size_t rows, int nseg, int heads, int hd, hipStream_t st) {
+    const int hp = padded_head(hd);
+    const size_t pieces = rows * nseg * heads * (hd / 4);
+    hipLaunchKernelGGL(unpad_heads_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, src, dst, pieces, hd / 4, hp / 4);
     return hipGetLastError();
 }
-size_t attn_train_pad_floats(const aft_config &c, size_t rows) {   // scratch the head-dim-16 path needs: qkv, o, d_o, dqkv padded
-    return c.num_head > 0 && c.model_dim / c.num_head == 16 ? rows * (size_t)c.num_head * 32 * 8 : 0;
+size_t attn_train_pad_floats(const aft_config &c, size_t rows) {   // scratch the padded-head path needs: qkv, o, d_o, dqkv padded
+    if (c.num_head <= 0) return 0;
+    const int hd = c.model_dim / c.num_head, hp = padded_head(hd);
+    return hp != hd ? rows * (size_t)c.num_head * hp * 8 : 0;
 }
 
 static AttnTrainArgs make_args(const aft_config &c, int planes, int tokens, float dropout_p, uint32_t seed) {
     AttnTrainArgs a{};
     a.planes = planes; a.tokens = tokens; a.heads = c.num_head; a.d = c.model_dim;
-    if (c.model_dim / c.num_head == 16) a.d = 32 * c.num_head;    // padded heads (the launchers re-lay the operands)
+    a.d = padded_head(c.model_dim / c.num_head) * c.num_head;     // padded heads (the launchers re-lay the operands): > model_dim
     a.ntiles = (tokens + 31) / 32;
     const float inv = 1.f / sqrtf((float)(c.model_dim / c.num_head));
     a.scale = inv;
@@ -855,22 +860,23 @@ hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o
                                  float dropout_p, uint32_t seed, hipStream_t st, float *pad) {
     AttnTrainArgs a = make_args(c, planes, tokens, dropout_p, seed);
     a.qkv = qkv; a.out = o; a.lse = lse;
-    const bool hd16 = c.model_dim / c.num_head == 16;
+    const int hd = c.model_dim / c.num_head, hp = padded_head(hd);
+    const bool padded = hp != hd;
     const size_t rows = (size_t)planes * tokens;
-    if (hd16) {
+    if (padded) {
         if (pad == nullptr) return hipErrorInvalidValue;
         float *qkv_p = pad, *o_p = pad + rows * 3 * a.d;
-        hipError_t e = pad16(qkv, qkv_p, rows, 3, c.num_head, st);
+        hipError_t e = pad_heads(qkv, qkv_p, rows, 3, c.num_head, hd, st);
         if (e != hipSuccess) return e;
         a.qkv = qkv_p; a.out = o_p;
     }
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
-    if (c.model_dim / c.num_head == 64)      // a head = two 32-feature blocks (round 5; covered, not tuned)
+    if (hp == 64)      // a head = two 32-feature blocks (round 5; covered, not tuned)
         hipLaunchKernelGGL(attn_train_fwd64_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
     else
         hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && hd16) e = unpad16(a.out, o, rows, 1, c.num_head, st);
+    if (e == hipSuccess && padded) e = unpad_heads(a.out, o, rows, 1, c.num_head, hd, st);
     return e;
 }
 
@@ -882,19 +888,20 @@ hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const fl
                                  hipStream_t st, float *pad) {
     AttnTrainArgs a = make_args(c, planes, tokens, dropout_p, seed);
     a.qkv = qkv; a.o = o; a.d_o = d_o; a.lse = const_cast<float *>(lse); a.dsum = dsum; a.out = dqkv;
-    if (c.model_dim / c.num_head == 16) {   // padded heads: re-lay the three operands, run on the padded image, drop the padding of dqkv
+    const int hd = c.model_dim / c.num_head;
+    if (padded_head(hd) != hd) {   // padded heads: re-lay the three operands, run on the padded image, drop the padding of dqkv
         if (pad == nullptr) return hipErrorInvalidValue;
         const size_t rows = (size_t)planes * tokens;
         float *qkv_p = pad, *o_p = qkv_p + rows * 3 * a.d, *do_p = o_p + rows * a.d, *dqkv_p = do_p + rows * a.d;
-        hipError_t e = pad16(qkv, qkv_p, rows, 3, c.num_head, st);
-        if (e == hipSuccess) e = pad16(o, o_p, rows, 1, c.num_head, st);
-        if (e == hipSuccess) e = pad16(d_o, do_p, rows, 1, c.num_head, st);
+        hipError_t e = pad_heads(qkv, qkv_p, rows, 3, c.num_head, hd, st);
+        if (e == hipSuccess) e = pad_heads(o, o_p, rows, 1, c.num_head, hd, st);
+        if (e == hipSuccess) e = pad_heads(d_o, do_p, rows, 1, c.num_head, hd, st);
         if (e != hipSuccess) return e;
-        aft_config c32 = c;
-        c32.model_dim = a.d;                 // 32 features per head: the plain path below, scales already set from the true head dim
+        aft_config cp = c;
+        cp.model_dim = a.d;                  // 32 or 64 features per head: the plain path below, scales already set from the true head dim
         AttnTrainArgs keep = a;
-        e = launch_attn_train_bwd_padded(c32, keep, qkv_p, o_p, do_p, dqkv_p, planes, tokens, st);
-        if (e == hipSuccess) e = unpad16(dqkv_p, dqkv, rows, 3, c.num_head, st);
+        e = launch_attn_train_bwd_padded(cp, keep, qkv_p, o_p, do_p, dqkv_p, planes, tokens, st);
+        if (e == hipSuccess) e = unpad_heads(dqkv_p, dqkv, rows, 3, c.num_head, hd, st);
         return e;
     }
     return launch_attn_train_bwd_padded(c, a, qkv, o, d_o, dqkv, planes, tokens, st);

@@ -18,7 +18,7 @@ Execution paths of ``forward``:
 
 Coverage is ONE predicate, asked once at construction (``aft_check_config``): a configuration the
 reference accepts but the gfx950 kernels do not cover (model_dim not a multiple of 32 up to 256, head dim
-other than 16 / 32 / 64, patch > 16 elements, a grid with no LDS band plan) is refused with a ``ValueError``
+not a multiple of 8 up to 64 or equal to 56, patch > 16 elements, a grid with no LDS band plan) is refused with a ``ValueError``
 when the model is built on a HIP device -- before any training -- instead of failing in the first ``eval()``
 forward.  ``AFT_ALLOW_COMPOSITE=1`` in the environment opts into running such a model entirely on the
 PyTorch-ROCm composite (logged).  The TRAINING kernels cover what inference covers; where a block of an accepted

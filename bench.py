@@ -903,6 +903,8 @@ def main() -> int:
                 for tag, over in (("d64_h2", dict(model_dim=64, num_head=2)), ("d96_h3", dict(model_dim=96, num_head=3)),
                                   ("d192_h6", dict(model_dim=192, num_head=6)), ("d256_h8", dict(model_dim=256, num_head=8)),
                                   ("d128_h8_hd16", dict(num_head=8)), ("d128_h2_hd64", dict(num_head=2)),
+                                  ("d128_h16_hd8", dict(num_head=16)), ("d96_h4_hd24", dict(model_dim=96, num_head=4)),
+                                  ("d192_h4_hd48", dict(model_dim=192, num_head=4)),
                                   ("grid_60x14", dict(ofdm=(60, 14), pilot=(6, 2), hidden=(7, 42, 280))),
                                   ("grid_12x14_28tok", dict(ofdm=(12, 14), pilot=(4, 2), hidden=(7, 42, 56)))):
                     r = batch_sweep(dict(C3, **over, batch=128), device, (128,), steps=10, warmup=3)

@@ -349,6 +349,11 @@ SETS = {
     "H16_ada_heads8": (dict(DEFAULT, num_layers=2, num_head=8, adaptive_hidden=[7, 42, 560], seed=161, attn_gain=0.25, head_gain=2.0), 4,
                        ["enc_out"]),
     "H64_forti_heads2": (dict(DEFAULT, num_layers=2, num_head=2, seed=641, attn_gain=24.0, ffn_gain=2.0, head_gain=4.0), 4, ["enc_out"]),
+    # heads that do not line up with the kernels' 32-feature blocks (late round 5): 4 heads of 24 at model_dim 96, 4 heads of 48 at 192
+    "H24_ada_d96_heads4": (dict(DEFAULT, num_layers=2, model_dim=96, num_head=4, adaptive_hidden=[7, 42, 560], seed=241, attn_gain=0.25,
+                                head_gain=2.0), 4, ["enc_out"]),
+    "H48_forti_d192_heads4": (dict(DEFAULT, num_layers=2, model_dim=192, num_head=4, seed=481, attn_gain=24.0, ffn_gain=2.0, head_gain=4.0), 3,
+                              ["enc_out"]),
     "S28_ada_tokens28": (dict(ofdm=[12, 14], pilot=[4, 2], patch=[3, 2], num_layers=2, model_dim=64, num_head=2,
                               adaptive_hidden=[7, 42, 56], max_seq_len=32, seed=281, attn_gain=0.5, head_gain=2.0), 5,
                          ["conv_enhanced", "enc_out"]),
@@ -381,6 +386,9 @@ if __name__ == "__main__":
     H16 = dict(DEFAULT, num_layers=2, num_head=8, dropout=0.0, seed=781, attn_gain=8.0)
     S28 = dict(DEFAULT, ofdm=(12, 14), pilot=(4, 2), num_layers=2, dropout=0.0, seed=782, attn_gain=8.0)
     H64 = dict(DEFAULT, num_layers=2, num_head=2, dropout=0.0, seed=783, attn_gain=8.0)      # head dim 64 (`num_head: 2`)
+    H24 = dict(DEFAULT, num_layers=2, model_dim=96, num_head=4, dropout=0.0, seed=784, attn_gain=8.0)   # head dim 24: heads straddle blocks
+    if not only or "G_grad_forti_h24" in only:
+        run_grad("G_grad_forti_h24", H24, 3)
     if not only or "G_grad_forti_h64" in only:
         run_grad("G_grad_forti_h64", H64, 3)
     if not only or "G_grad_forti_h16" in only:
@@ -393,7 +401,7 @@ if __name__ == "__main__":
               "G_grad64_forti_full": ("G_grad_forti_full", dict(DEFAULT, dropout=0.0, seed=779), 128),
               "G_grad64_ada_full": ("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128),
               "G_grad64_forti_h16": ("G_grad_forti_h16", H16, 3), "G_grad64_forti_s28": ("G_grad_forti_s28", S28, 5),
-              "G_grad64_forti_h64": ("G_grad_forti_h64", H64, 3)}
+              "G_grad64_forti_h64": ("G_grad_forti_h64", H64, 3), "G_grad64_forti_h24": ("G_grad_forti_h24", H24, 3)}
     for nm, (_f32, spec, batch) in GRAD64.items():
         if not only or nm in only:
             run_grad64(nm, spec, batch)

@@ -46,6 +46,12 @@ def test_loader_checks_version_and_host_only_calls():
     bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=80, num_head=5))
     assert lib.aft_workspace_bytes(ctypes.byref(bad), 8) == 0
     assert b"model_dim" in lib.aft_last_error()
+    # head dims: multiples of 8 up to 64 except 56 (a head may straddle at most two 32-feature blocks); the rest is refused with the reason
+    for d, heads, ok in ((128, 16, True), (96, 4, True), (192, 4, True), (160, 4, True), (224, 4, False), (96, 8, False), (128, 1, False),
+                         (160, 8, False), (128, 3, False)):
+        c = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=d, num_head=heads))
+        assert (lib.aft_workspace_bytes(ctypes.byref(c), 8) > 0) == ok, (d, heads)
+        assert ok or b"head dim" in lib.aft_last_error()
 
 
 def test_workspace_regions_are_inside_the_workspace():

@@ -39,7 +39,8 @@ def test_extension_is_loaded_in_tree():
     assert "libaft_hip.so" in maps
 
 
-OTHER_SHAPE_SETS = ["H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28"]   # head dim 16 / 64; 28 tokens (one masked key tile)
+OTHER_SHAPE_SETS = ["H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28",   # head dim 16 / 64; 28 tokens (one masked key tile)
+                    "H24_ada_d96_heads4", "H48_forti_d192_heads4"]                # head dims 24 / 48: heads that start anywhere in a 32-feature block
 
 
 @pytest.mark.parametrize("name", DEFAULT_SETS + ["C5_ada_large"] + OTHER_SHAPE_SETS)
@@ -325,7 +326,9 @@ def test_row_streaming_conv_does_not_depend_on_the_column_split():
 @pytest.mark.parametrize("d,heads", [(64, 2), (192, 6),                    # head dim 32: two / six waves per chain workgroup
                                      (128, 8), (64, 4), (192, 12), (256, 16),   # head dim 16: two heads per 32-feature block
                                      (128, 2), (64, 1), (192, 3), (256, 4),     # head dim 64: a head spans two blocks
-                                     (32, 1), (32, 2), (96, 3), (96, 6), (160, 5), (160, 10), (224, 7), (224, 14)])   # round 5: every multiple of 32
+                                     (32, 1), (32, 2), (96, 3), (96, 6), (160, 5), (160, 10), (224, 7), (224, 14),   # round 5: every multiple of 32
+                                     # late round 5: heads that start anywhere in a block -- head dims 8 / 24 / 40 / 48
+                                     (128, 16), (32, 4), (256, 32), (96, 4), (192, 8), (160, 4), (96, 2), (192, 4)])
 def test_other_model_dims_match_oracle(oracle_lib, adaptive, d, heads):
     """Every (model_dim, num_head) the kernels cover besides the default: nn.MultiheadAttention takes any num_head that divides
     model_dim (reference blocks/encoders.py:44-51).  Non-uniform softmax (attn_gain), 9 frames = ragged row tiles, run-to-run
@@ -498,7 +501,7 @@ def test_uncovered_configuration_is_refused_at_construction(monkeypatch):
     assert out.shape == (2, 120, 14) and model._engine is None          # composite ran, no C-ABI engine
 
 
-@pytest.mark.parametrize("name", ["H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28"])
+@pytest.mark.parametrize("name", OTHER_SHAPE_SETS)
 def test_module_surface_with_other_head_dims_and_small_grids(name):
     """`num_head: 8` at `model_dim: 128` (head dim 16), `num_head: 2` (head dim 64) and a 28-token grid through the MODULE, as the
     reference's YAML would configure them: eval() runs the HIP engine (golden parity, CPU inputs), train() differentiates through the
@@ -530,8 +533,22 @@ def test_module_surface_with_other_head_dims_and_small_grids(name):
         tgt = torch.from_numpy(g["target"]).to(dev)
         torch.view_as_real(est - tgt).pow(2).mean().backward()
         grads.append({n: p.grad.detach().cpu().numpy() for n, p in mdl.named_parameters()})
-    for n, ref in grads[0].items():
-        assert np.abs(grads[1][n] - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-12, n
+    off = [n for n, ref in grads[0].items() if np.abs(grads[1][n] - ref).max() > 2e-3 * np.abs(ref).max() + 1e-12]
+    if off:
+        # A pre-activation of the first conv stack that is ~0 takes different sides of its ReLU in two fp32 summation orders; the
+        # tensors upstream of it (pilot_upsampler, conv_block.0: |g|max ~ 1e-6) then differ by ~1e-2 although both are valid
+        # (H24 set: the CPU composite and PyTorch-ROCm fp32 agree with each other, the library's kernels with float64 --
+        # tools/debug/hd24_surface_repro.py).  Arbiter: the same module in float64 -- the library's gradients must sit on ITS side.
+        mdl = cls(sc_g, mc_g)
+        mdl.load_state_dict({k: torch.from_numpy(v) for k, v in g.state_dict().items()})
+        mdl.train().double()
+        m64 = tuple(x.double() if torch.is_tensor(x) and x.is_floating_point() else x for x in meta) if g.adaptive else None
+        est = mdl(pil.to(torch.complex128), m64) if g.adaptive else mdl(pil.to(torch.complex128))
+        torch.view_as_real(est - torch.from_numpy(g["target"]).cuda().to(torch.complex128)).pow(2).mean().backward()
+        g64 = {n: p.grad.detach().cpu().numpy() for n, p in mdl.named_parameters()}
+        for n in off:
+            assert n.startswith(("pilot_upsampler", "initial_enhancer")), n
+            assert np.abs(grads[1][n] - g64[n]).max() <= 1e-4 * np.abs(g64[n]).max(), n
 
 
 def test_stream_and_graph_semantics():
@@ -610,7 +627,7 @@ def test_linear_and_mse_kernels(oracle_lib):
         assert abs(got - want) <= 1e-6 * want   # device subtracts in fp32 (as torch does), oracle in fp64
 
 
-def _random_specs(n, seed):
+def _random_specs(n, seed, head_dims=(16, 32, 64)):
     """Random valid configurations: any grid the patch divides (token counts from 1 to 512, below one MFMA tile included), patches of
     <= 16 elements, model_dim any multiple of 32 up to 256 with head dim 16 / 32 / 64 (64 where it divides), 1-3 layers, both activations /
     positional encodings."""
@@ -625,7 +642,10 @@ def _random_specs(n, seed):
         if (not small and gs * gt < 32) or (small and gs * gt >= 32) or gs * gt > 512 or gs * p0 > 160 or gt * p1 > 28:
             continue
         d = int(rng.choice([32, 64, 96, 128, 160, 192, 224, 256]))
-        hd = int(rng.choice([16, 32, 64] if d % 64 == 0 else [16, 32]))
+        fits = [x for x in head_dims if d % x == 0]
+        if not fits:
+            continue
+        hd = int(rng.choice(fits))
         ps, pt = int(rng.integers(2, 13)), int(rng.integers(1, 4))
         out.append(dict(ofdm=(gs * p0, gt * p1), pilot=(ps, pt), patch=(p0, p1), num_layers=int(rng.integers(1, 4)),
                         model_dim=d, num_head=d // hd, activation=str(rng.choice(["gelu", "relu"])),
@@ -634,7 +654,7 @@ def _random_specs(n, seed):
     return out
 
 
-@pytest.mark.parametrize("spec", _random_specs(40, 2027), ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['model_dim']}h{s['num_head']}{'a' if s['adaptive'] else 'f'}")
+@pytest.mark.parametrize("spec", _random_specs(40, 2027) + _random_specs(20, 2031, head_dims=(8, 24, 40, 48)), ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['model_dim']}h{s['num_head']}{'a' if s['adaptive'] else 'f'}")
 def test_random_configurations_match_oracle(oracle_lib, spec):
     tokens = (spec["ofdm"][0] // spec["patch"][0]) * (spec["ofdm"][1] // spec["patch"][1])
     base = dict(ofdm=spec["ofdm"], pilot=spec["pilot"], patch=spec["patch"], num_layers=spec["num_layers"],

@@ -6,7 +6,8 @@ import pytest
 from helpers import Golden, TOL_ORACLE_OUT, TOL_ORACLE_STAGE, max_rel
 
 ALL_SETS = ["T_tiny_ada", "T_tiny_forti", "D_forti", "A_ada", "DH_forti_hot", "AH_ada_mid", "AS_ada_sin_relu",
-            "H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28"]     # head dims 16 / 64, a grid of 28 tokens
+            "H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28",     # head dims 16 / 64, a grid of 28 tokens
+            "H24_ada_d96_heads4", "H48_forti_d192_heads4"]                # heads of 24 / 48 features (not aligned with 32-feature blocks)
 
 
 @pytest.mark.parametrize("name", ALL_SETS)

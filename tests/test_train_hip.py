@@ -44,7 +44,10 @@ def _rel(a, b):
                                                      (128, 2, (12, 14), 6, "gelu"),
                                                      # every multiple of 32 (row-wise kernels with a half-filled last lane group)
                                                      (96, 3, (48, 14), 4, "gelu"), (32, 1, (48, 14), 2, "relu"), (160, 10, (24, 14), 2, "gelu"),
-                                                     (224, 7, (24, 14), 2, "relu"), (32, 2, (12, 14), 4, "gelu")])
+                                                     (224, 7, (24, 14), 2, "relu"), (32, 2, (12, 14), 4, "gelu"),
+                                                     # late round 5: head dims 8 / 24 (padded to 32-feature heads), 40 / 48 (to 64)
+                                                     (128, 16, (120, 14), 2, "gelu"), (96, 4, (48, 14), 4, "relu"), (192, 8, (24, 14), 2, "gelu"),
+                                                     (160, 4, (48, 14), 2, "gelu"), (96, 2, (120, 14), 2, "relu"), (192, 4, (12, 14), 4, "gelu")])
 def test_layer_forward_backward_matches_autograd(d, heads, ofdm, planes, act):
     from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
     cfg = _cfg(d, heads, ofdm, act)
@@ -488,6 +491,11 @@ def _random_train_specs(n, seed):
     out.append(dict(ofdm=(24, 14), pilot=(6, 2), patch=(3, 2), d=64, hd=64, act="relu", adaptive=False, batch=3))
     out.append(dict(ofdm=(48, 14), pilot=(6, 2), patch=(3, 2), d=96, hd=32, act="gelu", adaptive=True, batch=2))
     out.append(dict(ofdm=(24, 14), pilot=(6, 2), patch=(3, 2), d=160, hd=16, act="relu", adaptive=False, batch=2))
+    # late round 5: heads that start anywhere in a 32-feature block (head dims 24 / 48 / 8)
+    out.append(dict(ofdm=(48, 14), pilot=(6, 2), patch=(3, 2), d=96, hd=24, act="gelu", adaptive=True, batch=2))
+    out.append(dict(ofdm=(48, 14), pilot=(6, 2), patch=(3, 2), d=192, hd=48, act="gelu", adaptive=True, batch=2))
+    out.append(dict(ofdm=(24, 14), pilot=(6, 2), patch=(3, 2), d=128, hd=8, act="relu", adaptive=False, batch=3))
+    out.append(dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), d=160, hd=40, act="relu", adaptive=True, batch=2))
     return out
 
 
