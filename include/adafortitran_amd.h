@@ -71,7 +71,8 @@ typedef struct aft_config {
     int32_t num_scs, num_symbols;     /* OFDM grid S x T (120 x 14)                  */
     int32_t pilot_scs, pilot_symbols; /* pilot grid (12 x 2)                         */
     int32_t patch_scs, patch_symbols; /* patch (3 x 2): tokens = (S/p0)*(T/p1)       */
-    int32_t num_layers, model_dim, num_head;
+    int32_t num_layers, model_dim, num_head; /* covered (aft_check_config says why not otherwise): model_dim a multiple of 32 up to 256,
+                                       * model_dim / num_head a multiple of 8 up to 64 except 56, patches of <= 16 elements */
     int32_t activation;               /* AFT_ACT_*                                   */
     int32_t adaptive;                 /* 1 = AdaFortiTran (adapter tokens), 0 = FortiTran */
     int32_t hidden[3];                /* channel_adaptivity_hidden_sizes (adaptive only) */
