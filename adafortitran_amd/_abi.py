@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, Dict, Optional
 
-AFT_ABI_VERSION = 5
+AFT_ABI_VERSION = 6
 AFT_MAX_LAYERS = 32
 AFT_OK, AFT_ERR_ARG, AFT_ERR_SHAPE, AFT_ERR_HIP = 0, 1, 2, 3
 AFT_ACT_RELU, AFT_ACT_GELU = 0, 1
@@ -131,7 +131,7 @@ def pos_key_of(state: Dict[str, object]) -> str:
 
 #: every symbol include/adafortitran_amd.h declares (tests check the .so exports them all)
 EXPORTED_SYMBOLS = (
-    "aft_version", "aft_last_error", "aft_check_config", "aft_max_batch", "aft_workspace_bytes", "aft_workspace_region", "aft_forward_f32",
+    "aft_version", "aft_last_error", "aft_check_config", "aft_max_batch", "aft_workspace_bytes", "aft_workspace_region", "aft_workspace_lanes", "aft_forward_f32",
     "aft_packed_weights_bytes", "aft_pack_weights_f32", "aft_forward_prepacked_f32",
     "aft_linear_forward_f32", "aft_mse_partial_f32", "aft_stage_upsample_f32",
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",

@@ -54,6 +54,8 @@ def load_path(path: str):
     vp, cfgp, wp = C.c_void_p, C.POINTER(_abi.AftConfig), C.POINTER(_abi.AftWeights)
     lib.aft_check_config.argtypes = [cfgp]
     lib.aft_workspace_region.argtypes = [cfgp, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.aft_workspace_lanes.restype = C.c_int
+    lib.aft_workspace_lanes.argtypes = [cfgp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     lib.aft_max_batch.argtypes = [cfgp]
     lib.aft_forward_f32.argtypes = [cfgp, wp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]
     lib.aft_packed_weights_bytes.restype = C.c_size_t

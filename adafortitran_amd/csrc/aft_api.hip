@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "aft_internal.h"
 
@@ -166,6 +168,82 @@ static int hip_fail(const char *what, hipError_t e) {
     return AFT_ERR_HIP;
 }
 
+// ---- lanes (late round 5) ----
+// A forward whose launches are fewer than ~2.5 rounds of the persistent grids leaves CUs idle at the end of every launch (whole row
+// tiles / attention tasks over 256 CUs, section 5 of DESIGN.md).  Frames are independent, so such a forward is run as TWO (or more)
+// forwards over contiguous shares of the batch: share 0 on the caller's stream, the others on library-owned side streams forked from
+// and joined back into it with events -- the hardware then fills the tail of one share's launch with the other share's next one.
+// Each share is a complete forward with its own slice of the workspace (laid end to end, share 0 first); per-frame arithmetic does
+// not depend on the batch a frame travels in, so the bits are those of the single forward (tests/test_hip_parity.py).
+constexpr int kMaxLanes = 4;
+struct LanePlan {
+    int lanes;
+    int frames[kMaxLanes], first[kMaxLanes];
+    size_t ws_off[kMaxLanes];     // floats
+    size_t total_floats;
+};
+// When it pays (tools/debug/lanes_threshold.py, one lane against two, six configurations x batches): with at most one row tile per CU
+// every launch already sits at its latency floor and a second lane only adds launches (0.73-0.83 x); from there up to ~2.5 rounds of
+// the row-local chain's persistent grid two lanes win (default model: 16 frames 1.12 x, 32 1.03-1.10, 64 1.03-1.06, 96 1.02-1.04;
+// model_dim 256: 16 frames 1.32 x, 32 1.11; config 5's grid at 4 / 8 frames 1.27 / 1.15); beyond, one lane is as good or better (128
+// frames = 2.9 rounds: 0.98-1.02 by the box) and the per-kernel accounting stays that of one launch sequence.  model_dim below 128
+// (two- / three-wave chain workgroups, short launches): 0.93-1.02, not split.
+static int lanes_wanted(const aft_config &c, int batch) {
+    if (const char *e = getenv("AFT_LANES")) {      // A/B switch: 1 = never split, 2 .. 4 = always that many shares
+        const int v = atoi(e);
+        if (v >= 1 && v <= kMaxLanes) return std::min(v, batch);
+    }
+    const long tiles = ((long)2 * batch * tokens_of(c) + 31) / 32, cus = current_device_cus();
+    const long slots = cus * (c.model_dim <= 128 ? 3 : 1);       // workgroups of the chain kernel's persistent grid (k_chain.hip)
+    if (batch < 2 || c.model_dim < 128 || tiles <= cus) return 1;
+    return tiles * 100 < slots * 250 ? 2 : 1;
+}
+static LanePlan plan_lanes(const aft_config &c, int batch, int lanes) {
+    LanePlan p{};
+    p.lanes = std::max(1, std::min(lanes, std::min(batch, kMaxLanes)));
+    size_t off = 0;
+    for (int i = 0; i < p.lanes; ++i) {
+        p.first[i] = (int)((long)batch * i / p.lanes);
+        p.frames[i] = (int)((long)batch * (i + 1) / p.lanes) - p.first[i];
+        p.ws_off[i] = off;
+        off += plan_workspace(c, p.frames[i]).total_floats;
+    }
+    p.total_floats = off;
+    return p;
+}
+static size_t workspace_floats_any_lanes(const aft_config &c, int batch) {   // whatever lanes_wanted() answers at call time fits
+    size_t m = 0;
+    for (int l = 1; l <= kMaxLanes; ++l) m = std::max(m, plan_lanes(c, batch, l).total_floats);
+    return m;
+}
+// Side streams + fork / join events of one caller stream (created on first use, kept for the process: like the per-device attribute
+// caches, nothing here describes a call).  At most kLaneCacheMax caller streams get them; further ones run unsplit.
+struct LaneStreams {
+    hipStream_t side[kMaxLanes - 1];
+    hipEvent_t fork, join[kMaxLanes - 1];
+};
+static LaneStreams *lane_streams_for(hipStream_t user) {
+    constexpr int kLaneCacheMax = 16;
+    struct Entry { int dev; hipStream_t user; LaneStreams ls; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &en : cache)
+        if (en.dev == dev && en.user == user) return &en.ls;
+    if ((int)cache.size() >= kLaneCacheMax) return nullptr;
+    cache.reserve(kLaneCacheMax);      // entries never move: callers keep the pointer for the duration of a call
+    Entry en{dev, user, {}};
+    if (hipEventCreateWithFlags(&en.ls.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < kMaxLanes - 1; ++i)
+        if (hipStreamCreateWithFlags(&en.ls.side[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&en.ls.join[i], hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+    cache.push_back(en);
+    return &cache.back().ls;
+}
+
 // `fused` (whole forward only): the first launch computes x0 from conv_enhanced / tokens6 itself (no embed kernel) and
 // the last one leaves linear_2's output in the q buffer instead of storing x (the conv tail reads it from there).
 // `prepacked`: the caller's fragment-packed image of ALL layers (aft_pack_weights_f32), or NULL = pack into the workspace now.
@@ -234,7 +312,7 @@ int aft_max_batch(const aft_config *cfg) {
 
 size_t aft_workspace_bytes(const aft_config *cfg, int batch) {
     if (check_config(cfg) != AFT_OK || batch <= 0) return 0;
-    return plan_workspace(*cfg, batch).total_floats * sizeof(float);
+    return workspace_floats_any_lanes(*cfg, batch) * sizeof(float);
 }
 
 int aft_workspace_region(const aft_config *cfg, int batch, int region, size_t *offset_bytes, size_t *size_bytes) {
@@ -257,6 +335,23 @@ int aft_workspace_region(const aft_config *cfg, int batch, int region, size_t *o
     return AFT_OK;
 }
 
+int aft_workspace_lanes(const aft_config *cfg, int batch, int *lanes, int *frames, size_t *offset_bytes) {
+    int rc = check_config(cfg);
+    if (rc != AFT_OK) return rc;
+    if (batch <= 0 || !lanes || !frames || !offset_bytes) {
+        set_error("aft_workspace_lanes: bad batch or NULL result pointer");
+        return AFT_ERR_ARG;
+    }
+    static_assert(kMaxLanes == AFT_MAX_LANES, "header and implementation disagree");
+    const LanePlan lp = plan_lanes(*cfg, batch, lanes_wanted(*cfg, batch));
+    *lanes = lp.lanes;
+    for (int i = 0; i < kMaxLanes; ++i) {
+        frames[i] = i < lp.lanes ? lp.frames[i] : 0;
+        offset_bytes[i] = i < lp.lanes ? lp.ws_off[i] * sizeof(float) : 0;
+    }
+    return AFT_OK;
+}
+
 #define AFT_REQUIRE(cond, ...)        \
     do {                              \
         if (!(cond)) {                \
@@ -264,6 +359,9 @@ int aft_workspace_region(const aft_config *cfg, int batch, int region, size_t *o
             return AFT_ERR_ARG;       \
         }                             \
     } while (0)
+
+static int forward_lane(const aft_config *cfg, const aft_weights *w, const float *prepacked, const float *pilots, const float *snr,
+                        const float *ds, const float *dop, float *out, float *base, int batch, hipStream_t st);
 
 static int forward_impl(const aft_config *cfg, const aft_weights *w, const float *prepacked, const float *pilots,
                         const float *snr, const float *ds, const float *dop, float *out, void *workspace,
@@ -276,11 +374,42 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
                 "offsets: no workspace region may reach 2 GiB); split the batch", batch, max_batch_of(*cfg));
     // reference fortitran.py:157-158: meta_data is required when channel adaptation is enabled
     AFT_REQUIRE(!cfg->adaptive || (snr && ds && dop), "meta_data is required when channel adaptation is enabled");
+    hipStream_t user = static_cast<hipStream_t>(stream);
+    LanePlan lp = plan_lanes(*cfg, batch, lanes_wanted(*cfg, batch));
+    LaneStreams *ls = lp.lanes > 1 ? lane_streams_for(user) : nullptr;
+    if (lp.lanes > 1 && ls == nullptr) lp = plan_lanes(*cfg, batch, 1);
+    AFT_REQUIRE(workspace_bytes >= lp.total_floats * sizeof(float), "workspace too small: %zu < %zu bytes (aft_workspace_bytes)",
+                workspace_bytes, lp.total_floats * sizeof(float));
+    if (lp.lanes > 1) {
+        hipError_t ef = hipEventRecord(ls->fork, user);
+        for (int i = 1; i < lp.lanes && ef == hipSuccess; ++i) ef = hipStreamWaitEvent(ls->side[i - 1], ls->fork, 0);
+        if (ef != hipSuccess) return hip_fail("lanes(fork)", ef);
+    }
+    const int pil_floats = 2 * cfg->pilot_scs * cfg->pilot_symbols, out_floats = 2 * cfg->num_scs * cfg->num_symbols;   // complex64 per frame
+    int result = AFT_OK;
+    for (int i = 0; i < lp.lanes; ++i) {
+        const int f0 = lp.first[i];
+        const int rc_lane = forward_lane(cfg, w, prepacked, pilots + (size_t)f0 * pil_floats, snr ? snr + f0 : nullptr, ds ? ds + f0 : nullptr,
+                                         dop ? dop + f0 : nullptr, out + (size_t)f0 * out_floats, static_cast<float *>(workspace) + lp.ws_off[i],
+                                         lp.frames[i], i == 0 ? user : ls->side[i - 1]);
+        if (rc_lane != AFT_OK && result == AFT_OK) result = rc_lane;     // keep going: the join below must still happen
+    }
+    if (lp.lanes > 1) {
+        hipError_t ej = hipSuccess;
+        for (int i = 1; i < lp.lanes && ej == hipSuccess; ++i) {
+            ej = hipEventRecord(ls->join[i - 1], ls->side[i - 1]);
+            if (ej == hipSuccess) ej = hipStreamWaitEvent(user, ls->join[i - 1], 0);
+        }
+        if (ej != hipSuccess && result == AFT_OK) return hip_fail("lanes(join)", ej);
+    }
+    return result;
+}
+
+// one share of the batch: a complete forward on `st` in its own workspace slice
+static int forward_lane(const aft_config *cfg, const aft_weights *w, const float *prepacked, const float *pilots, const float *snr,
+                        const float *ds, const float *dop, float *out, float *base, int batch, hipStream_t st) {
     const Workspace ws = plan_workspace(*cfg, batch);
-    AFT_REQUIRE(workspace_bytes >= ws.total_floats * sizeof(float), "workspace too small: %zu < %zu bytes",
-                workspace_bytes, ws.total_floats * sizeof(float));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    float *base = static_cast<float *>(workspace);
+    int rc = AFT_OK;
     // prologue: the channel adapter, -- unless the caller owns a packed image -- the re-lay of the encoder weights into fragment
     // order, and the pilot_upsampler product over all planes, in ONE launch (none depends on anything the forward computes).
     // The activation buffer x is idle until the first encoder launch: it lends the upsampler its plane scratch when it is large enough

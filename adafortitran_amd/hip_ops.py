@@ -190,13 +190,19 @@ class HipEngine:
         'conv_enhanced' f32 [2B,S,T], 'tokens6' f32 [B,tokens,6], 'enc_out' f32 [2B,tokens,8|16] -- the production kernels'
         intermediates, for known-answer tests.  A copy, valid whatever runs next."""
         c = self.cfg
-        off, size = C.c_size_t(), C.c_size_t()
-        _lib.check(self.lib.aft_workspace_region(C.byref(c), batch, _abi.REGION_IDS[name], C.byref(off), C.byref(size)))
         ws = self._ws[self._stream()]
-        flat = ws[off.value:off.value + size.value].view(torch.float32).clone()
-        shape = {"conv_enhanced": (2 * batch, c.num_scs, c.num_symbols), "tokens6": (batch, self.tokens, 6),
-                 "enc_out": (2 * batch, self.tokens, -1)}[name]
-        return flat.view(*shape)
+        # the forward may have run as several lanes (contiguous shares of the batch, each with its own slice of the workspace)
+        lanes, frames, bases = C.c_int(), (C.c_int * 4)(), (C.c_size_t * 4)()
+        _lib.check(self.lib.aft_workspace_lanes(C.byref(c), batch, C.byref(lanes), frames, bases))
+        parts = []
+        for i in range(lanes.value):
+            off, size = C.c_size_t(), C.c_size_t()
+            _lib.check(self.lib.aft_workspace_region(C.byref(c), frames[i], _abi.REGION_IDS[name], C.byref(off), C.byref(size)))
+            flat = ws[bases[i] + off.value:bases[i] + off.value + size.value].view(torch.float32).clone()
+            shape = {"conv_enhanced": (2 * frames[i], c.num_scs, c.num_symbols), "tokens6": (frames[i], self.tokens, 6),
+                     "enc_out": (2 * frames[i], self.tokens, -1)}[name]
+            parts.append(flat.view(*shape))
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
     # -- per-stage entry points (tests) ----------------------------------------------------
     def stage_upsample(self, pilots: torch.Tensor) -> torch.Tensor:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AFT_ABI_VERSION 5   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
+#define AFT_ABI_VERSION 6   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
 #define AFT_MAX_LAYERS 32
 
 #define AFT_OK 0
@@ -120,9 +120,24 @@ int aft_max_batch(const aft_config *cfg);
 /* Bytes of scratch aft_forward_f32 needs for `batch` frames (0 on a bad config). */
 size_t aft_workspace_bytes(const aft_config *cfg, int batch);
 
+/* Lanes (no reference counterpart).  A forward whose launches would fill fewer than ~2.5 rounds of the kernels' persistent grids
+ * (128 frames of the default model are 2.9) is run as TWO complete forwards over contiguous shares of the batch: share 0 on the
+ * caller's stream, share 1 on a library-owned side stream that is forked from the caller's stream by an event when the call starts
+ * and joined back into it by an event before the call returns -- the hardware fills the idle tail of one share's launch with the
+ * other share's next launch.  To the caller the call is still asynchronous on ONE stream (everything the call enqueues is ordered
+ * after the stream's earlier work and before its later work; capturable in a hipGraph: the side stream joins the capture).  Frames
+ * are independent, so the output bits are those of the unsplit forward.  The side stream and its two events are created on the
+ * first such call per (device, caller stream) and kept; AFT_LANES=1 in the environment (read per call) switches the split off.
+ * aft_workspace_lanes reports the split the next forward of `batch` frames will use: lanes (1 .. AFT_MAX_LANES), and per lane its
+ * frame count and the byte offset of its slice of `workspace` (a lane's slice is laid out as the workspace of a forward of that many
+ * frames).  `frames` and `offset_bytes` are arrays of AFT_MAX_LANES entries. */
+#define AFT_MAX_LANES 4
+int aft_workspace_lanes(const aft_config *cfg, int batch, int *lanes, int *frames, size_t *offset_bytes);
+
 /* Where aft_forward_f32 LEAVES its intermediates in `workspace` (no reference counterpart; known-answer tests use it to pin
  * the kernels the forward itself launches -- the per-stage entry points further down do not always run the same kernels):
- * byte offset and byte size of one region for `batch` frames.  Regions stay valid until the next call on that workspace.
+ * byte offset and byte size of one region of a lane of `batch` frames, relative to that lane's slice of the workspace
+ * (aft_workspace_lanes; a forward that is not split has one lane at offset 0).  Regions stay valid until the next call on that workspace.
  *   AFT_REGION_CONV_ENHANCED  f32 [2B,S,T]            output of S1+S2 (fortitran.py:203-209), kept for the S7 residual
  *   AFT_REGION_TOKENS6        f32 [B,tokens,6]        ChannelAdapter output (channel_adaptivity.py:59-63); adaptive configs
  *   AFT_REGION_ENC_OUT        f32 [2B*tokens,stride]  linear_2's output (encoders.py:70), `stride` = 8 for patches of up to
@@ -142,7 +157,7 @@ int aft_workspace_region(const aft_config *cfg, int batch, int region, size_t *o
  * fortitran.py:167-173 needs no copy engine hop in front of the first launch -- the caller keeps the buffer unchanged until
  * the call's kernels have run (record an event behind the call).  `out`, `workspace` and the weights are device memory.
  * Launches: [adapter + weight re-lay] (one prologue launch), conv head, embedding + in-projection, L x (attention, row-local
- * chain), conv tail. */
+ * chain), conv tail -- once, or once per lane when a short forward is split ("Lanes" above). */
 int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pilots,
                     const float *snr, const float *ds, const float *dop, float *out,
                     void *workspace, size_t workspace_bytes, int batch, void *stream);

@@ -42,7 +42,10 @@ def test_loader_checks_version_and_host_only_calls():
     # (the attention tiles are sized for per-plane row tiles, planes x tokpad rows: the plane-resident encoder's layout)
     expect = 4 * (planes * 1680 + 128 * tokens * 6 + planes * tokens * d + planes * tokpad * d + 3 * planes * 4 * tokpad * 32
                   + 6 * 8 * d * d + planes * tokens * 8 + 2 * (22 * 64 * 4 + 160))   # + both conv stacks' 16x16x4 operand fragments and helper tables
-    assert expect <= nbytes <= expect + 10 * 256
+    # ABI 6: the forward may run as up to AFT_MAX_LANES = 4 shares of the batch, each with its own packed weights and fragment tables
+    # (aft_workspace_lanes); the size covers whichever split the call picks
+    expect += 4 * 3 * (6 * 8 * d * d + 2 * (22 * 64 * 4 + 160))
+    assert expect <= nbytes <= expect + 40 * 256
     bad = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=80, num_head=5))
     assert lib.aft_workspace_bytes(ctypes.byref(bad), 8) == 0
     assert b"model_dim" in lib.aft_last_error()
@@ -52,6 +55,36 @@ def test_loader_checks_version_and_host_only_calls():
         c = _abi.make_config(**dict(DEFAULT_SPEC, model_dim=d, num_head=heads))
         assert (lib.aft_workspace_bytes(ctypes.byref(c), 8) > 0) == ok, (d, heads)
         assert ok or b"head dim" in lib.aft_last_error()
+
+
+def test_lanes_split_the_batch_into_contiguous_shares_inside_the_workspace(monkeypatch):
+    """aft_workspace_lanes: the shares a forward of `batch` frames runs as (include/adafortitran_amd.h "Lanes"): contiguous,
+    non-empty, slices laid end to end and inside aft_workspace_bytes -- which must not depend on AFT_LANES (read per call)."""
+    lib = _lib.load()
+    cfg = _abi.make_config(**DEFAULT_SPEC, adaptive_hidden=(7, 42, 560))
+
+    def plan(batch):
+        lanes, frames, offs = ctypes.c_int(), (ctypes.c_int * 4)(), (ctypes.c_size_t * 4)()
+        assert lib.aft_workspace_lanes(ctypes.byref(cfg), batch, ctypes.byref(lanes), frames, offs) == _abi.AFT_OK
+        return lanes.value, list(frames)[:lanes.value], list(offs)[:lanes.value]
+
+    monkeypatch.delenv("AFT_LANES", raising=False)
+    sizes = {b: lib.aft_workspace_bytes(ctypes.byref(cfg), b) for b in (1, 2, 7, 64, 128)}
+    # 64 frames: 1.5 rounds of the persistent grids | 128: 2.9 | 8 frames: 140 row tiles, less than one per CU | one frame
+    assert plan(64)[0] == 2 and plan(16)[0] == 2 and plan(128)[0] == 1 and plan(8)[0] == 1 and plan(1)[0] == 1
+    for want in (1, 2, 3, 4):
+        monkeypatch.setenv("AFT_LANES", str(want))
+        for batch, total in sizes.items():
+            assert lib.aft_workspace_bytes(ctypes.byref(cfg), batch) == total
+            n, frames, offs = plan(batch)
+            assert n == min(want, batch) and sum(frames) == batch and min(frames) > 0 and max(frames) - min(frames) <= 1
+            assert offs[0] == 0 and all(o % 256 == 0 for o in offs) and offs == sorted(offs)
+            # the last slice ends inside the workspace: its own size is at most aft_workspace_bytes(its frames), which allows for
+            # three more copies of the packed weights and fragment tables than one unsplit forward needs
+            slack = 4 * 3 * (6 * 8 * 128 * 128 + 2 * (22 * 64 * 4 + 160)) + 40 * 256
+            assert offs[-1] + lib.aft_workspace_bytes(ctypes.byref(cfg), frames[-1]) - slack <= total
+    lanes = ctypes.c_int()
+    assert lib.aft_workspace_lanes(ctypes.byref(cfg), 0, ctypes.byref(lanes), None, None) == _abi.AFT_ERR_ARG
 
 
 def test_workspace_regions_are_inside_the_workspace():

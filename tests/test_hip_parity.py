@@ -580,6 +580,54 @@ def test_stream_and_graph_semantics():
     assert torch.equal(torch.view_as_real(static_out), torch.view_as_real(want))
 
 
+@pytest.mark.parametrize("batch", [2, 5, 33, 64, 130])
+def test_lanes_reproduce_the_unsplit_forward(batch, monkeypatch):
+    """include/adafortitran_amd.h "Lanes": a forward of fewer than ~2.5 rounds of the persistent grids runs as two complete forwards
+    over contiguous shares of the batch, share 1 on a library-owned side stream forked from / joined into the caller's.  Same bits
+    as the unsplit forward (AFT_LANES=1) for every split the switch allows, the intermediates the forward leaves behind included;
+    back-to-back calls on one stream and calls on two caller streams at once stay correct (each caller stream has its own side
+    stream and events)."""
+    g = Golden("A_ada")
+    eng = _engine(g)
+    inp = synth.make_inputs(batch, seed=77)
+    pil, meta = _t(inp["pilots"]), [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    monkeypatch.setenv("AFT_LANES", "1")
+    ref = eng.forward(pil, *meta).clone()
+    regions = {n: eng.forward_region(n, batch) for n in ("conv_enhanced", "tokens6", "enc_out")}
+    for want in (None, "2", "3", "4"):
+        if want is None:
+            monkeypatch.delenv("AFT_LANES")
+        else:
+            monkeypatch.setenv("AFT_LANES", want)
+        _poison_allocator(1e30)
+        for _ in range(3):                                        # back to back: the next call's fork waits for this call's join
+            out = eng.forward(pil, *meta)
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref)), want
+        for n, r in regions.items():
+            assert torch.equal(eng.forward_region(n, batch), r), (want, n)
+    # inside a hipGraph capture the side stream joins the capture (fork / join are event nodes of the graph)
+    monkeypatch.setenv("AFT_LANES", "2")
+    static_out = torch.empty_like(ref)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.forward(pil, *meta, out=static_out)
+    for _ in range(2):
+        static_out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(static_out), torch.view_as_real(ref))
+    monkeypatch.delenv("AFT_LANES", raising=False)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = []
+    for rep in range(4):
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(eng.forward(pil, *meta))
+    torch.cuda.synchronize()
+    assert all(torch.equal(torch.view_as_real(o), torch.view_as_real(ref)) for o in outs)
+
+
 def test_graph_capture_as_first_call():
     """No call-describing state in the library: in a fresh process the FIRST call may already be a
     hipGraph capture (kernel attributes / CU count are set per device on demand, nothing needs a warm
