@@ -127,7 +127,8 @@ size_t aft_workspace_bytes(const aft_config *cfg, int batch);
  * other share's next launch.  To the caller the call is still asynchronous on ONE stream (everything the call enqueues is ordered
  * after the stream's earlier work and before its later work; capturable in a hipGraph: the side stream joins the capture).  Frames
  * are independent, so the output bits are those of the unsplit forward.  The side stream and its two events are created on the
- * first such call per (device, caller stream) and kept; AFT_LANES=1 in the environment (read per call) switches the split off.
+ * first such call per (device, caller stream) and kept (for at most 16 caller streams per process; calls on further streams
+ * run unsplit); AFT_LANES=1 in the environment (read per call) switches the split off.
  * aft_workspace_lanes reports the split the next forward of `batch` frames will use: lanes (1 .. AFT_MAX_LANES), and per lane its
  * frame count and the byte offset of its slice of `workspace` (a lane's slice is laid out as the workspace of a forward of that many
  * frames).  `frames` and `offset_bytes` are arrays of AFT_MAX_LANES entries. */
