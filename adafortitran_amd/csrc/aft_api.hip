@@ -91,7 +91,9 @@ int check_config(const aft_config *c) {
         return AFT_ERR_SHAPE;
     }
     if (c->patch_scs * c->patch_symbols > kMaxPatchFeatures) {
-        set_error("patch %dx%d has more than %d elements", c->patch_scs, c->patch_symbols, kMaxPatchFeatures);
+        set_error("patch %dx%d has more than %d elements: the fused embedding stages linear_1's (patch + 6) x model_dim weights in the "
+                  "chain kernel's idle half of its LDS hidden buffer and linear_2's outputs ride in one 16-column MFMA tile", c->patch_scs,
+                  c->patch_symbols, kMaxPatchFeatures);
         return AFT_ERR_SHAPE;
     }
     if (c->precision != AFT_PRECISION_F32 && (c->precision != AFT_PRECISION_BF16X3 || (c->model_dim != 128 && c->model_dim != 256) ||
