@@ -628,6 +628,46 @@ def test_lanes_reproduce_the_unsplit_forward(batch, monkeypatch):
     assert all(torch.equal(torch.view_as_real(o), torch.view_as_real(ref)) for o in outs)
 
 
+def test_lanes_under_host_threads_and_many_caller_streams(monkeypatch):
+    """The library keeps one side stream + events per (device, caller stream), behind a mutex, for at most 16 caller streams: four
+    host threads forwarding at once on their own streams, then 24 caller streams in turn (the later ones run unsplit) -- the bits of
+    the unsplit forward every time."""
+    import threading
+    g = Golden("A_ada")
+    inp = synth.make_inputs(48, seed=78)
+    pil, meta = _t(inp["pilots"]), [_t(inp[k]) for k in ("snr", "ds", "dop")]
+    monkeypatch.setenv("AFT_LANES", "1")
+    ref = _engine(g).forward(pil, *meta).clone()
+    monkeypatch.delenv("AFT_LANES")
+    torch.cuda.synchronize()
+    bad = []
+
+    def worker(k):
+        eng, st = _engine(g), torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for it in range(40):
+                out = eng.forward(pil, *meta)
+                if it % 10 == 9:
+                    st.synchronize()
+                    if not torch.equal(torch.view_as_real(out), torch.view_as_real(ref)):
+                        bad.append((k, it))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad
+    eng = _engine(g)
+    for k in range(24):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            out = eng.forward(pil, *meta)
+        st.synchronize()
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref)), k
+
+
 def test_graph_capture_as_first_call():
     """No call-describing state in the library: in a fresh process the FIRST call may already be a
     hipGraph capture (kernel attributes / CU count are set per device on demand, nothing needs a warm
