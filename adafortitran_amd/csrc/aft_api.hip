@@ -184,21 +184,39 @@ struct LanePlan {
     size_t ws_off[kMaxLanes];     // floats
     size_t total_floats;
 };
-// When it pays (tools/debug/lanes_threshold.py, one lane against two, six configurations x batches): with at most one row tile per CU
-// every launch already sits at its latency floor and a second lane only adds launches (0.73-0.83 x); from there up to ~2.5 rounds of
-// the row-local chain's persistent grid two lanes win (default model: 16 frames 1.12 x, 32 1.03-1.10, 64 1.03-1.06, 96 1.02-1.04;
-// model_dim 256: 16 frames 1.32 x, 32 1.11; config 5's grid at 4 / 8 frames 1.27 / 1.15); beyond, one lane is as good or better (128
-// frames = 2.9 rounds: 0.98-1.02 by the box) and the per-kernel accounting stays that of one launch sequence.  model_dim below 128
-// (two- / three-wave chain workgroups, short launches): 0.93-1.02, not split.
+// When it pays (tools/debug/lanes_threshold.py and the tables of DESIGN.md section 5: one lane against two over eight configurations
+// x batches, four boxes):
+//  * at most one row tile per CU: every launch already sits at its latency floor and a second lane only adds launches (0.73-0.83 x);
+//    model_dim below 128 (two- / three-wave chain workgroups, short launches): 0.93-1.02 x.  One lane.
+//  * above ~15 row tiles per CU (4 000 at 256 CUs: 256 frames of the default model, 64 of config 5) the tails are a small share of
+//    every launch and two lanes cost 0-3 %.  One lane.
+//  * in between two lanes run at a flat ~0.98 of the best per-frame rate whatever the batch, while one lane swings between 0.91 and
+//    1.00 with how well the batch fills whole rounds of the three persistent grids (default model: 128 frames 1.00, 129 0.94,
+//    132 0.91, 120 0.95, 192 0.96).  So: one lane where the launches of ONE lane are nearly whole rounds -- the round efficiency
+//    n / (ceil(n / slots) slots) of the chain's row tiles, the attention tasks and the conv planes, weighted by their share of a
+//    forward (0.55 / 0.35 / 0.10), at least 0.97: 127 / 128 frames of the default model (0.985 at 128: the benchmark's batch keeps
+//    one launch sequence and its per-kernel accounting) -- else two (16 frames 1.12 x, 32 1.10, 64 1.03-1.06, 96 1.02-1.04,
+//    129 1.04, 132 1.07, 160 1.01, 192 1.03; model_dim 256: 16 frames 1.32 x, 64 1.05-1.08; config 5: 4 / 8 / 16 / 48 frames
+//    1.27 / 1.15 / 1.05 / 1.03; other head counts and model dims at 64 / 128 frames 0.99-1.10).
+static double round_efficiency(long n, long slots) {
+    const long rounds = (n + slots - 1) / std::max<long>(slots, 1);
+    return rounds > 0 ? (double)n / (double)(rounds * slots) : 1.0;
+}
 static int lanes_wanted(const aft_config &c, int batch) {
     if (const char *e = getenv("AFT_LANES")) {      // A/B switch: 1 = never split, 2 .. 4 = always that many shares
         const int v = atoi(e);
         if (v >= 1 && v <= kMaxLanes) return std::min(v, batch);
     }
-    const long tiles = ((long)2 * batch * tokens_of(c) + 31) / 32, cus = current_device_cus();
-    const long slots = cus * (c.model_dim <= 128 ? 3 : 1);       // workgroups of the chain kernel's persistent grid (k_chain.hip)
-    if (batch < 2 || c.model_dim < 128 || tiles <= cus) return 1;
-    return tiles * 100 < slots * 250 ? 2 : 1;
+    const long tokens = tokens_of(c), planes = 2L * batch, cus = current_device_cus();
+    const long tiles = (planes * tokens + 31) / 32;
+    if (batch < 2 || c.model_dim < 128 || tiles <= cus || tiles * 256 > 4000 * cus) return 1;
+    const int hd = c.model_dim / c.num_head;
+    const long chain_slots = cus * (c.model_dim <= 128 ? 3 : 1);                                  // k_chain.hip: workgroups per CU
+    const long attn_slots = cus * 4 * ((hd == 64 || hd == 24 || hd == 40 || hd == 48) ? 2 : 3);   // k_attn.hip: waves per SIMD
+    const long attn_tasks = planes * c.num_head * ((tokens + 31) / 32);
+    const double eff = 0.55 * round_efficiency(tiles, chain_slots) + 0.35 * round_efficiency(attn_tasks, attn_slots) +
+                       0.10 * round_efficiency(planes, cus);
+    return eff >= 0.97 ? 1 : 2;
 }
 static LanePlan plan_lanes(const aft_config &c, int batch, int lanes) {
     LanePlan p{};

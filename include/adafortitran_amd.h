@@ -120,8 +120,9 @@ int aft_max_batch(const aft_config *cfg);
 /* Bytes of scratch aft_forward_f32 needs for `batch` frames (0 on a bad config). */
 size_t aft_workspace_bytes(const aft_config *cfg, int batch);
 
-/* Lanes (no reference counterpart).  A forward whose launches would fill fewer than ~2.5 rounds of the kernels' persistent grids
- * (128 frames of the default model are 2.9) is run as TWO complete forwards over contiguous shares of the batch: share 0 on the
+/* Lanes (no reference counterpart).  A forward whose launches do not fill whole rounds of the kernels' persistent grids -- more than
+ * one row tile per CU, fewer than ~15, and not as well aligned as the default model's 127 / 128 frames (DESIGN.md section 5 has the
+ * rule and the measurements) -- is run as TWO complete forwards over contiguous shares of the batch: share 0 on the
  * caller's stream, share 1 on a library-owned side stream that is forked from the caller's stream by an event when the call starts
  * and joined back into it by an event before the call returns -- the hardware fills the idle tail of one share's launch with the
  * other share's next launch.  To the caller the call is still asynchronous on ONE stream (everything the call enqueues is ordered
