@@ -894,6 +894,7 @@ def main() -> int:
         if per_rank is not None:
             result["per_rank"] = per_rank
         if not args.stub:
+            result["config"]["lanes"] = lanes_of(wl.eng, B)    # launch sequences the timed forward ran as (1 at the stated batches)
             kernels, roof, enc_util, t_flow, fl, ups = kernel_report(wl, 20)
             roof["traffic"] = load_pmc_traffic()
             result.update({"roofline": roof, "kernels": kernels, "upsampler": ups, "forward_ms_one_event_pair": t_flow,
