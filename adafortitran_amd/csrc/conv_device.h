@@ -30,6 +30,7 @@ struct ConvArgs {
     unsigned long long *stamps;   // diagnostic build only (AFT_DIAG_STAMPS): per-workgroup s_memtime at the phase boundaries
     int plane0;                   // conv_stream16_kernel: first plane of this launch (a forward may launch its planes in two parts)
     const float *wfrag;           // conv_stream16_kernel: this stack's conv2 / conv3 weights as 16x16x4 operand fragments (conv_frag16_entry)
+    int ranges;                   // conv_stream_kernel<., true> (training): column ranges a plane is split into (1 | 2 | 4; 0 = 1)
 };
 
 // ---- conv2 / conv3 weights of one ConvEnhancer as v_mfma_f32_16x16x4_f32 A-operand fragments, packed by the forward's prologue launch

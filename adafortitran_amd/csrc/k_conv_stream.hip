@@ -101,7 +101,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
     // publication (round 5, found in the disassembly)
     volatile lds_int *flags = (volatile lds_int *)(smem + kFlags);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x, frame = n >> 1, part = n & 1;
+    // Column ranges (training instantiation only, late round 5): with fewer planes than CUs a plane is worked by `ranges` workgroups,
+    // each producing the output columns [ta, tb) and recomputing what it needs of its neighbours' columns -- conv3 columns
+    // [ta - 1, tb + 1), conv2 [ta - 2, tb + 2), conv1 [ta - 3, tb + 3), clipped to the plane.  Every column goes through the same
+    // instruction sequence as in the whole-plane sweep (same bits; columns two ranges both compute are stored twice with the same value).
+    const int ranges = TRAIN ? max(a.ranges, 1) : 1;
+    const int n = blockIdx.x / ranges, range = blockIdx.x - n * ranges, frame = n >> 1, part = n & 1;
+    const int wcols = (T + ranges - 1) / ranges, ta = range * wcols, tb = min(T, ta + wcols);
+    const int c3lo = max(ta - 1, 0), c3hi = min(tb + 1, T), c2lo = max(ta - 2, 0), c2hi = min(tb + 2, T);
+    const int c1lo = max(ta - 3, 0), c1hi = min(tb + 3, T), c1mid = c1lo + (c1hi - c1lo + 1) / 2;
     const bool matrix = wave < 4;
 #ifdef AFT_DIAG_STAMPS
     // slots 0..7: matrix wave 0, 8..15: helper wave 4 (thread 256)
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias3[e] = (TRAIN && !a.cb[2]) ? 0.f : a.cb[2][e + 4 * h];
         wait_count(4, 4);                        // the helpers' input plane
-        conv1_columns(wave, T / 2, T);
+        conv1_columns(wave, c1mid, c1hi);
     } else {
         // ---- helper waves: borders, input plane, conv1 of the first columns ----
         const int ht = tid - 256;   // 0..255
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         }
         signal_count(4);
         wait_count(4, 4);
-        conv1_columns(wave - 4, 0, T / 2);
+        conv1_columns(wave - 4, c1lo, c1mid);
     }
     SSTAMP(2);
     __syncthreads();   // fragments gathered (the staging area is dead), c1 complete (in0 is dead: it becomes the output plane)
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             asm volatile("" ::: "memory");
         };
         auto store_col = [&](int tout, float v0, float v1, float v2, float v3) {
-            if (tout < 0 || tout >= T) return;
+            if (tout < c3lo || tout >= c3hi) return;      // (a range's first / last conv3 sums lack a conv2 column of the neighbour range)
             if (ok3) {
                 float *p = dst + (tout + 1) * SP;
                 const float v[4] = {v0, v1, v2, v3};
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         };
         float b[36];
 #pragma unroll
-        for (int kb = 0; kb < 36; ++kb) b[kb] = b_at(kb, 0);
+        for (int kb = 0; kb < 36; ++kb) b[kb] = b_at(kb, c2lo);
         // conv2's bias in accumulator-register order, held in registers: every column's chain STARTS from it as the C operand of
         // its first MFMA (no copy, no LDS wait at the column boundary)
         f32x16 bias2v;
@@ -345,16 +353,16 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
                 }
             }
         };
-        request_mask(0);
-        {   // prologue: conv2 of column 0
+        request_mask(c2lo);
+        {   // prologue: conv2 of the first column
             f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
-            b[0] = b_at(0, 1);
+            b[0] = b_at(0, c2lo + 1);
 #pragma unroll
             for (int kb = 1; kb < 36; ++kb) {
                 acc2 = mfma_f32(wa2[kb], b[kb], acc2);
-                b[kb] = b_at(kb, 1);
+                b[kb] = b_at(kb, c2lo + 1);
             }
-            activate2(acc2, 0);
+            activate2(acc2, c2lo);
         }
         auto conv3_step = [&](int i) {   // ky = centre (16..31), below (0..15), above (32..47)
             const int e = i & 15;
@@ -372,8 +380,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         };
         constexpr int kLead = 4;   // conv2 MFMAs of the next column issued BEFORE the column hand-over (store + rotate wait for conv3's last MFMA)
 #pragma unroll 1
-        for (int tcol = 0; tcol < T - 1; ++tcol) {
-            const int tnext = min(tcol + 2, T - 1);
+        for (int tcol = c2lo; tcol < c2hi - 1; ++tcol) {
+            const int tnext = min(tcol + 2, c2hi - 1);
             request_mask(tcol + 1);
             f32x16 acc2 = mfma_f32(wa2[0], b[0], bias2v);
             b[0] = b_at(0, tnext);
@@ -399,12 +407,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
             }
             activate2(acc2, tcol + 1);
         }
-        store_col(T - 3, acc3[8], acc3[9], acc3[10], acc3[11]);
+        store_col(c2hi - 3, acc3[8], acc3[9], acc3[10], acc3[11]);
         rotate();
 #pragma unroll
         for (int i = 0; i < 48; ++i) conv3_step(i);      // conv3 of the last column
-        store_col(T - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
-        store_col(T - 1, acc3[4], acc3[5], acc3[6], acc3[7]);   // (registers 0..3 would be column T: zero padding)
+        store_col(c2hi - 2, acc3[8], acc3[9], acc3[10], acc3[11]);
+        store_col(c2hi - 1, acc3[4], acc3[5], acc3[6], acc3[7]);   // whole plane: registers 0..3 would be column T (zero padding); a range that ends inside the plane drops it
     } else {
         // ---- helper waves: conv3's zero borders, then conv4 (8 -> 1) column by column behind the matrix waves ----
         const int ht = tid - 256;
@@ -455,17 +463,19 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
                 win[c][2][2] = p[r2];
             }
         };
-        // window before the loop: kx = 1 <- LDS column 0 (zero border), kx = 2 <- LDS column 1 (symbol 0)
-        need(1);
-        load_col(0);
+        // window before the loop: kx = 1 <- LDS column ta (symbol ta - 1, or the zero border), kx = 2 <- LDS column ta + 1 (symbol ta)
+        need(ta + 1);
+        load_col(ta);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) win[c][ky][1] = win[c][ky][2];
-        load_col(1);
+        load_col(ta + 1);
 #pragma unroll
-        for (int t = 0; t < T; ++t) {        // fully unrolled: the window slides by renaming, no register moves
-            need(t + 2 < T ? t + 2 : T);     // symbol t + 1 (LDS column t + 2; the last one is the zero border)
+        for (int u = 0; u < T; ++u) {        // fully unrolled: the window slides by renaming, no register moves
+            const int t = ta + u;
+            if (t >= tb) break;
+            need(min(t + 2, c3hi));          // symbol t + 1 (LDS column t + 2; beyond the plane it is the zero border)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -486,7 +496,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
     // ---- the output plane leaves in one coalesced pass ----
     {
         const float *obuf = in0;
-        if (MODE == 0) {
+        if (MODE == 0 && ranges > 1) {      // this range's columns only
+            float *dst = a.out_plane + (size_t)n * (S * T);
+            for (int i = tid; i < S * T; i += kConvThreads) {
+                const int t = i % T;
+                if (t >= ta && t < tb) dst[i] = obuf[i];
+            }
+        } else if (MODE == 0) {
             f32x4 *dst = reinterpret_cast<f32x4 *>(a.out_plane + (size_t)n * (S * T));
             const f32x4 *src4 = reinterpret_cast<const f32x4 *>(obuf);
             for (int i = tid; i < S * T / 4; i += kConvThreads) dst[i] = src4[i];
@@ -989,7 +1005,12 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     if (a.mode == 2) {   // training path: plain plane in / out, stage tensors saved, masked activation
         hipError_t et = ensure_dynamic_lds(lds_train, reinterpret_cast<const void *>(conv_stream_kernel<0, true>), kStreamLds);
         if (et != hipSuccess) return et;
-        hipLaunchKernelGGL((conv_stream_kernel<0, true>), dim3(planes), dim3(kConvThreads), kStreamLds, st, a);
+        // column ranges when the planes would leave half (three quarters) of the CUs idle: 64 frames -- the reference's default batch --
+        // are 128 planes (AFT_CONV_NSPLIT=1|2|4 forces a split: tests, A/B)
+        const int cus = current_device_cus();
+        a.ranges = 4 * planes <= cus ? 4 : (2 * planes <= cus ? 2 : 1);
+        if (const char *f = getenv("AFT_CONV_NSPLIT")) a.ranges = atoi(f) == 4 ? 4 : (atoi(f) == 2 ? 2 : 1);
+        hipLaunchKernelGGL((conv_stream_kernel<0, true>), dim3(planes * a.ranges), dim3(kConvThreads), kStreamLds, st, a);
         return hipGetLastError();
     }
     // the 16x16x4 kernel needs the fragment image of the forward's prologue launch; AFT_CONV_MFMA32=1 keeps the 32x32x2 kernel (A/B runs)

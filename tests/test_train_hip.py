@@ -445,6 +445,36 @@ def test_conv_enhancer_forward_backward_matches_autograd(S, T, n):
         assert _rel(a, b) <= 2e-4, name
 
 
+@pytest.mark.parametrize("n", [3, 10, 130])
+def test_training_conv_column_ranges_reproduce_whole_planes(n, monkeypatch):
+    """With fewer planes than CUs the training conv kernel (conv_stream_kernel<0, true>, forward and data gradient) splits every
+    plane of the default grid into 2 or 4 column ranges that recompute their neighbours' edge columns (64 frames -- the reference's
+    default batch -- are 128 planes on 256 CUs): the output, the three saved activations' consumers (the data gradient and every
+    weight gradient) carry the same BITS whatever the split."""
+    import adafortitran_amd.blocks as blocks
+    torch.manual_seed(n)
+    enh = blocks.ConvEnhancer().cuda()
+    x = torch.randn(n, 1, 120, 14, device="cuda", requires_grad=True)
+    gy = torch.randn(n, 1, 120, 14, device="cuda")
+    params = list(enh.parameters())
+
+    def run(split):
+        if split is None:
+            monkeypatch.delenv("AFT_CONV_NSPLIT", raising=False)
+        else:
+            monkeypatch.setenv("AFT_CONV_NSPLIT", split)
+        enh.zero_grad(); x.grad = None
+        y = enh(x)
+        y.backward(gy)
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in params]
+
+    ref = run("1")
+    for split in ("2", "4", None):
+        got = run(split)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), (split, i)
+
+
 @pytest.mark.parametrize("rows,in_f,out_f,bias", [(560, 12, 128, True), (561, 6, 128, True), (1120, 128, 6, True),
                                                    (37, 1, 7, True), (128, 42, 560, False), (256, 24, 1680, True),
                                                    # the aligned fast path (gemm_fast_kernel) with ragged row / column tiles
