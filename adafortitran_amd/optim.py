@@ -99,10 +99,11 @@ class FlatParameters:
     def zero_grad(self) -> None:
         """Keep the grad views alive (set_to_none would detach them from the flat buffer)."""
         self.grad.zero_()
+        base = self.grad.data_ptr()     # (one pointer compare per parameter: this runs every step, on the host's critical path at small batches)
         for p, off in zip(self.params, self.offsets):
-            n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.grad[off:off + n].data_ptr():
-                p.grad = self.grad[off:off + n].view(p.shape)
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * off:
+                p.grad = self.grad[off:off + p.numel()].view(p.shape)
 
 
 class ShardedFlatAdam(torch.optim.Optimizer):

@@ -292,9 +292,11 @@ class HipLinear(torch.nn.Linear):
 
 
 def layer_params(layer: torch.nn.Module):
-    """The twelve parameter tensors of one nn.TransformerEncoderLayer, ABI order."""
-    named = dict(layer.named_parameters())
-    return tuple(named[n] for n in _abi.LAYER_PARAM_NAMES)
+    """The twelve parameter tensors of one nn.TransformerEncoderLayer, ABI order (_abi.LAYER_PARAM_NAMES).  Plain attribute reads:
+    this runs for every layer of every step, and walking named_parameters() cost 0.2 ms of host time per step."""
+    at = layer.self_attn
+    return (at.in_proj_weight, at.in_proj_bias, at.out_proj.weight, at.out_proj.bias, layer.linear1.weight, layer.linear1.bias,
+            layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
 
 
 def encoder_stack_train(x: torch.Tensor, layers, cfg: _abi.AftConfig, dropout_p: float) -> torch.Tensor:
