@@ -103,12 +103,15 @@ __device__ __forceinline__ float lane_from_above(float v) {   // lane i <- lane 
 }
 
 
-constexpr int kUpPix = 64, kUpPlanes = 64;
+// A block = 64 pixels x kUpPlanes planes.  16 planes (late round 5; 64 before): four times the blocks, a quarter of the serial work of
+// each -- at config 5 (6 720 pixels x 96 pilots) the product's 210 blocks of 1 536 fused multiply-adds per thread were the prologue
+// launch's critical path (13 of its 37 us); per element the sum runs in the same order whatever the block shape (same bits).
+constexpr int kUpPix = 64, kUpPlanes = 16, kUpPerThread = kUpPlanes / 4;
 __device__ __forceinline__ void upsample_planes_body(float *ups, const float *__restrict__ up_w, const float *__restrict__ up_b,
                                                      const float *__restrict__ pilots, float *__restrict__ planes_out, int npix,
                                                      int pf, int nplanes, int bx, int by) {
     const int wld = pf + 4;                       // row stride of the weight tile: 16-byte rows, conflict-free float4 reads
-    float *Ws = ups, *Ps = ups + kUpPix * wld;    // [64][pf + 4] | [64][pf]
+    float *Ws = ups, *Ps = ups + kUpPix * wld;    // [64][pf + 4] | [kUpPlanes][pf]
     const int tid = threadIdx.x, pix0 = bx * kUpPix, plane0 = by * kUpPlanes;
     const int nq = pf >> 2;
     for (int i = tid; i < kUpPix * nq; i += 256) {
@@ -124,14 +127,14 @@ __device__ __forceinline__ void upsample_planes_body(float *ups, const float *__
     __syncthreads();
     const int px = tid & 63, g = tid >> 6;
     const float b = pix0 + px < npix ? up_b[pix0 + px] : 0.f;
-    float acc[16];
+    float acc[kUpPerThread];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = b;
+    for (int i = 0; i < kUpPerThread; ++i) acc[i] = b;
     for (int q = 0; q < nq; ++q) {
         const f32x4 wv = *reinterpret_cast<const f32x4 *>(Ws + px * wld + 4 * q);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const f32x4 pv = *reinterpret_cast<const f32x4 *>(Ps + (g * 16 + i) * pf + 4 * q);   // wave-uniform address: broadcast
+        for (int i = 0; i < kUpPerThread; ++i) {
+            const f32x4 pv = *reinterpret_cast<const f32x4 *>(Ps + (g * kUpPerThread + i) * pf + 4 * q);   // wave-uniform address: broadcast
             float v = acc[i];
             v = fmaf(wv[0], pv[0], v);
             v = fmaf(wv[1], pv[1], v);
@@ -142,8 +145,8 @@ __device__ __forceinline__ void upsample_planes_body(float *ups, const float *__
     }
     if (pix0 + px < npix) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int n = plane0 + g * 16 + i;
+        for (int i = 0; i < kUpPerThread; ++i) {
+            const int n = plane0 + g * kUpPerThread + i;
             if (n < nplanes) planes_out[(size_t)n * npix + pix0 + px] = acc[i];
         }
     }
