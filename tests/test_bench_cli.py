@@ -76,6 +76,33 @@ def test_two_rank_control_flow_with_stubbed_gpu_work():
     assert pr["distinct_devices"] == 2 and pr["pids"] == 2
 
 
+def test_eight_rank_control_flow_with_stubbed_gpu_work():
+    """The same control flow at the world size the scaling curve ends on: eight ranks over gloo, eight identities in the record,
+    MAX over ranks = the slowest (rank 7 sleeps 8 x rank 0's time), one line."""
+    res = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--stub"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["frames_per_gpu"] == 128 and line["config"]["global_batch"] == 1024   # BASELINE config 4
+    pr = line["per_rank"]
+    assert pr["world_size"] == 8 and pr["pids"] == 8 and pr["distinct_devices"] == 8
+    assert [r[0] for r in pr["ranks"]] == list(range(8)) and [r[1] for r in pr["ranks"]] == list(range(8))
+    assert pr["slowest_rank"] == 7 and pr["device_ms_per_step_max"] > 4 * pr["device_ms_per_step_min"]
+    assert abs(line["value"] - 1024 / line["ms_per_step"] * 1e3) <= 0.01 * line["value"]
+
+
+def test_scale_curve_tool_prints_the_weak_scaling_table():
+    """tools/scale_curve.sh: bench.py --gpus {1,2,4,8} for one config, efficiency table from `value` (here on the stub)."""
+    e = dict(os.environ, AFT_SCALE_STUB="1", AFT_SCALE_STEPS="2", AFT_SCALE_WARMUP="0", AFT_SCALE_GPUS="1 2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    res = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_curve.sh"), "C3"], capture_output=True, text=True, env=e, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rows = [ln.split() for ln in res.stdout.splitlines() if ln.strip() and ln.split()[0] in ("1", "2")]
+    assert [r[0] for r in rows] == ["1", "2"] and float(rows[0][3]) == 1.0 and 0 < float(rows[1][3]) < 1.2
+
+
 def test_bench_line_stays_compact():
     """The driver parses the line; round 2's 7.5 KB line lost sub-records there.  Budget: the stub line (contract fields +
     per_rank) under 1.5 KB; the key set of the full line is fixed in bench.py (numbers only, prose lives in DESIGN.md 5)."""
@@ -94,8 +121,11 @@ def test_bench_full_line_on_gpu(tmp_path):
     assert len(raw) < 6500, len(raw)
     line = json.loads(raw)
     for key in ("roofline", "cpu_baseline", "kernels", "upsampler", "parity", "configs", "next_rows", "module_surface",
-                "value_h2d_inclusive", "split_precision", "batch_sweep"):
+                "value_h2d_inclusive", "value_resident", "split_precision", "batch_sweep"):
         assert key in line, key
+    # `value` is the number SURVEY 8(d) defines: the module surface fed CPU tensors, H2D inside the step
+    assert line["value"] == line["value_h2d_inclusive"] and "H2D of pilots + meta INSIDE the step" in line["config"]["workload"]
+    assert 0.9 < line["value"] / line["value_resident"] < 1.1 and line["module_surface"]["bit_identical_to_engine"]
     assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "mfma"
     assert set(line["configs"]) == {"C1", "C2", "C3", "C5"}
     bs = line["batch_sweep"]["C3"]

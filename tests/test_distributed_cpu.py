@@ -57,6 +57,34 @@ def test_two_rank_metric_equals_single_rank():
     assert abs(to_db(results[0][0]) - g.meta["metric_db"]) <= 1e-4
 
 
+def test_eight_rank_metric_equals_single_rank():
+    """World size 8 -- the node the scaling curve will be taken on: the fixture's 8 frames shard one per rank, the
+    single all-gather carries eight (sum, n) pairs, every rank ends with the 1-rank metric."""
+    name = "D_forti"
+    g = Golden(name)
+    world, port = 8, _free_port()
+    assert g["pilots"].shape[0] >= world
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, name, ret), nprocs=world, join=True)
+        results = dict(ret)
+    assert len({results[r][0] for r in range(world)}) == 1     # every rank holds the global value, bit for bit
+    assert sum(results[r][1] for r in range(world)) == g["out"].size
+    assert all(results[r][1] > 0 for r in range(world))         # no rank idle at 8 frames over 8 ranks
+    assert abs(results[0][0] - g.meta["metric_2xmse"]) <= 1e-5 * g.meta["metric_2xmse"]
+
+
+def test_shard_bounds_cover_the_baseline_configs_at_world_size_8():
+    """BASELINE configs 4 / 5: batch 1024 -> 128 per rank, batch 512 -> 64 per rank; ragged counts still partition exactly."""
+    assert [shard_bounds(1024, 8, r) for r in range(8)] == [(128 * r, 128 * (r + 1)) for r in range(8)]
+    assert [shard_bounds(512, 8, r) for r in range(8)] == [(64 * r, 64 * (r + 1)) for r in range(8)]
+    for n in (1, 7, 9, 1023, 1025):
+        cuts = [shard_bounds(n, 8, r) for r in range(8)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+
+
 def test_shard_bounds_partition():
     for n, w in ((1024, 8), (10, 3), (7, 8)):
         cuts = [shard_bounds(n, w, r) for r in range(w)]

@@ -175,6 +175,40 @@ def test_sharded_step_world_size_2_matches_single_process():
     assert np.allclose(out[0], want, rtol=1e-5, atol=1e-7)
 
 
+def test_sharded_step_world_size_8_matches_single_process():
+    """The node size of BASELINE configs 4 / 5: eight ranks, one sample each; the flat buffers are padded to 8 x 64 elements so that
+    every rank owns an equal shard (173 parameters -> 512 padded, 64 per rank: ranks 3..7 own padding only and must still take part
+    in both collectives)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(8, port, out), nprocs=8, join=True)
+    net = _net()
+    x, y = _data()
+    ref = torch.optim.Adam(net.parameters(), lr=1e-2)
+    for _ in range(4):
+        ref.zero_grad()
+        torch.nn.functional.mse_loss(net(x), y).backward()
+        ref.step()
+    want = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    assert all(np.array_equal(out[0], out[r]) for r in range(1, 8))      # ranks hold identical parameters
+    assert np.allclose(out[0], want, rtol=1e-5, atol=1e-7)
+
+
+def test_shard_layout_at_world_size_8():
+    """Shard arithmetic without a process group: padded length divisible by 8 x 64, shards tile it exactly."""
+    from adafortitran_amd.optim import FlatParameters
+    net = _net()
+    flat = FlatParameters(net.parameters(), pad_to=8 * 64)
+    n = sum(p.numel() for p in net.parameters())
+    assert flat.padded % (8 * 64) == 0 and flat.padded >= n
+    shard = flat.padded // 8
+    assert [(r * shard, (r + 1) * shard) for r in range(8)][-1][1] == flat.padded
+    flat.release()
+
+
 def test_flat_parameters_do_not_break_pickling_and_double_reduce_raises():
     """the ownership tag on a Parameter is a picklable token (torch.save(model) / mp.spawn used to fail on a
     weakref while an optimizer was alive); reduce_gradients() twice in one step raises instead of mixing averaged and
