@@ -8,8 +8,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, Dict, Optional
 
-AFT_ABI_VERSION = 6
-AFT_MAX_LAYERS = 32
+AFT_ABI_VERSION = 7
+AFT_ENGINE_PACKED, AFT_ENGINE_GENERAL = 0, 1
 AFT_OK, AFT_ERR_ARG, AFT_ERR_SHAPE, AFT_ERR_HIP = 0, 1, 2, 3
 AFT_ACT_RELU, AFT_ACT_GELU = 0, 1
 AFT_ENCODER_AUTO, AFT_ENCODER_LAUNCHES, AFT_ENCODER_PLANE = 0, 1, 2
@@ -60,7 +60,7 @@ class AftWeights(C.Structure):
         ("lin1_w", _fp), ("lin1_b", _fp),
         ("pos", _fp),
         ("lin2_w", _fp), ("lin2_b", _fp),
-        ("layers", AftLayerWeights * AFT_MAX_LAYERS),
+        ("layers", C.POINTER(AftLayerWeights)),     # host array of num_layers entries (any layer count)
     ]
 
 
@@ -112,9 +112,12 @@ def make_weights(cfg: AftConfig, ptr: Callable[[str], int], pos_key: Optional[st
     w.lin1_w, w.lin1_b = ptr(f"{_TE}.linear_1.weight"), ptr(f"{_TE}.linear_1.bias")
     w.lin2_w, w.lin2_b = ptr(f"{_TE}.linear_2.weight"), ptr(f"{_TE}.linear_2.bias")
     w.pos = ptr(pos_key or f"{_TE}.positional_encoding.position_embeddings")
+    table = (AftLayerWeights * cfg.num_layers)()
+    w.layers = C.cast(table, C.POINTER(AftLayerWeights))
+    w._layer_table = table          # the struct holds a bare pointer: keep the host array alive with it
     for i in range(cfg.num_layers):
         lp = f"{_TE}.transformer.layers.{i}"
-        lw = w.layers[i]
+        lw = table[i]
         lw.in_proj_w, lw.in_proj_b = ptr(lp + ".self_attn.in_proj_weight"), ptr(lp + ".self_attn.in_proj_bias")
         lw.out_proj_w, lw.out_proj_b = ptr(lp + ".self_attn.out_proj.weight"), ptr(lp + ".self_attn.out_proj.bias")
         lw.lin1_w, lw.lin1_b = ptr(lp + ".linear1.weight"), ptr(lp + ".linear1.bias")
@@ -131,7 +134,7 @@ def pos_key_of(state: Dict[str, object]) -> str:
 
 #: every symbol include/adafortitran_amd.h declares (tests check the .so exports them all)
 EXPORTED_SYMBOLS = (
-    "aft_version", "aft_last_error", "aft_check_config", "aft_max_batch", "aft_workspace_bytes", "aft_workspace_region", "aft_workspace_lanes", "aft_forward_f32",
+    "aft_version", "aft_last_error", "aft_check_config", "aft_engine_of", "aft_set_switch", "aft_get_switch", "aft_max_batch", "aft_workspace_bytes", "aft_workspace_region", "aft_workspace_lanes", "aft_forward_f32",
     "aft_packed_weights_bytes", "aft_pack_weights_f32", "aft_forward_prepacked_f32",
     "aft_linear_forward_f32", "aft_mse_partial_f32", "aft_stage_upsample_f32",
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",

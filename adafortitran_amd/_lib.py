@@ -53,6 +53,9 @@ def load_path(path: str):
     lib.aft_workspace_bytes.argtypes = [C.POINTER(_abi.AftConfig), C.c_int]
     vp, cfgp, wp = C.c_void_p, C.POINTER(_abi.AftConfig), C.POINTER(_abi.AftWeights)
     lib.aft_check_config.argtypes = [cfgp]
+    lib.aft_engine_of.argtypes = [cfgp]
+    lib.aft_set_switch.argtypes = [C.c_char_p, C.c_char_p]
+    lib.aft_get_switch.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     lib.aft_workspace_region.argtypes = [cfgp, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.aft_workspace_lanes.restype = C.c_int
     lib.aft_workspace_lanes.argtypes = [cfgp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
@@ -114,6 +117,34 @@ def check(rc: int) -> None:
     if rc in (_abi.AFT_ERR_ARG, _abi.AFT_ERR_SHAPE):
         raise ValueError(msg)
     raise AftError(msg)
+
+
+def set_switch(name: str, value) -> None:
+    """A measurement / A-B switch of the library (header: aft_set_switch).  The library reads the AFT_* environment once, when it is
+    loaded; afterwards switches change only through this call (``value`` None = unset) -- never through os.environ."""
+    check(load().aft_set_switch(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_switch(name: str):
+    """Current value of a switch (str) or None when it is unset."""
+    buf = C.create_string_buffer(256)
+    return buf.value.decode() if load().aft_get_switch(name.encode(), buf, 256) else None
+
+
+class switch:
+    """``with _lib.switch("AFT_LANES", 1): ...`` -- set a switch for a block and restore what it was."""
+
+    def __init__(self, name: str, value) -> None:
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_switch(self.name)
+        set_switch(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_switch(self.name, self.old)
+        return False
 
 
 def current_stream_ptr(device) -> int:

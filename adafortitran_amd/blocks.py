@@ -199,17 +199,18 @@ class TransformerEncoderForChannels(nn.Module):
     def hip_train_gap(self) -> Optional[str]:
         """None when ``loss.backward()`` through this encoder runs the library's training kernels on a HIP device, else why it is
         differentiated by PyTorch-ROCm autograd instead (the estimator logs this once at construction: no silent fallback).
-        Covered: every model_dim the inference engine takes (multiples of 32 up to 256), head dim 32 (the kernels' own shape), 64 (two
-        32-feature blocks per head) and every other multiple of 8 up to 48 (run as zero-padded 32- or 64-feature heads), any token count,
-        gelu / relu, post-norm, dim_feedforward = 2 model_dim (what the reference builds, encoders.py:44-51)."""
+        Covered: every model_dim the inference engines take (multiples of 8 up to 512: the fused row-local kernels at 128, launch
+        sequences elsewhere), every head dim up to 128 (32 is the kernels' own shape; 64 / 96 / 128 run two / three / four 32-feature
+        blocks per head, anything else as zero-padded heads of the next multiple of 32), any token count, gelu / relu, post-norm,
+        dim_feedforward = 2 model_dim (what the reference builds, encoders.py:44-51)."""
         layer0 = self.transformer.layers[0]
         d, heads = layer0.self_attn.embed_dim, layer0.self_attn.num_heads
         if not self.hip_training:
             return "hip_training is switched off on this module"
-        if d % 32 or not 32 <= d <= 256:
-            return f"model_dim {d} is not a multiple of 32 up to 256"
-        if d % heads or d // heads not in (8, 16, 24, 32, 40, 48, 64):
-            return f"head dim {d / heads:g}: the attention kernels cover head dims that are multiples of 8 up to 64, except 56"
+        if d % 8 or not 8 <= d <= 512:
+            return f"model_dim {d} is not a multiple of 8 up to 512"
+        if d % heads or d // heads > 128:
+            return f"head dim {d / heads:g}: the attention kernels cover heads of up to 128 features"
         if layer0.activation not in (F.gelu, F.relu) or layer0.norm_first or layer0.linear1.out_features != 2 * d:
             return "encoder layer is not the reference's post-norm gelu / relu layer with dim_feedforward = 2 model_dim"
         return None

@@ -7,8 +7,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
+
+extern char **environ;
 
 #include "aft_internal.h"
 
@@ -48,7 +52,56 @@ hipError_t ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, size_t by
     return e;
 }
 
+// ---- switches: the "AFT_*" environment, read once at load; aft_set_switch afterwards (header) ----
+namespace {
+struct Switches {
+    std::mutex mu;
+    std::map<std::string, std::string> table;
+    Switches() {      // static initialisation of the shared object: before any call, on the loading thread
+        for (char **e = environ; e != nullptr && *e != nullptr; ++e) {
+            if (strncmp(*e, "AFT_", 4) != 0) continue;
+            const char *eq = strchr(*e, '=');
+            if (eq != nullptr) table[std::string(*e, eq - *e)] = std::string(eq + 1);
+        }
+    }
+};
+Switches &switches() {
+    static Switches s;
+    return s;
+}
+struct SwitchesAtLoad { SwitchesAtLoad() { switches(); } } g_switches_at_load;
+}  // namespace
+bool switch_on(const char *name) {
+    Switches &s = switches();
+    std::lock_guard<std::mutex> lock(s.mu);
+    return s.table.find(name) != s.table.end();
+}
+int switch_int(const char *name, int dflt) {
+    Switches &s = switches();
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto it = s.table.find(name);
+    return it == s.table.end() ? dflt : atoi(it->second.c_str());
+}
+
+WeightsDev weights_window(const aft_weights &w, int first, int count) {
+    WeightsDev d{};
+    d.up_w = w.up_w; d.up_b = w.up_b;
+    for (int i = 0; i < 4; ++i) { d.enh_w[i] = w.enh_w[i]; d.enh_b[i] = w.enh_b[i]; d.ref_w[i] = w.ref_w[i]; d.ref_b[i] = w.ref_b[i]; }
+    for (int e = 0; e < 3; ++e)
+        for (int j = 0; j < 3; ++j) { d.ada_w[e][j] = w.ada_w[e][j]; d.ada_b[e][j] = w.ada_b[e][j]; }
+    d.lin1_w = w.lin1_w; d.lin1_b = w.lin1_b; d.pos = w.pos; d.lin2_w = w.lin2_w; d.lin2_b = w.lin2_b;
+    for (int i = 0; i < count && i < kLayerWindow && w.layers != nullptr; ++i) d.layers[i] = w.layers[first + i];
+    return d;
+}
+
 static int tokens_of(const aft_config &c) { return (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols); }
+
+bool packed_engine_ok(const aft_config &c) {
+    if (c.num_head <= 0 || c.model_dim <= 0 || c.model_dim % c.num_head != 0) return false;
+    const int hd = c.model_dim / c.num_head;
+    return c.model_dim >= 32 && c.model_dim <= 256 && c.model_dim % 32 == 0 && hd >= 8 && hd <= 64 && hd % 8 == 0 && hd != 56 &&
+           c.patch_scs * c.patch_symbols <= kMaxPatchFeatures;
+}
 
 int check_config(const aft_config *c) {
     if (c == nullptr) {
@@ -61,43 +114,42 @@ int check_config(const aft_config *c) {
                   c->patch_symbols);
         return AFT_ERR_SHAPE;
     }
-    if (c->pilot_scs <= 0 || c->pilot_symbols <= 0 || c->num_layers <= 0 || c->num_layers > AFT_MAX_LAYERS) {
-        set_error("bad pilot grid or layer count (layers=%d, max %d)", c->num_layers, AFT_MAX_LAYERS);
+    if (c->pilot_scs <= 0 || c->pilot_symbols <= 0 || c->num_layers <= 0) {     // any layer count (encoders.py:52-55)
+        set_error("bad pilot grid %dx%d or layer count %d", c->pilot_scs, c->pilot_symbols, c->num_layers);
         return AFT_ERR_SHAPE;
     }
-    // The row-local chain kernel gives every wave one 32-feature block of every activation and keeps a 32-row tile's whole hidden
-    // layer (2 x model_dim wide) in the registers of its model_dim / 32 waves: any multiple of 32 up to 256 is an instantiation of
-    // the same body (251 VGPRs at 256); wider models would need a second kernel that tiles the feature dimension through LDS.
-    if (c->model_dim < 32 || c->model_dim > 256 || c->model_dim % 32 != 0) {
-        set_error("model_dim %d not covered by the gfx950 kernels (multiples of 32 up to 256: the row-local chain keeps a row tile's "
-                  "hidden layer in the registers of model_dim / 32 waves)", c->model_dim);
+    // Two engines (aft_engine_of).  The PACKED one: the row-local chain kernel gives every wave one 32-feature block of every
+    // activation and keeps a 32-row tile's whole hidden layer (2 x model_dim wide) in the registers of its model_dim / 32 waves
+    // (251 VGPRs at 256); q / k / v^T live in 32-feature blocks whose fragment slots hold 8 features, a head may straddle at most
+    // two blocks; the fused embedding stages linear_1's (patch + 6) x model_dim weights in the chain kernel's idle LDS and
+    // linear_2's outputs ride in one 16-column MFMA tile: model_dim a multiple of 32 up to 256, head dims that are multiples of 8 up
+    // to 64 except 56, patches of up to 16 elements.  The GENERAL one (round 6): row-major GEMM / attention / LayerNorm launches for
+    // everything else the reference's schema (> 0, schemas.py:124-127) and nn.TransformerEncoderLayer (encoders.py:44-55) build
+    // within: model_dim a multiple of 8 up to 512, any num_head that divides it with heads of up to 128 features, patches of up to
+    // 32 elements.  What is still refused, and why:
+    if (c->model_dim < 8 || c->model_dim > 512 || c->model_dim % 8 != 0) {
+        set_error("model_dim %d not covered by the gfx950 kernels (multiples of 8 up to 512: the row-wise LayerNorm / activation kernels "
+                  "hold a row in at most 8 floats per lane and move it in 16-byte pieces)", c->model_dim);
         return AFT_ERR_SHAPE;
     }
-    // nn.MultiheadAttention takes any num_head that divides model_dim (reference blocks/encoders.py:44-51, schemas.py:124-127).
-    // q / k / v^T live in 32-feature blocks whose fragment slots hold 8 features each; a 32x32x2 MFMA chain contracts the slots it
-    // is given.  Head dims 32 (the tuned shape), 16 and 64 have their own instantiations; every other multiple of 8 up to 48 runs
-    // the generic one (a head = a run of slots that starts anywhere in a block: exact logits work, whole-block value products).
-    // Refused: head dims that are not multiples of 8 (a head would split a fragment slot), 56 (a head can straddle THREE blocks:
-    // three O^T accumulators and three V^T tiles do not fit in 256 VGPRs beside the operands) and > 64 (four accumulators).
+    // nn.MultiheadAttention takes any num_head that divides model_dim (reference blocks/encoders.py:44-51, schemas.py:124-127)
     const int hd = c->num_head > 0 && c->model_dim % c->num_head == 0 ? c->model_dim / c->num_head : 0;
-    if (hd < 8 || hd > 64 || hd % 8 != 0 || hd == 56) {
-        set_error("head dim %d not covered (model_dim=%d, num_head=%d): the attention kernels take head dims that are multiples of 8 up "
-                  "to 64, except 56 -- q / k / v^T are held in 8-feature fragment slots, and a head may straddle at most two 32-feature "
-                  "blocks", hd, c->model_dim, c->num_head);
+    if (hd < 1 || hd > 128) {
+        set_error("head dim not covered (model_dim=%d, num_head=%d): num_head must divide model_dim (nn.MultiheadAttention demands it) "
+                  "and a head may have at most 128 features (four 32-feature accumulator blocks per query tile)", c->model_dim, c->num_head);
         return AFT_ERR_SHAPE;
     }
     if (tokens_of(*c) < 1) {
         set_error("no tokens");
         return AFT_ERR_SHAPE;
     }
-    if (c->patch_scs * c->patch_symbols > kMaxPatchFeatures) {
-        set_error("patch %dx%d has more than %d elements: the fused embedding stages linear_1's (patch + 6) x model_dim weights in the "
-                  "chain kernel's idle half of its LDS hidden buffer and linear_2's outputs ride in one 16-column MFMA tile", c->patch_scs,
-                  c->patch_symbols, kMaxPatchFeatures);
+    if (c->patch_scs * c->patch_symbols > kMaxPatchGeneral) {
+        set_error("patch %dx%d has more than %d elements (the embedding kernels hold a token's patch in registers; the reference's "
+                  "default is 3x2)", c->patch_scs, c->patch_symbols, kMaxPatchGeneral);
         return AFT_ERR_SHAPE;
     }
     if (c->precision != AFT_PRECISION_F32 && (c->precision != AFT_PRECISION_BF16X3 || (c->model_dim != 128 && c->model_dim != 256) ||
-                                              hd != kHeadDim || tokens_of(*c) < kTile)) {
+                                              hd != kHeadDim || tokens_of(*c) < kTile || !packed_engine_ok(*c))) {
         set_error("precision %d: the split-precision tier (AFT_PRECISION_BF16X3) is instantiated for model_dim 128 and 256, head dim 32, "
                   ">= 32 tokens", c->precision);
         return AFT_ERR_SHAPE;
@@ -107,9 +159,9 @@ int check_config(const aft_config *c) {
         return AFT_ERR_ARG;
     }
     {
-        const int p = c->patch_scs * c->patch_symbols;
+        const int p = c->patch_scs * c->patch_symbols;      // (the general engine's tail reads linear_2's output: nothing beside the plane)
         if (!conv_plan_ok(c->num_scs, c->num_symbols, c->pilot_scs * c->pilot_symbols) ||
-            !conv_plan_ok(c->num_scs, c->num_symbols, p * c->model_dim + p)) {
+            !conv_plan_ok(c->num_scs, c->num_symbols, packed_engine_ok(*c) ? p * c->model_dim + p : 0)) {
             set_error("OFDM grid %dx%d: no LDS band plan for the fused conv stack (too many symbols per row band)",
                       c->num_scs, c->num_symbols);
             return AFT_ERR_SHAPE;
@@ -134,6 +186,25 @@ Workspace plan_workspace(const aft_config &c, int batch) {
     size_t off = 0;
     ws.conv_enhanced = off; off += align64((size_t)ws.planes * c.num_scs * c.num_symbols);
     ws.tokens6 = off;       off += align64((size_t)batch * ws.tokens * 6);
+    if (!packed_engine_ok(c)) {   // general engine: row-major tensors of one layer at a time (run_encoder_general)
+        const size_t d = c.model_dim, ff = 2 * d;
+        ws.x = off;        off += align64(std::max(rows * d, (size_t)ws.planes * c.num_scs * c.num_symbols));   // also the upsampler's plane scratch
+        ws.attn = off;     off += align64(rows * d);
+        ws.q = ws.k = ws.vt = ws.wpack = off;
+        ws.out6 = off;     off += align64(rows * out6_stride(c));
+        ws.convfrag = off; off += align64(2 * kConvFragFloats);
+        ws.g_x1 = off;     off += align64(rows * d);
+        ws.g_y = off;      off += align64(rows * d);
+        ws.g_s = off;      off += align64(rows * d);
+        ws.g_stats = off;  off += align64(rows * 2);
+        ws.g_qkv = off;    off += align64(rows * 3 * d);
+        ws.g_lse = off;    off += align64(rows * c.num_head);
+        ws.g_a = off;      off += align64(rows * ff);
+        ws.g_hd = off;     off += align64(rows * ff);
+        ws.g_pad = off;    off += align64(attn_train_pad_floats(c, rows));
+        ws.total_floats = off;
+        return ws;
+    }
     ws.x = off;             off += align64((rows + 31) / 32 * 32 * c.model_dim);   // whole 32-row tiles (tile-blocked x)
     // attention tiles: global 32-row tiles (layer-by-layer path) or ceil(tokens/32) tiles per plane (plane-resident path)
     ws.attn = off;          off += align64(std::max((size_t)round_up((int)rows, kTile), (size_t)ws.planes * ws.tokpad) * c.model_dim);
@@ -155,8 +226,12 @@ static size_t largest_region_bytes(const aft_config &c, int batch) {
     const Workspace ws = plan_workspace(c, batch);
     const size_t rows = (size_t)ws.planes * ws.tokens;
     const size_t per_head = (size_t)ws.planes * ws.tokpad * c.model_dim;
-    const size_t biggest = std::max({rows * (size_t)c.model_dim, per_head, (size_t)ws.planes * c.num_scs * c.num_symbols,
-                                     rows * (size_t)out6_stride(c)});
+    size_t biggest = std::max({rows * (size_t)c.model_dim, per_head, (size_t)ws.planes * c.num_scs * c.num_symbols,
+                               rows * (size_t)out6_stride(c)});
+    if (!packed_engine_ok(c)) {   // general engine: q | k | v with padded heads is its largest tensor
+        const size_t hp = (size_t)(c.model_dim / c.num_head + 31) / 32 * 32;
+        biggest = std::max(biggest, rows * 3 * std::max((size_t)c.model_dim, hp * c.num_head));
+    }
     return biggest * sizeof(float);
 }
 
@@ -203,8 +278,9 @@ static double round_efficiency(long n, long slots) {
     return rounds > 0 ? (double)n / (double)(rounds * slots) : 1.0;
 }
 static int lanes_wanted(const aft_config &c, int batch) {
-    if (const char *e = getenv("AFT_LANES")) {      // A/B switch: 1 = never split, 2 .. 4 = always that many shares
-        const int v = atoi(e);
+    if (!packed_engine_ok(c)) return 1;         // the general engine's launches are dispatcher-scheduled grids, not persistent rounds
+    if (switch_on("AFT_LANES")) {               // A/B switch: 1 = never split, 2 .. 4 = always that many shares
+        const int v = switch_int("AFT_LANES", 0);
         if (v >= 1 && v <= kMaxLanes) return std::min(v, batch);
     }
     const long tokens = tokens_of(c), planes = 2L * batch, cus = current_device_cus();
@@ -236,39 +312,85 @@ static size_t workspace_floats_any_lanes(const aft_config &c, int batch) {   // 
     for (int l = 1; l <= kMaxLanes; ++l) m = std::max(m, plan_lanes(c, batch, l).total_floats);
     return m;
 }
-// Side streams + fork / join events of one caller stream (created on first use, kept for the process: like the per-device attribute
-// caches, nothing here describes a call).  At most kLaneCacheMax caller streams get them; further ones run unsplit.
+// Side streams + fork / join events of one caller stream (created on first use, up to the lane count a call asks for; nothing here
+// describes a call).  The kLaneCacheMax most recently used (device, caller stream) pairs keep theirs; a further stream evicts the
+// least recently used entry that no call is using right now (its streams and events are destroyed: the runtime releases them once
+// their pending work has drained).  When no entry can be had -- a create call failed (what was created is destroyed again) or every
+// entry is in use by calls in flight on other host threads -- the caller runs the shares one after the other on the caller's stream.
 struct LaneStreams {
     hipStream_t side[kMaxLanes - 1];
     hipEvent_t fork, join[kMaxLanes - 1];
+    int n_side;
 };
-static LaneStreams *lane_streams_for(hipStream_t user) {
-    constexpr int kLaneCacheMax = 16;
-    struct Entry { int dev; hipStream_t user; LaneStreams ls; };
-    static std::mutex mu;
-    static std::vector<Entry> cache;
+namespace {
+constexpr int kLaneCacheMax = 16;
+struct LaneEntry { bool used; int dev; hipStream_t user; LaneStreams ls; int in_use; unsigned long long tick; };
+std::mutex g_lane_mu;
+LaneEntry g_lane_cache[kLaneCacheMax];      // fixed storage: a leased entry never moves
+unsigned long long g_lane_tick = 0;
+void destroy_lane_streams(LaneStreams &ls) {
+    for (int i = 0; i < ls.n_side; ++i) {
+        (void)hipEventDestroy(ls.join[i]);
+        (void)hipStreamDestroy(ls.side[i]);
+    }
+    if (ls.fork) (void)hipEventDestroy(ls.fork);
+    ls = LaneStreams{};
+}
+bool grow_lane_streams(LaneStreams &ls, int sides) {     // create side streams / join events up to `sides`; false: nothing changed
+    if (ls.fork == nullptr && hipEventCreateWithFlags(&ls.fork, hipEventDisableTiming) != hipSuccess) { ls.fork = nullptr; return false; }
+    while (ls.n_side < sides) {
+        hipStream_t s = nullptr;
+        hipEvent_t e = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(s); return false; }
+        ls.side[ls.n_side] = s;
+        ls.join[ls.n_side] = e;
+        ++ls.n_side;
+    }
+    return true;
+}
+}  // namespace
+static LaneStreams *acquire_lane_streams(hipStream_t user, int lanes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    for (auto &en : cache)
-        if (en.dev == dev && en.user == user) return &en.ls;
-    if ((int)cache.size() >= kLaneCacheMax) return nullptr;
-    cache.reserve(kLaneCacheMax);      // entries never move: callers keep the pointer for the duration of a call
-    Entry en{dev, user, {}};
-    if (hipEventCreateWithFlags(&en.ls.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    for (int i = 0; i < kMaxLanes - 1; ++i)
-        if (hipStreamCreateWithFlags(&en.ls.side[i], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&en.ls.join[i], hipEventDisableTiming) != hipSuccess)
-            return nullptr;
-    cache.push_back(en);
-    return &cache.back().ls;
+    std::lock_guard<std::mutex> lock(g_lane_mu);
+    LaneEntry *hit = nullptr, *victim = nullptr;
+    for (auto &en : g_lane_cache) {
+        if (en.used && en.dev == dev && en.user == user) { hit = &en; break; }
+        if (!en.used) { if (victim == nullptr || victim->used) victim = &en; }
+        else if (en.in_use == 0 && (victim == nullptr || (victim->used && en.tick < victim->tick))) victim = &en;
+    }
+    if (hit == nullptr) {
+        if (victim == nullptr) return nullptr;                 // sixteen entries, all leased to calls in flight
+        if (victim->used) destroy_lane_streams(victim->ls);    // least recently used idle entry
+        *victim = LaneEntry{true, dev, user, LaneStreams{}, 0, 0};
+        hit = victim;
+    }
+    if (!grow_lane_streams(hit->ls, lanes - 1)) {
+        if (hit->in_use == 0) {                                 // leave nothing half-built behind (a later call tries again)
+            destroy_lane_streams(hit->ls);
+            hit->used = false;
+        }
+        return nullptr;
+    }
+    ++hit->in_use;
+    hit->tick = ++g_lane_tick;
+    return &hit->ls;
+}
+static void release_lane_streams(LaneStreams *ls) {
+    if (ls == nullptr) return;
+    std::lock_guard<std::mutex> lock(g_lane_mu);
+    for (auto &en : g_lane_cache)
+        if (&en.ls == ls) { --en.in_use; return; }
 }
 
 // `fused` (whole forward only): the first launch computes x0 from conv_enhanced / tokens6 itself (no embed kernel) and
 // the last one leaves linear_2's output in the q buffer instead of storing x (the conv tail reads it from there).
 // `prepacked`: the caller's fragment-packed image of ALL layers (aft_pack_weights_f32), or NULL = pack into the workspace now.
-static int run_encoder(const aft_config &c, const aft_weights &w, const Workspace &ws, float *base, int first_layer,
-                       int last_layer, hipStream_t st, bool fused = false, const float *prepacked = nullptr) {
+// `w`: the non-layer pointers (+ a window of the first layers for the kernels that take the table by value); `layers`: the HOST array
+// of all num_layers layers.
+static int run_encoder(const aft_config &c, const WeightsDev &w, const aft_layer_weights *layers, const Workspace &ws, float *base,
+                       int first_layer, int last_layer, hipStream_t st, bool fused = false, const float *prepacked = nullptr) {
     float *x = base + ws.x, *attn = base + ws.attn, *q = base + ws.q, *k = base + ws.k, *vt = base + ws.vt;
     const int rows = ws.planes * ws.tokens;
     const size_t pl = packed_layer_floats(c.model_dim);
@@ -276,7 +398,7 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
     hipError_t e;
     if (prepacked == nullptr) {
         // weights arrive in torch layout on every call (stateless ABI): re-lay them into fragment order
-        e = launch_pack_weights(c, w, base + ws.wpack + first_layer * pl, first_layer, last_layer - first_layer + 1, st);
+        e = launch_pack_weights(c, layers + first_layer, base + ws.wpack + first_layer * pl, last_layer - first_layer + 1, st);
         if (e != hipSuccess) return hip_fail("pack_weights", e);
     }
     // whole forward and the caller asks for it: ONE launch for the encoder (k_encoder.hip).  AUTO means the launches:
@@ -298,18 +420,56 @@ static int run_encoder(const aft_config &c, const aft_weights &w, const Workspac
         first.lin1_w = w.lin1_w; first.lin1_b = w.lin1_b; first.pos = w.pos;
         last.lin2_w = w.lin2_w; last.lin2_b = w.lin2_b; last.out6 = base + ws.out6;
     }
-    e = launch_chain(c, nullptr, nullptr, &w.layers[first_layer], wp + first_layer * pl, nullptr, x, q, k, vt, rows,
+    e = launch_chain(c, nullptr, nullptr, &layers[first_layer], wp + first_layer * pl, nullptr, x, q, k, vt, rows,
                      ws.tokens, ws.tokpad, st, fused ? &first : nullptr);
     if (e != hipSuccess) return hip_fail("chain(qkv)", e);
     for (int l = first_layer; l <= last_layer; ++l) {
-        e = launch_attention(c, q, k, vt, w.layers[l].in_proj_b, attn, ws.planes, ws.tokens, ws.tokpad, st);
+        e = launch_attention(c, q, k, vt, layers[l].in_proj_b, attn, ws.planes, ws.tokens, ws.tokpad, st);
         if (e != hipSuccess) return hip_fail("attention", e);
         const bool more = l < last_layer;
-        e = launch_chain(c, &w.layers[l], wp + l * pl, more ? &w.layers[l + 1] : nullptr,
+        e = launch_chain(c, &layers[l], wp + l * pl, more ? &layers[l + 1] : nullptr,
                          more ? wp + (l + 1) * pl : nullptr, attn, x, q, k, vt, rows, ws.tokens, ws.tokpad, st,
                          fused ? (more ? &middle : &last) : nullptr);
         if (e != hipSuccess) return hip_fail("chain(mlp)", e);
     }
+    return AFT_OK;
+}
+
+// ---- the general engine (round 6) ----
+// One nn.TransformerEncoderLayer in eval mode on row-major x [rows][d], in place: the launch sequence of the training forward
+// (aft_train.hip) with dropout off -- in-projection GEMM, attention (heads padded to 32-feature blocks where needed), out-projection GEMM,
+// residual + LayerNorm, linear1 GEMM, activation, linear2 GEMM, residual + LayerNorm -- for every shape the packed engine does not
+// take.  The tensors between the launches are one layer's worth of workspace, re-used layer after layer.
+#define GSTEP(name, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(name, e_);    \
+    } while (0)
+static int general_layer(const aft_config &c, const aft_layer_weights &lw, const Workspace &ws, float *base, float *x, hipStream_t st) {
+    const int rows = ws.planes * ws.tokens, d = c.model_dim, ff = 2 * d;
+    float *qkv = base + ws.g_qkv, *attn = base + ws.attn, *y = base + ws.g_y, *x1 = base + ws.g_x1, *s = base + ws.g_s,
+          *stats = base + ws.g_stats, *a = base + ws.g_a, *hd = base + ws.g_hd;
+    GSTEP("general: in-projection", launch_gemm(0, x, lw.in_proj_w, qkv, lw.in_proj_b, rows, 3 * d, d, d, d, 3 * d, false, st));
+    GSTEP("general: attention", launch_attn_train_fwd(c, qkv, attn, base + ws.g_lse, ws.planes, ws.tokens, 0.f, 0u, st, base + ws.g_pad));
+    GSTEP("general: out-projection", launch_gemm(0, attn, lw.out_proj_w, y, lw.out_proj_b, rows, d, d, d, d, d, false, st));
+    GSTEP("general: norm1", launch_add_ln_fwd(x, y, lw.norm1_w, lw.norm1_b, s, stats, x1, rows, d, 1e-5f, 0.f, 0u, st));
+    GSTEP("general: linear1", launch_gemm(0, x1, lw.lin1_w, a, lw.lin1_b, rows, ff, d, d, d, ff, false, st));
+    GSTEP("general: activation", launch_act_fwd(c.activation, a, hd, rows, ff, 0.f, 0u, st));
+    GSTEP("general: linear2", launch_gemm(0, hd, lw.lin2_w, y, lw.lin2_b, rows, d, ff, ff, ff, d, false, st));
+    GSTEP("general: norm2", launch_add_ln_fwd(x1, y, lw.norm2_w, lw.norm2_b, s, stats, x, rows, d, 1e-5f, 0.f, 0u, st));
+    return AFT_OK;
+}
+// embedding -> layers -> linear_2 into out6 [rows][out6_stride] (what the conv tail reads)
+static int run_encoder_general(const aft_config &c, const WeightsDev &w, const aft_layer_weights *layers, const Workspace &ws, float *base,
+                               int batch, hipStream_t st) {
+    float *x = base + ws.x;
+    const int rows = ws.planes * ws.tokens, d = c.model_dim, p = c.patch_scs * c.patch_symbols;
+    GSTEP("general: embedding", launch_embed_any(c, w, base + ws.conv_enhanced, c.adaptive ? base + ws.tokens6 : nullptr, x, batch, st));
+    for (int l = 0; l < c.num_layers; ++l) {
+        const int rc = general_layer(c, layers[l], ws, base, x, st);
+        if (rc != AFT_OK) return rc;
+    }
+    GSTEP("general: linear_2", launch_gemm(0, x, w.lin2_w, base + ws.out6, w.lin2_b, rows, p, d, d, d, out6_stride(c), false, st));
     return AFT_OK;
 }
 
@@ -324,6 +484,36 @@ int aft_version(void) { return AFT_ABI_VERSION; }
 const char *aft_last_error(void) { return g_err; }
 
 int aft_check_config(const aft_config *cfg) { return check_config(cfg); }
+
+int aft_engine_of(const aft_config *cfg) {
+    if (check_config(cfg) != AFT_OK) return -1;
+    return packed_engine_ok(*cfg) ? AFT_ENGINE_PACKED : AFT_ENGINE_GENERAL;
+}
+
+int aft_set_switch(const char *name, const char *value) {
+    if (name == nullptr || strncmp(name, "AFT_", 4) != 0) {
+        set_error("aft_set_switch: switch names start with AFT_");
+        return AFT_ERR_ARG;
+    }
+    Switches &s = switches();
+    std::lock_guard<std::mutex> lock(s.mu);
+    if (value == nullptr) s.table.erase(name);
+    else s.table[name] = value;
+    return AFT_OK;
+}
+
+int aft_get_switch(const char *name, char *buf, size_t n) {
+    if (name == nullptr) return 0;
+    Switches &s = switches();
+    std::lock_guard<std::mutex> lock(s.mu);
+    auto it = s.table.find(name);
+    if (it == s.table.end()) return 0;
+    if (buf != nullptr && n > 0) {
+        strncpy(buf, it->second.c_str(), n - 1);
+        buf[n - 1] = 0;
+    }
+    return 1;
+}
 
 int aft_max_batch(const aft_config *cfg) {
     if (check_config(cfg) != AFT_OK) return 0;
@@ -395,12 +585,15 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
     // reference fortitran.py:157-158: meta_data is required when channel adaptation is enabled
     AFT_REQUIRE(!cfg->adaptive || (snr && ds && dop), "meta_data is required when channel adaptation is enabled");
     hipStream_t user = static_cast<hipStream_t>(stream);
-    LanePlan lp = plan_lanes(*cfg, batch, lanes_wanted(*cfg, batch));
-    LaneStreams *ls = lp.lanes > 1 ? lane_streams_for(user) : nullptr;
-    if (lp.lanes > 1 && ls == nullptr) lp = plan_lanes(*cfg, batch, 1);
+    AFT_REQUIRE(w->layers != nullptr, "aft_weights.layers is NULL (host array of num_layers entries)");
+    const LanePlan lp = plan_lanes(*cfg, batch, lanes_wanted(*cfg, batch));
     AFT_REQUIRE(workspace_bytes >= lp.total_floats * sizeof(float), "workspace too small: %zu < %zu bytes (aft_workspace_bytes)",
                 workspace_bytes, lp.total_floats * sizeof(float));
-    if (lp.lanes > 1) {
+    // side streams for the shares beyond the first; none to be had (header, "Lanes") = the shares run one after the other on the
+    // caller's stream in the same workspace layout: same bits, and aft_workspace_lanes stays true
+    LaneStreams *ls = lp.lanes > 1 ? acquire_lane_streams(user, lp.lanes) : nullptr;
+    struct Lease { LaneStreams *p; ~Lease() { release_lane_streams(p); } } lease{ls};
+    if (ls != nullptr) {
         hipError_t ef = hipEventRecord(ls->fork, user);
         for (int i = 1; i < lp.lanes && ef == hipSuccess; ++i) ef = hipStreamWaitEvent(ls->side[i - 1], ls->fork, 0);
         if (ef != hipSuccess) return hip_fail("lanes(fork)", ef);
@@ -411,10 +604,10 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
         const int f0 = lp.first[i];
         const int rc_lane = forward_lane(cfg, w, prepacked, pilots + (size_t)f0 * pil_floats, snr ? snr + f0 : nullptr, ds ? ds + f0 : nullptr,
                                          dop ? dop + f0 : nullptr, out + (size_t)f0 * out_floats, static_cast<float *>(workspace) + lp.ws_off[i],
-                                         lp.frames[i], i == 0 ? user : ls->side[i - 1]);
+                                         lp.frames[i], i == 0 || ls == nullptr ? user : ls->side[i - 1]);
         if (rc_lane != AFT_OK && result == AFT_OK) result = rc_lane;     // keep going: the join below must still happen
     }
-    if (lp.lanes > 1) {
+    if (ls != nullptr) {
         hipError_t ej = hipSuccess;
         for (int i = 1; i < lp.lanes && ej == hipSuccess; ++i) {
             ej = hipEventRecord(ls->join[i - 1], ls->side[i - 1]);
@@ -429,22 +622,34 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
 static int forward_lane(const aft_config *cfg, const aft_weights *w, const float *prepacked, const float *pilots, const float *snr,
                         const float *ds, const float *dop, float *out, float *base, int batch, hipStream_t st) {
     const Workspace ws = plan_workspace(*cfg, batch);
+    const bool general = !packed_engine_ok(*cfg);
+    const WeightsDev wd = weights_window(*w, 0, cfg->num_layers);
     int rc = AFT_OK;
     // prologue: the channel adapter, -- unless the caller owns a packed image -- the re-lay of the encoder weights into fragment
     // order, and the pilot_upsampler product over all planes, in ONE launch (none depends on anything the forward computes).
     // The activation buffer x is idle until the first encoder launch: it lends the upsampler its plane scratch when it is large enough
-    float *wpack = prepacked != nullptr ? nullptr : base + ws.wpack;
-    const size_t x_floats = (size_t)ws.planes * ws.tokens * cfg->model_dim, up_floats = (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
-    float *up_planes = x_floats >= up_floats && prologue_upsample_ok(*cfg, *w) ? base + ws.x : nullptr;
-    hipError_t e = launch_prologue(*cfg, *w, snr, ds, dop, base + ws.tokens6, batch, wpack, pilots, up_planes, st, base + ws.convfrag);
+    float *wpack = prepacked != nullptr || general ? nullptr : base + ws.wpack;      // (the general engine reads the weights as PyTorch holds them)
+    const size_t x_floats = general ? ((size_t)1 << 62) : (size_t)ws.planes * ws.tokens * cfg->model_dim;   // general: x is sized for the planes
+    const size_t up_floats = (size_t)ws.planes * cfg->num_scs * cfg->num_symbols;
+    float *up_planes = x_floats >= up_floats && prologue_upsample_ok(*cfg, wd) ? base + ws.x : nullptr;
+    hipError_t e = launch_prologue(*cfg, wd, snr, ds, dop, base + ws.tokens6, batch, wpack, pilots, up_planes, st, base + ws.convfrag);
     if (e != hipSuccess) return hip_fail("prologue(adapter + pack_weights + upsampler product)", e);
-    e = launch_upsample(*cfg, *w, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr, up_planes != nullptr,
+    if (wpack != nullptr && cfg->num_layers > kLayerWindow) {     // the prologue launch packs the window of layers its argument holds
+        e = launch_pack_weights(*cfg, w->layers + kLayerWindow, wpack + packed_layer_floats(cfg->model_dim) * kLayerWindow,
+                                cfg->num_layers - kLayerWindow, st);
+        if (e != hipSuccess) return hip_fail("pack_weights(layers beyond the prologue's window)", e);
+    }
+    e = launch_upsample(*cfg, wd, pilots, base + ws.conv_enhanced, batch, st, x_floats >= up_floats ? base + ws.x : nullptr, up_planes != nullptr,
                         base + ws.convfrag);
     if (e != hipSuccess) return hip_fail("upsample", e);
-    // patch embedding + linear_1 + positions run inside the first chain launch, linear_2 inside the last one
-    rc = run_encoder(*cfg, *w, ws, base, 0, cfg->num_layers - 1, st, true, prepacked != nullptr ? prepacked : wpack);
+    if (general) {
+        rc = run_encoder_general(*cfg, wd, w->layers, ws, base, batch, st);
+    } else {
+        // patch embedding + linear_1 + positions run inside the first chain launch, linear_2 inside the last one
+        rc = run_encoder(*cfg, wd, w->layers, ws, base, 0, cfg->num_layers - 1, st, true, prepacked != nullptr ? prepacked : wpack);
+    }
     if (rc != AFT_OK) return rc;
-    e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6, base + ws.convfrag + kConvFragFloats);
+    e = launch_tail(*cfg, wd, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6, base + ws.convfrag + kConvFragFloats);
     if (e != hipSuccess) return hip_fail("tail", e);
     return AFT_OK;
 }
@@ -457,6 +662,7 @@ int aft_forward_f32(const aft_config *cfg, const aft_weights *w, const float *pi
 
 size_t aft_packed_weights_bytes(const aft_config *cfg) {
     if (check_config(cfg) != AFT_OK) return 0;
+    if (!packed_engine_ok(*cfg)) return 64;     // the general engine reads the weights in place: a token image keeps the prepacked calls valid
     return packed_layer_floats(cfg->model_dim) * cfg->num_layers * sizeof(float);
 }
 
@@ -466,7 +672,9 @@ int aft_pack_weights_f32(const aft_config *cfg, const aft_weights *w, void *pack
     AFT_REQUIRE(w && packed, "NULL pointer argument");
     AFT_REQUIRE(packed_bytes >= aft_packed_weights_bytes(cfg), "packed-weight buffer too small: %zu < %zu bytes", packed_bytes,
                 aft_packed_weights_bytes(cfg));
-    hipError_t e = launch_pack_weights(*cfg, *w, static_cast<float *>(packed), 0, cfg->num_layers, static_cast<hipStream_t>(stream));
+    AFT_REQUIRE(w->layers != nullptr, "aft_weights.layers is NULL (host array of num_layers entries)");
+    if (!packed_engine_ok(*cfg)) return AFT_OK;
+    hipError_t e = launch_pack_weights(*cfg, w->layers, static_cast<float *>(packed), cfg->num_layers, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? AFT_OK : hip_fail("pack_weights", e);
 }
 
@@ -517,7 +725,7 @@ int aft_stage_upsample_f32(const aft_config *cfg, const aft_weights *w, const fl
     int rc = check_config(cfg);
     if (rc != AFT_OK) return rc;
     AFT_REQUIRE(w && pilots && conv_enhanced && batch > 0, "bad argument");
-    hipError_t e = launch_upsample(*cfg, *w, pilots, conv_enhanced, batch, static_cast<hipStream_t>(stream));
+    hipError_t e = launch_upsample(*cfg, weights_window(*w, 0, 0), pilots, conv_enhanced, batch, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? AFT_OK : hip_fail("upsample", e);
 }
 
@@ -527,7 +735,7 @@ int aft_stage_adapter_f32(const aft_config *cfg, const aft_weights *w, const flo
     if (rc != AFT_OK) return rc;
     AFT_REQUIRE(cfg->adaptive, "adapter stage needs an adaptive config");
     AFT_REQUIRE(w && snr && ds && dop && tokens6 && batch > 0, "bad argument");
-    hipError_t e = launch_adapter(*cfg, *w, snr, ds, dop, tokens6, batch, static_cast<hipStream_t>(stream));
+    hipError_t e = launch_adapter(*cfg, weights_window(*w, 0, 0), snr, ds, dop, tokens6, batch, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? AFT_OK : hip_fail("adapter", e);
 }
 
@@ -537,7 +745,8 @@ int aft_stage_embed_f32(const aft_config *cfg, const aft_weights *w, const float
     if (rc != AFT_OK) return rc;
     AFT_REQUIRE(w && conv_enhanced && x && batch > 0, "bad argument");
     AFT_REQUIRE(!cfg->adaptive || tokens6, "adaptive config needs tokens6");
-    hipError_t e = launch_embed(*cfg, *w, conv_enhanced, tokens6, x, batch, static_cast<hipStream_t>(stream));
+    hipError_t e = packed_engine_ok(*cfg) ? launch_embed(*cfg, weights_window(*w, 0, 0), conv_enhanced, tokens6, x, batch, static_cast<hipStream_t>(stream))
+                                          : launch_embed_any(*cfg, weights_window(*w, 0, 0), conv_enhanced, tokens6, x, batch, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? AFT_OK : hip_fail("embed", e);
 }
 
@@ -545,7 +754,7 @@ int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int
                                 size_t scratch_bytes, int batch, void *stream) {
     int rc = check_config(cfg);
     if (rc != AFT_OK) return rc;
-    AFT_REQUIRE(w && x && scratch && batch > 0, "bad argument");
+    AFT_REQUIRE(w && w->layers && x && scratch && batch > 0, "bad argument");
     AFT_REQUIRE(layer >= 0 && layer < cfg->num_layers, "layer %d out of range", layer);
     AFT_REQUIRE(batch <= max_batch_of(*cfg), "batch %d exceeds aft_max_batch = %d", batch, max_batch_of(*cfg));
     Workspace ws = plan_workspace(*cfg, batch);
@@ -553,9 +762,10 @@ int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int
     // run on the caller's x: point the plan's x slot at it (offsets are relative to scratch)
     float *base = static_cast<float *>(scratch);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!packed_engine_ok(*cfg)) return general_layer(*cfg, w->layers[layer], ws, base, x, st);
     const int rows = ws.planes * ws.tokens;
     float *wp = base + ws.wpack + layer * packed_layer_floats(cfg->model_dim);
-    hipError_t e = launch_pack_weights(*cfg, *w, wp, layer, 1, st);
+    hipError_t e = launch_pack_weights(*cfg, w->layers + layer, wp, 1, st);
     if (e != hipSuccess) return hip_fail("pack_weights", e);
     e = launch_chain(*cfg, nullptr, nullptr, &w->layers[layer], wp, nullptr, x, base + ws.q, base + ws.k, base + ws.vt,
                      rows, ws.tokens, ws.tokpad, st);
@@ -573,7 +783,15 @@ int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float 
     int rc = check_config(cfg);
     if (rc != AFT_OK) return rc;
     AFT_REQUIRE(w && x && conv_enhanced && out && batch > 0, "bad argument");
-    hipError_t e = launch_tail(*cfg, *w, x, conv_enhanced, out, batch, static_cast<hipStream_t>(stream));
+    {   // this call owns no scratch: the conv kernel applies linear_2 itself, from weights staged in its LDS beside the plane
+        const int p = cfg->patch_scs * cfg->patch_symbols;
+        if (cfg->model_dim % 16 != 0 || !conv_plan_ok(cfg->num_scs, cfg->num_symbols, p * cfg->model_dim + p)) {
+            set_error("aft_stage_tail_f32: linear_2 (%d x %d) does not fit the conv kernel's LDS beside the plane, or model_dim is not a "
+                      "multiple of 16 -- only aft_forward_f32 serves this configuration", p, cfg->model_dim);
+            return AFT_ERR_SHAPE;
+        }
+    }
+    hipError_t e = launch_tail(*cfg, weights_window(*w, 0, 0), x, conv_enhanced, out, batch, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? AFT_OK : hip_fail("tail", e);
 }
 
@@ -581,10 +799,15 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                            size_t workspace_bytes, int batch, int reps, void *stream) {
     int rc = check_config(cfg);
     if (rc != AFT_OK) return rc;
-    AFT_REQUIRE(w && workspace && batch > 0 && reps > 0, "bad argument");
+    AFT_REQUIRE(w && w->layers && workspace && batch > 0 && reps > 0, "bad argument");
     AFT_REQUIRE(batch <= max_batch_of(*cfg), "batch %d exceeds aft_max_batch = %d", batch, max_batch_of(*cfg));
+    if (!packed_engine_ok(*cfg)) {
+        set_error("aft_profile_kernel_f32 replays the packed engine's kernel classes; this configuration runs the general engine");
+        return AFT_ERR_SHAPE;
+    }
     const Workspace ws = plan_workspace(*cfg, batch);
     AFT_REQUIRE(workspace_bytes >= ws.total_floats * sizeof(float), "workspace too small");
+    const WeightsDev wd = weights_window(*w, 0, cfg->num_layers);
     AFT_REQUIRE(cfg->num_layers >= 2 || which != AFT_KERNEL_CHAIN, "chain profile needs >= 2 layers");
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *base = static_cast<float *>(workspace);
@@ -597,12 +820,12 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                 AFT_REQUIRE(out != nullptr, "upsample profile needs the pilots pointer in `out`");
                 // as the forward: the planes of the pilot_upsampler product lie in x (computed by the prologue launch in the forward;
                 // here whatever x holds -- the conv stack's time does not depend on its data)
-                e = launch_upsample(*cfg, *w, out, base + ws.conv_enhanced, batch, st,
+                e = launch_upsample(*cfg, wd, out, base + ws.conv_enhanced, batch, st,
                                     (size_t)ws.planes * ws.tokens * cfg->model_dim >= (size_t)ws.planes * cfg->num_scs * cfg->num_symbols ? x : nullptr,
-                                    prologue_upsample_ok(*cfg, *w), base + ws.convfrag);
+                                    prologue_upsample_ok(*cfg, wd), base + ws.convfrag);
                 break;
             case AFT_KERNEL_EMBED:
-                e = launch_embed(*cfg, *w, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, x, batch, st);
+                e = launch_embed(*cfg, wd, base + ws.conv_enhanced, cfg->adaptive ? base + ws.tokens6 : nullptr, x, batch, st);
                 break;
             case AFT_KERNEL_QKV: {   // as in the forward: embedding fused in front of the in-projection
                 ChainFusion f{};
@@ -635,7 +858,7 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
             }
             case AFT_KERNEL_ENCODER_PLANE:
                 AFT_REQUIRE(cfg->model_dim == 128, "the plane-resident encoder is instantiated for model_dim 128");
-                e = launch_encoder_plane(*cfg, *w, base + ws.wpack, base + ws.conv_enhanced,
+                e = launch_encoder_plane(*cfg, wd, base + ws.wpack, base + ws.conv_enhanced,
                                          cfg->adaptive ? base + ws.tokens6 : nullptr, x, attn, q, k, vt, base + ws.out6,
                                          ws.planes, ws.tokens, ws.tokpad, st);
                 break;
@@ -645,14 +868,14 @@ int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int whic
                 const float *cond = out + (size_t)batch * cfg->pilot_scs * cfg->pilot_symbols * 2;   // [snr | ds | dop] behind the pilots
                 // AFT_PROLOGUE_NO_UP=1 (measurement only): the launch without the pilot_upsampler product -- bench.py charges the
                 // difference to the upsampler stage (the stage is K0 + K1 + K2)
-                e = launch_prologue(*cfg, *w, cond, cond + batch, cond + 2 * batch, base + ws.tokens6, batch, base + ws.wpack, out,
-                                    lend && prologue_upsample_ok(*cfg, *w) && !getenv("AFT_PROLOGUE_NO_UP") ? x : nullptr, st,
+                e = launch_prologue(*cfg, wd, cond, cond + batch, cond + 2 * batch, base + ws.tokens6, batch, base + ws.wpack, out,
+                                    lend && prologue_upsample_ok(*cfg, wd) && !switch_on("AFT_PROLOGUE_NO_UP") ? x : nullptr, st,
                                     base + ws.convfrag);
                 break;
             }
             case AFT_KERNEL_TAIL:
                 AFT_REQUIRE(out != nullptr, "tail profile needs an output buffer");
-                e = launch_tail(*cfg, *w, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6, base + ws.convfrag + kConvFragFloats);
+                e = launch_tail(*cfg, wd, nullptr, base + ws.conv_enhanced, out, batch, st, base + ws.out6, base + ws.convfrag + kConvFragFloats);
                 break;
             default:
                 set_error("unknown kernel id %d", which);

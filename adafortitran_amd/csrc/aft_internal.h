@@ -141,6 +141,10 @@ __device__ __forceinline__ bool dropmask_keep(uint32_t row_word, uint32_t col_wo
 //                                            operand fragments (conv_device.h: conv_frag16_entry; rebuilt per call by the prologue)
 struct Workspace {
     size_t conv_enhanced, tokens6, x, attn, q, k, vt, wpack, out6, convfrag, total_floats;
+    // general engine only (row-major tensors of ONE layer, re-used layer after layer): x1 = LN1 output, y = projection outputs
+    // before the residual joins, s / stats = pre-norm sum and (mean, rstd) that launch_add_ln_fwd also writes, qkv [rows][3d],
+    // lse, a / hd = FFN pre-activation and activation [rows][2d], pad = padded-head images of qkv and o
+    size_t g_x1, g_y, g_s, g_stats, g_qkv, g_lse, g_a, g_hd, g_pad;
     int tokens, tokpad, planes;
 };
 
@@ -149,6 +153,29 @@ Workspace plan_workspace(const aft_config &c, int batch);
 // error plumbing (thread-local message, see aft_api.hip)
 void set_error(const char *fmt, ...);
 int check_config(const aft_config *c);
+// The launch sequence a configuration runs (aft_engine_of): decided by the configuration alone.
+bool packed_engine_ok(const aft_config &c);
+
+// Measurement / A-B switches (aft_set_switch in the header): a table filled ONCE from the "AFT_*" environment variables when the
+// library is loaded and changed only through the ABI afterwards -- nothing on a call path calls getenv().
+bool switch_on(const char *name);                 // set (to anything)
+int switch_int(const char *name, int dflt);       // atoi of the value, dflt when unset
+
+// The pointer table kernels receive BY VALUE: the public aft_weights with a window of at most kLayerWindow layers inline (the public
+// struct holds a host pointer to any number of layers; kernel arguments cannot follow it).
+constexpr int kLayerWindow = 32;
+struct WeightsDev {
+    const float *up_w, *up_b;
+    const float *enh_w[4], *enh_b[4];
+    const float *ref_w[4], *ref_b[4];
+    const float *ada_w[3][3], *ada_b[3][3];
+    const float *lin1_w, *lin1_b;
+    const float *pos;
+    const float *lin2_w, *lin2_b;
+    aft_layer_weights layers[kLayerWindow];
+};
+// everything but the layers + layers [first, first + count) of w.layers at layers[0 ..)
+WeightsDev weights_window(const aft_weights &w, int first, int count);
 
 // Per-DEVICE facts (aft_api.hip).  The library keeps no state that describes a call, but two things
 // are properties of a device, not of a call: its CU count (persistent grids are sized to it) and the
@@ -172,20 +199,24 @@ hipError_t ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, size_t by
 // planes_ready: scratch_planes already holds the upsampled planes (the forward's prologue launch computed them)
 // conv_frag: this stack's fragment image (kConvFragFloats floats, written by launch_prologue) or NULL
 constexpr size_t kConvFragFloats = 22 * 64 * 4 + 160;   // = conv_device.h kFragFloats, per ConvEnhancer (16-byte multiple)
-hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots,
+hipError_t launch_upsample(const aft_config &c, const WeightsDev &w, const float *pilots,
                            float *conv_enhanced, int batch, hipStream_t st, float *scratch_planes = nullptr, bool planes_ready = false,
                            const float *conv_frag = nullptr);
-hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
+hipError_t launch_adapter(const aft_config &c, const WeightsDev &w, const float *snr, const float *ds,
                           const float *dop, float *tokens6, int batch, hipStream_t st);
 // Whole forward: adapter (if c.adaptive), the weight re-pack (if packed != NULL, all layers) and the pilot_upsampler product over all
 // planes (if up_planes != NULL and prologue_upsample_ok: [2 batch][S*T] floats) as ONE launch (k_misc.hip)
-bool prologue_upsample_ok(const aft_config &c, const aft_weights &w);
+bool prologue_upsample_ok(const aft_config &c, const WeightsDev &w);
 // conv_frag != NULL: + both ConvEnhancers' conv2 / conv3 weights as 16x16x4 operand fragments (2 x kConvFragFloats floats)
-hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const float *snr, const float *ds, const float *dop,
+hipError_t launch_prologue(const aft_config &c, const WeightsDev &w, const float *snr, const float *ds, const float *dop,
                            float *tokens6, int batch, float *packed, const float *pilots, float *up_planes, hipStream_t st,
                            float *conv_frag = nullptr);
-hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced,
+hipError_t launch_embed(const aft_config &c, const WeightsDev &w, const float *conv_enhanced,
                         const float *tokens6, float *x, int batch, hipStream_t st);
+// the same stage for ANY model_dim and patches of up to kMaxPatchGeneral elements (general engine, k_misc.hip)
+constexpr int kMaxPatchGeneral = 32;
+hipError_t launch_embed_any(const aft_config &c, const WeightsDev &w, const float *conv_enhanced,
+                            const float *tokens6, float *x, int batch, hipStream_t st);
 // Row-local chain on [rows, d]: (mlp) x <- LN2(x1 + FFN(x1)), x1 = LN1(x + attn Wo^T + bo);
 // (qkv) q,k,vt <- split(x Wqkv^T + b).  `mlp_w` may be NULL (QKV only), `qkv_w` may be NULL.
 // `*_packed` = that layer's block of the fragment-packed weight image (launch_pack_weights).
@@ -198,7 +229,7 @@ struct ChainFusion {
     float *out6 = nullptr;
     bool x_blocked = false;   // x between the launches in tile-blocked order (ChainArgs::x_blocked): the whole-forward sequence only
 };
-inline int out6_stride(const aft_config &c) { return c.patch_scs * c.patch_symbols <= 8 ? 8 : 16; }
+inline int out6_stride(const aft_config &c) { return round_up(c.patch_scs * c.patch_symbols, 8); }   // 8 | 16 (packed engine); 24 | 32 too (general)
 hipError_t launch_chain(const aft_config &c, const aft_layer_weights *mlp_w, const float *mlp_packed,
                         const aft_layer_weights *qkv_w, const float *qkv_packed, const float *attn, float *x,
                         float *q, float *k, float *vt, int rows, int tokens, int tokpad, hipStream_t st,
@@ -207,19 +238,19 @@ size_t packed_layer_floats(int d);
 // Plane-resident encoder (k_encoder.hip): embedding + all layers + linear_2 of every plane in ONE launch, one 12-wave
 // workgroup per plane.  encoder_plane_ok: the shape is instantiated (d = 128).
 bool encoder_plane_ok(const aft_config &c);
-hipError_t launch_encoder_plane(const aft_config &c, const aft_weights &w, const float *wpack, const float *conv_enhanced,
+hipError_t launch_encoder_plane(const aft_config &c, const WeightsDev &w, const float *wpack, const float *conv_enhanced,
                                 const float *tokens6, float *x, float *attn, float *q, float *k, float *vt, float *out6,
                                 int planes, int tokens, int tokpad, hipStream_t st);
 // Re-lay the encoder GEMM weights of layers [first, first+count) into MFMA-fragment order.
-hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float *packed, int first_layer, int count,
-                               hipStream_t st);
+// `layers`: HOST array of `count` layers; the image starts at layers[0]'s block (any count: windows of kLayerWindow per launch)
+hipError_t launch_pack_weights(const aft_config &c, const aft_layer_weights *layers, float *packed, int count, hipStream_t st);
 // qbias = the layer's in_proj_bias (first d entries are the query bias, applied at fragment load).
 hipError_t launch_attention(const aft_config &c, const float *q, const float *k, const float *vt, const float *qbias,
                             float *attn, int planes, int tokens, int tokpad, hipStream_t st);
 // true when the fused conv-stack kernel has an LDS band plan for an S x T grid with `extra_floats` of side data
 bool conv_plan_ok(int S, int T, int extra_floats);
 // x = encoder output [rows][d] (linear_2 applied here), or NULL with out6 = linear_2 output [rows][out6_stride(c)]
-hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
+hipError_t launch_tail(const aft_config &c, const WeightsDev &w, const float *x, const float *conv_enhanced,
                        float *out, int batch, hipStream_t st, const float *out6 = nullptr, const float *conv_frag = nullptr);
 hipError_t launch_linear(const float *weight, const float *bias, const float *pilots, float *out, int batch,
                          int in_features, int out_features, hipStream_t st);

@@ -153,7 +153,7 @@ int aft_encoder_layer_fwd_train_chained_f32(const aft_config *cfg, const aft_lay
     const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     // the NEXT layer's in-projection as the tail of this layer's row-local kernel (same tape layout: the layers share cfg and batch)
     const bool chain_next = next_w && next_w->in_proj_w && next_w->in_proj_b && next_tape && next_qkv_written;
-    if (chain_fwd_train_ok(*cfg, rows) && !getenv("AFT_TRAIN_UNFUSED_FWD")) {
+    if (chain_fwd_train_ok(*cfg, rows) && !switch_on("AFT_TRAIN_UNFUSED_FWD")) {
         // everything row-local behind the attention in ONE launch, the tape written from its epilogues (k_chain_bwd.hip);
         // the packed weight image lives in the scratch's packed_t region (8 d^2 floats needed, see plan_scratch)
         STEP("row-local forward chain", launch_chain_fwd_train(*cfg, *w, tp + t.attn, x_in, sc + s.packed_t, tp + t.s1, tp + t.st1, tp + t.x1,
@@ -231,7 +231,7 @@ int aft_encoder_layer_bwd_f32(const aft_config *cfg, const aft_layer_weights *w,
     ReduceBatchScope reductions;
     const uint32_t drop_th = dropout_p > 0.f ? (uint32_t)((double)dropout_p * 4294967296.0) : 0u;
     const float drop_ks = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
-    if (chain_bwd_ok(*cfg, rows) && !getenv("AFT_TRAIN_UNFUSED_BWD")) {
+    if (chain_bwd_ok(*cfg, rows) && !switch_on("AFT_TRAIN_UNFUSED_BWD")) {
         // everything row-local in ONE launch: dx_out -> g2, gff, g2b (operands of the weight gradients), g1 = d(attention
         // output), dx_in = the residual branch of dL/dx, per-tile LayerNorm parameter sums
         float *lnp = sc + s.lnp;

@@ -71,7 +71,7 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
         return hipGetLastError();
     }
 #ifdef AFT_DIAG_STAMPS
-    if (getenv("AFT_STAMPS")) {   // per-task stamps + in-kernel clock (diagnostic build only)
+    if (switch_on("AFT_STAMPS")) {   // per-task stamps + in-kernel clock (diagnostic build only)
         static unsigned long long *dbuf = nullptr;
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 8 * 16384);
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 8 * 16384);
@@ -134,10 +134,10 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
     // the two benchmark grids with the token count at compile time (120 x 14 -> 280 tokens, 240 x 28 -> 1120): the tile loop's trip
     // count, the last-tiles logic and the padding masks resolve in the compiler -- 125 VGPRs and no scalar spills instead of 168 and 40,
     // -2.7 % time at 280 tokens (A/B knob: AFT_ATTN_GENERIC=1 runs the generic instantiation; same bits)
-    else if (tokens == 280 && !getenv("AFT_ATTN_GENERIC"))
+    else if (tokens == 280 && !switch_on("AFT_ATTN_GENERIC"))
         hipLaunchKernelGGL((attn_kernel<32, 280>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
                            scale_log2e, ntasks, no_stamps);
-    else if (tokens == 1120 && !getenv("AFT_ATTN_GENERIC"))
+    else if (tokens == 1120 && !switch_on("AFT_ATTN_GENERIC"))
         hipLaunchKernelGGL((attn_kernel<32, 1120>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
                            scale_log2e, ntasks, no_stamps);
     else

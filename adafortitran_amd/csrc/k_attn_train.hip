@@ -552,6 +552,26 @@ __global__ __launch_bounds__(kAtThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     attn_bwd_q_body<2>(a, lds, words);
 }
 
+// ---- heads of up to 96 / 128 features (round 6, the general engine): three / four 32-feature blocks per head, the same bodies.  The
+// staging buffers no longer fit the 64 KB of static LDS (2 x NB x 9.5 KB), so they lie in the dynamic region in front of the mask
+// words; registers are whatever the bodies need (two or one wave per SIMD): covered, not tuned.
+template <int NB>
+__global__ __launch_bounds__(kAtThreads) void attn_train_fwd_wide_kernel(const AttnTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+    attn_train_fwd_body<NB>(a, reinterpret_cast<float (*)[NB * kAtBufFloats]>(dyn_lds), reinterpret_cast<uint32_t *>(dyn_lds + 2 * NB * kAtBufFloats));
+}
+template <int NB>
+__global__ __launch_bounds__(kAtThreads) void attn_bwd_q_wide_kernel(const AttnTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+    attn_bwd_q_body<NB>(a, reinterpret_cast<float (*)[NB * kAtBufFloats]>(dyn_lds), reinterpret_cast<uint32_t *>(dyn_lds + 2 * NB * kAtBufFloats));
+}
+template <int NB>
+__global__ __launch_bounds__(kAtThreads) void attn_bwd_kv_wide_kernel(const AttnTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+    attn_bwd_kv_body<NB>(a, reinterpret_cast<float (*)[NB * kAtBufFloats]>(dyn_lds), reinterpret_cast<uint32_t *>(dyn_lds + 2 * NB * kAtBufFloats));
+}
+static size_t wide_lds_bytes(int nb, int ntiles) { return sizeof(float) * 2 * nb * kAtBufFloats + (size_t)ntiles * 32 * sizeof(uint32_t); }
+
 // ---- dQ, dK and dV in ONE pass (round 3): own = key tile, walks the query tiles (staged: Q, dO) ----
 // The two-kernel backward recomputes S and dP in both passes: 7 products of 16 MFMAs per (query tile, key tile) pair for 5
 // useful ones.  Here a workgroup owns one whole (plane, head): its three waves take the key tiles three at a time (pass p:
@@ -807,7 +827,21 @@ __global__ __launch_bounds__(kAtThreads * GROUPS) __attribute__((amdgpu_waves_pe
 // re-lay passes per layer -- covered, not tuned -- but every gradient comes from this library's kernels
 // (reference blocks/encoders.py:44-51 builds whatever num_head the YAML says; trainer.py:195-233 trains it).
 // pad: dst [rows][nseg][heads][hp] <- src [rows][nseg][heads][hd]; unpad: the reverse.  One 16-byte piece per thread.
-static int padded_head(int hd) { return hd == 32 || hd == 64 ? hd : hd < 32 ? 32 : 64; }
+static int padded_head(int hd) { return (hd + 31) / 32 * 32; }   // 32 | 64 | 96 | 128 features
+// any head dim (round 6: not a multiple of 4 -- model_dim 120 with 8 heads): one float per thread
+__global__ __launch_bounds__(256) void pad_heads1_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n, int hd, int hp) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // element of dst: (row, seg * heads + head, j in 0 .. hp - 1)
+    if (v >= n) return;
+    const size_t rh = v / hp;
+    const int j = (int)(v - rh * hp);
+    dst[v] = j < hd ? src[rh * hd + j] : 0.f;
+}
+__global__ __launch_bounds__(256) void unpad_heads1_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n, int hd, int hp) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // element of dst
+    if (v >= n) return;
+    const size_t rh = v / hd;
+    dst[v] = src[rh * hp + (v - rh * hd)];
+}
 __global__ __launch_bounds__(256) void pad_heads_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t pieces, int hd4, int hp4) {
     const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;      // piece of dst: (row, seg * heads + head, j4 in 0 .. hp4 - 1)
     if (v >= pieces) return;
@@ -825,12 +859,22 @@ __global__ __launch_bounds__(256) void unpad_heads_kernel(const float *__restric
 }
 static hipError_t pad_heads(const float *src, float *dst, size_t rows, int nseg, int heads, int hd, hipStream_t st) {
     const int hp = padded_head(hd);
+    if (hd % 4 != 0) {
+        const size_t n = rows * nseg * heads * hp;
+        hipLaunchKernelGGL(pad_heads1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, hd, hp);
+        return hipGetLastError();
+    }
     const size_t pieces = rows * nseg * heads * (hp / 4);
     hipLaunchKernelGGL(pad_heads_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, src, dst, pieces, hd / 4, hp / 4);
     return hipGetLastError();
 }
 static hipError_t unpad_heads(const float *src, float *dst, size_t rows, int nseg, int heads, int hd, hipStream_t st) {
     const int hp = padded_head(hd);
+    if (hd % 4 != 0) {
+        const size_t n = rows * nseg * heads * hd;
+        hipLaunchKernelGGL(unpad_heads1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, hd, hp);
+        return hipGetLastError();
+    }
     const size_t pieces = rows * nseg * heads * (hd / 4);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, src, dst, pieces, hd / 4, hp / 4);
     return hipGetLastError();
@@ -871,7 +915,16 @@ hipError_t launch_attn_train_fwd(const aft_config &c, const float *qkv, float *o
         a.qkv = qkv_p; a.out = o_p;
     }
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
-    if (hp == 64)      // a head = two 32-feature blocks (round 5; covered, not tuned)
+    if (hp == 96 || hp == 128) {   // three / four blocks per head (round 6; the general engine)
+        static PerDeviceOnce attr3, attr4;
+        const size_t lds = wide_lds_bytes(hp / 32, a.ntiles);
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        hipError_t ea = hp == 96 ? ensure_dynamic_lds(attr3, reinterpret_cast<const void *>(attn_train_fwd_wide_kernel<3>), 160 * 1024)
+                                 : ensure_dynamic_lds(attr4, reinterpret_cast<const void *>(attn_train_fwd_wide_kernel<4>), 160 * 1024);
+        if (ea != hipSuccess) return ea;
+        if (hp == 96) hipLaunchKernelGGL(attn_train_fwd_wide_kernel<3>, dim3(wgs), dim3(kAtThreads), lds, st, a);
+        else hipLaunchKernelGGL(attn_train_fwd_wide_kernel<4>, dim3(wgs), dim3(kAtThreads), lds, st, a);
+    } else if (hp == 64)      // a head = two 32-feature blocks (round 5; covered, not tuned)
         hipLaunchKernelGGL(attn_train_fwd64_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
     else
         hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(wgs), dim3(kAtThreads), (size_t)a.ntiles * 32 * sizeof(uint32_t), st, a);
@@ -910,6 +963,25 @@ hipError_t launch_attn_train_bwd(const aft_config &c, const float *qkv, const fl
 static hipError_t launch_attn_train_bwd_padded(const aft_config &c, AttnTrainArgs a, const float *qkv, const float *o, const float *d_o,
                                                float *dqkv, int planes, int tokens, hipStream_t st) {
     a.qkv = qkv; a.o = o; a.d_o = d_o; a.out = dqkv;
+    if (const int hp = c.model_dim / c.num_head; hp == 96 || hp == 128) {   // three / four blocks per head: the two-pass form (round 6)
+        static PerDeviceOnce attr[4];
+        const size_t lds = wide_lds_bytes(hp / 32, a.ntiles);
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        const void *fq = hp == 96 ? reinterpret_cast<const void *>(attn_bwd_q_wide_kernel<3>) : reinterpret_cast<const void *>(attn_bwd_q_wide_kernel<4>);
+        const void *fk = hp == 96 ? reinterpret_cast<const void *>(attn_bwd_kv_wide_kernel<3>) : reinterpret_cast<const void *>(attn_bwd_kv_wide_kernel<4>);
+        hipError_t ea = ensure_dynamic_lds(attr[hp == 96 ? 0 : 1], fq, 160 * 1024);
+        if (ea == hipSuccess) ea = ensure_dynamic_lds(attr[hp == 96 ? 2 : 3], fk, 160 * 1024);
+        if (ea != hipSuccess) return ea;
+        const int wgsw = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
+        if (hp == 96) {
+            hipLaunchKernelGGL(attn_bwd_q_wide_kernel<3>, dim3(wgsw), dim3(kAtThreads), lds, st, a);     // also writes D_i = dO_i . O_i
+            hipLaunchKernelGGL(attn_bwd_kv_wide_kernel<3>, dim3(wgsw), dim3(kAtThreads), lds, st, a);    // reads it
+        } else {
+            hipLaunchKernelGGL(attn_bwd_q_wide_kernel<4>, dim3(wgsw), dim3(kAtThreads), lds, st, a);
+            hipLaunchKernelGGL(attn_bwd_kv_wide_kernel<4>, dim3(wgsw), dim3(kAtThreads), lds, st, a);
+        }
+        return hipGetLastError();
+    }
     if (c.model_dim / c.num_head == 64) {   // head dim 64: the two-pass form with two 32-feature blocks per head (round 5)
         const int wgs64 = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
         const size_t wb = (size_t)a.ntiles * 32 * sizeof(uint32_t);
@@ -920,7 +992,7 @@ static hipError_t launch_attn_train_bwd_padded(const aft_config &c, AttnTrainArg
     const int wgs = planes * a.heads * ((a.ntiles + kAtWaves - 1) / kAtWaves);
     const size_t words_bytes = (size_t)a.ntiles * 32 * sizeof(uint32_t);
     // one pass (attn_bwd_kernel) unless its three LDS tables do not fit beside the static staging, or the two-pass form is asked for (A/B)
-    const bool two_pass = getenv("AFT_TRAIN_ATTN_BWD_SPLIT") != nullptr;   // read per call: tools/debug/attn_bwd_check.py flips it
+    const bool two_pass = switch_on("AFT_TRAIN_ATTN_BWD_SPLIT");   // read per call: tools/debug/attn_bwd_check.py flips it
     const size_t group_lds = sizeof(float) * kAtBwdStatic + 3 * words_bytes;
     if (!two_pass && group_lds <= 64 * 1024) {
         // four problems per workgroup (twelve waves, one workgroup per CU) when their LDS fits four times; else the three-wave shape
@@ -932,13 +1004,13 @@ static hipError_t launch_attn_train_bwd_padded(const aft_config &c, AttnTrainArg
         // frames; 96: 5.71 vs 5.83, 160: 8.97 vs 9.65, 192: 10.33 vs 10.76).  (round 5)
         const int problems = planes * a.heads, cus = current_device_cus();
         int groups = (4 * group_lds <= 160 * 1024 && problems % (4 * cus) == 0) ? 4 : 1;
-        if (getenv("AFT_ATTN_BWD_3WAVE")) groups = 1;
-        if (const char *g = getenv("AFT_ATTN_BWD_GROUPS")) {     // A/B: force 1 or 4 where the shape allows it
-            const int want = atoi(g);
+        if (switch_on("AFT_ATTN_BWD_3WAVE")) groups = 1;
+        if (switch_on("AFT_ATTN_BWD_GROUPS")) {     // A/B: force 1 or 4 where the shape allows it
+            const int want = switch_int("AFT_ATTN_BWD_GROUPS", 0);
             if ((want == 1 || want == 4) && problems % want == 0 && (size_t)want * group_lds <= 160 * 1024) groups = want;
         }
         const bool four = groups == 4;
-        const bool tok280 = tokens == 280 && !getenv("AFT_ATTN_GENERIC");
+        const bool tok280 = tokens == 280 && !switch_on("AFT_ATTN_GENERIC");
         const void *fn = four ? (tok280 ? reinterpret_cast<const void *>(attn_bwd_kernel<280, 4>) : reinterpret_cast<const void *>(attn_bwd_kernel<0, 4>))
                               : (tok280 ? reinterpret_cast<const void *>(attn_bwd_kernel<280, 1>) : reinterpret_cast<const void *>(attn_bwd_kernel<0, 1>));
         static PerDeviceOnce lds_attr[4];

@@ -64,7 +64,7 @@ static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
     const int blocks = std::min((args.rows + 31) / 32, resident);
     const size_t lds = S::LDS_BYTES;
 #ifdef AFT_DIAG_STAMPS
-    if (getenv("AFT_STAMPS")) {   // phase stamps, printed on the host (never in the product build)
+    if (switch_on("AFT_STAMPS")) {   // phase stamps, printed on the host (never in the product build)
         static unsigned long long *dbuf = nullptr;
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 4096);
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
@@ -151,19 +151,23 @@ static hipError_t launch_chain_v(const ChainArgs &args, hipStream_t st) {
 // Packed-weight block of one layer inside the workspace (floats): [in_proj 3D*D][out_proj D*D][lin1 2D*D][lin2 D*2D]
 size_t packed_layer_floats(int d) { return (size_t)8 * d * d; }
 
-__global__ __launch_bounds__(256) void pack_weights_kernel(const aft_weights w, float *__restrict__ packed, int d,
+__global__ __launch_bounds__(256) void pack_weights_kernel(const WeightsDev w, float *__restrict__ packed, int d,
                                                            int num_layers, int split) {
     pack_weights_vec(w, packed, d, 0, num_layers, split, (size_t)blockIdx.x * 256 + threadIdx.x);   // one float4 of the image
 }
 
-hipError_t launch_pack_weights(const aft_config &c, const aft_weights &w, float *packed, int first_layer, int count,
-                               hipStream_t st) {
-    aft_weights shifted = w;   // kernel indexes layers from 0: shift the window
-    for (int i = 0; i < count; ++i) shifted.layers[i] = w.layers[first_layer + i];
-    const size_t vecs = packed_layer_floats(c.model_dim) * count / 4;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, shifted, packed,
-                       c.model_dim, count, c.precision == AFT_PRECISION_BF16X3 ? 1 : 0);
-    return hipGetLastError();
+hipError_t launch_pack_weights(const aft_config &c, const aft_layer_weights *layers, float *packed, int count, hipStream_t st) {
+    for (int first = 0; first < count; first += kLayerWindow) {   // the kernel takes a window of the layer table by value
+        const int n = std::min(kLayerWindow, count - first);
+        WeightsDev win{};
+        for (int i = 0; i < n; ++i) win.layers[i] = layers[first + i];
+        const size_t vecs = packed_layer_floats(c.model_dim) * n / 4;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, st, win,
+                           packed + packed_layer_floats(c.model_dim) * first, c.model_dim, n, c.precision == AFT_PRECISION_BF16X3 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 template <int D, int ACT>

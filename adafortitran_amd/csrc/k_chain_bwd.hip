@@ -768,7 +768,7 @@ static hipError_t launch_chain_fwd_train_t(const ChainTrainArgs &args, hipStream
     if (ea != hipSuccess) return ea;
     const int blocks = std::min((args.rows + 31) / 32, current_device_cus() * 3);
 #ifdef AFT_DIAG_STAMPS
-    if (getenv("AFT_STAMPS")) {   // diagnostic build only: mean cycles per phase of a tile (wave 0), and when the workgroups started
+    if (switch_on("AFT_STAMPS")) {   // diagnostic build only: mean cycles per phase of a tile (wave 0), and when the workgroups started
         const int ntiles = (args.rows + 31) / 32;
         static unsigned long long *dbuf = nullptr;
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 8192);
@@ -813,13 +813,12 @@ hipError_t launch_chain_fwd_train(const aft_config &c, const aft_layer_weights &
                                   float *s1, float *st1, float *x1, float *a_pre, float *hd, float *s2, float *st2, float *x_out,
                                   int rows, uint32_t seed1, uint32_t seed2, uint32_t seed3, uint32_t threshold, float keep_scale,
                                   hipStream_t st, const float *next_in_proj_w, const float *next_in_proj_b, float *next_qkv) {
-    aft_weights one{};
-    one.layers[0] = w;
+    aft_layer_weights one = w;
     const bool qkv = next_in_proj_w && next_in_proj_b && next_qkv;
-    if (qkv) one.layers[0].in_proj_w = next_in_proj_w;   // the image's in-projection slot carries the NEXT layer's matrix
+    if (qkv) one.in_proj_w = next_in_proj_w;   // the image's in-projection slot carries the NEXT layer's matrix
     aft_config c1 = c;
     c1.precision = AFT_PRECISION_F32;
-    hipError_t e = launch_pack_weights(c1, one, packed, 0, 1, st);
+    hipError_t e = launch_pack_weights(c1, &one, packed, 1, st);
     if (e != hipSuccess) return e;
     const size_t dd = (size_t)c.model_dim * c.model_dim;
     ChainTrainArgs a{};
@@ -873,7 +872,7 @@ static hipError_t launch_chain_bwd_t(const ChainBwdArgs &args, hipStream_t st) {
     constexpr int D = 128;
     using B = ChainBwdShape<D>;
     static PerDeviceOnce lds_attr[2];
-    const bool ragged = (args.rows & 31) != 0 || getenv("AFT_CHAIN_BWD_RAGGED") != nullptr;      // a partial last tile: the instantiation with per-row guards (the variable forces it: A/B)
+    const bool ragged = (args.rows & 31) != 0 || switch_on("AFT_CHAIN_BWD_RAGGED");      // a partial last tile: the instantiation with per-row guards (the variable forces it: A/B)
     hipError_t ea = ragged ? ensure_dynamic_lds(lds_attr[1], reinterpret_cast<const void *>(chain_bwd_kernel<D, ACT, true>), B::LDS_BYTES)
                            : ensure_dynamic_lds(lds_attr[0], reinterpret_cast<const void *>(chain_bwd_kernel<D, ACT, false>), B::LDS_BYTES);
     if (ea != hipSuccess) return ea;

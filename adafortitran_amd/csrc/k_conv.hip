@@ -754,11 +754,11 @@ static hipError_t launch_conv(ConvArgs &a, int planes, int extra_floats, hipStre
     const bool fixed = a.S == 120 && a.T == 14 && a.SP == 128 && a.band_rows == 120 && a.nbands == 1 && a.ntiles == 4 && a.nseg == 2;
     // default grid, inference, inputs as the whole forward provides them: the column-streaming pipeline (k_conv_stream.hip);
     // AFT_CONV_BANDED=1 keeps the banded kernel (A/B runs)
-    if (fixed && conv_stream_ok(a) && !getenv("AFT_CONV_BANDED")) return launch_conv_stream(a, planes, st);   // (training: mode 2)
+    if (fixed && conv_stream_ok(a) && !switch_on("AFT_CONV_BANDED")) return launch_conv_stream(a, planes, st);   // (training: mode 2)
     if (fixed) return launch_conv_geo<TRAIN, true>(a, planes, lds, st);
     // planes that need several bands here (config 5: five bands of two row tiles): the whole-height column-streaming kernel
     // (k_conv_rows.hip) when its shape conditions hold; AFT_CONV_BANDED=1 keeps the banded kernel (A/B runs)
-    if (!TRAIN && a.nbands > 1 && conv_rows_ok(a, planes) && !getenv("AFT_CONV_BANDED")) return launch_conv_rows(a, planes, st);
+    if (!TRAIN && a.nbands > 1 && conv_rows_ok(a, planes) && !switch_on("AFT_CONV_BANDED")) return launch_conv_rows(a, planes, st);
     return launch_conv_geo<TRAIN, false>(a, planes, lds, st);
 }
 
@@ -768,7 +768,7 @@ static hipError_t launch_conv_geo(ConvArgs &a, int planes, size_t lds, hipStream
     hipError_t ea = ensure_dynamic_lds(lds_attr, reinterpret_cast<const void *>(conv_stack_kernel<TRAIN, FIXED>), 160 * 1024);
     if (ea != hipSuccess) return ea;
 #ifdef AFT_DIAG_STAMPS
-    if (!TRAIN && getenv("AFT_STAMPS")) {   // diagnostic build only: mean cycles per phase (thread 0 of every workgroup)
+    if (!TRAIN && switch_on("AFT_STAMPS")) {   // diagnostic build only: mean cycles per phase (thread 0 of every workgroup)
         static unsigned long long *dbuf = nullptr;
         const int nb = planes * a.nbands;
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 4096);
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void upsample_planes_kernel(const float *__res
     upsample_planes_body(ups, up_w, up_b, pilots, planes_out, npix, pf, nplanes, blockIdx.x, blockIdx.y);
 }
 
-hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const float *pilots, float *conv_enhanced,
+hipError_t launch_upsample(const aft_config &c, const WeightsDev &w, const float *pilots, float *conv_enhanced,
                            int batch, hipStream_t st, float *scratch_planes, bool planes_ready, const float *conv_frag) {
     static_assert(kConvFragFloats == (size_t)kFragFloats, "fragment image size");
     ConvArgs a{};
@@ -850,7 +850,7 @@ hipError_t launch_upsample(const aft_config &c, const aft_weights &w, const floa
     return launch_conv<false>(a, 2 * batch, a.pf, st);
 }
 
-hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x, const float *conv_enhanced,
+hipError_t launch_tail(const aft_config &c, const WeightsDev &w, const float *x, const float *conv_enhanced,
                        float *out, int batch, hipStream_t st, const float *out6, const float *conv_frag) {
     ConvArgs a{};
     a.mode = 1;
@@ -864,7 +864,9 @@ hipError_t launch_tail(const aft_config &c, const aft_weights &w, const float *x
     for (int i = 0; i < 4; ++i) { a.cw[i] = w.ref_w[i]; a.cb[i] = w.ref_b[i]; }
     a.out_complex = out;
     const int p = a.p0 * a.p1;
-    return launch_conv<false>(a, 2 * batch, p * a.d + p, st);
+    // LDS beside the plane: linear_2's weights when the kernel applies it (x given).  The packed engine keeps that reservation with
+    // out6 as well (its band plans, hence its bits, are those of rounds 2-5); the general engine's out6 tail reserves nothing.
+    return launch_conv<false>(a, 2 * batch, out6 != nullptr && !packed_engine_ok(c) ? 0 : p * a.d + p, st);
 }
 
 }  // namespace aft

@@ -672,7 +672,7 @@ hipError_t launch_conv_rows(ConvArgs &a, int planes, hipStream_t st) {
     const size_t lds = sizeof(float) * conv_rows_lds_floats(a.S, wcols);
     static PerDeviceOnce lds_head, lds_tail, lds_head16, lds_tail16;
     // the 16x16x4 matrix phase needs the operand fragments of the forward's prologue launch; AFT_CONV_MFMA32=1 keeps the 32x32x2 kernel (A/B)
-    const bool m16 = a.wfrag != nullptr && getenv("AFT_CONV_MFMA32") == nullptr;
+    const bool m16 = a.wfrag != nullptr && !switch_on("AFT_CONV_MFMA32");
     hipError_t e;
     if (m16)
         e = a.mode == 0 ? ensure_dynamic_lds(lds_head16, reinterpret_cast<const void *>(conv_rows16_kernel<0>), 160 * 1024)

@@ -1009,19 +1009,19 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
         // are 128 planes (AFT_CONV_NSPLIT=1|2|4 forces a split: tests, A/B)
         const int cus = current_device_cus();
         a.ranges = 4 * planes <= cus ? 4 : (2 * planes <= cus ? 2 : 1);
-        if (const char *f = getenv("AFT_CONV_NSPLIT")) a.ranges = atoi(f) == 4 ? 4 : (atoi(f) == 2 ? 2 : 1);
+        if (switch_on("AFT_CONV_NSPLIT")) { const int f = switch_int("AFT_CONV_NSPLIT", 1); a.ranges = f == 4 ? 4 : (f == 2 ? 2 : 1); }
         hipLaunchKernelGGL((conv_stream_kernel<0, true>), dim3(planes * a.ranges), dim3(kConvThreads), kStreamLds, st, a);
         return hipGetLastError();
     }
     // the 16x16x4 kernel needs the fragment image of the forward's prologue launch; AFT_CONV_MFMA32=1 keeps the 32x32x2 kernel (A/B runs)
-    const bool m16 = a.wfrag != nullptr && getenv("AFT_CONV_MFMA32") == nullptr;
+    const bool m16 = a.wfrag != nullptr && !switch_on("AFT_CONV_MFMA32");
     hipError_t e;
     // column ranges when the planes would leave half (three quarters) of the CUs idle; AFT_CONV_NSPLIT=1|2|4 forces a split (tests, A/B)
     int nsplit = 1;
     if (m16) {
         const int cus = current_device_cus();
         nsplit = 4 * planes <= cus ? 4 : (2 * planes <= cus ? 2 : 1);
-        if (const char *f = getenv("AFT_CONV_NSPLIT")) nsplit = atoi(f) == 4 ? 4 : (atoi(f) == 2 ? 2 : 1);
+        if (switch_on("AFT_CONV_NSPLIT")) { const int f = switch_int("AFT_CONV_NSPLIT", 1); nsplit = f == 4 ? 4 : (f == 2 ? 2 : 1); }
     }
     const void *fn16 = a.mode == 0 ? (nsplit == 4 ? reinterpret_cast<const void *>(conv_stream16_kernel<0, 4>)
                                                   : nsplit == 2 ? reinterpret_cast<const void *>(conv_stream16_kernel<0, 2>)
@@ -1038,7 +1038,7 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     if (e != hipSuccess) return e;
 #ifdef AFT_DIAG_STAMPS
     static unsigned long long *dbuf = nullptr;
-    const bool stamp = getenv("AFT_STAMPS") != nullptr && planes <= 4096;
+    const bool stamp = switch_on("AFT_STAMPS") && planes <= 4096;
     if (stamp) {
         if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * 4096);
         (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * 4096);
@@ -1064,7 +1064,7 @@ hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
         // ranges -- 0.42 (four ranges) or 0.62 (two) of a round instead of 1.0.  Same bits (ranges reproduce whole planes).
         const int cus = current_device_cus();
         const int rem = planes % cus, whole = planes - rem;
-        const bool forced = getenv("AFT_CONV_NSPLIT") != nullptr;
+        const bool forced = switch_on("AFT_CONV_NSPLIT");
         if (!forced && nsplit == 1 && whole > 0 && rem > 0 && 2 * rem <= cus) {
             const int ns2 = 4 * rem <= cus ? 4 : 2;
             hipError_t ea = ensure_dynamic_lds(lds16[(a.mode == 0 ? 0 : 3) + (ns2 == 4 ? 2 : 1)],

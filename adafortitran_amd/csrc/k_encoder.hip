@@ -30,7 +30,7 @@
 namespace aft {
 
 struct EncoderArgs {
-    aft_weights w;                          // torch vectors per layer, linear_1 / linear_2 / positions (3.4 KB of kernarg)
+    WeightsDev w;                          // torch vectors per layer, linear_1 / linear_2 / positions (3.4 KB of kernarg)
     const float *wpack;                     // fragment-packed GEMM weights [L][8 d^2]
     const float *conv_enhanced, *tokens6;   // [planes][S][T], [frames][tokens][6] or NULL
     float *x, *attn, *q, *k, *vt, *out6;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(EncoderShape<D>::THREADS, EncoderShape<D>::THREADS 
 
 bool encoder_plane_ok(const aft_config &c) {
     // 3 groups x 51 KB of LDS, 12 waves: the d = 128 / head dim 32 shape is the one instantiated (>= 32 tokens: a row tile inside one plane)
-    return c.model_dim == 128 && c.num_head == 4 && (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols) >= kTile;
+    return c.model_dim == 128 && c.num_head == 4 && c.num_layers <= kLayerWindow && (c.num_scs / c.patch_scs) * (c.num_symbols / c.patch_symbols) >= kTile;
 }
 
 template <int ACT>
@@ -161,7 +161,7 @@ static hipError_t launch_encoder_plane_t(const EncoderArgs &args, hipStream_t st
     return hipGetLastError();
 }
 
-hipError_t launch_encoder_plane(const aft_config &c, const aft_weights &w, const float *wpack, const float *conv_enhanced,
+hipError_t launch_encoder_plane(const aft_config &c, const WeightsDev &w, const float *wpack, const float *conv_enhanced,
                                 const float *tokens6, float *x, float *attn, float *q, float *k, float *vt, float *out6,
                                 int planes, int tokens, int tokpad, hipStream_t st) {
     EncoderArgs a{};

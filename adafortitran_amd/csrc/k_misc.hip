@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void adapter_kernel(const AdapterArgs a) {
     adapter_body(a, blockIdx.x, blockIdx.y, sm);
 }
 
-static AdapterArgs adapter_args(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
+static AdapterArgs adapter_args(const aft_config &c, const WeightsDev &w, const float *snr, const float *ds,
                                 const float *dop, float *tokens6) {
     AdapterArgs a{};
     a.cond[0] = snr; a.cond[1] = ds; a.cond[2] = dop;
@@ -106,7 +106,7 @@ static AdapterArgs adapter_args(const aft_config &c, const aft_weights &w, const
     return a;
 }
 
-hipError_t launch_adapter(const aft_config &c, const aft_weights &w, const float *snr, const float *ds,
+hipError_t launch_adapter(const aft_config &c, const WeightsDev &w, const float *snr, const float *ds,
                           const float *dop, float *tokens6, int batch, hipStream_t st) {
     const AdapterArgs a = adapter_args(c, w, snr, ds, dop, tokens6);
     hipLaunchKernelGGL(adapter_kernel, dim3(batch, 3), dim3(256), sizeof(float) * (a.h0 + a.h1), st, a);
@@ -131,7 +131,7 @@ struct PrologueArgs {
     int frag_blocks;
 };
 
-__global__ __launch_bounds__(256) void prologue_kernel(const aft_weights w, const PrologueArgs a) {
+__global__ __launch_bounds__(256) void prologue_kernel(const WeightsDev w, const PrologueArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     int blk = blockIdx.x;
     if (blk < a.adapter_blocks) {            // workgroup-uniform: the barriers inside are safe
@@ -169,11 +169,11 @@ __global__ __launch_bounds__(256) void prologue_kernel(const aft_weights w, cons
     upsample_planes_body(sm, w.up_w, w.up_b, a.pilots, a.up_planes, a.npix, a.pf, a.nplanes, blk % a.up_bx, blk / a.up_bx);
 }
 
-bool prologue_upsample_ok(const aft_config &c, const aft_weights &w) {
+bool prologue_upsample_ok(const aft_config &c, const WeightsDev &w) {
     return upsample_planes_ok(w.up_w, c.pilot_scs * c.pilot_symbols);
 }
 
-hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const float *snr, const float *ds, const float *dop,
+hipError_t launch_prologue(const aft_config &c, const WeightsDev &w, const float *snr, const float *ds, const float *dop,
                            float *tokens6, int batch, float *packed, const float *pilots, float *up_planes, hipStream_t st,
                            float *conv_frag) {
     PrologueArgs a{};
@@ -188,9 +188,9 @@ hipError_t launch_prologue(const aft_config &c, const aft_weights &w, const floa
         lds = sizeof(float) * (a.ad.h0 + a.ad.h1);
     }
     if (packed != nullptr) {
-        a.packed = packed; a.d = c.model_dim; a.num_layers = c.num_layers;
+        a.packed = packed; a.d = c.model_dim; a.num_layers = std::min(c.num_layers, kLayerWindow);   // the window `w` holds; the caller packs the rest
         a.split = c.precision == AFT_PRECISION_BF16X3 ? 1 : 0;
-        a.pack_blocks = (int)((packed_layer_floats(c.model_dim) * c.num_layers / 4 + 255) / 256);
+        a.pack_blocks = (int)((packed_layer_floats(c.model_dim) * a.num_layers / 4 + 255) / 256);
     }
     int up_blocks = 0;
     if (up_planes != nullptr && prologue_upsample_ok(c, w)) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
     }
 }
 
-hipError_t launch_embed(const aft_config &c, const aft_weights &w, const float *conv_enhanced, const float *tokens6,
+hipError_t launch_embed(const aft_config &c, const WeightsDev &w, const float *conv_enhanced, const float *tokens6,
                         float *x, int batch, hipStream_t st) {
     EmbedArgs a{};
     a.conv_enhanced = conv_enhanced; a.tokens6 = tokens6;
@@ -452,6 +452,66 @@ hipError_t launch_pilot_gather(const float *hzero_ls, float *pilots, int *counts
     hipLaunchKernelGGL(pilot_gather_kernel, dim3((batch + 3) / 4), dim3(256), 0, st,
                        reinterpret_cast<const float2 *>(hzero_ls), reinterpret_cast<float2 *>(pilots), counts, batch,
                        grid_elems, expected);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same stage (S3 + S4-concat + linear_1 + positions) for the general engine: ANY model_dim, patches of up to 32 elements.
+// A workgroup takes 8 token rows: their <= 38 input features go to LDS once, thread c' walks the output columns c = c', c' + 256, ..
+// with row c of W1 ([d][din], as PyTorch holds it) in registers across the 8 rows.  x[row][c] = b1[c] + pos[t][c] + sum_f W1[c][f] in[f],
+// summed in feature order.  Write-bound like embed_kernel; a few microseconds of a general-engine forward.
+// ---------------------------------------------------------------------------------------------
+constexpr int kEmbAnyRows = 8, kEmbAnyDin = kMaxPatchGeneral + 6;
+__global__ __launch_bounds__(256) void embed_any_kernel(const EmbedArgs a) {
+    __shared__ float in[kEmbAnyRows][kEmbAnyDin];
+    const int tid = threadIdx.x, tw = a.T / a.p1, p = a.p0 * a.p1;
+    const long rows = (long)a.planes * a.tokens, row0 = (long)blockIdx.x * kEmbAnyRows;
+    for (int i = tid; i < kEmbAnyRows * a.din; i += 256) {
+        const int r = i / a.din, f = i - r * a.din;
+        const long row = row0 + r;
+        float v = 0.f;
+        if (row < rows) {
+            const int n = (int)(row / a.tokens), t = (int)(row - (long)n * a.tokens);
+            if (f < p) {
+                const int tq = t / tw, tr = t - tq * tw;
+                v = a.conv_enhanced[((size_t)n * a.S + tq * a.p0 + f / a.p1) * a.T + tr * a.p1 + f % a.p1];
+            } else {
+                v = a.tokens6[((size_t)(n >> 1) * a.tokens + t) * 6 + (f - p)];
+            }
+        }
+        in[r][f] = v;
+    }
+    __syncthreads();
+    for (int c = tid; c < a.d; c += 256) {
+        float w[kEmbAnyDin];
+#pragma unroll
+        for (int f = 0; f < kEmbAnyDin; ++f) w[f] = f < a.din ? a.w1[(size_t)c * a.din + f] : 0.f;
+        const float b = a.b1[c];
+        for (int r = 0; r < kEmbAnyRows; ++r) {
+            const long row = row0 + r;
+            if (row >= rows) break;
+            const int t = (int)(row % a.tokens);
+            float acc = b + a.pos[(size_t)t * a.d + c];
+#pragma unroll
+            for (int f = 0; f < kEmbAnyDin; ++f) acc = fmaf(w[f], in[r][f], acc);
+            a.x[(size_t)row * a.d + c] = acc;
+        }
+    }
+}
+
+hipError_t launch_embed_any(const aft_config &c, const WeightsDev &w, const float *conv_enhanced, const float *tokens6,
+                            float *x, int batch, hipStream_t st) {
+    EmbedArgs a{};
+    a.conv_enhanced = conv_enhanced; a.tokens6 = tokens6;
+    a.w1 = w.lin1_w; a.b1 = w.lin1_b; a.pos = w.pos; a.x = x;
+    a.S = c.num_scs; a.T = c.num_symbols; a.p0 = c.patch_scs; a.p1 = c.patch_symbols;
+    a.tokens = (a.S / a.p0) * (a.T / a.p1);
+    a.d = c.model_dim;
+    a.din = a.p0 * a.p1 + (c.adaptive ? 6 : 0);
+    a.planes = 2 * batch;
+    if (a.p0 * a.p1 > kMaxPatchGeneral || (c.adaptive && tokens6 == nullptr)) return hipErrorInvalidValue;
+    const long rows = (long)a.planes * a.tokens;
+    hipLaunchKernelGGL(embed_any_kernel, dim3((unsigned)((rows + kEmbAnyRows - 1) / kEmbAnyRows)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -133,6 +133,108 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
         slices[(size_t)blockIdx.x * 3 * N + i] = part[0][i] + part[1][i] + part[2][i] + part[3][i];
 }
 
+// The same two kernels for ANY n <= 512 (the general engine, DESIGN.md 4.6: model dims that are not multiples of 32, and 288 .. 512):
+// column lane + 64 q exists when it is < n; everything else as above.
+constexpr int kLnAnyNpl = 8;
+__global__ __launch_bounds__(256) void add_ln_fwd_any_kernel(const float *__restrict__ res, const float *__restrict__ y,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float *__restrict__ s_out, float *__restrict__ stats,
+                                                             float *__restrict__ out, int rows, int n, float eps, uint32_t seed,
+                                                             uint32_t threshold, float keep_scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[kLnAnyNpl];
+    float sum = 0.f;
+    const uint32_t rw = dropmask_row_word(seed, (uint32_t)row);
+    const float inv_n = 1.f / (float)n;
+#pragma unroll
+    for (int q = 0; q < kLnAnyNpl; ++q) {
+        const int col = lane + 64 * q;
+        const bool ok = col < n;
+        float t = ok ? y[(size_t)row * n + col] : 0.f;
+        if (threshold) t *= tdrop(rw, dropmask_col_word(seed, (uint32_t)col), threshold, keep_scale);
+        v[q] = ok ? res[(size_t)row * n + col] + t : 0.f;
+        sum += v[q];
+    }
+    const float mean = wave_sum(sum) * inv_n;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < kLnAnyNpl; ++q) var += lane + 64 * q < n ? (v[q] - mean) * (v[q] - mean) : 0.f;
+    const float rstd = rsqrtf(wave_sum(var) * inv_n + eps);
+#pragma unroll
+    for (int q = 0; q < kLnAnyNpl; ++q) {
+        const int col = lane + 64 * q;
+        if (col >= n) continue;
+        s_out[(size_t)row * n + col] = v[q];
+        out[(size_t)row * n + col] = (v[q] - mean) * rstd * gamma[col] + beta[col];
+    }
+    if (lane == 0) {
+        stats[2 * (size_t)row] = mean;
+        stats[2 * (size_t)row + 1] = rstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_any_kernel(const float *__restrict__ dy, const float *__restrict__ s,
+                                                         const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                         float *__restrict__ ds, float *__restrict__ dbranch,
+                                                         float *__restrict__ slices, int rows, int n, int rows_per_block, uint32_t seed,
+                                                         uint32_t threshold, float keep_scale) {
+    extern __shared__ float part_any[];     // [4][3 n]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    const float inv_n = 1.f / (float)n;
+    float dg[kLnAnyNpl], db[kLnAnyNpl], dbr[kLnAnyNpl], gm[kLnAnyNpl];
+    uint32_t cw[kLnAnyNpl];
+#pragma unroll
+    for (int q = 0; q < kLnAnyNpl; ++q) {
+        dg[q] = 0.f;
+        db[q] = 0.f;
+        dbr[q] = 0.f;
+        gm[q] = lane + 64 * q < n ? gamma[lane + 64 * q] : 0.f;
+        cw[q] = dropmask_col_word(seed, (uint32_t)(lane + 64 * q));
+    }
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+        const uint32_t rw = dropmask_row_word(seed, (uint32_t)row);
+        float g[kLnAnyNpl], xh[kLnAnyNpl], a = 0.f, b = 0.f;
+#pragma unroll
+        for (int q = 0; q < kLnAnyNpl; ++q) {
+            const int col = lane + 64 * q;
+            const bool ok = col < n;
+            const float d = ok ? dy[(size_t)row * n + col] : 0.f;
+            xh[q] = ok ? (s[(size_t)row * n + col] - mean) * rstd : 0.f;
+            g[q] = d * gm[q];
+            a += g[q];
+            b += g[q] * xh[q];
+            dg[q] += d * xh[q];
+            db[q] += d;
+        }
+        a = wave_sum(a) * inv_n;
+        b = wave_sum(b) * inv_n;
+#pragma unroll
+        for (int q = 0; q < kLnAnyNpl; ++q) {
+            const int col = lane + 64 * q;
+            if (col >= n) continue;
+            const float v = rstd * (g[q] - a - xh[q] * b);
+            ds[(size_t)row * n + col] = v;
+            const float vb = threshold ? v * tdrop(rw, cw[q], threshold, keep_scale) : v;
+            dbranch[(size_t)row * n + col] = vb;
+            dbr[q] += vb;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kLnAnyNpl; ++q) {
+        const int col = lane + 64 * q;
+        if (col >= n) continue;
+        part_any[wave * 3 * n + col] = dg[q];
+        part_any[wave * 3 * n + n + col] = db[q];
+        part_any[wave * 3 * n + 2 * n + col] = dbr[q];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * n; i += 256)
+        slices[(size_t)blockIdx.x * 3 * n + i] = part_any[i] + part_any[3 * n + i] + part_any[6 * n + i] + part_any[9 * n + i];
+}
+
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
@@ -455,6 +557,8 @@ hipError_t launch_add_ln_fwd(const float *res, const float *y, const float *gamm
         hipLaunchKernelGGL((add_ln_fwd_kernel<3, true>), grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
     else if (n == 224)
         hipLaunchKernelGGL((add_ln_fwd_kernel<4, true>), grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, eps, seed, th, ks);
+    else if (n >= 1 && n <= 64 * kLnAnyNpl)
+        hipLaunchKernelGGL(add_ln_fwd_any_kernel, grid, block, 0, st, res, y, gamma, beta, s_out, stats, out, rows, n, eps, seed, th, ks);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -485,6 +589,9 @@ hipError_t launch_ln_bwd(const float *dy, const float *s, const float *stats, co
         hipLaunchKernelGGL((ln_bwd_kernel<3, true>), dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
     else if (n == 224)
         hipLaunchKernelGGL((ln_bwd_kernel<4, true>), dim3(nb), dim3(256), 0, st, dy, s, stats, gamma, ds, dbranch, slices, rows, rpb, seed, th, ks);
+    else if (n >= 1 && n <= 64 * kLnAnyNpl)
+        hipLaunchKernelGGL(ln_bwd_any_kernel, dim3(nb), dim3(256), sizeof(float) * 12 * n, st, dy, s, stats, gamma, ds, dbranch, slices, rows, n,
+                           rpb, seed, th, ks);
     else
         return hipErrorInvalidValue;
     // slices[b][0..n) = dgamma partials, [n..2n) = dbeta partials, [2n..3n) = branch bias gradient

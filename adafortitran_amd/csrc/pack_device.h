@@ -10,7 +10,7 @@ using bf16x8_pack = __attribute__((ext_vector_type(8))) __bf16;
 
 // v = index of the float4 inside the image [layer][in_proj 3dd | out_proj dd | lin1 2dd | lin2 2dd]; layers are taken from
 // w.layers[first_layer + i], the image starts at layer first_layer's block
-__device__ __forceinline__ void pack_weights_vec(const aft_weights &w, float *__restrict__ packed, int d, int first_layer,
+__device__ __forceinline__ void pack_weights_vec(const WeightsDev &w, float *__restrict__ packed, int d, int first_layer,
                                                  int num_layers, int split, size_t v) {
     const size_t per_layer = (size_t)8 * d * d;
     if (v * 4 >= per_layer * num_layers) return;

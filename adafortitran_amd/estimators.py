@@ -16,11 +16,13 @@ Execution paths of ``forward``:
     SURVEY.md 8f-1); only reshapes, concatenations and the loss are PyTorch ops.
   * ``device: cpu`` -> the same composite on ATen's CPU kernels (what the reference itself runs).
 
-Coverage is ONE predicate, asked once at construction (``aft_check_config``): a configuration the
-reference accepts but the gfx950 kernels do not cover (model_dim not a multiple of 32 up to 256, head dim
-not a multiple of 8 up to 64 or equal to 56, patch > 16 elements, a grid with no LDS band plan) is refused with a ``ValueError``
-when the model is built on a HIP device -- before any training -- instead of failing in the first ``eval()``
-forward.  ``AFT_ALLOW_COMPOSITE=1`` in the environment opts into running such a model entirely on the
+Coverage is ONE predicate, asked once at construction (``aft_check_config``).  Covered: any layer count, model_dim
+any multiple of 8 up to 512, any num_head that divides it with heads of up to 128 features, patches of up to 32
+elements -- the tuned fragment-packed engine where its shape conditions hold (model_dim a multiple of 32 up to 256,
+head dims 8 .. 64 in steps of 8 except 56, patches of up to 16 elements), the row-major general engine elsewhere
+(``hip_engine_name()`` says which).  A configuration the reference accepts beyond that (a larger model_dim or
+head, a grid with no LDS band plan) is refused with a ``ValueError`` when the model is built on a HIP device --
+before any training -- instead of failing in the first ``eval()`` forward.  ``AFT_ALLOW_COMPOSITE=1`` in the environment opts into running such a model entirely on the
 PyTorch-ROCm composite (logged).  The TRAINING kernels cover what inference covers; where a block of an accepted
 model is nevertheless differentiated by PyTorch-ROCm autograd (switched off by hand, a conv grid without a band plan), the
 constructor logs a warning naming the block and the reason, and ``training_backends()`` returns the same.
@@ -210,6 +212,16 @@ class BaseFortiTranEstimator(nn.Module):
             return
         raise ValueError(f"configuration not covered by the gfx950 kernels: {reason}. Build the model with "
                          "device='cpu', or set AFT_ALLOW_COMPOSITE=1 to run the PyTorch-ROCm composite instead.")
+
+    def hip_engine_name(self) -> Optional[str]:
+        """``"packed"`` / ``"general"``: the launch sequence ``aft_forward_f32`` runs for this configuration (include/adafortitran_amd.h
+        ``aft_engine_of``: a property of the configuration alone); None off the HIP device or when the configuration is not covered."""
+        if not self._hip_covered:
+            return None
+        from . import _lib
+        import ctypes
+        cfg = _abi.config_from_pydantic(self.system_config, self.model_config, self.use_channel_adaptation)
+        return {_abi.AFT_ENGINE_PACKED: "packed", _abi.AFT_ENGINE_GENERAL: "general"}.get(_lib.load().aft_engine_of(ctypes.byref(cfg)))
 
     def training_backends(self) -> dict:
         """{block: None | reason}: None = ``loss.backward()`` through that block runs this library's hand-written kernels on a HIP

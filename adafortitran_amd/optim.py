@@ -102,7 +102,7 @@ class FlatParameters:
         base = self.grad.data_ptr()     # (one pointer compare per parameter: this runs every step, on the host's critical path at small batches)
         for p, off in zip(self.params, self.offsets):
             g = p.grad
-            if g is None or g.data_ptr() != base + 4 * off:
+            if g is None or g.data_ptr() != base + self.grad.element_size() * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)
 
 

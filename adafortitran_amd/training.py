@@ -303,7 +303,7 @@ def encoder_stack_train(x: torch.Tensor, layers, cfg: _abi.AftConfig, dropout_p:
     """Run ``layers`` (an iterable of nn.TransformerEncoderLayer) in training mode on the HIP path."""
     layers = list(layers)
     seeds = torch.randint(0, 2 ** 62, (len(layers),), dtype=torch.int64).tolist()
-    if os.environ.get("AFT_TRAIN_NO_QKV_CHAIN") or not layers:   # A/B switch: every layer runs its own in-projection GEMM
+    if _lib.get_switch("AFT_TRAIN_NO_QKV_CHAIN") or not layers:   # A/B switch: every layer runs its own in-projection GEMM
         for layer, seed in zip(layers, seeds):
             x = HipEncoderLayerFunction.apply(x, cfg, dropout_p, seed, *layer_params(layer))
         return x

@@ -378,15 +378,13 @@ def prologue_product_share_ms(wl, pro_in, reps=30):
     is what the product costs the forward and is charged to the upsampler stage."""
     import numpy as np
     import torch
+    from adafortitran_amd import _lib
     from adafortitran_amd.hip_ops import profile_kernel
     res = {"with": [], "without": []}
     try:
         for _ in range(5):
             for key in ("with", "without"):
-                if key == "without":
-                    os.environ["AFT_PROLOGUE_NO_UP"] = "1"
-                else:
-                    os.environ.pop("AFT_PROLOGUE_NO_UP", None)
+                _lib.set_switch("AFT_PROLOGUE_NO_UP", "1" if key == "without" else None)
                 profile_kernel(wl.eng, "prologue", wl.B, 3, pro_in)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -395,7 +393,7 @@ def prologue_product_share_ms(wl, pro_in, reps=30):
                 e1.synchronize()
                 res[key].append(e0.elapsed_time(e1) / reps)
     finally:
-        os.environ.pop("AFT_PROLOGUE_NO_UP", None)
+        _lib.set_switch("AFT_PROLOGUE_NO_UP", None)
     w, wo = float(np.median(res["with"])), float(np.median(res["without"]))
     return max(w - wo, 0.0), w, wo
 
@@ -515,18 +513,18 @@ def config_record(c, device, steps, warmup, oracle_sample, kernel_reps):
 
 class unsplit:
     """AFT_LANES=1 for the block: the library then runs every forward as ONE launch sequence (include/adafortitran_amd.h "Lanes") --
-    what the per-kernel accounting (aft_profile_kernel_f32 replays a kernel class on the UNSPLIT workspace layout) is defined on.  The
-    switch is read per call.  At the headline batch the library does not split anyway (2.9 rounds of the persistent grids)."""
+    what the per-kernel accounting (aft_profile_kernel_f32 replays a kernel class on the UNSPLIT workspace layout) is defined on.  A
+    library switch (aft_set_switch: the library never reads the environment on a call path).  At the headline batch the library does
+    not split anyway (2.9 rounds of the persistent grids)."""
 
     def __enter__(self):
-        self.old = os.environ.get("AFT_LANES")
-        os.environ["AFT_LANES"] = "1"
+        from adafortitran_amd import _lib
+        self.old = _lib.get_switch("AFT_LANES")
+        _lib.set_switch("AFT_LANES", 1)
 
     def __exit__(self, *exc):
-        if self.old is None:
-            os.environ.pop("AFT_LANES", None)
-        else:
-            os.environ["AFT_LANES"] = self.old
+        from adafortitran_amd import _lib
+        _lib.set_switch("AFT_LANES", self.old)
 
 
 def lanes_of(eng, batch):
@@ -678,14 +676,27 @@ def cpu_baseline(wl):
     # candidate and the threads roamed over both sockets).  Now: the process is pinned to ONE socket's physical cores (one logical
     # CPU per core) for the baseline, the candidates are thread counts up to that many cores, each candidate is the MEDIAN of three
     # forwards behind an untimed one, and the table goes into the record.
+    # sched_setaffinity(0, ..) moves the CALLING thread only, and torch's intra-op pool exists by now: every thread of the
+    # process (/proc/self/task) is pinned, threads created later inherit the mask, and the mask actually in force goes into the record.
     cores = one_socket_cores()
-    old_affinity = None
+    old_affinity, pinned_threads = None, 0
+
+    def pin_all(cpus):
+        n = 0
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+                n += 1
+            except (OSError, ValueError):
+                pass
+        return n
+
     try:
         if cores and hasattr(os, "sched_setaffinity"):
             old_affinity = os.sched_getaffinity(0)
             usable = sorted(set(cores) & old_affinity)
             if usable:
-                os.sched_setaffinity(0, usable)
+                pinned_threads = pin_all(usable)
                 cores = usable
     except OSError:
         old_affinity = None
@@ -713,9 +724,10 @@ def cpu_baseline(wl):
             call()
             times.append(time.perf_counter() - t0)
         torch.set_num_threads(default_threads)
+    affinity_used = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     if old_affinity is not None:
         try:
-            os.sched_setaffinity(0, old_affinity)
+            pin_all(old_affinity)
         except OSError:
             pass
     med = float(np.median(times))
@@ -723,7 +735,7 @@ def cpu_baseline(wl):
            "sample": f"{len(times)} forwards of B={wl.B} (same workload), median {med * 1e3:.0f} ms; threads chosen by a sweep (median of 3 "
                      f"forwards each) on one socket's {ncore} physical cores; torch {torch.__version__} CPU composite",
            "thread_sweep_fps": {str(k): round(wl.B / v, 1) for k, v in sorted(sweep.items())},
-           "spread": round((max(times) - min(times)) / med, 3),
+           "spread": round((max(times) - min(times)) / med, 3), "affinity_cpus": affinity_used, "threads_pinned": pinned_threads,
            "cpu_model": info["cpu_model"], "sockets": info["sockets"], "physical_cores": info["physical_cores"]}
     try:    # the C oracle (oracle/aft_oracle.c) on a smaller bounded sample, for the record
         from oracle import oracle

@@ -36,8 +36,7 @@
 extern "C" {
 #endif
 
-#define AFT_ABI_VERSION 6   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
-#define AFT_MAX_LAYERS 32
+#define AFT_ABI_VERSION 7   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
 
 #define AFT_OK 0
 #define AFT_ERR_ARG 1   /* NULL pointer, bad batch, workspace too small ...          */
@@ -71,8 +70,11 @@ typedef struct aft_config {
     int32_t num_scs, num_symbols;     /* OFDM grid S x T (120 x 14)                  */
     int32_t pilot_scs, pilot_symbols; /* pilot grid (12 x 2)                         */
     int32_t patch_scs, patch_symbols; /* patch (3 x 2): tokens = (S/p0)*(T/p1)       */
-    int32_t num_layers, model_dim, num_head; /* covered (aft_check_config says why not otherwise): model_dim a multiple of 32 up to 256,
-                                       * model_dim / num_head a multiple of 8 up to 64 except 56, patches of <= 16 elements */
+    int32_t num_layers, model_dim, num_head; /* covered (aft_check_config says why not otherwise): any layer count, model_dim a multiple
+                                       * of 8 up to 512, model_dim / num_head up to 128, patches of <= 32 elements.  Two engines behind one
+                                       * call (aft_engine_of): the fragment-packed launch sequence -- model_dim a multiple of 32 up to 256,
+                                       * head dim a multiple of 8 up to 64 except 56, patches of <= 16 elements -- and the row-major
+                                       * general sequence for everything else (slower) */
     int32_t activation;               /* AFT_ACT_*                                   */
     int32_t adaptive;                 /* 1 = AdaFortiTran (adapter tokens), 0 = FortiTran */
     int32_t hidden[3];                /* channel_adaptivity_hidden_sizes (adaptive only) */
@@ -101,7 +103,8 @@ typedef struct aft_weights {
     const float *lin1_w, *lin1_b;    /* transformer_encoder.linear_1 [d, p(+6)], [d]          */
     const float *pos;                /* positional table rows [>=tokens, d] (learnable or sinusoid) */
     const float *lin2_w, *lin2_b;    /* transformer_encoder.linear_2 [p, d], [p]              */
-    aft_layer_weights layers[AFT_MAX_LAYERS];
+    const aft_layer_weights *layers; /* HOST array of cfg->num_layers entries (any layer count: nn.TransformerEncoder stacks
+                                        whatever num_layers says, encoders.py:52-55); read during the call only            */
 } aft_weights;
 
 int aft_version(void);
@@ -111,6 +114,22 @@ const char *aft_last_error(void);
  * aft_last_error().  The estimator calls it at construction (the reference validates its config in
  * __init__, fortitran.py:52-81), so an uncovered shape is refused before any training starts. */
 int aft_check_config(const aft_config *cfg);
+
+/* Which launch sequence aft_forward_f32 runs for `cfg` (a property of the configuration alone -- never of the batch, so a frame's
+ * output bits do not depend on the batch it travels in): AFT_ENGINE_PACKED = the tuned fragment-packed kernels (chain + attention,
+ * DESIGN.md 4.1 / 4.2), AFT_ENGINE_GENERAL = the row-major sequence that covers every shape the reference builds within the bounds
+ * above (GEMM / attention / LayerNorm kernels of the training path, dropout off); < 0 = not covered (aft_check_config says why). */
+#define AFT_ENGINE_PACKED 0
+#define AFT_ENGINE_GENERAL 1
+int aft_engine_of(const aft_config *cfg);
+
+/* Measurement / A-B switches (no reference counterpart).  The library reads every environment variable that starts with "AFT_" ONCE,
+ * when it is loaded; afterwards a switch changes only through aft_set_switch (value NULL = unset) -- no getenv() on any call path, so
+ * forwards on several host threads never race a setenv() elsewhere in the process.  aft_get_switch copies the current value into
+ * buf (at most n bytes including the terminator) and returns 1, or returns 0 when the switch is unset.  The switches in use are
+ * listed in DESIGN.md section 5; none of them changes results beyond summation order, and the product never sets one. */
+int aft_set_switch(const char *name, const char *value);
+int aft_get_switch(const char *name, char *buf, size_t n);
 
 /* Largest `batch` one aft_forward_f32 call accepts for `cfg` (0 on a bad config): the kernels use 32-bit byte offsets
  * into each workspace region, so no region (q / k / v^T: 2*batch*tokpad*model_dim floats) may reach 2 GiB.  The reference
@@ -128,9 +147,12 @@ size_t aft_workspace_bytes(const aft_config *cfg, int batch);
  * other share's next launch.  To the caller the call is still asynchronous on ONE stream (everything the call enqueues is ordered
  * after the stream's earlier work and before its later work; capturable in a hipGraph: the side stream joins the capture).  Frames
  * are independent, so the output bits are those of the unsplit forward.  The side stream and its two events are created on the
- * first such call per (device, caller stream) and kept (for at most 16 caller streams per process; calls on further streams
- * run unsplit); AFT_LANES=1 in the environment (read per call) switches the split off.
- * aft_workspace_lanes reports the split the next forward of `batch` frames will use: lanes (1 .. AFT_MAX_LANES), and per lane its
+ * first such call per (device, caller stream) and kept for the 16 most recently used caller streams of the process (the least
+ * recently used idle entry is destroyed when a seventeenth stream arrives).  Should the side stream be unavailable (creation failed,
+ * or all 16 entries are in use by calls in flight on other host threads) the shares run one after the other on the caller's stream
+ * in the SAME workspace layout -- slower, same bits, and aft_workspace_lanes stays true.  The switch AFT_LANES=1 (aft_set_switch)
+ * turns the split off.
+ * aft_workspace_lanes reports the split a forward of `batch` frames uses: lanes (1 .. AFT_MAX_LANES), and per lane its
  * frame count and the byte offset of its slice of `workspace` (a lane's slice is laid out as the workspace of a forward of that many
  * frames).  `frames` and `offset_bytes` are arrays of AFT_MAX_LANES entries. */
 #define AFT_MAX_LANES 4
@@ -142,8 +164,8 @@ int aft_workspace_lanes(const aft_config *cfg, int batch, int *lanes, int *frame
  * (aft_workspace_lanes; a forward that is not split has one lane at offset 0).  Regions stay valid until the next call on that workspace.
  *   AFT_REGION_CONV_ENHANCED  f32 [2B,S,T]            output of S1+S2 (fortitran.py:203-209), kept for the S7 residual
  *   AFT_REGION_TOKENS6        f32 [B,tokens,6]        ChannelAdapter output (channel_adaptivity.py:59-63); adaptive configs
- *   AFT_REGION_ENC_OUT        f32 [2B*tokens,stride]  linear_2's output (encoders.py:70), `stride` = 8 for patches of up to
- *                                                     8 elements, else 16; columns [0, patch elements) are valid
+ *   AFT_REGION_ENC_OUT        f32 [2B*tokens,stride]  linear_2's output (encoders.py:70), `stride` = the patch element count rounded
+ *                                                     up to 8 / 16 / 24 / 32; columns [0, patch elements) are valid
  * Returns AFT_OK, or AFT_ERR_ARG / AFT_ERR_SHAPE (bad region, batch or config). */
 #define AFT_REGION_CONV_ENHANCED 0
 #define AFT_REGION_TOKENS6 1
@@ -322,11 +344,13 @@ int aft_stage_adapter_f32(const aft_config *cfg, const aft_weights *w, const flo
 int aft_stage_embed_f32(const aft_config *cfg, const aft_weights *w, const float *conv_enhanced,
                         const float *tokens6, float *x, int batch, void *stream);
 /* One nn.TransformerEncoderLayer in eval mode, in place on x [2B*tokens, d]
- * (encoders.py:69).  `scratch` needs aft_workspace_bytes(cfg,batch) bytes. */
+ * (encoders.py:69).  `scratch` needs aft_workspace_bytes(cfg,batch) bytes.  Runs the engine aft_engine_of(cfg) names. */
 int aft_stage_encoder_layer_f32(const aft_config *cfg, const aft_weights *w, int layer, float *x,
                                 void *scratch, size_t scratch_bytes, int batch, void *stream);
 /* linear_2 + S6 + S7 + S8 + complex recombination (encoders.py:70, fortitran.py:225-231,180):
- * x [2B*tokens, d], conv_enhanced [2B,S,T] -> out complex64 [B,S,T]. */
+ * x [2B*tokens, d], conv_enhanced [2B,S,T] -> out complex64 [B,S,T].  This call owns no scratch, so linear_2's weights must fit the
+ * conv kernel's LDS beside the plane (AFT_ERR_SHAPE otherwise, e.g. 32-element patches at model_dim 512 on the default grid: only
+ * aft_forward_f32 serves those). */
 int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float *x,
                        const float *conv_enhanced, float *out, int batch, void *stream);
 

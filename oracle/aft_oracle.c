@@ -212,7 +212,7 @@ static int check_cfg(const aft_config *c) {
     if (c->num_scs <= 0 || c->num_symbols <= 0 || c->patch_scs <= 0 || c->patch_symbols <= 0 ||
         c->num_scs % c->patch_scs || c->num_symbols % c->patch_symbols)
         return AFT_ERR_SHAPE;
-    if (c->num_layers <= 0 || c->num_layers > AFT_MAX_LAYERS || c->model_dim <= 0 ||
+    if (c->num_layers <= 0 || c->model_dim <= 0 ||
         c->num_head <= 0 || c->model_dim % c->num_head)
         return AFT_ERR_SHAPE;
     if (c->adaptive && (c->hidden[2] != 2 * tokens_of(c) || c->hidden[0] <= 0 || c->hidden[1] <= 0))

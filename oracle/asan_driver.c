@@ -6,7 +6,8 @@
  *   asan_driver <case.bin> <out.bin>
  *
  * case.bin : aft_config | int32 batch | int32 adaptive-meta flag | uint64 n_floats | float blob[n_floats]
- *            | aft_weights whose "pointers" are (offset into blob + 1), 0 = NULL
+ *            | aft_weights whose "pointers" are (offset into blob + 1), 0 = NULL (its `layers` slot is 0)
+ *            | aft_layer_weights[num_layers], same encoding (ABI 7: the layer table is a host array behind a pointer)
  *            | uint64 offsets(+1) of pilots, snr, ds, dop inside the blob
  * out.bin  : complex64 [batch, S, T] as floats
  */
@@ -42,16 +43,27 @@ int main(int argc, char **argv) {
     need(blob != NULL && fread(blob, sizeof(float), n, f) == n, "short blob");
     aft_weights w;
     need(fread(&w, sizeof(w), 1, f) == 1, "short weight table");
+    need(cfg.num_layers > 0 && cfg.num_layers < (1 << 20), "bad layer count");
+    aft_layer_weights *layers = (aft_layer_weights *)malloc((size_t)cfg.num_layers * sizeof(aft_layer_weights));   /* exact size */
+    need(layers != NULL && fread(layers, sizeof(aft_layer_weights), (size_t)cfg.num_layers, f) == (size_t)cfg.num_layers, "short layer table");
     uint64_t io[4];
     need(fread(io, 8, 4, f) == 4, "short io table");
     fclose(f);
     /* offsets (+1) -> pointers */
+    w.layers = NULL;
     uintptr_t *slots = (uintptr_t *)&w;
     for (size_t i = 0; i < sizeof(w) / sizeof(uintptr_t); ++i)
         if (slots[i]) {
             need(slots[i] - 1 < n, "weight offset out of range");
             slots[i] = (uintptr_t)(blob + (slots[i] - 1));
         }
+    slots = (uintptr_t *)layers;
+    for (size_t i = 0; i < (size_t)cfg.num_layers * sizeof(aft_layer_weights) / sizeof(uintptr_t); ++i)
+        if (slots[i]) {
+            need(slots[i] - 1 < n, "layer weight offset out of range");
+            slots[i] = (uintptr_t)(blob + (slots[i] - 1));
+        }
+    w.layers = layers;
     const float *in[4];
     for (int i = 0; i < 4; ++i) in[i] = io[i] ? blob + (io[i] - 1) : NULL;
     const size_t out_floats = (size_t)batch * cfg.num_scs * cfg.num_symbols * 2;
@@ -66,6 +78,7 @@ int main(int argc, char **argv) {
     need(f != NULL && fwrite(out, sizeof(float), out_floats, f) == out_floats, "cannot write output");
     fclose(f);
     free(out);
+    free(layers);
     free(blob);
     return 0;
 }

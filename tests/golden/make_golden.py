@@ -357,6 +357,22 @@ SETS = {
     "S28_ada_tokens28": (dict(ofdm=[12, 14], pilot=[4, 2], patch=[3, 2], num_layers=2, model_dim=64, num_head=2,
                               adaptive_hidden=[7, 42, 56], max_seq_len=32, seed=281, attn_gain=0.5, head_gain=2.0), 5,
                          ["conv_enhanced", "enc_out"]),
+    # round 6: what the reference builds and the packed engine does not take -- the general engine's shapes.
+    # model_dim 512 (8 heads of 64), heads of 128 / 56 features, a model_dim off the multiples of 32 with heads of 25 features,
+    # a 24-element patch, and 40 layers (more than one window of the by-value layer table; packed engine)
+    "W512_ada_d512_heads8": (dict(DEFAULT, num_layers=2, model_dim=512, num_head=8, adaptive_hidden=[7, 42, 560], seed=5121,
+                                  attn_gain=0.25, head_gain=2.0), 3, ["enc_out"]),
+    "H128_forti_d256_heads2": (dict(DEFAULT, num_layers=2, model_dim=256, num_head=2, seed=1281, attn_gain=24.0, ffn_gain=2.0,
+                                    head_gain=4.0), 3, ["enc_out"]),
+    "H56_ada_d224_heads4": (dict(DEFAULT, num_layers=2, model_dim=224, num_head=4, adaptive_hidden=[7, 42, 560], seed=561,
+                                 attn_gain=0.25, head_gain=2.0), 3, ["enc_out"]),
+    "D200_forti_d200_heads8": (dict(DEFAULT, num_layers=2, model_dim=200, num_head=8, seed=2001, attn_gain=16.0, head_gain=2.0), 3,
+                               ["enc_out"]),
+    "P24_ada_patch12x2": (dict(ofdm=[96, 14], pilot=[12, 2], patch=[12, 2], num_layers=2, model_dim=128, num_head=4,
+                               adaptive_hidden=[7, 42, 112], max_seq_len=64, seed=241224, attn_gain=0.5, head_gain=2.0), 4,
+                          ["conv_enhanced", "enc_out"]),
+    "L40_forti_layers40": (dict(ofdm=[12, 14], pilot=[4, 2], patch=[3, 2], num_layers=40, model_dim=32, num_head=1,
+                                max_seq_len=32, seed=4001, attn_gain=4.0), 3, ["enc_out"]),
     "C5_ada_large": (dict(ofdm=[240, 28], pilot=[24, 4], patch=[3, 2], num_layers=12, model_dim=256, num_head=8,
                           adaptive_hidden=[7, 42, 2240], max_seq_len=1120, seed=55, attn_gain=0.5, head_gain=2.0),
                      1, []),
@@ -387,6 +403,13 @@ if __name__ == "__main__":
     S28 = dict(DEFAULT, ofdm=(12, 14), pilot=(4, 2), num_layers=2, dropout=0.0, seed=782, attn_gain=8.0)
     H64 = dict(DEFAULT, num_layers=2, num_head=2, dropout=0.0, seed=783, attn_gain=8.0)      # head dim 64 (`num_head: 2`)
     H24 = dict(DEFAULT, num_layers=2, model_dim=96, num_head=4, dropout=0.0, seed=784, attn_gain=8.0)   # head dim 24: heads straddle blocks
+    # round 6: the general engine's training shapes -- heads of 128 features (four 32-feature blocks), model_dim 512
+    H128 = dict(DEFAULT, num_layers=2, model_dim=256, num_head=2, dropout=0.0, seed=785, attn_gain=8.0)
+    D512 = dict(DEFAULT, num_layers=2, model_dim=512, num_head=8, dropout=0.0, seed=786, attn_gain=8.0)
+    if not only or "G_grad_forti_h128" in only:
+        run_grad("G_grad_forti_h128", H128, 3)
+    if not only or "G_grad_forti_d512" in only:
+        run_grad("G_grad_forti_d512", D512, 2)
     if not only or "G_grad_forti_h24" in only:
         run_grad("G_grad_forti_h24", H24, 3)
     if not only or "G_grad_forti_h64" in only:
@@ -401,7 +424,8 @@ if __name__ == "__main__":
               "G_grad64_forti_full": ("G_grad_forti_full", dict(DEFAULT, dropout=0.0, seed=779), 128),
               "G_grad64_ada_full": ("G_grad_ada_full", dict(DEFAULT, adaptive_hidden=[7, 42, 560], dropout=0.0, seed=780), 128),
               "G_grad64_forti_h16": ("G_grad_forti_h16", H16, 3), "G_grad64_forti_s28": ("G_grad_forti_s28", S28, 5),
-              "G_grad64_forti_h64": ("G_grad_forti_h64", H64, 3), "G_grad64_forti_h24": ("G_grad_forti_h24", H24, 3)}
+              "G_grad64_forti_h64": ("G_grad_forti_h64", H64, 3), "G_grad64_forti_h24": ("G_grad_forti_h24", H24, 3),
+              "G_grad64_forti_h128": ("G_grad_forti_h128", H128, 3), "G_grad64_forti_d512": ("G_grad_forti_d512", D512, 2)}
     for nm, (_f32, spec, batch) in GRAD64.items():
         if not only or nm in only:
             run_grad64(nm, spec, batch)

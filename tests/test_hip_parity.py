@@ -40,7 +40,11 @@ def test_extension_is_loaded_in_tree():
 
 
 OTHER_SHAPE_SETS = ["H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28",   # head dim 16 / 64; 28 tokens (one masked key tile)
-                    "H24_ada_d96_heads4", "H48_forti_d192_heads4"]                # head dims 24 / 48: heads that start anywhere in a 32-feature block
+                    "H24_ada_d96_heads4", "H48_forti_d192_heads4",                # head dims 24 / 48: heads that start anywhere in a 32-feature block
+                    # round 6, the general engine: model_dim 512, heads of 128 / 56 / 25 features, a 24-element patch;
+                    # and 40 layers on the packed engine (more than one window of the layer table the kernels take by value)
+                    "W512_ada_d512_heads8", "H128_forti_d256_heads2", "H56_ada_d224_heads4", "D200_forti_d200_heads8", "P24_ada_patch12x2",
+                    "L40_forti_layers40"]
 
 
 @pytest.mark.parametrize("name", DEFAULT_SETS + ["C5_ada_large"] + OTHER_SHAPE_SETS)
@@ -165,7 +169,7 @@ def _poison_allocator(value):
 
 
 @pytest.mark.parametrize("batch", [3, 40, 64, 130, 170])
-def test_conv_stream_column_ranges_reproduce_whole_planes(monkeypatch, batch):
+def test_conv_stream_column_ranges_reproduce_whole_planes(switches, batch):
     """Small batches split every plane of the default grid into 2 or 4 column ranges (k_conv_stream.hip, NSPLIT), and the planes
     beyond a whole number of one-plane-per-CU rounds (130 frames = 260 planes: 4; 170 frames: 84) run as a second launch of ranges:
     the ranges recompute what they need of their neighbours' columns and every output element goes through the same instruction
@@ -179,9 +183,9 @@ def test_conv_stream_column_ranges_reproduce_whole_planes(monkeypatch, batch):
     pil, meta = _t(inp["pilots"]), [_t(inp[k]) for k in ("snr", "ds", "dop")]
     outs = {}
     for ns in ("1", "2", "4"):
-        monkeypatch.setenv("AFT_CONV_NSPLIT", ns)
+        switches.set("AFT_CONV_NSPLIT", ns)
         outs[ns] = (eng.forward(pil, *meta).clone(), eng.forward_region("conv_enhanced", batch))
-    monkeypatch.delenv("AFT_CONV_NSPLIT")
+    switches.unset("AFT_CONV_NSPLIT")
     auto = eng.forward(pil, *meta).clone()
     for ns in ("2", "4"):
         assert torch.equal(outs[ns][1], outs["1"][1]), f"conv_enhanced differs at NSPLIT={ns}"
@@ -272,7 +276,7 @@ def test_other_grid_geometries_match_oracle(oracle_lib, ofdm, pilot, patch, adap
 
 @pytest.mark.parametrize("ofdm,pilot,patch,adaptive,batch", [((240, 28), (24, 4), (3, 2), True, 3), ((180, 20), (12, 4), (3, 2), False, 1),
                                                               ((96, 40), (8, 5), (3, 2), True, 2), ((100, 36), (10, 4), (2, 2), False, 5)])
-def test_tall_planes_run_the_row_streaming_conv_kernel(oracle_lib, monkeypatch, ofdm, pilot, patch, adaptive, batch):
+def test_tall_planes_run_the_row_streaming_conv_kernel(oracle_lib, switches, ofdm, pilot, patch, adaptive, batch):
     """Planes that need several bands in the banded conv kernel (17 channel planes > 160 KB of LDS) run k_conv_rows.hip in the whole
     forward: all rows per workgroup, four-column rings, column ranges with recomputed halo columns (2 or 4 ranges at these batches;
     8 / 6 / 4 row tiles, the last tile of the 100-row grid partly outside the plane).  Against the oracle, and against the banded
@@ -292,15 +296,15 @@ def test_tall_planes_run_the_row_streaming_conv_kernel(oracle_lib, monkeypatch, 
     assert np.abs(out.cpu().numpy() - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
     # the head stage of the kernel the forward launched (conv_rows16_kernel), straight from the workspace
     assert max_rel(eng.forward_region("conv_enhanced", batch).cpu().numpy(), dump["conv_enhanced"]) <= TOL_HIP_OUT
-    monkeypatch.setenv("AFT_CONV_MFMA32", "1")                             # round 4's 32x32x2 row-streaming kernel: rounding-level agreement
+    switches.set("AFT_CONV_MFMA32", "1")                             # round 4's 32x32x2 row-streaming kernel: rounding-level agreement
     mfma32 = eng.forward(pil, *meta).clone()
-    monkeypatch.delenv("AFT_CONV_MFMA32")
+    switches.unset("AFT_CONV_MFMA32")
     assert float((mfma32 - out).abs().max()) <= 2e-6 * float(out.abs().max())
     eng.workspace(batch).view(torch.float32).fill_(float("nan"))           # stale workspace: same bits
     assert torch.equal(torch.view_as_real(eng.forward(pil, *meta)), torch.view_as_real(out))
-    monkeypatch.setenv("AFT_CONV_BANDED", "1")
+    switches.set("AFT_CONV_BANDED", "1")
     banded = eng.forward(pil, *meta).clone()
-    monkeypatch.delenv("AFT_CONV_BANDED")
+    switches.unset("AFT_CONV_BANDED")
     assert float((banded - out).abs().max()) <= 2e-6 * float(out.abs().max())
 
 
@@ -482,18 +486,19 @@ def test_module_engine_cache_and_invalidation():
         assert np.allclose((out3 - out0).cpu().numpy(), 0.5 + 0.5j, atol=1e-6)
 
 
-def test_uncovered_configuration_is_refused_at_construction(monkeypatch):
+def test_uncovered_configuration_is_refused_at_construction(switches):
     """One coverage predicate, asked at construction on the HIP device: a shape the reference accepts but
     the kernels do not cover raises a ValueError before any training, unless the caller opts
     into the PyTorch-ROCm composite."""
-    # model_dim 80 (5 heads of 16): accepted by the reference's schema, not by the kernels (multiples of 32 up to 256)
+    # model_dim 100 (5 heads of 20): accepted by the reference's schema (> 0), not by the kernels (multiples of 8 up to 512; round 5's
+    # example, model_dim 80, runs the general engine since round 6)
     sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
-    kw = dict(model_type="fortitran", patch_size=(3, 2), num_layers=2, model_dim=80, num_head=5)
+    kw = dict(model_type="fortitran", patch_size=(3, 2), num_layers=2, model_dim=100, num_head=5)
     assert A.FortiTranEstimator(sc, A.ModelConfig(device="cpu", **kw)) is not None      # CPU: the reference's own path
-    monkeypatch.delenv("AFT_ALLOW_COMPOSITE", raising=False)
+    switches.unset("AFT_ALLOW_COMPOSITE")
     with pytest.raises(ValueError, match="not covered by the gfx950 kernels"):
         A.FortiTranEstimator(sc, A.ModelConfig(device="cuda", **kw))
-    monkeypatch.setenv("AFT_ALLOW_COMPOSITE", "1")
+    switches.set("AFT_ALLOW_COMPOSITE", "1")
     model = A.FortiTranEstimator(sc, A.ModelConfig(device="cuda", **kw)).eval()
     pil = torch.from_numpy(synth.make_inputs(2, seed=3)["pilots"])
     with torch.no_grad():
@@ -581,7 +586,7 @@ def test_stream_and_graph_semantics():
 
 
 @pytest.mark.parametrize("batch", [2, 5, 33, 64, 130])
-def test_lanes_reproduce_the_unsplit_forward(batch, monkeypatch):
+def test_lanes_reproduce_the_unsplit_forward(batch, switches):
     """include/adafortitran_amd.h "Lanes": a forward of fewer than ~2.5 rounds of the persistent grids runs as two complete forwards
     over contiguous shares of the batch, share 1 on a library-owned side stream forked from / joined into the caller's.  Same bits
     as the unsplit forward (AFT_LANES=1) for every split the switch allows, the intermediates the forward leaves behind included;
@@ -591,14 +596,14 @@ def test_lanes_reproduce_the_unsplit_forward(batch, monkeypatch):
     eng = _engine(g)
     inp = synth.make_inputs(batch, seed=77)
     pil, meta = _t(inp["pilots"]), [_t(inp[k]) for k in ("snr", "ds", "dop")]
-    monkeypatch.setenv("AFT_LANES", "1")
+    switches.set("AFT_LANES", "1")
     ref = eng.forward(pil, *meta).clone()
     regions = {n: eng.forward_region(n, batch) for n in ("conv_enhanced", "tokens6", "enc_out")}
     for want in (None, "2", "3", "4"):
         if want is None:
-            monkeypatch.delenv("AFT_LANES")
+            switches.unset("AFT_LANES")
         else:
-            monkeypatch.setenv("AFT_LANES", want)
+            switches.set("AFT_LANES", want)
         _poison_allocator(1e30)
         for _ in range(3):                                        # back to back: the next call's fork waits for this call's join
             out = eng.forward(pil, *meta)
@@ -606,7 +611,7 @@ def test_lanes_reproduce_the_unsplit_forward(batch, monkeypatch):
         for n, r in regions.items():
             assert torch.equal(eng.forward_region(n, batch), r), (want, n)
     # inside a hipGraph capture the side stream joins the capture (fork / join are event nodes of the graph)
-    monkeypatch.setenv("AFT_LANES", "2")
+    switches.set("AFT_LANES", "2")
     static_out = torch.empty_like(ref)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
@@ -616,7 +621,7 @@ def test_lanes_reproduce_the_unsplit_forward(batch, monkeypatch):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(torch.view_as_real(static_out), torch.view_as_real(ref))
-    monkeypatch.delenv("AFT_LANES", raising=False)
+    switches.unset("AFT_LANES")
     streams = [torch.cuda.Stream() for _ in range(2)]
     outs = []
     for rep in range(4):
@@ -628,7 +633,7 @@ def test_lanes_reproduce_the_unsplit_forward(batch, monkeypatch):
     assert all(torch.equal(torch.view_as_real(o), torch.view_as_real(ref)) for o in outs)
 
 
-def test_lanes_under_host_threads_and_many_caller_streams(monkeypatch):
+def test_lanes_under_host_threads_and_many_caller_streams(switches):
     """The library keeps one side stream + events per (device, caller stream), behind a mutex, for at most 16 caller streams: four
     host threads forwarding at once on their own streams, then 24 caller streams in turn (the later ones run unsplit) -- the bits of
     the unsplit forward every time."""
@@ -636,9 +641,9 @@ def test_lanes_under_host_threads_and_many_caller_streams(monkeypatch):
     g = Golden("A_ada")
     inp = synth.make_inputs(48, seed=78)
     pil, meta = _t(inp["pilots"]), [_t(inp[k]) for k in ("snr", "ds", "dop")]
-    monkeypatch.setenv("AFT_LANES", "1")
+    switches.set("AFT_LANES", "1")
     ref = _engine(g).forward(pil, *meta).clone()
-    monkeypatch.delenv("AFT_LANES")
+    switches.unset("AFT_LANES")
     torch.cuda.synchronize()
     bad = []
 
@@ -715,6 +720,111 @@ def test_linear_and_mse_kernels(oracle_lib):
         assert abs(got - want) <= 1e-6 * want   # device subtracts in fp32 (as torch does), oracle in fp64
 
 
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("d,heads", [(512, 8), (512, 4), (384, 4), (448, 8),      # head dims 64 / 128 / 96 / 56 above model_dim 256
+                                     (288, 9), (320, 5), (512, 16),                 # head dims 32 / 64 / 32: the one- and two-block attention kernels
+                                     (224, 4), (128, 1), (96, 1), (256, 2),         # inside the packed engine's model dims: heads of 56 / 128 / 96 / 128
+                                     (80, 5), (200, 8), (120, 8), (96, 8), (40, 2), (8, 1), (72, 2)])   # model dims off the multiples of 32; heads of 16 / 25 / 15 / 12 / 20 / 8 / 36
+def test_general_engine_matches_oracle(oracle_lib, adaptive, d, heads):
+    """Round 6: everything nn.TransformerEncoderLayer builds up to model_dim 512 / head dim 128 that the packed engine
+    does not take runs the GENERAL engine (row-major GEMM / attention / LayerNorm launches, include/adafortitran_amd.h aft_engine_of).
+    Non-uniform softmax, 9 frames (ragged tiles), run-to-run determinism, every encoder layer on the oracle's own layer input, the
+    whole forward against the oracle, batch independence of the bits."""
+    import ctypes
+    from adafortitran_amd import _lib
+    spec = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=2, model_dim=d, num_head=heads)
+    hid = (7, 42, 560) if adaptive else None
+    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=640 + heads, attn_gain=0.25 if adaptive else 16.0, head_gain=2.0)
+    cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+    assert _lib.load().aft_engine_of(ctypes.byref(cfg)) == _abi.AFT_ENGINE_GENERAL
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    inp = synth.make_inputs(9, seed=65)
+    meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+    out = eng.forward(_t(inp["pilots"]), *meta)
+    assert torch.equal(torch.view_as_real(eng.forward(_t(inp["pilots"]), *meta)), torch.view_as_real(out))
+    few = eng.forward(_t(inp["pilots"][:4]), *[(m[:4] if m is not None else None) for m in meta])
+    assert torch.equal(torch.view_as_real(few), torch.view_as_real(out[:4]))            # a frame's bits do not depend on its batch
+    orc = oracle_lib.Oracle(cfg, sd)
+    ref, dump = orc.forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3), dump=True)
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+    xin = dump["x0"]
+    for layer in range(spec["num_layers"]):
+        y = eng.stage_encoder_layer(layer, _t(xin)).cpu().numpy()
+        assert max_rel(y, dump["layer_out"][layer]) <= TOL_HIP_OUT, layer
+        xin = dump["layer_out"][layer]
+
+
+@pytest.mark.parametrize("ofdm,pilot,patch,d,heads,layers", [((96, 14), (12, 2), (12, 2), 128, 4, 2),     # 24-element patch, 56 tokens
+                                                            ((64, 16), (8, 2), (8, 4), 64, 2, 1),         # 32-element patch, 32 tokens
+                                                            ((60, 20), (6, 4), (5, 5), 512, 8, 1),        # 25 elements at model_dim 512
+                                                            ((12, 14), (4, 2), (3, 2), 32, 1, 70),        # 70 layers, packed engine (three windows)
+                                                            ((30, 8), (6, 2), (3, 2), 40, 5, 35)])        # 35 layers, general engine
+def test_large_patches_and_any_layer_count_match_oracle(oracle_lib, ofdm, pilot, patch, d, heads, layers):
+    """Patches of up to 32 elements (the packed engine's fused embedding takes 16) and any number of layers (ABI 7: aft_weights.layers is
+    a host array; the kernels that take the table by value are launched per window of 32 layers)."""
+    tokens = (ofdm[0] // patch[0]) * (ofdm[1] // patch[1])
+    spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=layers, model_dim=d, num_head=heads)
+    for adaptive in (False, True):
+        hid = (5, 11, 2 * tokens) if adaptive else None
+        sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=77, head_gain=2.0, max_seq_len=max(64, tokens))
+        cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+        from adafortitran_amd.hip_ops import engine_from_numpy
+        eng = engine_from_numpy(cfg, sd, DEV)
+        inp = synth.make_inputs(5, ofdm=ofdm, pilot=pilot, seed=78)
+        meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+        out = eng.forward(_t(inp["pilots"]), *meta).cpu().numpy()
+        ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"], *([inp["snr"], inp["ds"], inp["dop"]] if adaptive else [None] * 3))
+        assert np.isfinite(out).all() and np.abs(out - ref).max() <= TOL_HIP_OUT * np.abs(ref).max(), adaptive
+
+
+def test_general_engine_through_the_module_surface():
+    """A model the packed engine does not take, built through the reference's module surface on the HIP device: eval() forwards run
+    the general engine (one aft_forward_f32 call), match the same module's CPU composite -- what the reference itself computes -- and
+    the state_dict moves both ways unchanged."""
+    sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
+    kw = dict(model_type="adafortitran", patch_size=(3, 2), num_layers=2, model_dim=320, num_head=5, channel_adaptivity_hidden_sizes=[7, 42, 560],
+              adaptive_token_length=6)
+    torch.manual_seed(3)
+    cpu = A.AdaFortiTranEstimator(sc, A.ModelConfig(device="cpu", **kw)).eval()
+    gpu = A.AdaFortiTranEstimator(sc, A.ModelConfig(device="cuda", **kw)).eval()
+    gpu.load_state_dict(cpu.state_dict())
+    assert gpu.hip_engine_name() == "general" and all(v is None for v in gpu.training_backends().values())
+    inp = synth.make_inputs(6, seed=4)
+    pil, meta = torch.from_numpy(inp["pilots"]), synth.meta_tuple(inp)
+    with torch.no_grad():
+        want, got = cpu(pil, meta), gpu(pil, meta)
+    assert gpu._engine is not None and got.device.type == "cuda"
+    assert (got.cpu() - want).abs().max() <= TOL_HIP_OUT * want.abs().max()
+
+
+def _random_specs_general(n, seed):
+    """Random configurations from what round 6 added: model_dim any multiple of 8 up to 512, any head count that divides it with heads
+    of at most 128 features, patches of up to 32 elements, 1-3 layers -- keeping only draws the packed engine does NOT take."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        p0, p1 = int(rng.integers(1, 9)), int(rng.integers(1, 5))
+        if p0 * p1 > 32:
+            continue
+        gs, gt = int(rng.integers(2, 24)), int(rng.integers(1, 8))
+        if gs * gt > 300 or gs * p0 > 160 or gt * p1 > 28:
+            continue
+        d = 8 * int(rng.integers(1, 65))
+        divs = [h for h in range(1, d + 1) if d % h == 0 and d // h <= 128]
+        heads = int(rng.choice(divs))
+        hd = d // heads
+        packed = d % 32 == 0 and d <= 256 and hd % 8 == 0 and hd <= 64 and hd != 56 and p0 * p1 <= 16
+        if packed:
+            continue
+        ps, pt = int(rng.integers(2, 13)), int(rng.integers(1, 4))
+        out.append(dict(ofdm=(gs * p0, gt * p1), pilot=(ps, pt), patch=(p0, p1), num_layers=int(rng.integers(1, 4)),
+                        model_dim=d, num_head=heads, activation=str(rng.choice(["gelu", "relu"])),
+                        pos=str(rng.choice(["learnable", "sinusoidal"])), adaptive=bool(rng.integers(0, 2)),
+                        batch=int(rng.integers(1, 6))))
+    return out
+
+
 def _random_specs(n, seed, head_dims=(16, 32, 64)):
     """Random valid configurations: any grid the patch divides (token counts from 1 to 512, below one MFMA tile included), patches of
     <= 16 elements, model_dim any multiple of 32 up to 256 with head dim 16 / 32 / 64 (64 where it divides), 1-3 layers, both activations /
@@ -742,7 +852,7 @@ def _random_specs(n, seed, head_dims=(16, 32, 64)):
     return out
 
 
-@pytest.mark.parametrize("spec", _random_specs(40, 2027) + _random_specs(20, 2031, head_dims=(8, 24, 40, 48)), ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['model_dim']}h{s['num_head']}{'a' if s['adaptive'] else 'f'}")
+@pytest.mark.parametrize("spec", _random_specs(40, 2027) + _random_specs(20, 2031, head_dims=(8, 24, 40, 48)) + _random_specs_general(30, 2039), ids=lambda s: f"{s['ofdm'][0]}x{s['ofdm'][1]}p{s['patch'][0]}x{s['patch'][1]}d{s['model_dim']}h{s['num_head']}{'a' if s['adaptive'] else 'f'}")
 def test_random_configurations_match_oracle(oracle_lib, spec):
     tokens = (spec["ofdm"][0] // spec["patch"][0]) * (spec["ofdm"][1] // spec["patch"][1])
     base = dict(ofdm=spec["ofdm"], pilot=spec["pilot"], patch=spec["patch"], num_layers=spec["num_layers"],

@@ -44,7 +44,10 @@ def _serialize(g: Golden, path: str) -> None:
         f.write(np.array([g["pilots"].shape[0], int(g.adaptive)], np.int32).tobytes())
         f.write(np.array([n], np.uint64).tobytes())
         f.write(np.concatenate(chunks).tobytes())
+        table = bytes(weights._layer_table)               # the layer table travels behind the struct; its pointer slot is rebuilt by the driver
+        weights.layers = None
         f.write(bytes(weights))
+        f.write(table)
         f.write(np.array(io, np.uint64).tobytes())
     assert C.sizeof(weights) % 8 == 0
 

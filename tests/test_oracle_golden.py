@@ -7,7 +7,10 @@ from helpers import Golden, TOL_ORACLE_OUT, TOL_ORACLE_STAGE, max_rel
 
 ALL_SETS = ["T_tiny_ada", "T_tiny_forti", "D_forti", "A_ada", "DH_forti_hot", "AH_ada_mid", "AS_ada_sin_relu",
             "H16_ada_heads8", "H64_forti_heads2", "S28_ada_tokens28",     # head dims 16 / 64, a grid of 28 tokens
-            "H24_ada_d96_heads4", "H48_forti_d192_heads4"]                # heads of 24 / 48 features (not aligned with 32-feature blocks)
+            "H24_ada_d96_heads4", "H48_forti_d192_heads4",                # heads of 24 / 48 features (not aligned with 32-feature blocks)
+            # round 6: the general engine's shapes (model_dim 512, heads of 128 / 56 / 25 features, a 24-element patch) and 40 layers
+            "W512_ada_d512_heads8", "H128_forti_d256_heads2", "H56_ada_d224_heads4", "D200_forti_d200_heads8", "P24_ada_patch12x2",
+            "L40_forti_layers40"]
 
 
 @pytest.mark.parametrize("name", ALL_SETS)

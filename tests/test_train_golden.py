@@ -36,6 +36,8 @@ TOL = {"G_grad_forti": (2e-5, 5e-4), "G_grad_ada": (2e-3, 2e-3),
        "G_grad_forti_h16": (2e-5, 5e-4), "G_grad_forti_s28": (2e-5, 5e-4), "G_grad_forti_h64": (2e-5, 5e-4),
        # late round 5: 4 heads of 24 at model_dim 96 -- heads that straddle the kernels' 32-feature blocks
        "G_grad_forti_h24": (2e-5, 5e-4),
+       # round 6: the general engine's shapes -- 2 heads of 128 at model_dim 256, model_dim 512 (8 heads of 64)
+       "G_grad_forti_h128": (2e-5, 5e-4), "G_grad_forti_d512": (2e-5, 5e-4),
        # full depth at the benchmark's batch (6 layers, B = 128; inputs regenerated bit-exactly from the fixture's seed)
        "G_grad_forti_full": (2e-4, None), "G_grad_ada_full": (4e-3, None)}
 # HIP vs float64 at full depth: (element base, norm base); + COND_FACTOR x the tensor's measured conditioning.
@@ -49,7 +51,8 @@ BASE64 = {"G_grad_forti_full": (1e-4, 5e-5), "G_grad_ada_full": (4e-3, 2e-3), "G
           #  position_embeddings there, fixture against fixture -- base = twice that)
           "G_grad_forti_h16": (2e-5, 2e-5), "G_grad_forti_s28": (2e-5, 2e-5),
           "G_grad_forti_h64": (4e-5, 4e-5),     # (the reference's own fp32 step: 2.1e-5 from float64 on position_embeddings)
-          "G_grad_forti_h24": (4e-5, 4e-5)}     # (... 1.6e-5 on the last conv bias, 1.3e-5 on position_embeddings)
+          "G_grad_forti_h24": (4e-5, 4e-5),     # (... 1.6e-5 on the last conv bias, 1.3e-5 on position_embeddings)
+          "G_grad_forti_h128": (4e-5, 4e-5), "G_grad_forti_d512": (4e-5, 4e-5)}
 COND_FACTOR = 2.0
 
 
@@ -258,14 +261,16 @@ def test_hip_gradients_are_as_close_to_float64_as_pytorch_fp32(adaptive):
     assert clean == 2, f"only {clean} input seeds without a differing ReLU decision between HIP and PyTorch-ROCm in 12 tries"
 
 
-@pytest.mark.parametrize("name", ["G_grad_ada", "G_grad_forti", "G_grad_forti_h16", "G_grad_forti_s28", "G_grad_forti_h64", "G_grad_forti_h24"])
+@pytest.mark.parametrize("name", ["G_grad_ada", "G_grad_forti", "G_grad_forti_h16", "G_grad_forti_s28", "G_grad_forti_h64", "G_grad_forti_h24",
+                                  "G_grad_forti_h128", "G_grad_forti_d512"])
 def test_composite_training_step_matches_reference_gradients_cpu(name):
     g, model, loss = _step(name, "cpu")
     _check(g, model, loss, TOL[name][0])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["G_grad_ada", "G_grad_forti", "G_grad_forti_h16", "G_grad_forti_s28", "G_grad_forti_h64", "G_grad_forti_h24"])
+@pytest.mark.parametrize("name", ["G_grad_ada", "G_grad_forti", "G_grad_forti_h16", "G_grad_forti_s28", "G_grad_forti_h64", "G_grad_forti_h24",
+                                  "G_grad_forti_h128", "G_grad_forti_d512"])
 def test_hip_training_step_matches_reference_gradients(name):
     g, model, loss = _step(name, "cuda")
     assert model.transformer_encoder._hip_train_eligible(torch.empty(2, 280, 128, device="cuda"))

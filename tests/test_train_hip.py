@@ -47,7 +47,13 @@ def _rel(a, b):
                                                      (224, 7, (24, 14), 2, "relu"), (32, 2, (12, 14), 4, "gelu"),
                                                      # late round 5: head dims 8 / 24 (padded to 32-feature heads), 40 / 48 (to 64)
                                                      (128, 16, (120, 14), 2, "gelu"), (96, 4, (48, 14), 4, "relu"), (192, 8, (24, 14), 2, "gelu"),
-                                                     (160, 4, (48, 14), 2, "gelu"), (96, 2, (120, 14), 2, "relu"), (192, 4, (12, 14), 4, "gelu")])
+                                                     (160, 4, (48, 14), 2, "gelu"), (96, 2, (120, 14), 2, "relu"), (192, 4, (12, 14), 4, "gelu"),
+                                                     # round 6, the general engine's shapes: model_dim up to 512 / off the multiples of 32, heads
+                                                     # of 56 / 96 / 128 features (three / four 32-feature blocks) and of 25 / 20 / 15 (scalar re-lay)
+                                                     (512, 8, (48, 14), 2, "gelu"), (512, 4, (24, 14), 2, "relu"), (384, 4, (48, 14), 2, "gelu"),
+                                                     (256, 2, (120, 14), 2, "gelu"), (224, 4, (48, 14), 2, "relu"), (448, 8, (12, 14), 4, "gelu"),
+                                                     (200, 8, (48, 14), 2, "gelu"), (80, 4, (24, 14), 4, "relu"), (120, 8, (48, 14), 2, "gelu"),
+                                                     (288, 9, (24, 14), 2, "gelu"), (96, 1, (120, 14), 2, "relu"), (8, 1, (12, 14), 2, "gelu")])
 def test_layer_forward_backward_matches_autograd(d, heads, ofdm, planes, act):
     from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
     cfg = _cfg(d, heads, ofdm, act)
@@ -105,7 +111,7 @@ def test_layer_training_bits_do_not_depend_on_stale_memory(value):
 
 
 @pytest.mark.parametrize("ofdm,heads,d", [((120, 14), 4, 128), ((24, 14), 4, 128), ((240, 28), 4, 128), ((48, 14), 8, 256)])
-def test_one_pass_attention_backward_agrees_with_the_two_pass_form(ofdm, heads, d, monkeypatch):
+def test_one_pass_attention_backward_agrees_with_the_two_pass_form(ofdm, heads, d, switches):
     """attn_bwd_kernel (dQ, dK, dV in one pass, the default) against the two kernels it replaced
     (AFT_TRAIN_ATTN_BWD_SPLIT, read per launch): same masks, same products, sums in a different order --
     every gradient within 2e-6 of its tensor's |g|max; both forms bit-reproducible run to run.  Geometries: 9 key tiles
@@ -125,9 +131,9 @@ def test_one_pass_attention_backward_agrees_with_the_two_pass_form(ofdm, heads, 
         out.backward(gout)
         return [x.grad.clone()] + [p.grad.clone() for p in layer_params(layer)]
 
-    monkeypatch.delenv("AFT_TRAIN_ATTN_BWD_SPLIT", raising=False)
+    switches.unset("AFT_TRAIN_ATTN_BWD_SPLIT")
     one, one_again = run(), run()
-    monkeypatch.setenv("AFT_TRAIN_ATTN_BWD_SPLIT", "1")
+    switches.set("AFT_TRAIN_ATTN_BWD_SPLIT", "1")
     two = run()
     for i, (a, b, c) in enumerate(zip(one, one_again, two)):
         assert torch.equal(a, b), i
@@ -135,17 +141,17 @@ def test_one_pass_attention_backward_agrees_with_the_two_pass_form(ofdm, heads, 
     assert any(not torch.equal(a, c) for a, c in zip(one, two))   # the switch did select another kernel
     # the launcher picks three- or twelve-wave workgroups (one or four problems each) by the problem count: same arithmetic per
     # problem, so the same bits (2 planes x heads problems here: a multiple of four)
-    monkeypatch.delenv("AFT_TRAIN_ATTN_BWD_SPLIT")
-    monkeypatch.setenv("AFT_ATTN_BWD_GROUPS", "4")
+    switches.unset("AFT_TRAIN_ATTN_BWD_SPLIT")
+    switches.set("AFT_ATTN_BWD_GROUPS", "4")
     four = run()
-    monkeypatch.setenv("AFT_ATTN_BWD_GROUPS", "1")
+    switches.set("AFT_ATTN_BWD_GROUPS", "1")
     three = run()
     for i, (a, b) in enumerate(zip(four, three)):
         assert torch.equal(a, b), i
 
 
 @pytest.mark.parametrize("d,heads,ofdm", [(128, 4, (120, 14)), (128, 4, (24, 14)), (256, 8, (48, 14))])
-def test_stack_with_chained_in_projections_matches_the_unchained_stack(d, heads, ofdm, monkeypatch):
+def test_stack_with_chained_in_projections_matches_the_unchained_stack(d, heads, ofdm, switches):
     """encoder_stack_train links the layers through their tapes: layer l's row-local kernel computes layer l + 1's
     in-projection (aft_encoder_layer_fwd_train_chained_f32).  Against the same stack with every layer running its own
     in-projection GEMM (AFT_TRAIN_NO_QKV_CHAIN): same seeds, same masks; output and every gradient within 2e-6 of the
@@ -167,9 +173,9 @@ def test_stack_with_chained_in_projections_matches_the_unchained_stack(d, heads,
         out.backward(gout)
         return [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for layer in layers for p in layer_params(layer)]
 
-    monkeypatch.delenv("AFT_TRAIN_NO_QKV_CHAIN", raising=False)
+    switches.unset("AFT_TRAIN_NO_QKV_CHAIN")
     chained = run()
-    monkeypatch.setenv("AFT_TRAIN_NO_QKV_CHAIN", "1")
+    switches.set("AFT_TRAIN_NO_QKV_CHAIN", "1")
     plain = run()
     for i, (a, b) in enumerate(zip(chained, plain)):
         if d == 256:
@@ -189,7 +195,7 @@ def test_stack_with_chained_in_projections_matches_the_unchained_stack(d, heads,
         ref = layer(ref)
     ref.backward(gout)
     ref_g = [xr.grad.clone()] + [p.grad.clone() for layer in layers for p in layer_params(layer)]
-    monkeypatch.delenv("AFT_TRAIN_NO_QKV_CHAIN", raising=False)
+    switches.unset("AFT_TRAIN_NO_QKV_CHAIN")
     for layer in layers:
         layer.zero_grad()
     xh = x0.clone().requires_grad_(True)
@@ -446,7 +452,7 @@ def test_conv_enhancer_forward_backward_matches_autograd(S, T, n):
 
 
 @pytest.mark.parametrize("n", [3, 10, 130])
-def test_training_conv_column_ranges_reproduce_whole_planes(n, monkeypatch):
+def test_training_conv_column_ranges_reproduce_whole_planes(n, switches):
     """With fewer planes than CUs the training conv kernel (conv_stream_kernel<0, true>, forward and data gradient) splits every
     plane of the default grid into 2 or 4 column ranges that recompute their neighbours' edge columns (64 frames -- the reference's
     default batch -- are 128 planes on 256 CUs): the output, the three saved activations' consumers (the data gradient and every
@@ -460,9 +466,9 @@ def test_training_conv_column_ranges_reproduce_whole_planes(n, monkeypatch):
 
     def run(split):
         if split is None:
-            monkeypatch.delenv("AFT_CONV_NSPLIT", raising=False)
+            switches.unset("AFT_CONV_NSPLIT")
         else:
-            monkeypatch.setenv("AFT_CONV_NSPLIT", split)
+            switches.set("AFT_CONV_NSPLIT", split)
         enh.zero_grad(); x.grad = None
         y = enh(x)
         y.backward(gy)
@@ -651,7 +657,7 @@ def test_grad_scaler_branch_of_the_reference_trainer():
 
 
 @pytest.mark.parametrize("p,batch", [(0.0, 8), (0.1, 8), (0.0, 128)])
-def test_fused_forward_chain_reproduces_the_launch_sequence_tape(monkeypatch, p, batch):
+def test_fused_forward_chain_reproduces_the_launch_sequence_tape(switches, p, batch):
     """the tight A/B that backs the training path's golden tolerances.  The fused row-local forward
     (chain_fwd_train_kernel: out_proj + LN1 + FFN + LN2, tape written from its epilogues) against the launch sequence it
     replaced (AFT_TRAIN_UNFUSED_FWD, read per call), same layer, same inputs, same dropout seed: the layer output and EVERY
@@ -677,9 +683,9 @@ def test_fused_forward_chain_reproduces_the_launch_sequence_tape(monkeypatch, p,
     res = {}
     for mode in ("fused", "unfused"):
         if mode == "unfused":
-            monkeypatch.setenv("AFT_TRAIN_UNFUSED_FWD", "1")
+            switches.set("AFT_TRAIN_UNFUSED_FWD", "1")
         else:
-            monkeypatch.delenv("AFT_TRAIN_UNFUSED_FWD", raising=False)
+            switches.unset("AFT_TRAIN_UNFUSED_FWD")
         tape = torch.zeros(nt, dtype=torch.uint8, device="cuda")
         scr = torch.zeros(nscr, dtype=torch.uint8, device="cuda")
         out = torch.empty_like(x)
@@ -692,13 +698,13 @@ def test_fused_forward_chain_reproduces_the_launch_sequence_tape(monkeypatch, p,
             off += al(n)
         segs["out"] = out.view(-1).clone()
         res[mode] = segs
-    monkeypatch.delenv("AFT_TRAIN_UNFUSED_FWD", raising=False)
+    switches.unset("AFT_TRAIN_UNFUSED_FWD")
     for k in res["fused"]:
         assert _rel(res["fused"][k], res["unfused"][k]) <= 1e-6, k
 
 
 @pytest.mark.parametrize("grid,planes,p", [((24, 14), 2, 0.0), ((120, 14), 2, 0.1), ((120, 14), 16, 0.1)])
-def test_fused_backward_chain_reproduces_the_launch_sequence_gradients(monkeypatch, grid, planes, p):
+def test_fused_backward_chain_reproduces_the_launch_sequence_gradients(switches, grid, planes, p):
     """... and the fused row-local backward (chain_bwd_kernel) against the five launches it replaced
     (AFT_TRAIN_UNFUSED_BWD): dx and every parameter gradient within 2e-6 of the tensor's max, with and without dropout."""
     from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
@@ -711,9 +717,9 @@ def test_fused_backward_chain_reproduces_the_launch_sequence_gradients(monkeypat
 
     def run(unfused):
         if unfused:
-            monkeypatch.setenv("AFT_TRAIN_UNFUSED_BWD", "1")
+            switches.set("AFT_TRAIN_UNFUSED_BWD", "1")
         else:
-            monkeypatch.delenv("AFT_TRAIN_UNFUSED_BWD", raising=False)
+            switches.unset("AFT_TRAIN_UNFUSED_BWD")
         layer.zero_grad()
         x = x0.clone().requires_grad_(True)
         out = HipEncoderLayerFunction.apply(x, cfg, p, 5, *layer_params(layer))
@@ -721,6 +727,6 @@ def test_fused_backward_chain_reproduces_the_launch_sequence_gradients(monkeypat
         return [x.grad.clone()] + [q.grad.clone() for q in layer_params(layer)]
 
     fused, unfused = run(False), run(True)
-    monkeypatch.delenv("AFT_TRAIN_UNFUSED_BWD", raising=False)
+    switches.unset("AFT_TRAIN_UNFUSED_BWD")
     for name, u, v in zip(["dx", *_abi.LAYER_PARAM_NAMES], fused, unfused):
         assert _rel(u, v) <= 2e-6, name

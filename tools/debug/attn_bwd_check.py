@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from adafortitran_amd import _abi  # noqa: E402
+from adafortitran_amd import _lib   # switches change through the ABI (the library reads the environment once, at load)
 from adafortitran_amd.training import HipEncoderLayerFunction, layer_params  # noqa: E402
 
 
@@ -18,9 +19,9 @@ def rel(a, b):
 def dqkv_of(cfg, layer, x, gout, planes, d, two_pass):
     """dqkv [rows][3d] as the attention backward left it in the scratch buffer (offsets: plan_scratch, aft_train.hip)"""
     if two_pass:
-        os.environ["AFT_TRAIN_ATTN_BWD_SPLIT"] = "1"
+        _lib.set_switch("AFT_TRAIN_ATTN_BWD_SPLIT", "1")
     else:
-        os.environ.pop("AFT_TRAIN_ATTN_BWD_SPLIT", None)
+        _lib.set_switch("AFT_TRAIN_ATTN_BWD_SPLIT", None)
     grabbed = []
     real_empty = torch.empty
 

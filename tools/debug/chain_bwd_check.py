@@ -5,11 +5,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from adafortitran_amd import _abi
+from adafortitran_amd import _lib   # switches change through the ABI (the library reads the environment once, at load)
 from adafortitran_amd.training import HipEncoderLayerFunction, layer_params
 
 def run(layer, cfg, x0, gout, p, seed, unfused):
-    if unfused: os.environ["AFT_TRAIN_UNFUSED_BWD"] = "1"
-    else: os.environ.pop("AFT_TRAIN_UNFUSED_BWD", None)
+    if unfused: _lib.set_switch("AFT_TRAIN_UNFUSED_BWD", "1")
+    else: _lib.set_switch("AFT_TRAIN_UNFUSED_BWD", None)
     layer.zero_grad()
     x = x0.clone().requires_grad_(True)
     out = HipEncoderLayerFunction.apply(x, cfg, p, seed, *layer_params(layer))

@@ -18,8 +18,8 @@ for p, batch in ((0.0, 8), (0.1, 8), (0.0, 128)):
     w = _layer_struct(_abi.AftLayerWeights, params); st = _lib.current_stream_ptr(x.device)
     res = {}
     for mode in ("fused", "unfused"):
-        if mode == "unfused": os.environ["AFT_TRAIN_UNFUSED_FWD"] = "1"
-        else: os.environ.pop("AFT_TRAIN_UNFUSED_FWD", None)
+        if mode == "unfused": _lib.set_switch("AFT_TRAIN_UNFUSED_FWD", "1")
+        else: _lib.set_switch("AFT_TRAIN_UNFUSED_FWD", None)
         tape = torch.zeros(nt, dtype=torch.uint8, device="cuda"); scr = torch.zeros(nscr, dtype=torch.uint8, device="cuda"); out = torch.empty_like(x)
         _lib.check(lib.aft_encoder_layer_fwd_train_f32(C.byref(cfg), C.byref(w), x.data_ptr(), out.data_ptr(), tape.data_ptr(), nt, scr.data_ptr(), nscr, batch, p, 5, st))
         torch.cuda.synchronize()

@@ -5,6 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from adafortitran_amd import _abi, synth
+from adafortitran_amd import _lib   # switches change through the ABI (the library reads the environment once, at load)
 from adafortitran_amd.hip_ops import engine_from_numpy
 SPEC = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=6, model_dim=128, num_head=4)
 HID = (7, 42, 560)
@@ -17,8 +18,8 @@ for BT in [int(x) for x in os.environ.get("AFT_BATCHES", "16,32,64,96,128,256").
     pil, meta = dev(inp["pilots"]), [dev(inp[k]) for k in ("snr", "ds", "dop")]
     ref = None
     for L in ("1", "2", "3", "4", None):
-        if L is None: os.environ.pop("AFT_LANES", None)
-        else: os.environ["AFT_LANES"] = L
+        if L is None: _lib.set_switch("AFT_LANES", None)
+        else: _lib.set_switch("AFT_LANES", L)
         for _ in range(10): out = eng.forward(pil, *meta)
         torch.cuda.synchronize()
         best = 1e9

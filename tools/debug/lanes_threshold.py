@@ -4,6 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from adafortitran_amd import _abi, synth
+from adafortitran_amd import _lib   # switches change through the ABI (the library reads the environment once, at load)
 from adafortitran_amd.hip_ops import engine_from_numpy
 dev = lambda a: torch.from_numpy(a).cuda()
 def gflop(spec, hid, B):
@@ -26,7 +27,7 @@ for spec, hid, batches in CASES:
         pil, meta = dev(inp["pilots"]), [dev(inp[k]) for k in ("snr", "ds", "dop")]
         res = {}
         for L in ("1", "2"):
-            os.environ["AFT_LANES"] = L
+            _lib.set_switch("AFT_LANES", L)
             for _ in range(10): eng.forward(pil, *meta)
             torch.cuda.synchronize()
             best = 1e9
@@ -37,6 +38,6 @@ for spec, hid, batches in CASES:
                 torch.cuda.synchronize()
                 best = min(best, (time.perf_counter() - t0) / n)
             res[L] = best
-        os.environ.pop("AFT_LANES")
+        _lib.set_switch("AFT_LANES", None)
         tiles = (2 * B * eng.tokens + 31) // 32
         print(f"grid {spec['ofdm']} d={spec['model_dim']} B={B:5d}: {gflop(spec, hid, B):8.2f} GF, {tiles:6d} row tiles: one lane {res['1'] * 1e3:.4f} ms, two {res['2'] * 1e3:.4f} ms  -> {res['1'] / res['2']:.3f}x")

@@ -21,9 +21,11 @@ inp = synth.make_inputs(B, ofdm=SPEC["ofdm"], pilot=SPEC["pilot"], seed=20251114
 dev = lambda a: torch.from_numpy(a).to("cuda:0")
 pil, meta = dev(inp["pilots"]), [dev(inp[k]) for k in ("snr", "ds", "dop")]
 out = torch.empty((B, *SPEC["ofdm"]), dtype=torch.complex64, device="cuda:0")
-stamps = os.environ.pop("AFT_STAMPS", None)   # only meaningful with a --diag build
+from adafortitran_amd import _lib
+stamps = _lib.get_switch("AFT_STAMPS")   # only meaningful with a --diag build; off for the first forward
+_lib.set_switch("AFT_STAMPS", None)
 eng.forward(pil, *meta, out=out); torch.cuda.synchronize()
-if stamps: os.environ["AFT_STAMPS"] = stamps
+if stamps: _lib.set_switch("AFT_STAMPS", stamps)
 res = {}
 for name in which:
     io = pil if name == "upsample" else (out if name == "tail" else None)
