@@ -38,15 +38,29 @@ def _compile(src: str, force: bool, objdir: str, extra) -> str:
     return obj
 
 
+CHECK_FLAGS = ("-DAFT_CHECKED=1",)   # the checked build (aft_internal.h: asserts, fenced hand-overs, bounded polls); never the product
+
+
+def build_checked(force: bool = False, verbose: bool = False) -> str:
+    """`libaft_hip_check.so`: the same sources with -DAFT_CHECKED=1, run against the product build by tests/test_checked_build.py."""
+    return build(force=force, verbose=verbose, variant="check", extra_flags=CHECK_FLAGS)
+
+
 def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
-    """The product library (variant ""), or an A/B variant `libaft_hip_<variant>.so` compiled with extra -D flags
-    (tools/ab_kernels.py loads several of them in one process; variants always rebuild from scratch)."""
+    """The product library (variant ""), or a variant `libaft_hip_<variant>.so` compiled with extra -D flags into its own object
+    directory (tools/ab_kernels.py loads several of them in one process; the checked build is one).  A variant rebuilds when a source
+    is newer than its objects or when its flags changed."""
     objdir, lib = CSRC, LIB
     if variant:
         objdir = os.path.join(CSRC, "build_" + variant)
         os.makedirs(objdir, exist_ok=True)
         lib = os.path.join(CSRC, f"libaft_hip_{variant}.so")
-        force = True
+        stamp = os.path.join(objdir, "flags.txt")
+        flags_now = " ".join(list(extra_flags) + (["-DAFT_DIAG_STAMPS"] if DIAG else []))
+        if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+            force = True
+            with open(stamp, "w") as fh:
+                fh.write(flags_now)
     with ThreadPoolExecutor(max_workers=4) as pool:
         objs = list(pool.map(lambda s: _compile(s, force, objdir, extra_flags), SOURCES))
     if force or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
@@ -58,7 +72,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
 
 
 if __name__ == "__main__":
-    # python -m adafortitran_amd.build [--force] [--diag] [--variant NAME -DX=1 -DY=2 ...]
+    # python -m adafortitran_amd.build [--force] [--diag] [--variant NAME -DX=1 -DY=2 ...]      (--variant check -DAFT_CHECKED=1 = build_checked)
     DIAG = "--diag" in sys.argv
     var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
     build(force="--force" in sys.argv or DIAG, verbose=True, variant=var, extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")])

@@ -599,6 +599,23 @@ static int forward_impl(const aft_config *cfg, const aft_weights *w, const float
         if (ef != hipSuccess) return hip_fail("lanes(fork)", ef);
     }
     const int pil_floats = 2 * cfg->pilot_scs * cfg->pilot_symbols, out_floats = 2 * cfg->num_scs * cfg->num_symbols;   // complex64 per frame
+#ifdef AFT_CHECKED
+    {   // workspace-plan invariants: shares cover the batch exactly once, slices are disjoint, in order and inside the caller's buffer,
+        // every region of a slice lies inside it and starts on a 256-byte boundary
+        int covered = 0;
+        for (int i = 0; i < lp.lanes; ++i) {
+            const Workspace wl = plan_workspace(*cfg, lp.frames[i]);
+            AFT_HOST_ASSERT(lp.first[i] == covered && lp.frames[i] > 0, "lane shares are not a partition of the batch");
+            covered += lp.frames[i];
+            AFT_HOST_ASSERT(lp.ws_off[i] % 64 == 0 && (lp.ws_off[i] + wl.total_floats) * sizeof(float) <= workspace_bytes, "lane slice outside the workspace");
+            AFT_HOST_ASSERT(i + 1 == lp.lanes || lp.ws_off[i] + wl.total_floats <= lp.ws_off[i + 1], "lane slices overlap");
+            const size_t regions[] = {wl.conv_enhanced, wl.tokens6, wl.x, wl.attn, wl.q, wl.k, wl.vt, wl.wpack, wl.out6, wl.convfrag,
+                                      wl.g_x1, wl.g_y, wl.g_s, wl.g_stats, wl.g_qkv, wl.g_lse, wl.g_a, wl.g_hd, wl.g_pad};
+            for (size_t r : regions) AFT_HOST_ASSERT(r % 64 == 0 && r <= wl.total_floats, "workspace region outside its slice");
+        }
+        AFT_HOST_ASSERT(covered == batch, "lane shares do not cover the batch");
+    }
+#endif
     int result = AFT_OK;
     for (int i = 0; i < lp.lanes; ++i) {
         const int f0 = lp.first[i];

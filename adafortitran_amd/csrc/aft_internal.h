@@ -22,6 +22,29 @@ constexpr int kSchedSlots = 2048;       // (xcc id, se id, sh id, cu id) -> one 
 
 inline __host__ __device__ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// ---- the CHECKED build (python -m adafortitran_amd.build --variant check -DAFT_CHECKED=1; SURVEY.md section 5 "LDS-bounds asserts in
+// debug builds"; GPU AddressSanitizer is not available on this pool).  Never the product: it exists to be run against it.
+//   * AFT_DEV_ASSERT: index / slot / ring-offset checks in the wave-specialised conv pipelines; a violation is __builtin_trap -> the
+//     launch faults and the next HIP call reports it, instead of a silent wrong LDS word.
+//   * AFT_CHECKED_FENCE: the LDS-flag hand-overs of k_conv_stream.hip publish WITHOUT a release fence in the product (gfx950 serves one
+//     wave's LDS requests in issue order); the checked build puts the fence back, so "same bits as the product build" on the soak
+//     test is a test of that assumption.
+//   * AFT_SPIN_GUARD: a poll that does not end within ~2^22 sleeps traps (a lost hand-over becomes a fault, not a hung box).
+//   * AFT_HOST_ASSERT: workspace-plan invariants in aft_api.hip (regions inside the workspace, lanes disjoint).
+#ifdef AFT_CHECKED
+#define AFT_DEV_ASSERT(cond) do { if (!(cond)) __builtin_trap(); } while (0)
+#define AFT_CHECKED_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define AFT_SPIN_GUARD_INIT() unsigned aft_spin_ = 0
+#define AFT_SPIN_GUARD() do { if (++aft_spin_ > (1u << 22)) __builtin_trap(); } while (0)
+#define AFT_HOST_ASSERT(cond, what) do { if (!(cond)) { set_error("checked build: %s", what); return AFT_ERR_ARG; } } while (0)
+#else
+#define AFT_DEV_ASSERT(cond) ((void)0)
+#define AFT_CHECKED_FENCE() ((void)0)
+#define AFT_SPIN_GUARD_INIT() ((void)0)
+#define AFT_SPIN_GUARD() ((void)0)
+#define AFT_HOST_ASSERT(cond, what) ((void)0)
+#endif
+
 // fp32 MFMA with one scalar instruction behind it.  Measured (tools/micro/valu_cost.hip short): a v_mfma_f32_32x32x2_f32
 // that directly follows another one in the instruction stream issues ~6 cycles late (143 TFLOP/s for back-to-back
 // chains, one or two accumulators, 1 or 3 waves per SIMD alike); ONE scalar instruction between them (s_nop 0, s_mov)

@@ -53,8 +53,14 @@ __device__ __forceinline__ float rows_from_above16(float v) {   // lane i <- lan
 
 // LDS (floats): in0 [wmax][SP] | c1 [8][4][SP] | c3 [8][4][SP] (its start stages the conv2 / conv3 weights first) | obuf [S][wcols] |
 // bias2 [32] | w1s [80] | w4s [80]
+// (checked build: + 16 words behind the tables -- which symbol each slot of the two rings holds, see conv_rows16_kernel)
+#ifdef AFT_CHECKED
+constexpr int kRingTagFloats = 16;
+#else
+constexpr int kRingTagFloats = 0;
+#endif
 __host__ __device__ inline size_t conv_rows_lds_floats(int S, int wcols) {
-    return (size_t)(wcols + 8) * kRowsSP + 2 * (size_t)8 * kRingPlane + (size_t)S * wcols + 32 + 80 + 80;
+    return (size_t)(wcols + 8) * kRowsSP + 2 * (size_t)8 * kRingPlane + (size_t)S * wcols + 32 + 80 + 80 + kRingTagFloats;
 }
 
 // MODE 0 = head (a.in_plane = upsampled planes [planes][S][T] -> a.out_plane), 1 = tail (a.lin2_out + a.resid -> a.out_complex)
@@ -352,6 +358,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows16_kernel(const ConvArg
     float *c3 = c1 + 8 * kRingPlane;
     float *obuf = c3 + 8 * kRingPlane;
     float *bias2 = obuf + (size_t)S * wcols, *w1s = bias2 + 32, *w4s = w1s + 80;
+#ifdef AFT_CHECKED
+    // The ring protocol, checked: tag[slot] = the symbol a slot of the conv1 ring ([0..3]) / conv3 ring ([4..7]) holds, written with the
+    // column; every reader asserts that the slot it is about to read holds the symbol it wants ("an iteration only reads what earlier
+    // iterations wrote and only writes slots nobody reads in the same iteration", the file header).
+    volatile int *ring_tag = reinterpret_cast<volatile int *>(w4s + 80);
+    if (tid < 8) ring_tag[tid] = -(1 << 30);
+#endif
 
     // ---- phase 0: the operand fragments (22 lane-linear 16-byte loads per wave), the small tables, the input columns ----
     f32x4 fq[kFragQuads];
@@ -423,6 +436,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows16_kernel(const ConvArg
             win9[2][kx] = src[kx * SP + r2];
         }
         float *dst = c1 + ((4 * h) * kRing + (sym & 3)) * SP + lr;
+#ifdef AFT_CHECKED
+        AFT_DEV_ASSERT(lr >= 0 && lr < SP && (dst + 7 * kRingPlane) < c3);
+        if (tid == 0) ring_tag[sym & 3] = sym;
+#endif
 #pragma unroll
         for (int k = 0; k < 2; ++k) {      // two channels per v_pk_fma_f32, the same fma chain per channel in tap order
             f32x2 acc2 = f32x2{w1s[72 + 4 * h + 2 * k], w1s[72 + 4 * h + 2 * k + 1]};
@@ -449,6 +466,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows16_kernel(const ConvArg
             for (int k9 = 0; k9 < 9; ++k9) {
                 const int ky = k9 / 3, kx = k9 % 3;
                 const int off = ((sym + kx - 1) & 3) * SP + (ky == 0 ? r0 : ky == 1 ? lr : r2);
+#ifdef AFT_CHECKED
+                AFT_DEV_ASSERT(ring_tag[4 + ((sym + kx - 1) & 3)] == sym + kx - 1);     // conv4 reads conv3's symbols sym - 1 .. sym + 1
+#endif
                 acc2[cp] = __builtin_elementwise_fma(f32x2{p[off], p[kRingPlane + off]},
                                                      f32x2{w4s[(4 * h + 2 * cp) * 9 + k9], w4s[(4 * h + 2 * cp + 1) * 9 + k9]}, acc2[cp]);
             }
@@ -479,6 +499,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows16_kernel(const ConvArg
     float bv[3][2][4];
     auto load_b = [&](int kx, int cih, int tcol) {                   // conv2 column tcol: conv1 symbol tcol + kx - 1
         const float *q = bsrc + 4 * cih * kRingPlane + ((tcol + kx - 1) & 3) * SP;
+#ifdef AFT_CHECKED
+        AFT_DEV_ASSERT(ring_tag[(tcol + kx - 1) & 3] == tcol + kx - 1 && q >= c1 && q + 3 < c3);   // conv2 column tcol reads conv1's symbol tcol + kx - 1
+#endif
         const f32x2 lo = *reinterpret_cast<const f32x2 *>(q), hi = *reinterpret_cast<const f32x2 *>(q + 2);
         bv[kx][cih][0] = lo[0]; bv[kx][cih][1] = lo[1]; bv[kx][cih][2] = hi[0]; bv[kx][cih][3] = hi[1];
     };
@@ -517,6 +540,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows16_kernel(const ConvArg
     auto store_col = [&](int tout, const float (&Y)[2][6]) {
         const bool inr = tout >= 0 && tout < T;
         if (inr && tout < c3first) return;
+#ifdef AFT_CHECKED
+        if (tid == 0) ring_tag[4 + (tout & 3)] = tout;
+#endif
 #pragma unroll
         for (int cohi = 0; cohi < 2; ++cohi) {
             float o0 = Y[0][2 + cohi] + rows_from_below16(Y[1][cohi]) + Y[1][4 + cohi];

@@ -193,10 +193,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         }
     };
     auto wait_count = [&](int slot, int count) {   // workgroup-scope hand-over through an LDS counter
-        while (flags[slot] < count) __builtin_amdgcn_s_sleep(2);
+        AFT_DEV_ASSERT(slot >= 0 && slot < 16 && count >= 0);
+        AFT_SPIN_GUARD_INIT();
+        while (flags[slot] < count) { __builtin_amdgcn_s_sleep(2); AFT_SPIN_GUARD(); }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     auto signal_count = [&](int slot) {
+        AFT_DEV_ASSERT(slot >= 0 && slot < 16);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_fetch_add(const_cast<lds_int *>(flags + slot), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
@@ -281,7 +284,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         // flag store behind them in the instruction stream (a release fence would also drain this wave's pending operand reads:
         // a stall of the MFMA chain at every column)
         auto publish = [&](int columns_done) {
+            AFT_DEV_ASSERT(wave >= 0 && wave < 4 && columns_done >= 0 && columns_done <= T);
             asm volatile("" ::: "memory");
+            AFT_CHECKED_FENCE();
             if (lane == 0) flags[wave] = columns_done;
             asm volatile("" ::: "memory");
         };
@@ -446,10 +451,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
         int have = 0;        // conv3 columns known to be published by all four matrix waves
         auto need = [&](int columns) {
             if (have >= columns) return;
+            AFT_DEV_ASSERT(columns >= 0 && columns <= T);
+            AFT_SPIN_GUARD_INIT();
             for (;;) {   // one 16-byte LDS read per poll, a long sleep between polls: a polling wave costs its SIMD's matrix wave issue slots
                 const i32x4 f = *(const volatile lds_i32x4 *)(flags);
                 const int m = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (m >= columns) { have = m; break; }
+                AFT_SPIN_GUARD();
                 __builtin_amdgcn_s_sleep(8);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -601,10 +609,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         for (int q = 0; q < kFragQuads; ++q) fq[q] = fp[q * 64];
     }
     auto wait_count = [&](int slot, int count) {   // workgroup-scope hand-over through an LDS counter
-        while (flags[slot] < count) __builtin_amdgcn_s_sleep(2);
+        AFT_DEV_ASSERT(slot >= 0 && slot < 16 && count >= 0);
+        AFT_SPIN_GUARD_INIT();
+        while (flags[slot] < count) { __builtin_amdgcn_s_sleep(2); AFT_SPIN_GUARD(); }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     auto signal_count = [&](int slot) {
+        AFT_DEV_ASSERT(slot >= 0 && slot < 16);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_fetch_add(const_cast<lds_int *>(flags + slot), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
@@ -644,17 +655,22 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         // order, so a reader that sees the flag finds the data stores before it already done; the compiler barriers keep the flag
         // store behind them in the instruction stream (a release fence would drain this wave's pending operand reads)
         auto publish = [&](int columns_done) {
+            AFT_DEV_ASSERT(wave >= 0 && wave < 4 && columns_done >= 0 && columns_done <= T);
             asm volatile("" ::: "memory");
+            AFT_CHECKED_FENCE();
             if (lane == 0) flags[wave] = columns_done;
             asm volatile("" ::: "memory");
         };
         int have1 = 0;   // conv1 columns known to be published by all four helper waves (wave-uniform)
         auto need_c1 = [&](int columns) {
             if (have1 >= columns) return;
+            AFT_DEV_ASSERT(columns >= 0 && columns <= T);
+            AFT_SPIN_GUARD_INIT();
             for (;;) {
                 const i32x4 f = *(const volatile lds_i32x4 *)(flags + 8);
                 const int m = __builtin_amdgcn_readfirstlane(min(min(f[0], f[1]), min(f[2], f[3])));
                 if (m >= columns) { have1 = m; break; }
+                AFT_SPIN_GUARD();
                 __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -871,6 +887,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                     }
                 }
                 asm volatile("" ::: "memory");
+                AFT_DEV_ASSERT(hw >= 0 && hw < 4 && t >= 0 && t < T);
+                AFT_CHECKED_FENCE();
                 if (lane == 0) flags[8 + hw] = t + 1;     // LDS order: the column's stores are done when a reader sees the count
                 asm volatile("" ::: "memory");
             }
@@ -910,10 +928,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         int have = 0;        // conv3 columns known to be published by all four matrix waves
         auto need = [&](int columns) {
             if (have >= columns) return;
+            AFT_DEV_ASSERT(columns >= 0 && columns <= T);
+            AFT_SPIN_GUARD_INIT();
             for (;;) {   // one 16-byte LDS read per poll, a long sleep between polls: a polling wave costs its SIMD's matrix wave issue slots
                 const i32x4 f = *(const volatile lds_i32x4 *)(flags);
                 const int m = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (m >= columns) { have = m; break; }
+                AFT_SPIN_GUARD();
                 // a poll is ~6 instructions on the SIMD the matrix wave needs: a column takes ~5 000 cycles, so sleep long while
                 // columns are far apart and short only for the last ones, whose conv4 is the kernel's tail
                 if (columns >= T - 1) __builtin_amdgcn_s_sleep(2);

@@ -466,11 +466,13 @@ __global__ __launch_bounds__(256) void embed_any_kernel(const EmbedArgs a) {
     __shared__ float in[kEmbAnyRows][kEmbAnyDin];
     const int tid = threadIdx.x, tw = a.T / a.p1, p = a.p0 * a.p1;
     const long rows = (long)a.planes * a.tokens, row0 = (long)blockIdx.x * kEmbAnyRows;
-    for (int i = tid; i < kEmbAnyRows * a.din; i += 256) {
-        const int r = i / a.din, f = i - r * a.din;
+    // every slot of `in` is written: the products below run over all kEmbAnyDin slots with zero weights beyond din, and 0 x whatever
+    // the LDS held (a NaN bit pattern left by another kernel) is not 0 (caught by the module-surface tests, where the preceding kernels differ)
+    for (int i = tid; i < kEmbAnyRows * kEmbAnyDin; i += 256) {
+        const int r = i / kEmbAnyDin, f = i - r * kEmbAnyDin;
         const long row = row0 + r;
         float v = 0.f;
-        if (row < rows) {
+        if (row < rows && f < a.din) {
             const int n = (int)(row / a.tokens), t = (int)(row - (long)n * a.tokens);
             if (f < p) {
                 const int tq = t / tw, tr = t - tq * tw;

@@ -206,7 +206,8 @@ class BaseFortiTranEstimator(nn.Module):
                     self.logger.warning("training: %s is differentiated by PyTorch-ROCm autograd, not by the library's kernels (%s); "
                                         "inference (eval() + no_grad) runs the HIP engine either way", block, gap)
             return
-        if os.environ.get("AFT_ALLOW_COMPOSITE") == "1":
+        from . import _lib
+        if _lib.get_switch("AFT_ALLOW_COMPOSITE") == "1":      # the AFT_* environment as the library read it at load, or aft_set_switch
             self.logger.warning("configuration not covered by the gfx950 kernels (%s): AFT_ALLOW_COMPOSITE=1, "
                                 "running the PyTorch-ROCm composite for training AND evaluation", reason)
             return
