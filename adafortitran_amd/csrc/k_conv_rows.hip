@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows16_kernel(const ConvArg
         }
         float *dst = c1 + ((4 * h) * kRing + (sym & 3)) * SP + lr;
 #ifdef AFT_CHECKED
-        AFT_DEV_ASSERT(lr >= 0 && lr < SP && (dst + 7 * kRingPlane) < c3);
+        AFT_DEV_ASSERT(lr >= 0 && lr < SP && dst >= c1 && (dst + 3 * kRingPlane) < c3);      // channels 4 h .. 4 h + 3 of the conv1 ring
         if (tid == 0) ring_tag[sym & 3] = sym;
 #endif
 #pragma unroll
@@ -500,7 +500,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_rows16_kernel(const ConvArg
     auto load_b = [&](int kx, int cih, int tcol) {                   // conv2 column tcol: conv1 symbol tcol + kx - 1
         const float *q = bsrc + 4 * cih * kRingPlane + ((tcol + kx - 1) & 3) * SP;
 #ifdef AFT_CHECKED
-        AFT_DEV_ASSERT(ring_tag[(tcol + kx - 1) & 3] == tcol + kx - 1 && q >= c1 && q + 3 < c3);   // conv2 column tcol reads conv1's symbol tcol + kx - 1
+        // conv2 column tcol reads conv1's symbol tcol + kx - 1.  (A halo lane of tile 0 reads one float in front of the ring -- the last
+        // element of the input columns, inside the allocation; its products never reach a stored result.)
+        // (The sweep requests the operands of column `ce` behind its last column: a prefetch nobody consumes, of whatever the slots hold.)
+        AFT_DEV_ASSERT((tcol >= ce || ring_tag[(tcol + kx - 1) & 3] == tcol + kx - 1) && q + 1 >= c1 && q + 3 < c3);
 #endif
         const f32x2 lo = *reinterpret_cast<const f32x2 *>(q), hi = *reinterpret_cast<const f32x2 *>(q + 2);
         bv[kx][cih][0] = lo[0]; bv[kx][cih][1] = lo[1]; bv[kx][cih][2] = hi[0]; bv[kx][cih][3] = hi[1];
