@@ -580,6 +580,20 @@ def batch_sweep(c, device, batches, steps=20, warmup=5):
     return rec
 
 
+def general_shape_rate(c, device, steps=5, warmup=2):
+    """A configuration the packed engine does not take (aft_engine_of = GENERAL): frames/s of forward + MSE partial at the config's
+    batch and the whole forward's algorithmic FLOP rate as a fraction of the fp32 roof (no per-kernel replay: aft_profile_kernel_f32
+    knows the packed engine's classes only)."""
+    import torch
+    wl = Workload(c, device)
+    wall, _, _ = timed_steps(wl, wl.step, steps, warmup, torch.cuda.synchronize)
+    fl = algorithmic_flops(c, wl.B)
+    rec = [round(wl.B * steps / wall, 1), round(fl["forward_total"] * steps / wall / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)]
+    del wl
+    torch.cuda.empty_cache()
+    return rec
+
+
 def split_precision_record(c, device, steps, warmup, oracle_sample):
     """The opt-in split-precision tier (aft_config.precision = AFT_PRECISION_BF16X3: encoder GEMMs and attention products on
     bf16 hi/lo terms, fp32 accumulation) on the headline workload -- REPORTED SEPARATELY, never `value`."""
@@ -958,7 +972,14 @@ def main() -> int:
                                   ("grid_12x14_28tok", dict(ofdm=(12, 14), pilot=(4, 2), hidden=(7, 42, 56)))):
                     r = batch_sweep(dict(C3, **over, batch=128), device, (128,), steps=10, warmup=3)
                     others[tag] = [r["value"][0], r["dominant_frac"][0]]
-                result["other_shapes"] = {"fields": "frames/s, dominant kernel's fraction of the fp32 roof (B=128, adaptive)", **others}
+                    # the GENERAL engine's shapes (round 6, VERDICT r5 item 3: covered, not tuned -- row-major GEMM / attention / LayerNorm launches):
+                # frames/s and the whole forward's fraction of the fp32 roof (algorithmic FLOPs of the config / step time)
+                for tag, over in (("d512_h8", dict(model_dim=512, num_head=8)), ("d512_h4_hd128", dict(model_dim=512, num_head=4)),
+                                  ("d256_h2_hd128", dict(model_dim=256, num_head=2)), ("d224_h4_hd56", dict(model_dim=224, num_head=4)),
+                                  ("d200_h8_hd25", dict(model_dim=200, num_head=8))):
+                    others["general_" + tag] = general_shape_rate(dict(C3, **over, batch=128), device)
+                result["other_shapes"] = {"fields": "frames/s, dominant kernel's fraction of the fp32 roof (B=128, adaptive); general_*: "
+                                                    "frames/s, whole forward's fraction of the fp32 roof", **others}
             except Exception as exc:
                 result["other_shapes"] = {"error": f"{type(exc).__name__}: {exc}"[:160]}
             if head["model_dim"] in (128, 256):

@@ -30,10 +30,15 @@ AFT_FWD=6 pmc none prologue     # the forwards' prologue launches (adapter + wei
 # training step: kernel trace of the HIP path + the A/B line against PyTorch-ROCm autograd
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_trace" -- python3 "$REPO/tools/train_bench.py" --only hip --steps 10 --warmup 3 > "$OUT/train_trace.log" 2>&1
 python3 "$REPO/tools/train_bench.py" --steps 20 --warmup 5 2>/dev/null | grep "^{" | tail -1 > "$OUT/train_bench_line.json"
+# config 5 (240 x 28, 12 layers, d = 256, 64 frames per GPU) and a general-engine shape (d = 512, 8 heads) as their own kernel traces
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5_trace" -- python3 "$REPO/bench.py" --config C5 --steps 5 --warmup 2 --headline-only > "$OUT/c5_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/general_trace" -- python3 "$REPO/tools/general_forward.py" > "$OUT/general_trace.log" 2>&1
 cd "$REPO"
 python3 tools/train_step_breakdown.py "$OUT/train_trace" > "$OUT/train_kernel_trace_summary.txt" 2>&1
 python3 tools/summarize_prof.py "$OUT/bench_trace" > "$OUT/kernel_trace_summary.txt" 2>&1
 python3 tools/summarize_prof.py "$OUT/plane_trace" > "$OUT/plane_kernel_trace_summary.txt" 2>&1
+python3 tools/summarize_prof.py "$OUT/c5_trace" > "$OUT/c5_kernel_trace_summary.txt" 2>&1
+python3 tools/summarize_prof.py "$OUT/general_trace" > "$OUT/general_kernel_trace_summary.txt" 2>&1
 python3 tools/summarize_prof.py "$OUT/split_trace" > "$OUT/split_kernel_trace_summary.txt" 2>&1
 python3 tools/summarize_prof.py "$OUT"/pmc_chain_* "$OUT"/pmc_attn_* "$OUT"/pmc_conv_head_* "$OUT"/pmc_conv_tail_* "$OUT"/pmc_prologue_* > "$OUT/pmc_summary.txt" 2>&1
 cp "$OUT"/bench_trace/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null

@@ -19,7 +19,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 for name in ("kernel_stats.csv", "kernel_trace_summary.txt", "plane_kernel_trace_summary.txt", "split_kernel_trace_summary.txt",
-             "pmc_summary.txt", "bench_under_rocprof.json", "train_kernel_trace_summary.txt", "train_bench_line.json"):
+             "pmc_summary.txt", "bench_under_rocprof.json", "train_kernel_trace_summary.txt", "train_bench_line.json",
+             "c5_kernel_trace_summary.txt", "general_kernel_trace_summary.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join("profiles", f"{tag}_{name}"))
