@@ -141,12 +141,12 @@ EXPORTED_SYMBOLS = (
     "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",
     "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
     "aft_encoder_layer_fwd_train_f32", "aft_encoder_layer_fwd_train_chained_f32", "aft_encoder_layer_bwd_f32", "aft_adam_step_f32",
-    "aft_conv_enhancer_fwd_train_f32", "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_bwd_f32",
+    "aft_conv_enhancer_fwd_train_f32", "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_fwd_scratch_bytes", "aft_conv_enhancer_bwd_f32",
     "aft_dense_fwd_f32", "aft_dense_bwd_scratch_bytes", "aft_dense_bwd_f32",
     "aft_adapter_fwd_train_f32", "aft_adapter_bwd_f32",
 )
 #: size queries (return size_t, not a status code)
 SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_packed_weights_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
-                "aft_conv_enhancer_scratch_bytes", "aft_dense_bwd_scratch_bytes")
+                "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_fwd_scratch_bytes", "aft_dense_bwd_scratch_bytes")
 REGION_IDS = {"conv_enhanced": 0, "tokens6": 1, "enc_out": 2}   # aft_workspace_region
 KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6, "encoder_plane": 7, "prologue": 8}

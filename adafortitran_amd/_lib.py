@@ -88,7 +88,9 @@ def load_path(path: str):
     p4 = C.c_void_p * 4
     lib.aft_conv_enhancer_scratch_bytes.restype = C.c_size_t
     lib.aft_conv_enhancer_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
-    lib.aft_conv_enhancer_fwd_train_f32.argtypes = [C.POINTER(p4), C.POINTER(p4), vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.aft_conv_enhancer_fwd_scratch_bytes.restype = C.c_size_t
+    lib.aft_conv_enhancer_fwd_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.aft_conv_enhancer_fwd_train_f32.argtypes = [C.POINTER(p4), C.POINTER(p4), vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_conv_enhancer_bwd_f32.argtypes = [C.POINTER(p4), vp, vp, vp, vp, vp, vp, C.POINTER(p4), C.POINTER(p4), C.c_int, vp,
                                               C.c_size_t, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_dense_bwd_scratch_bytes.restype = C.c_size_t

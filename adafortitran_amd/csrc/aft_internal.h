@@ -371,8 +371,9 @@ hipError_t launch_act_bwd(int act, const float *a, float *dh, float *dbias, floa
                           uint32_t seed, bool accumulate, hipStream_t st);
 hipError_t launch_add(const float *a, const float *b, float *out, size_t n, hipStream_t st);
 // ConvEnhancer training forward / backward-dgrad on plain planes (k_conv.hip) and its weight gradients (k_conv_train.hip)
+// frag: kConvFragFloats floats of scratch for the default grid's 16x16x4 training kernel (NULL: the 32x32x2 kernels)
 hipError_t launch_conv_train(const float *const w[4], const float *const b[4], const float *x, float *y, float *const save[3],
-                             const float *const mask[3], int planes, int S, int T, hipStream_t st);
+                             const float *const mask[3], int planes, int S, int T, hipStream_t st, float *frag = nullptr);
 constexpr int kConvFlipFloats = 72 + 2304 + 2304 + 72;   // conv4^T | conv3^T | conv2^T | conv1^T
 hipError_t launch_conv_flip_weights(const float *const w[4], float *dst, hipStream_t st);
 hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, const float *c3, const float *g1,

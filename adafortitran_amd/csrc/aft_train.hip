@@ -332,18 +332,28 @@ int aft_dense_bwd_f32(const float *x, const float *weight, const float *dy, floa
 size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols) {
     if (planes <= 0 || num_scs <= 0 || num_symbols <= 0 || !conv_plan_ok(num_scs, num_symbols, 0)) return 0;
     return sizeof(float) * (al64((size_t)planes * 48 * num_scs * num_symbols) + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols)) +
-                            al64(kConvFlipFloats));
+                            al64(kConvFlipFloats) + al64(kConvFragFloats));
+}
+
+size_t aft_conv_enhancer_fwd_scratch_bytes(int planes, int num_scs, int num_symbols) {
+    if (planes <= 0 || num_scs <= 0 || num_symbols <= 0 || !conv_plan_ok(num_scs, num_symbols, 0)) return 0;
+    return sizeof(float) * al64(kConvFragFloats);
 }
 
 int aft_conv_enhancer_fwd_train_f32(const float *const weights[4], const float *const biases[4], const float *x, float *y,
-                                    float *c1, float *c2, float *c3, int planes, int num_scs, int num_symbols, void *stream) {
+                                    float *c1, float *c2, float *c3, void *scratch, size_t scratch_bytes, int planes, int num_scs,
+                                    int num_symbols, void *stream) {
     if (!weights || !biases || !x || !y || !c1 || !c2 || !c3 || planes <= 0 || num_scs <= 0 || num_symbols <= 0) {
         set_error("bad ConvEnhancer argument");
         return AFT_ERR_ARG;
     }
+    if (scratch != nullptr && scratch_bytes < aft_conv_enhancer_fwd_scratch_bytes(planes, num_scs, num_symbols)) {
+        set_error("ConvEnhancer forward scratch too small");
+        return AFT_ERR_ARG;
+    }
     float *const save[3] = {c1, c2, c3};
     STEP("conv forward", launch_conv_train(weights, biases, x, y, save, nullptr, planes, num_scs, num_symbols,
-                                           static_cast<hipStream_t>(stream)));
+                                           static_cast<hipStream_t>(stream), static_cast<float *>(scratch)));
     return AFT_OK;
 }
 
@@ -364,13 +374,14 @@ int aft_conv_enhancer_bwd_f32(const float *const weights[4], const float *x, con
     float *g3 = static_cast<float *>(scratch), *g2 = g3 + plane8, *g1 = g2 + 4 * plane8;
     float *slices = static_cast<float *>(scratch) + al64(6 * plane8);
     float *flip = slices + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols));
+    float *frag = flip + al64(kConvFlipFloats);      // the flipped weights as 16x16x4 operand fragments (default grid)
     // dgrad: the stack run on dy with conv4^T (1->8), conv3^T (8->32), conv2^T (32->8), conv1^T (8->1);
     // stage outputs masked by the saved activations = g3, g2, g1
     STEP("conv weight transposition", launch_conv_flip_weights(weights, flip, st));
     const float *const flipped_weights[4] = {flip, flip + 72, flip + 72 + 2304, flip + 72 + 4608};
     float *const save[3] = {g3, g2, g1};
     const float *const mask[3] = {c3, c2, c1};
-    STEP("conv dgrad", launch_conv_train(flipped_weights, nullptr, dy, dx, save, mask, planes, num_scs, num_symbols, st));
+    STEP("conv dgrad", launch_conv_train(flipped_weights, nullptr, dy, dx, save, mask, planes, num_scs, num_symbols, st, frag));
     STEP("conv wgrad", launch_conv_wgrad(x, c1, c2, c3, g1, g2, g3, dy, dweights, dbiases, slices, planes, num_scs, num_symbols,
                                          accumulate != 0, st));
     return AFT_OK;

@@ -158,6 +158,8 @@ inline bool upsample_planes_ok(const float *up_w, int pf) {
 
 // k_conv_stream.hip: default grid, inference, head with pre-computed upsampled planes (a.in_plane) or tail on linear_2's output
 // (a.lin2_out); returns hipErrorNotSupported when the arguments need the banded kernel
+// the fragment image (kFragFloats floats) of one ConvEnhancer from its four conv weights / biases (cb NULL: no biases), k_conv_stream.hip
+hipError_t launch_conv_frag_pack(const float *const cw[4], const float *const cb[4], float *dst, hipStream_t st);
 bool conv_stream_ok(const ConvArgs &a);
 hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st);
 // k_conv_rows.hip: inference on grids whose planes need more than one band in k_conv.hip (config 5): whole-height workgroups that

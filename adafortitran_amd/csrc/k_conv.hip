@@ -799,13 +799,18 @@ static hipError_t launch_conv_geo(ConvArgs &a, int planes, size_t lds, hipStream
 // mask = {}.  Backward (dgrad): x = dL/dy, w = transposed + flipped weights of conv4..conv1, b = {},
 // mask = {c3, c2, c1}, save = the pre-activation gradients {g3, g2, g1}; y = dL/dx.
 hipError_t launch_conv_train(const float *const w[4], const float *const b[4], const float *x, float *y, float *const save[3],
-                             const float *const mask[3], int planes, int S, int T, hipStream_t st) {
+                             const float *const mask[3], int planes, int S, int T, hipStream_t st, float *frag) {
     ConvArgs a{};
     a.mode = 2;
     a.S = S; a.T = T;
     a.in_plane = x; a.out_plane = y;
     for (int i = 0; i < 4; ++i) { a.cw[i] = w[i]; a.cb[i] = b ? b[i] : nullptr; }
     for (int i = 0; i < 3; ++i) { a.save[i] = save ? save[i] : nullptr; a.mask[i] = mask ? mask[i] : nullptr; }
+    if (frag != nullptr && S == 120 && T == 14) {   // the default grid's 16x16x4 training kernel reads the weights as operand fragments
+        hipError_t e = launch_conv_frag_pack(w, b, frag, st);
+        if (e != hipSuccess) return e;
+        a.wfrag = frag;
+    }
     return launch_conv<true>(a, planes, 0, st);
 }
 

@@ -553,7 +553,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream_kernel(const ConvArg
 // the range, the hand-over counters stay absolute.  Every output element goes through the same instruction sequence whatever the
 // split, so a batch of 16 frames (four ranges per plane) reproduces the same frames inside a batch of 128 bit for bit.
 // =====================================================================================================================================
-template <int MODE, int NSPLIT = 1>
+// TRAIN (round 6; MODE 0 = plain plane in, plain plane out): what conv_stream_kernel<0, true> adds -- the three hidden activations saved
+// as [plane][C][T][S] (backward: the pre-activation gradients the weight-gradient kernels need) and a masked activation (backward: the
+// ReLU derivative from the forward's saved activation instead of bias + ReLU) -- in this kernel's layouts: conv2's 32 channels of a
+// pixel pair leave from the accumulators as they lie (channel 16 mt + 4 (lane / 16) + v, rows r0 / r0 + 1 of pixel tiles 0 / 1), the
+// mask values of a column are requested one column ahead (conv2) / one iteration ahead (conv3), so no sweep waits for them.
+template <int MODE, int NSPLIT = 1, bool TRAIN = false>
 __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *in0 = smem + kIn0, *c1 = smem + kC1, *c3 = smem + kC3;
@@ -634,15 +639,19 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
         }
         const int p = lane & 15, g = lane >> 4;
         const int r0 = 4 + kTileRows * wave - 1 + 2 * p;                 // local row of this lane's pixel in tile pt = 0 (pt = 1: r0 + 1)
-        bool ok3[2];
+        bool ok3[2], ok2v[2];
         float relu_hi[2];
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             const int jj = 2 * p + pt, r = r0 + pt, gr = r - 4;
             const bool ok2 = gr >= 0 && gr < S;                          // conv2 output inside the plane (else zero padding)
+            ok2v[pt] = ok2;
             relu_hi[pt] = ok2 ? __builtin_inff() : 0.f;
             ok3[pt] = ok2 && jj >= 1 && jj <= kTileRows && r < LR - 3;
         }
+        // training: element index of (stage channel c, column t, this lane's row of pixel tile pt) in a [plane][C][T][S] stage tensor
+        const unsigned grow0 = (unsigned)(r0 - 4);                       // plane row of pixel tile 0 (tile 1: + 1); valid where ok2v / ok3 say so
+        auto stage_index = [&](int nch, int c, int t, int pt) { return ((unsigned)(n * nch + c) * T + (unsigned)t) * S + grow0 + (unsigned)pt; };
         // conv2's B operands: for (kx, ci half) the four rows r0 - 1 .. r0 + 2 of conv1's column t' + kx serve both pixel tiles and
         // the three ky (row r0 + pt + ky - 1): 24 registers per column, two 8-byte LDS reads per (kx, ci half)
         const float *bsrc = c1 + g * kPlane + r0 - 1;                    // + 4 cih planes + (t' + kx) SP
@@ -690,13 +699,61 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             for (int rt = 0; rt < 5; ++rt) a3[pt][rt] = rt == 0 ? bias3v : zero4;   // as if the zero column -1 had been swept: output column 0's bias
         f32x4 x2[2][2];   // [pt][mt]: conv2's activation of the current column = conv3's B operands
         f32x4 acc2[2][2];
-        auto relu2 = [&]() {
+        f32x4 m2[TRAIN ? 2 : 1][TRAIN ? 2 : 1];   // training, backward: the forward's conv2 activation of the column being swept (the mask)
+        float m3[TRAIN ? 2 : 1][TRAIN ? 2 : 1];   // ... conv3's, of the next column to be stored: [pt][co half]
+        auto request_mask2 = [&](int tcol) {       // one column ahead of relu2(tcol)
+            if constexpr (TRAIN) {
+                if (a.mask[1]) {
+                    const ConvSrd m = conv_srd(a.mask[1]);
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                m2[pt][mt][v] = ok2v[pt] ? conv_ld(m, stage_index(32, 16 * mt + 4 * g + v, tcol, pt)) : 0.f;
+                }
+            }
+        };
+        auto request_mask3 = [&](int tout) {       // ahead of store_col(tout)
+            if constexpr (TRAIN) {
+                if (a.mask[2] && tout >= 0 && tout < T) {
+                    const ConvSrd m = conv_srd(a.mask[2]);
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int cohi = 0; cohi < 2; ++cohi) m3[pt][cohi] = ok3[pt] ? conv_ld(m, stage_index(8, 4 * cohi + g, tout, pt)) : 0.f;
+                }
+            }
+        };
+        auto relu2 = [&](int tcol) {
+            (void)tcol;
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) x2[pt][mt][v] = __builtin_amdgcn_fmed3f(acc2[pt][mt][v], 0.f, relu_hi[pt]);
+            if constexpr (TRAIN) {
+                if (a.mask[1]) {
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) x2[pt][mt][v] = (ok2v[pt] && m2[pt][mt][v] > 0.f) ? acc2[pt][mt][v] : 0.f;
+                }
+                if (a.save[1]) {
+                    const ConvSrd sv = conv_srd(a.save[1]);
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (ok2v[pt]) conv_st(sv, stage_index(32, 16 * mt + 4 * g + v, tcol, pt), x2[pt][mt][v]);
+                }
+            }
         };
         // conv2 MFMA u (0..11) of group gi = (kx, ci half): ky = u / 4, pixel tile (u / 2) % 2, channel tile u % 2
         auto conv2_step = [&](int gi, int u) {
@@ -727,8 +784,20 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                 // row j = 2p + 1 (pt 1): ky = 0 from (pt 0, lane p), ky = 2 from (pt 0, lane p + 1)
                 float o0 = Y[0][2 + cohi] + row16_from_below(Y[1][cohi]) + Y[1][4 + cohi];
                 float o1 = Y[1][2 + cohi] + Y[0][cohi] + row16_from_above(Y[0][4 + cohi]);
-                o0 = fmaxf(o0, 0.f);       // (the bias rode in as the accumulator's initial value)
-                o1 = fmaxf(o1, 0.f);
+                if (TRAIN && a.mask[2]) {  // backward: the forward's saved activation decides (no bias, no ReLU)
+                    o0 = m3[0][cohi] > 0.f ? o0 : 0.f;
+                    o1 = m3[1][cohi] > 0.f ? o1 : 0.f;
+                } else {
+                    o0 = fmaxf(o0, 0.f);   // (the bias rode in as the accumulator's initial value)
+                    o1 = fmaxf(o1, 0.f);
+                }
+                if constexpr (TRAIN) {
+                    if (a.save[2]) {
+                        const ConvSrd sv = conv_srd(a.save[2]);
+                        if (ok3[0]) conv_st(sv, stage_index(8, 4 * cohi + g, tout, 0), o0);
+                        if (ok3[1]) conv_st(sv, stage_index(8, 4 * cohi + g, tout, 1), o1);
+                    }
+                }
                 p0[4 * cohi * kPlane + (tout + 1) * SP] = o0;
                 p1[4 * cohi * kPlane + (tout + 1) * SP] = o1;
             }
@@ -744,6 +813,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             }
         };
         SSTAMP(2);
+        request_mask2(c2lo);
+        request_mask3(c3first);
         need_c1(min(c2lo + 2, T));
 #pragma unroll
         for (int gi = 0; gi < 6; ++gi) load_b(gi >> 1, gi & 1, c2lo);
@@ -756,10 +827,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             if (gi == 0) need_c1(min(c2lo + 3, T));
             load_b(gi >> 1, gi & 1, c2lo + 1);
         }
-        relu2();
+        relu2(c2lo);
 #pragma unroll 1
         for (int tcol = c2lo; tcol < c2hi - 1; ++tcol) {
             const int tnext = min(tcol + 2, c2hi - 1);
+            request_mask2(tcol + 1);       // (training, backward) the column whose conv2 this iteration runs
             need_c1(min(tnext + 2, T));
             // 80 conv3 MFMAs of column tcol merged with the 72 conv2 MFMAs of column tcol + 1; the B operands of a conv2 group are
             // re-requested for column tcol + 2 right behind their last use (pinned: the compiler otherwise sinks all reads to the end
@@ -784,10 +856,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                     float Y[2][6];
                     finished(a3, Y);
                     store_col(tcol - 2, Y);
+                    request_mask3(max(tcol - 1, c3first));     // the next iteration's column (the first complete one until the sweep reaches it)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            relu2();
+            relu2(tcol + 1);
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -798,6 +871,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             float Y[2][6], Z[2][6];
             finished(a3, Y);
             store_col(c2hi - 3, Y);
+            request_mask3(c2hi - 2);
 #pragma unroll
             for (int m = 0; m < 80; ++m)
                 if (m % 10 < 6) conv3_step(m);     // tiles 2, 4, 1 only: tiles 0, 3 hold the kx = 0 registers = output column T (padding)
@@ -809,7 +883,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                 Z[pt][4] = n3[pt][4][0]; Z[pt][5] = n3[pt][4][1];
             }
             store_col(c2hi - 2, Y);
-            if (NSPLIT == 1 || c2hi == T) store_col(T - 1, Z);
+            if (NSPLIT == 1 || c2hi == T) {
+                request_mask3(T - 1);
+                store_col(T - 1, Z);
+            }
         }
     } else {
         // ---- helper waves: input plane, borders, conv1 of all columns (published column by column), conv4 behind the matrix waves ----
@@ -883,7 +960,17 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                             acc2 = __builtin_elementwise_fma(f32x2{x, x}, w[k][k9], acc2);     // per channel: the same fma chain in tap order
                         }
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) dst[(2 * k + q) * kPlane + t * SP] = ok ? fmaxf(acc2[q], 0.f) : 0.f;
+                        for (int q = 0; q < 2; ++q) {
+                            float v = fmaxf(acc2[q], 0.f);
+                            if constexpr (TRAIN) {
+                                if (ok) {
+                                    const unsigned gi = ((unsigned)(n * 8 + 4 * h + 2 * k + q) * T + t) * S + gr;
+                                    if (a.mask[0]) v = conv_ld(conv_srd(a.mask[0]), gi) > 0.f ? acc2[q] : 0.f;
+                                    if (a.save[0]) conv_st(conv_srd(a.save[0]), gi, v);
+                                }
+                            }
+                            dst[(2 * k + q) * kPlane + t * SP] = ok ? v : 0.f;
+                        }
                     }
                 }
                 asm volatile("" ::: "memory");
@@ -1013,6 +1100,42 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
 #undef SSTAMP
 }
 
+// The fragment image of ONE ConvEnhancer for the training instantiation (the forward's prologue launch packs the inference images):
+// [22 x 64 x 4 operand quads | 2 x 80 helper tables] from conv_block.{0,2,4,6} as the caller holds them.  cb == NULL (the backward's
+// data-gradient pass runs the stack on transposed, flipped weights WITHOUT biases): the bias entries are zero.
+struct FragPackArgs { const float *cw[4], *cb[4]; float *dst; };
+__global__ __launch_bounds__(256) void conv_frag_pack_kernel(const FragPackArgs q) {
+    const int v = blockIdx.x * 256 + threadIdx.x;      // one 16-byte piece of the image
+    constexpr int kPieces = kFragFloats / 4;
+    if (v >= kPieces) return;
+    const bool nb = q.cb[0] == nullptr;
+    f32x4 o;
+    if (v < kFragQuads * 64) {
+        const int quad = v >> 6, lane = v & 63;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int e = 4 * quad + jj;
+            o[jj] = (nb && e >= 76) ? 0.f : conv_frag16_entry(q.cw[1], nb ? q.cw[1] : q.cb[1], q.cw[2], nb ? q.cw[2] : q.cb[2], e, lane);
+        }
+    } else {
+        const int i0 = 4 * (v - kFragQuads * 64), h = i0 / 80;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int i = i0 - 80 * h + jj;
+            const bool is_bias = (i >= 36 && i < 40) || i >= 76;
+            o[jj] = (nb && is_bias) ? 0.f : conv_helper_entry(q.cw[0], nb ? q.cw[0] : q.cb[0], q.cw[3], nb ? q.cw[3] : q.cb[3], h, i);
+        }
+    }
+    *reinterpret_cast<f32x4 *>(q.dst + (size_t)v * 4) = o;
+}
+hipError_t launch_conv_frag_pack(const float *const cw[4], const float *const cb[4], float *dst, hipStream_t st) {
+    FragPackArgs q{};
+    for (int i = 0; i < 4; ++i) { q.cw[i] = cw[i]; q.cb[i] = cb ? cb[i] : nullptr; }
+    q.dst = dst;
+    hipLaunchKernelGGL(conv_frag_pack_kernel, dim3((kFragFloats / 4 + 255) / 256), dim3(256), 0, st, q);
+    return hipGetLastError();
+}
+
 bool conv_stream_ok(const ConvArgs &a) {
     if (a.S != S || a.T != T) return false;
     if (a.mode == 0 || a.mode == 2) return a.in_plane != nullptr && (reinterpret_cast<uintptr_t>(a.out_plane) & 15) == 0;
@@ -1022,15 +1145,33 @@ bool conv_stream_ok(const ConvArgs &a) {
 
 hipError_t launch_conv_stream(ConvArgs &a, int planes, hipStream_t st) {
     if (!conv_stream_ok(a)) return hipErrorNotSupported;
-    static PerDeviceOnce lds_head, lds_tail, lds_train;
+    static PerDeviceOnce lds_head, lds_tail, lds_train, lds_train16[3];
     if (a.mode == 2) {   // training path: plain plane in / out, stage tensors saved, masked activation
-        hipError_t et = ensure_dynamic_lds(lds_train, reinterpret_cast<const void *>(conv_stream_kernel<0, true>), kStreamLds);
-        if (et != hipSuccess) return et;
         // column ranges when the planes would leave half (three quarters) of the CUs idle: 64 frames -- the reference's default batch --
         // are 128 planes (AFT_CONV_NSPLIT=1|2|4 forces a split: tests, A/B)
         const int cus = current_device_cus();
         a.ranges = 4 * planes <= cus ? 4 : (2 * planes <= cus ? 2 : 1);
         if (switch_on("AFT_CONV_NSPLIT")) { const int f = switch_int("AFT_CONV_NSPLIT", 1); a.ranges = f == 4 ? 4 : (f == 2 ? 2 : 1); }
+        if (a.wfrag != nullptr && !switch_on("AFT_CONV_MFMA32")) {
+            // round 6: the 16x16x4 formulation (conv_stream16_kernel<0, NSPLIT, true>) on the fragment image the caller's scratch holds
+            // (launch_conv_train packs it in front of this launch); AFT_CONV_MFMA32=1 keeps the 32x32x2 kernel (A/B, tests)
+            a.plane0 = 0;
+            const dim3 grid(planes * a.ranges), block(kConvThreads);
+            hipError_t e16;
+            if (a.ranges == 4) {
+                e16 = ensure_dynamic_lds(lds_train16[2], reinterpret_cast<const void *>(conv_stream16_kernel<0, 4, true>), kStreamLds);
+                if (e16 == hipSuccess) hipLaunchKernelGGL((conv_stream16_kernel<0, 4, true>), grid, block, kStreamLds, st, a);
+            } else if (a.ranges == 2) {
+                e16 = ensure_dynamic_lds(lds_train16[1], reinterpret_cast<const void *>(conv_stream16_kernel<0, 2, true>), kStreamLds);
+                if (e16 == hipSuccess) hipLaunchKernelGGL((conv_stream16_kernel<0, 2, true>), grid, block, kStreamLds, st, a);
+            } else {
+                e16 = ensure_dynamic_lds(lds_train16[0], reinterpret_cast<const void *>(conv_stream16_kernel<0, 1, true>), kStreamLds);
+                if (e16 == hipSuccess) hipLaunchKernelGGL((conv_stream16_kernel<0, 1, true>), grid, block, kStreamLds, st, a);
+            }
+            return e16 != hipSuccess ? e16 : hipGetLastError();
+        }
+        hipError_t et = ensure_dynamic_lds(lds_train, reinterpret_cast<const void *>(conv_stream_kernel<0, true>), kStreamLds);
+        if (et != hipSuccess) return et;
         hipLaunchKernelGGL((conv_stream_kernel<0, true>), dim3(planes * a.ranges), dim3(kConvThreads), kStreamLds, st, a);
         return hipGetLastError();
     }

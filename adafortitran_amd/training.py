@@ -154,9 +154,10 @@ class HipConvEnhancerFunction(torch.autograd.Function):
         c1 = torch.empty((n, 8, T, S), dtype=torch.float32, device=x.device)
         c2 = torch.empty((n, 32, T, S), dtype=torch.float32, device=x.device)
         c3 = torch.empty((n, 8, T, S), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.aft_conv_enhancer_fwd_scratch_bytes(n, S, T), dtype=torch.uint8, device=x.device)
         _lib.check(lib.aft_conv_enhancer_fwd_train_f32(C.byref(_ptr4(ws)), C.byref(_ptr4(bs)), x.data_ptr(), y.data_ptr(),
-                                                       c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), n, S, T,
-                                                       _lib.current_stream_ptr(x.device)))
+                                                       c1.data_ptr(), c2.data_ptr(), c3.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                                       n, S, T, _lib.current_stream_ptr(x.device)))
         ctx.save_for_backward(x, c1, c2, c3, *ws)
         ctx.param_objs = (w1, b1, w2, b2, w3, b3, w4, b4)
         return y

@@ -291,9 +291,13 @@ int aft_dense_bwd_f32(const float *x, const float *weight, const float *dy, floa
 /* ConvEnhancer (reference src/models/blocks/enhancers.py:5-31: conv 1->8->32->8->1, ReLU after the
  * first three) in train() mode on `planes` real planes x, y: f32 [planes, S, T].  weights[k] / biases[k]
  * are conv_block.{0,2,4,6}.{weight,bias} in PyTorch layout.  c1, c2, c3 receive the activations the
- * backward needs: f32 [planes, C, T, S] with C = 8, 32, 8 (an internal layout; treat as opaque). */
+ * backward needs: f32 [planes, C, T, S] with C = 8, 32, 8 (an internal layout; treat as opaque).
+ * `scratch`: aft_conv_enhancer_fwd_scratch_bytes() bytes the call may overwrite (the weights re-laid as MFMA operand fragments for the
+ * default grid's kernel; ABI 7), or NULL = the kernels that read the weights in place. */
+size_t aft_conv_enhancer_fwd_scratch_bytes(int planes, int num_scs, int num_symbols);
 int aft_conv_enhancer_fwd_train_f32(const float *const weights[4], const float *const biases[4], const float *x, float *y,
-                                    float *c1, float *c2, float *c3, int planes, int num_scs, int num_symbols, void *stream);
+                                    float *c1, float *c2, float *c3, void *scratch, size_t scratch_bytes, int planes, int num_scs,
+                                    int num_symbols, void *stream);
 
 /* Backward of that call: dy = dL/dy -> dx = dL/dx and the eight parameter gradients (PyTorch layouts;
  * overwritten, or added to when accumulate != 0).  weights[k] are the module's conv weights as in the forward call:

@@ -402,7 +402,11 @@ if __name__ == "__main__":
     H16 = dict(DEFAULT, num_layers=2, num_head=8, dropout=0.0, seed=781, attn_gain=8.0)
     S28 = dict(DEFAULT, ofdm=(12, 14), pilot=(4, 2), num_layers=2, dropout=0.0, seed=782, attn_gain=8.0)
     H64 = dict(DEFAULT, num_layers=2, num_head=2, dropout=0.0, seed=783, attn_gain=8.0)      # head dim 64 (`num_head: 2`)
-    H24 = dict(DEFAULT, num_layers=2, model_dim=96, num_head=4, dropout=0.0, seed=784, attn_gain=8.0)   # head dim 24: heads straddle blocks
+    # head dim 24: heads straddle blocks.  (Seed: round 5's 784 has a ReLU pre-activation of the final refiner within fp32 rounding of
+    # zero -- the step's gradients move by 4e-3 with the summation order of the conv kernel in FRONT of it; of twenty other seeds none
+    # has one (tools/debug/h24_seed_search.py: the 16x16x4 and the 32x32x2 training conv kernels and PyTorch-ROCm autograd all within
+    # 5e-5 of float64), 7853 is the cleanest.)
+    H24 = dict(DEFAULT, num_layers=2, model_dim=96, num_head=4, dropout=0.0, seed=7853, attn_gain=8.0)
     # round 6: the general engine's training shapes -- heads of 128 features (four 32-feature blocks), model_dim 512
     H128 = dict(DEFAULT, num_layers=2, model_dim=256, num_head=2, dropout=0.0, seed=785, attn_gain=8.0)
     D512 = dict(DEFAULT, num_layers=2, model_dim=512, num_head=8, dropout=0.0, seed=786, attn_gain=8.0)
