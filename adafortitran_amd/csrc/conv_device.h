@@ -94,6 +94,15 @@ __device__ __forceinline__ float conv_ld(ConvSrd r, unsigned idx) {
 __device__ __forceinline__ void conv_st(ConvSrd r, unsigned idx, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, idx * 4u, 0, 0);
 }
+__device__ __forceinline__ f32x2 conv_ld2(ConvSrd r, unsigned idx) {
+    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, idx * 4u, 0, 0));
+}
+// two adjacent elements (idx, idx + 1) as one 8-byte store; gfx950 only needs dword alignment of the address
+__device__ __forceinline__ void conv_st2(ConvSrd r, unsigned idx, float v0, float v1) {
+    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)}, r, idx * 4u, 0, 0);
+}
 
 __device__ __forceinline__ float lane_from_below(float v) {   // lane i <- lane i-1 (DPP wave_shr:1)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));

@@ -586,6 +586,23 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
     // output (another XCD's L2 or the memory side) is the one latency nothing in this kernel can hide
     f32x4 fq[kFragQuads];
     float vin[7];
+    // training, backward: the forward's conv3 activation decides the conv1 stage's mask -- every column's four values of a helper thread
+    // (local row 32 hw + j, channel half h) are requested here, with the input plane (column by column inside the conv1 loop the
+    // helpers, which the sweeps wait for, paid one round trip per column)
+    float mk[TRAIN ? T : 1][TRAIN ? 4 : 1];
+    if constexpr (TRAIN) {
+        if (!matrix && a.mask[0]) {
+            const int mlr = 32 * (wave - 4) + j, mgr = mlr - 4;
+            if (mlr >= 1 && mlr < LR - 1 && mgr >= 0 && mgr < S) {
+                const ConvSrd m = conv_srd(a.mask[0]);
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        mk[t][c] = (NSPLIT == 1 || (t >= c1lo && t < c1hi)) ? conv_ld(m, ((unsigned)(n * 8 + 4 * h + c) * T + t) * S + mgr) : 0.f;
+            }
+        }
+    }
     if (!matrix) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
@@ -705,13 +722,24 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
             if constexpr (TRAIN) {
                 if (a.mask[1]) {
                     const ConvSrd m = conv_srd(a.mask[1]);
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
+                    if (ok2v[0] && ok2v[1]) {      // the pixel pair of a channel: one 8-byte load
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                            for (int v = 0; v < 4; ++v)
-                                m2[pt][mt][v] = ok2v[pt] ? conv_ld(m, stage_index(32, 16 * mt + 4 * g + v, tcol, pt)) : 0.f;
+                            for (int v = 0; v < 4; ++v) {
+                                const f32x2 pr = conv_ld2(m, stage_index(32, 16 * mt + 4 * g + v, tcol, 0));
+                                m2[0][mt][v] = pr[0];
+                                m2[1][mt][v] = pr[1];
+                            }
+                    } else {
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                    m2[pt][mt][v] = ok2v[pt] ? conv_ld(m, stage_index(32, 16 * mt + 4 * g + v, tcol, pt)) : 0.f;
+                    }
                 }
             }
         };
@@ -743,15 +771,22 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
 #pragma unroll
                             for (int v = 0; v < 4; ++v) x2[pt][mt][v] = (ok2v[pt] && m2[pt][mt][v] > 0.f) ? acc2[pt][mt][v] : 0.f;
                 }
-                if (a.save[1]) {
+                if (a.save[1]) {       // the pixel pair (rows r0, r0 + 1 = tiles 0, 1) of a channel is 8 contiguous bytes of the stage tensor
                     const ConvSrd sv = conv_srd(a.save[1]);
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
+                    if (ok2v[0] && ok2v[1]) {
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                            for (int v = 0; v < 4; ++v)
-                                if (ok2v[pt]) conv_st(sv, stage_index(32, 16 * mt + 4 * g + v, tcol, pt), x2[pt][mt][v]);
+                            for (int v = 0; v < 4; ++v) conv_st2(sv, stage_index(32, 16 * mt + 4 * g + v, tcol, 0), x2[0][mt][v], x2[1][mt][v]);
+                    } else {
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                    if (ok2v[pt]) conv_st(sv, stage_index(32, 16 * mt + 4 * g + v, tcol, pt), x2[pt][mt][v]);
+                    }
                 }
             }
         };
@@ -794,8 +829,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                 if constexpr (TRAIN) {
                     if (a.save[2]) {
                         const ConvSrd sv = conv_srd(a.save[2]);
-                        if (ok3[0]) conv_st(sv, stage_index(8, 4 * cohi + g, tout, 0), o0);
-                        if (ok3[1]) conv_st(sv, stage_index(8, 4 * cohi + g, tout, 1), o1);
+                        if (ok3[0] && ok3[1]) conv_st2(sv, stage_index(8, 4 * cohi + g, tout, 0), o0, o1);
+                        else {
+                            if (ok3[0]) conv_st(sv, stage_index(8, 4 * cohi + g, tout, 0), o0);
+                            if (ok3[1]) conv_st(sv, stage_index(8, 4 * cohi + g, tout, 1), o1);
+                        }
                     }
                 }
                 p0[4 * cohi * kPlane + (tout + 1) * SP] = o0;
@@ -965,7 +1003,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_stream16_kernel(const ConvA
                             if constexpr (TRAIN) {
                                 if (ok) {
                                     const unsigned gi = ((unsigned)(n * 8 + 4 * h + 2 * k + q) * T + t) * S + gr;
-                                    if (a.mask[0]) v = conv_ld(conv_srd(a.mask[0]), gi) > 0.f ? acc2[q] : 0.f;
+                                    if (a.mask[0]) v = mk[t][2 * k + q] > 0.f ? acc2[q] : 0.f;
                                     if (a.save[0]) conv_st(conv_srd(a.save[0]), gi, v);
                                 }
                             }
