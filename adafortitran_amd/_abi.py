@@ -138,7 +138,7 @@ EXPORTED_SYMBOLS = (
     "aft_packed_weights_bytes", "aft_pack_weights_f32", "aft_forward_prepacked_f32",
     "aft_linear_forward_f32", "aft_mse_partial_f32", "aft_stage_upsample_f32",
     "aft_stage_adapter_f32", "aft_stage_embed_f32", "aft_stage_encoder_layer_f32",
-    "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",
+    "aft_stage_tail_f32", "aft_profile_kernel_f32", "aft_debug_fill_lds_f32", "aft_debug_peek_lds_f32", "aft_pilot_gather_f32", "aft_ls_mse_db_f32",
     "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
     "aft_encoder_layer_fwd_train_f32", "aft_encoder_layer_fwd_train_chained_f32", "aft_encoder_layer_bwd_f32", "aft_adam_step_f32",
     "aft_conv_enhancer_fwd_train_f32", "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_fwd_scratch_bytes", "aft_conv_enhancer_bwd_f32",

@@ -73,6 +73,8 @@ def load_path(path: str):
     lib.aft_stage_encoder_layer_f32.argtypes = [cfgp, wp, C.c_int, vp, vp, C.c_size_t, C.c_int, vp]
     lib.aft_stage_tail_f32.argtypes = [cfgp, wp, vp, vp, vp, C.c_int, vp]
     lib.aft_profile_kernel_f32.argtypes = [cfgp, wp, C.c_int, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
+    lib.aft_debug_fill_lds_f32.argtypes = [C.c_float, vp]
+    lib.aft_debug_peek_lds_f32.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.aft_pilot_gather_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.aft_ls_mse_db_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
     lwp, lgp = C.POINTER(_abi.AftLayerWeights), C.POINTER(_abi.AftLayerGrads)

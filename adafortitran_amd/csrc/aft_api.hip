@@ -737,6 +737,17 @@ int aft_ls_mse_db_f32(const float *ls, const float *ideal, float *db, int batch,
     return e == hipSuccess ? AFT_OK : hip_fail("ls_mse_db", e);
 }
 
+int aft_debug_fill_lds_f32(float value, void *stream) {
+    hipError_t e = launch_fill_lds(value, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("fill_lds", e);
+}
+
+int aft_debug_peek_lds_f32(float *out, int workgroups, int n, void *stream) {
+    AFT_REQUIRE(out && workgroups > 0 && n > 0 && n <= 10240, "bad argument");
+    hipError_t e = launch_peek_lds(out, workgroups, n, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AFT_OK : hip_fail("peek_lds", e);
+}
+
 int aft_stage_upsample_f32(const aft_config *cfg, const aft_weights *w, const float *pilots, float *conv_enhanced,
                            int batch, void *stream) {
     int rc = check_config(cfg);

@@ -281,6 +281,8 @@ hipError_t launch_pilot_gather(const float *hzero_ls, float *pilots, int *counts
                                int expected, hipStream_t st);
 hipError_t launch_ls_mse_db(const float *ls, const float *ideal, float *db, int batch, int grid_elems, hipStream_t st);
 hipError_t launch_mse(const float *est, const float *ref, double *sum_sq, long long n_complex, hipStream_t st);
+hipError_t launch_fill_lds(float value, hipStream_t st);   // test hook: every CU's LDS filled with `value`
+hipError_t launch_peek_lds(float *out, int workgroups, int n, hipStream_t st);   // ... and what a kernel finds in its LDS at start
 
 
 // ---- training path: row-major GEMMs, attention with saved LSE, row-wise pieces ----

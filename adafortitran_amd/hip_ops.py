@@ -247,6 +247,23 @@ class HipEngine:
         return out
 
 
+def fill_lds(value: float, device="cuda:0") -> None:
+    """Test hook (aft_debug_fill_lds_f32): every CU's LDS filled with ``value`` on the current stream -- what the next kernels find in
+    their LDS at start."""
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().aft_debug_fill_lds_f32(C.c_float(value), _lib.current_stream_ptr(dev)))
+
+
+def peek_lds(workgroups: int = 1024, n: int = 1024, device="cuda:0") -> torch.Tensor:
+    """Test hook (aft_debug_peek_lds_f32): what ``workgroups`` fresh workgroups find in the first ``n`` floats of their LDS."""
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        out = torch.empty((workgroups, n), dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().aft_debug_peek_lds_f32(out.data_ptr(), workgroups, n, _lib.current_stream_ptr(dev)))
+    return out
+
+
 def profile_kernel(eng: HipEngine, which: str, batch: int, reps: int, io: Optional[torch.Tensor] = None) -> None:
     """Enqueue ``reps`` launches of one kernel class on the current stream (bench.py roofline leg)."""
     ws = eng.workspace(batch)

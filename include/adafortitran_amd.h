@@ -377,6 +377,17 @@ int aft_stage_tail_f32(const aft_config *cfg, const aft_weights *w, const float 
 int aft_profile_kernel_f32(const aft_config *cfg, const aft_weights *w, int which, float *out,
                            void *workspace, size_t workspace_bytes, int batch, int reps, void *stream);
 
+/* ---- test hook (no reference counterpart) ----
+ * Fill the LDS of every CU of the current device with `value` (a NaN, 1e30 ...): what a kernel finds in its LDS at start is whatever
+ * the previous kernel on that CU left there, and a kernel that multiplies a zero weight with an LDS word it never wrote computes
+ * 0 x NaN (round 6: embed_any_kernel did; caught only because another test's kernels had run before).  The allocator-poisoning
+ * tests cannot reach LDS; this can: workgroups of 160 KB each, enough of them that every CU runs at least one.  Asynchronous on
+ * `stream`. */
+int aft_debug_fill_lds_f32(float value, void *stream);
+/* The other half of the hook: what a kernel that writes nothing finds in its LDS.  `workgroups` workgroups (256 threads, 40 KB of
+ * LDS each) copy the first `n` (<= 10240) floats of their LDS to out[workgroup][n] (device memory). */
+int aft_debug_peek_lds_f32(float *out, int workgroups, int n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
