@@ -212,10 +212,11 @@ def test_hot_kernels_compile_without_register_spills():
             m = re.search(r"VGPRs Spill: (\d+)", line)
             if m and name:
                 report[name] = int(m.group(1))
-    spills = {k: v for k, v in report.items() if "attn_kernelILi32E" in k or "attn_kernelILi16E" in k or "conv_stream_kernel" in k or "conv_stream16_kernel" in k}
+    spills = {k: v for k, v in report.items() if "attn_kernelILi32E" in k or "attn_kernelILi16E" in k or "attn16_kernel" in k or "conv_stream_kernel" in k or "conv_stream16_kernel" in k}
     # attention HD 32 (generic, 280 tokens, 1120 tokens) / 16, conv stream head / tail (conv_stream16_kernel x 1 / 2 / 4 column ranges and
     # the 32x32x2 kernel) / training
-    assert len(spills) == 16 and all(v == 0 for v in spills.values()), report      # (+ 3: the training instantiations of conv_stream16_kernel, round 6)
+    # (round 6: + the three training instantiations of conv_stream16_kernel, + attn16_kernel<0 | 280>: head dim 16 on 16x16x4 MFMAs)
+    assert len(spills) == 18 and all(v == 0 for v in spills.values()), report
     assert all(v <= 4 for k, v in report.items() if "attn_kernelILi64E" in k), report
     # the row-local training kernels (forward chain with / without the in-projection tail, backward chain; gelu and relu) sit at the
     # 168 registers three waves per SIMD allow: a scratch reload is a VMEM load whose wait drains vmcnt
