@@ -971,6 +971,28 @@ def test_batches_above_the_offset_limit_run_in_chunks():
         eng.forward(pil_h, *meta_h)                              # CPU tensors without the promise that they are pinned
 
 
+def test_general_engine_batches_above_the_offset_limit_run_in_chunks(oracle_lib):
+    """The same for the general engine, with its real limit: at model_dim 512 its largest tensor is q | k | v (rows x 1536 floats), so
+    aft_max_batch is 624 frames on the default grid; 650 frames run as 624 + 26, a frame's bits do not depend on the chunk it lands in
+    (prepacked calls are accepted and ignore the token image), and an oracle sample pins the values."""
+    spec = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=1, model_dim=512, num_head=8)
+    sd = synth.make_state_dict(**spec, adaptive_hidden=None, seed=21, head_gain=2.0)
+    cfg = _abi.make_config(**spec)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    eng = engine_from_numpy(cfg, sd, DEV)
+    assert eng.max_batch == (2 ** 31 - 1) // (2 * 280 * 3 * 512 * 4) == 624
+    inp = synth.make_inputs(650, seed=22)
+    pil = _t(inp["pilots"])
+    out = eng.forward(pil)
+    a, b = eng.forward(pil[:300]), eng.forward(pil[300:])
+    assert torch.equal(torch.view_as_real(out[:300]), torch.view_as_real(a)) and torch.equal(torch.view_as_real(out[300:]), torch.view_as_real(b))
+    assert torch.equal(torch.view_as_real(eng.forward(pil, cache_packed=True)), torch.view_as_real(out))
+    ref = oracle_lib.Oracle(cfg, sd).forward(inp["pilots"][620:628], None, None, None)
+    assert np.abs(out[620:628].cpu().numpy() - ref).max() <= TOL_HIP_OUT * np.abs(ref).max()
+    del eng, out, a, b
+    torch.cuda.empty_cache()
+
+
 def test_largest_accepted_batch_has_no_offset_overflow():
     """B = aft_max_batch exactly (7281 frames for the default model: q / k / v^T blocks just under 2 GiB, 11 GB of
     workspace): frames at both ends of the batch must equal the same frames run as a small batch, bit for bit; one
