@@ -665,10 +665,39 @@ struct ReduceJobs {
     int njobs;
 };
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobs q) {
-    __shared__ float part[4][64];
+    __shared__ float part[8][64];
     int jb = 0;
     while (jb + 1 < q.njobs && (int)blockIdx.x >= q.first_block[jb + 1]) ++jb;
     const ReduceArgs &a = q.job[jb];
+    // round 6: when the columns pair up (even stride and count -- every weight-gradient job) a thread takes TWO adjacent columns with
+    // 8-byte loads and the slice index is split over eight thread groups instead of four: half the load instructions for the same
+    // bytes in flight and the same workgroup count (16-byte loads with a quarter of the workgroups measured 4 x slower in round 5).
+    // Fixed summation order as before (deterministic run to run); the order differs from the 4-byte form's.
+    if (((a.stride | (size_t)(a.n * a.nout)) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.slices) & 7) == 0) {
+        const int c2 = threadIdx.x & 31, zg = threadIdx.x >> 5, i2 = (blockIdx.x - q.first_block[jb]) * 64 + 2 * c2;
+        f32x2 t2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t2[u] = f32x2{0.f, 0.f};
+        if (i2 < a.n * a.nout) {
+            int z = zg;
+            for (; z + 56 < a.nz; z += 64) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t2[u] += *reinterpret_cast<const f32x2 *>(a.slices + (size_t)(z + 8 * u) * a.stride + i2);
+            }
+            for (; z < a.nz; z += 8) t2[0] += *reinterpret_cast<const f32x2 *>(a.slices + (size_t)z * a.stride + i2);
+        }
+        const f32x2 tsum = ((t2[0] + t2[1]) + (t2[2] + t2[3])) + ((t2[4] + t2[5]) + (t2[6] + t2[7]));
+        part[zg][2 * c2] = tsum[0];
+        part[zg][2 * c2 + 1] = tsum[1];
+        __syncthreads();
+        const int c = threadIdx.x & 63, i = (blockIdx.x - q.first_block[jb]) * 64 + c;
+        if (threadIdx.x < 64 && i < a.n * a.nout) {
+            const float t = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+            float *o = a.out[i / a.n] + i % a.n;
+            *o = a.accumulate ? *o + t : t;
+        }
+        return;
+    }
     const int c = threadIdx.x & 63, zq = threadIdx.x >> 6, i = (blockIdx.x - q.first_block[jb]) * 64 + c;
     float s[8];
 #pragma unroll
