@@ -1002,24 +1002,31 @@ static hipError_t launch_attn_train_bwd_padded(const aft_config &c, AttnTrainArg
         // workgroups (measured, ms per training step, three- vs twelve-wave: 32 frames 2.93 vs 3.80, 64 frames -- the reference's
         // default batch -- 4.30 vs 4.81: its 128 twelve-wave workgroups left half the CUs idle and the kernel took as long as at 128
         // frames; 96: 5.71 vs 5.83, 160: 8.97 vs 9.65, 192: 10.33 vs 10.76).  (round 5)
+        // Round 6, measured and NOT adopted: TWO problems per workgroup (six waves) when the problems are exactly two per CU -- 64 frames
+        // of the default model, the reference's default batch: 512 problems = 256 six-wave workgroups, one per CU, instead of 512
+        // three-wave ones -- 4.18-4.20 ms per 64-frame training step against 4.14-4.16 (same box, interleaved): a six-wave workgroup's
+        // waves are placed as unevenly as a three-wave one's (fact 10).  The instantiation stays behind AFT_ATTN_BWD_GROUPS=2 (A/B, tests).
         const int problems = planes * a.heads, cus = current_device_cus();
         int groups = (4 * group_lds <= 160 * 1024 && problems % (4 * cus) == 0) ? 4 : 1;
         if (switch_on("AFT_ATTN_BWD_3WAVE")) groups = 1;
-        if (switch_on("AFT_ATTN_BWD_GROUPS")) {     // A/B: force 1 or 4 where the shape allows it
+        if (switch_on("AFT_ATTN_BWD_GROUPS")) {     // A/B: force 1, 2 or 4 where the shape allows it
             const int want = switch_int("AFT_ATTN_BWD_GROUPS", 0);
-            if ((want == 1 || want == 4) && problems % want == 0 && (size_t)want * group_lds <= 160 * 1024) groups = want;
+            if ((want == 1 || want == 2 || want == 4) && problems % want == 0 && (size_t)want * group_lds <= 160 * 1024) groups = want;
         }
-        const bool four = groups == 4;
         const bool tok280 = tokens == 280 && !switch_on("AFT_ATTN_GENERIC");
-        const void *fn = four ? (tok280 ? reinterpret_cast<const void *>(attn_bwd_kernel<280, 4>) : reinterpret_cast<const void *>(attn_bwd_kernel<0, 4>))
-                              : (tok280 ? reinterpret_cast<const void *>(attn_bwd_kernel<280, 1>) : reinterpret_cast<const void *>(attn_bwd_kernel<0, 1>));
-        static PerDeviceOnce lds_attr[4];
-        hipError_t ea = ensure_dynamic_lds(lds_attr[(four ? 2 : 0) + (tok280 ? 1 : 0)], fn, four ? 160 * 1024 : 64 * 1024);
+        const int gi = groups == 4 ? 2 : groups == 2 ? 1 : 0;
+        const void *fns[3][2] = {{reinterpret_cast<const void *>(attn_bwd_kernel<0, 1>), reinterpret_cast<const void *>(attn_bwd_kernel<280, 1>)},
+                                 {reinterpret_cast<const void *>(attn_bwd_kernel<0, 2>), reinterpret_cast<const void *>(attn_bwd_kernel<280, 2>)},
+                                 {reinterpret_cast<const void *>(attn_bwd_kernel<0, 4>), reinterpret_cast<const void *>(attn_bwd_kernel<280, 4>)}};
+        static PerDeviceOnce lds_attr[3][2];
+        hipError_t ea = ensure_dynamic_lds(lds_attr[gi][tok280 ? 1 : 0], fns[gi][tok280 ? 1 : 0], groups == 1 ? 64 * 1024 : 160 * 1024);
         if (ea != hipSuccess) return ea;
         const dim3 grid(problems / groups), block(kAtThreads * groups);
         const size_t lds = group_lds * groups;
-        if (four && tok280) hipLaunchKernelGGL((attn_bwd_kernel<280, 4>), grid, block, lds, st, a);
-        else if (four) hipLaunchKernelGGL((attn_bwd_kernel<0, 4>), grid, block, lds, st, a);
+        if (groups == 4 && tok280) hipLaunchKernelGGL((attn_bwd_kernel<280, 4>), grid, block, lds, st, a);
+        else if (groups == 4) hipLaunchKernelGGL((attn_bwd_kernel<0, 4>), grid, block, lds, st, a);
+        else if (groups == 2 && tok280) hipLaunchKernelGGL((attn_bwd_kernel<280, 2>), grid, block, lds, st, a);
+        else if (groups == 2) hipLaunchKernelGGL((attn_bwd_kernel<0, 2>), grid, block, lds, st, a);
         else if (tok280) hipLaunchKernelGGL((attn_bwd_kernel<280, 1>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((attn_bwd_kernel<0, 1>), grid, block, lds, st, a);
         return hipGetLastError();
