@@ -95,7 +95,6 @@ __device__ __forceinline__ void conv_st(ConvSrd r, unsigned idx, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, idx * 4u, 0, 0);
 }
 __device__ __forceinline__ f32x2 conv_ld2(ConvSrd r, unsigned idx) {
-    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, idx * 4u, 0, 0));
 }
 // two adjacent elements (idx, idx + 1) as one 8-byte store; gfx950 only needs dword alignment of the address

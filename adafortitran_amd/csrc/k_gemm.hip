@@ -244,7 +244,11 @@ struct ActBwdArgs {
 constexpr int EPI_NONE = 0, EPI_LN = 1, EPI_ACT = 2, EPI_ACTBWD = 3;
 // CSUM (TN only): also the column sums of A over this block's rows (db = A^T 1, the bias gradient that goes with
 // dW = A^T B): each lane adds up the A fragments it feeds to the matrix cores anyway, one VALU add per two MFMAs.
-template <int OP, int BM, int EPI = EPI_NONE, bool CSUM = false>
+// WN = waves along the columns of the 128-column tile: 2 (each wave 32 TI x 64, the 2 x 2 wave grid of the 64- and 128-row tiles) or 4
+// (each wave BM x 32: the 96-ROW tile of round 6 -- three row tiles per wave, three workgroups per CU.  71 680 token rows are 1 120
+// tiles of 64 rows on 1 024 resident workgroups -- a second round of 96 lone tiles -- but 747 tiles of 96 rows on 768: one round, 0.97
+// of a plane per CU.  Same k order per output element: the same bits whichever tile height runs.)
+template <int OP, int BM, int EPI = EPI_NONE, bool CSUM = false, int WN = 2>
 __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*Bs)[GBK * GLD], const float *__restrict__ A,
                                                const float *__restrict__ B, float *__restrict__ C, const float *__restrict__ bias,
                                                int M, int N, int K, int lda, int ldb, int ldc, int k_chunk, size_t c_slice,
@@ -265,8 +269,11 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
         for (int i = threadIdx.x; i < N; i += 256) ln_colw[i] = dropmask_col_word(actb->seed, (uint32_t)i);
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    constexpr int TI = BM / 64, NUA = BM / 64;
+    static_assert(WN == 2 || (WN == 4 && OP != 2 && EPI == EPI_NONE && !CSUM), "the 1 x 4 wave grid serves the plain NT / NN products");
+    const int wm = WN == 2 ? wave >> 1 : 0, wn = WN == 2 ? wave & 1 : wave;
+    constexpr int WM = 4 / WN, TI = BM / (32 * WM), TJ = GBN / (32 * WN);   // MFMA tiles per wave: TI along m, TJ along n
+    constexpr int NUA = (BM + 63) / 64;                                      // A-tile vec4 per thread (a 96-row tile: the upper quarter idle)
+    constexpr int WROWS = 32 * TI, WCOLS = 32 * TJ;                          // a wave's piece of the output tile
     constexpr bool A_KC = OP != 2, B_KC = OP == 0;   // operand rows contiguous in k (else contiguous in m / n)
     const int ntn = (N + GBN - 1) / GBN, ntm = (M + BM - 1) / BM;
     const int ntiles = OP == 2 ? 1 : ntn * ntm, tstep = OP == 2 ? 1 : gx;
@@ -298,7 +305,7 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
     unsigned oa[NUA], ob[2], sa0 = 0, sb0 = 0;   // this tile's lane offsets (range-checked) and scalar origins
     auto locate = [&](int m0, int n0) {
 #pragma unroll
-        for (int u = 0; u < NUA; ++u) oa[u] = m0 + xa[u] < M ? va[u] : kGemmOutOfRange;
+        for (int u = 0; u < NUA; ++u) oa[u] = (BM % 64 == 0 || xa[u] < BM) && m0 + xa[u] < M ? va[u] : kGemmOutOfRange;
 #pragma unroll
         for (int u = 0; u < 2; ++u) ob[u] = n0 + xb[u] < N ? vb[u] : kGemmOutOfRange;
         sa0 = (unsigned)(A_KC ? m0 * lda + kbeg : kbeg * lda + m0) * 4u;
@@ -306,9 +313,9 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
     };
     auto fetch = [&](int step) {
 #pragma unroll
-        for (int u = 0; u < NUA; ++u) ra[u] = gemm_ld(sa, oa[u], sa0 + step * ka);
+        for (int u = 0; u < NUA; ++u) ra[u] = gemm_ld(sa, oa[u], __builtin_amdgcn_readfirstlane(sa0 + step * ka));
 #pragma unroll
-        for (int u = 0; u < 2; ++u) rb[u] = gemm_ld(sb, ob[u], sb0 + step * kb_);
+        for (int u = 0; u < 2; ++u) rb[u] = gemm_ld(sb, ob[u], __builtin_amdgcn_readfirstlane(sb0 + step * kb_));
     };
     auto stage = [&](int buf) {
         if constexpr (A_KC) store_kc(As[buf], tid, ra); else store_xc(As[buf], tid, ra);
@@ -332,10 +339,10 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
     }
     while (tile < ntiles) {
         // accumulators start from the bias: register e of column tile tj is column 32*tj + 8*(e>>2) + 4h + (e&3)
-        f32x16 acc[TI][2];
-        const unsigned bcol = (unsigned)(n0 + wn * 64 + 4 * h) * 4u;
+        f32x16 acc[TI][TJ];
+        const unsigned bcol = (unsigned)(n0 + wn * WCOLS + 4 * h) * 4u;
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+        for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f32x4 bv = gemm_ld(sbias, bcol + (32 * tj + 8 * s) * 4u, 0);   // zeros without a bias or beyond N
@@ -344,6 +351,11 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[ti][tj][4 * s + c] = bv[c];
             }
+        // The bias loads land in the accumulators themselves.  Left pending, the compiler's wait for them sits in front of the k loop's
+        // first MFMAs -- INSIDE the loop, behind the step's fetch, as vmcnt(0): every k step of the 64-row kernels then waited for the
+        // operand loads it had just issued (found in the ISA in round 6; the other three waves of the SIMD covered most of it: 20 us of
+        // a 6.8-ms training step).  Waited for here, once per tile, beside the wait for the tile's first operands that stage(0) needs.
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         const int next = tile + tstep;
         int m1 = 0, n1 = 0;
         if (next < ntiles) origin(next, m1, n1);
@@ -383,16 +395,18 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
                 locate(m1, n1);
                 fetch(0);
             }
-            const float *as = As[buf] + h * GLD + wm * (BM / 2) + j;
-            const float *bs = Bs[buf] + h * GLD + wn * 64 + j;
+            const float *as = As[buf] + h * GLD + wm * WROWS + j;
+            const float *bs = Bs[buf] + h * GLD + wn * WCOLS + j;
 #pragma unroll
             for (int kb = 0; kb < GBK / 2; ++kb) {
-                const float b0 = bs[2 * kb * GLD], b1 = bs[2 * kb * GLD + 32];
+                float bv[TJ];
+#pragma unroll
+                for (int tj = 0; tj < TJ; ++tj) bv[tj] = bs[2 * kb * GLD + 32 * tj];
 #pragma unroll
                 for (int ti = 0; ti < TI; ++ti) {
                     const float av = as[2 * kb * GLD + 32 * ti];
-                    acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av, acc[ti][0], 0, 0, 0);
-                    acc[ti][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, av, acc[ti][1], 0, 0, 0);
+#pragma unroll
+                    for (int tj = 0; tj < TJ; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[tj], av, acc[ti][tj], 0, 0, 0);
                     if constexpr (CSUM) asum[ti] += av;
                 }
             }
@@ -524,13 +538,13 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
         const bool full = m0 + BM <= M && n0 + GBN <= N;
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
-            const int row = m0 + wm * (BM / 2) + ti * 32 + j;
-            float *crow = C + (size_t)row * ldc + n0 + wn * 64 + 4 * h;
+            const int row = m0 + wm * WROWS + ti * 32 + j;
+            float *crow = C + (size_t)row * ldc + n0 + wn * WCOLS + 4 * h;
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
+            for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    if (!full && (row >= M || n0 + wn * 64 + 4 * h + 32 * tj + 8 * s >= N)) continue;
+                    if (!full && (row >= M || n0 + wn * WCOLS + 4 * h + 32 * tj + 8 * s >= N)) continue;
                     f32x4 *p = reinterpret_cast<f32x4 *>(crow + 32 * tj + 8 * s);
                     f32x4 v = {acc[ti][tj][4 * s], acc[ti][tj][4 * s + 1], acc[ti][tj][4 * s + 2], acc[ti][tj][4 * s + 3]};
                     if (accumulate) v += *p;
@@ -543,7 +557,7 @@ __device__ __forceinline__ void gemm_fast_body(float (*As)[GBK * GLD], float (*B
 #pragma unroll
                 for (int ti = 0; ti < TI; ++ti) {
                     const float v = asum[ti] + __shfl_xor(asum[ti], 32);   // the two k parities
-                    const int m = m0 + wm * (BM / 2) + ti * 32 + j;
+                    const int m = m0 + wm * WROWS + ti * 32 + j;
                     if (h == 0 && m < M) csum_out[m] = v;
                 }
             }
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const float *__restrict_
                                                         int accumulate) {
     __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
-    gemm_fast_body<OP, BM>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, ldc, k_chunk, c_slice, accumulate, (int)blockIdx.x,
+    gemm_fast_body<OP, BM, EPI_NONE, false, BM == 96 ? 4 : 2>(As, Bs, A, B, C, bias, M, N, K, lda, ldb, ldc, k_chunk, c_slice, accumulate, (int)blockIdx.x,
                            (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x);
 }
 
@@ -610,10 +624,11 @@ struct TnBatch {
 __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(const TnBatch q) {
     __shared__ __attribute__((aligned(16))) float As[2][GBK * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GBK * GLD];
+    const int block = (int)blockIdx.x;
     int jb = 0;
-    while (jb + 1 < q.njobs && (int)blockIdx.x >= q.job[jb + 1].first_block) ++jb;
+    while (jb + 1 < q.njobs && block >= q.job[jb + 1].first_block) ++jb;
     const TnBatchJob &t = q.job[jb];
-    const int local = blockIdx.x - t.first_block, z = local / t.blocks_per_slice, tile = local % t.blocks_per_slice;
+    const int local = block - t.first_block, z = local / t.blocks_per_slice, tile = local % t.blocks_per_slice;
     if (t.csum_slices != nullptr)
         gemm_fast_body<2, 128, EPI_NONE, true>(As, Bs, t.A, t.B, t.slices, nullptr, t.M, t.N, q.R, t.lda, t.ldb, t.N, q.chunk,
                                                (size_t)t.M * t.N, 0, tile % t.tiles_n, tile / t.tiles_n, z, 1, nullptr, nullptr,
@@ -810,10 +825,12 @@ static void gemm_go(const float *A, const float *B, float *C, const float *bias,
                     int ldc, bool accumulate, hipStream_t st) {
     const int ntiles = ((N + GBN - 1) / GBN) * ((M + BM - 1) / BM);
     const int cus = current_device_cus();
-    const dim3 grid(std::min(ntiles, cus * (BM == 128 ? 2 : 4)), 1, 1);   // resident workgroups per CU (VGPR bound: 192 / 120); swept 2..8
+    const dim3 grid(std::min(ntiles, cus * (BM == 128 ? 2 : BM == 96 ? 3 : 4)), 1, 1);   // resident workgroups per CU (VGPR bound); swept 2..8
     if (gemm_fast_ok(OP, M, N, K, lda, ldb, ldc))
         hipLaunchKernelGGL((gemm_fast_kernel<OP, BM>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
                            (int)accumulate);
+    else if constexpr (BM == 96)
+        return;   // (not reached: launch_gemm asks for 96 rows on the aligned path only)
     else if (gemm_vec_ok(OP, A, B, M, N, K, lda, ldb))
         hipLaunchKernelGGL((gemm_kernel<OP, BM, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, K, (size_t)0,
                            (int)accumulate);
@@ -825,8 +842,26 @@ static void gemm_go(const float *A, const float *B, float *C, const float *bias,
 hipError_t launch_gemm(int op, const float *A, const float *B, float *C, const float *bias, int M, int N, int K, int lda,
                        int ldb, int ldc, bool accumulate, hipStream_t st) {
     // 64-row tiles: the tile-walking kernel then needs 120 VGPRs (4 workgroups per CU) instead of 192 (2), which
-    // measures faster on every shape of the training step than 128-row tiles
-    if (op == 0) {
+    // measures faster on every shape of the training step than 128-row tiles.  96-row tiles (3 workgroups per CU) where they save a
+    // ROUND of tiles over the resident workgroups (round 6; the model below counts rounds x rows a CU works through) -- the same bits.
+    // Only for one column tile (N <= 128): the 96-row kernel itself is 5-10 % slower per flop (three waves per SIMD, 24 MFMAs between
+    // barriers) and wins only where the 64-row form leaves a lone last round -- 71 680 rows x (384 -> 128): 70.5 -> 67.9 us; with
+    // several column tiles it measured slower at every row count (tools/debug/gemm_tile_ab.py).
+    int rows = 64;
+    if (gemm_fast_ok(op, M, N, K, lda, ldb, ldc) && (N <= GBN || switch_int("AFT_GEMM_BM", 0) == 96)) {
+        const int forced = switch_int("AFT_GEMM_BM", 0);
+        const long long cus = current_device_cus(), ntn = (N + GBN - 1) / GBN;
+        auto cost = [&](int bm, int per_cu) {
+            const long long tiles = (M + bm - 1) / bm * ntn, slots = cus * per_cu;
+            return (tiles + slots - 1) / slots * bm * per_cu;
+        };
+        rows = forced == 64 || forced == 96 ? forced : cost(96, 3) < cost(64, 4) ? 96 : 64;
+    }
+    if (op == 0 && rows == 96) {
+        gemm_go<0, 96>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
+    } else if (op == 1 && rows == 96) {
+        gemm_go<1, 96>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
+    } else if (op == 0) {
         gemm_go<0, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);
     } else if (op == 1) {
         gemm_go<1, 64>(A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, st);

@@ -510,6 +510,41 @@ def test_dense_layer_forward_backward_matches_autograd(rows, in_f, out_f, bias):
         assert _rel(a, b) <= 1e-4
 
 
+@pytest.mark.parametrize("rows,in_f,out_f", [(71680, 128, 384), (71680, 384, 128), (1000, 128, 132), (2064, 48, 200), (97, 64, 128),
+                                              (35840, 128, 256)])
+def test_dense_layer_96_row_tiles_have_the_64_row_tiles_bits(rows, in_f, out_f, switches):
+    """Round 6: the plain NT / NN products pick 96-row output tiles (three workgroups per CU) where that saves a round of tiles over the
+    resident workgroups (71 680 token rows: 747 tiles on 768 workgroups instead of 1 120 on 1 024).  Every output element sums its k
+    steps in the same order in both tilings: forced either way (switch AFT_GEMM_BM) or chosen, the SAME bits -- full, ragged row and
+    ragged column tiles."""
+    from adafortitran_amd.training import HipLinear
+    torch.manual_seed(rows + in_f)
+    lin = HipLinear(in_f, out_f, bias=True).cuda()
+    lin.hip_training = True
+    x = torch.randn(rows, in_f, device="cuda", requires_grad=True)
+    gy = torch.randn(rows, out_f, device="cuda")
+
+    def run(bm):
+        if bm is None:
+            switches.unset("AFT_GEMM_BM")
+        else:
+            switches.set("AFT_GEMM_BM", bm)
+        lin.zero_grad(); x.grad = None
+        y = lin(x)
+        y.backward(gy)
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in lin.parameters()]
+
+    ref = run("64")
+    for bm in ("96", None):
+        got = run(bm)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), (bm, i)
+    lin.hip_training = False
+    lin.zero_grad(); x.grad = None
+    y0 = lin(x); y0.backward(gy)
+    assert _rel(ref[0], y0.detach()) <= 1e-5 and _rel(ref[1], x.grad) <= 1e-5
+
+
 def _random_train_specs(n, seed):
     rng = np.random.default_rng(seed)
     out = []
