@@ -129,9 +129,18 @@ __global__ __launch_bounds__(256) void wgrad32x8_kernel(const Wgrad32x8Args a) {
 // One thread per pixel position (row fastest) of kWg81Planes consecutive planes: the 72 accumulators run over the
 // planes in registers and meet in ONE wave reduction per workgroup (round 1 reduced after every single plane: 72 x 6
 // cross-lane steps per pixel were the whole 40 us of this kernel); one slice per workgroup.
+// Both products of a stack (conv1: g1 x input, shift +; conv4: a3 x dy, shift -) in ONE launch: blockIdx.z picks the product (round 6).
 constexpr int kWg81Planes = 8;
-__global__ __launch_bounds__(256) void wgrad8x1_kernel(const float *__restrict__ A8, const float *__restrict__ B1,
-                                                       float *__restrict__ slices, int planes, int S, int T, int sign) {
+struct Wgrad8x1Args {
+    const float *A8[2], *B1[2];
+    float *slices[2];
+    int sign[2];
+    int planes, S, T;
+};
+__global__ __launch_bounds__(256) void wgrad8x1_kernel(const Wgrad8x1Args a) {
+    const float *__restrict__ A8 = a.A8[blockIdx.z], *__restrict__ B1 = a.B1[blockIdx.z];
+    float *__restrict__ slices = a.slices[blockIdx.z];
+    const int planes = a.planes, S = a.S, T = a.T, sign = a.sign[blockIdx.z];
     __shared__ float red[4 * 36 * 65];
     const int p = blockIdx.x * 256 + threadIdx.x;   // p = t * S + s
     const int n0 = blockIdx.y * kWg81Planes, n1 = min(planes, n0 + kWg81Planes);
@@ -187,19 +196,28 @@ __global__ __launch_bounds__(256) void wgrad8x1_kernel(const float *__restrict__
     }
 }
 
-// per-channel sums of X [planes][C][npix] (bias gradients): one workgroup per (plane, channel),
-// slices[plane][C]
-__global__ __launch_bounds__(256) void chsum_kernel(const float *__restrict__ X, float *__restrict__ slices, int npix) {
+// per-channel sums of X [planes][C][npix] (bias gradients): one workgroup per (plane, channel), slices[plane][C]; the four tensors of a
+// stack (g1, g2, g3, dy: 8 + 32 + 8 + 1 channels) in ONE launch (round 6: four launches of 5-13 us each before)
+struct ChsumArgs {
+    const float *X[4];
+    float *slices[4];
+    int first[5];   // first[k] = blocks before tensor k = planes * (channels of tensors < k)
+    int npix;
+};
+__global__ __launch_bounds__(256) void chsum_kernel(const ChsumArgs a) {
     __shared__ float part[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float *x = X + (size_t)blockIdx.x * npix;   // blockIdx.x = plane * C + channel
+    const int k = (int)blockIdx.x >= a.first[3] ? 3 : (int)blockIdx.x >= a.first[2] ? 2 : (int)blockIdx.x >= a.first[1] ? 1 : 0;
+    const int local = (int)blockIdx.x - a.first[k], npix = a.npix;   // local = plane * C + channel
+    float *__restrict__ slices = a.slices[k] + local;
+    const float *x = a.X[k] + (size_t)local * npix;
     float v = 0.f;
     for (int p = threadIdx.x; p < npix; p += 256) v += x[p];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     if (lane == 0) part[wave] = v;
     __syncthreads();
-    if (threadIdx.x == 0) slices[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    if (threadIdx.x == 0) *slices = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // The data gradient of the stack is the stack itself run on dy with the transposed, flipped weights
@@ -256,18 +274,24 @@ hipError_t launch_conv_wgrad(const float *x, const float *c1, const float *c2, c
     if ((e = launch_reduce_slices(sl3, dw[2], 2304, grid, 2304, accumulate, st)) != hipSuccess) return e;
     // conv1: dW1[co][tap] = sum g1[co][p] x[p + (tap-1)];  conv4: dW4[ci][tap] = sum a3[ci][p'] dy[p' - (tap-1)]
     const int pchunks = (planes + kWg81Planes - 1) / kWg81Planes;
-    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, pchunks), dim3(256), 0, st, g1, x, sl1, planes, S, T, +1);
+    const Wgrad8x1Args w81{{g1, c3}, {x, dy}, {sl1, sl4}, {+1, -1}, planes, S, T};
+    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, pchunks, 2), dim3(256), 0, st, w81);
     if ((e = launch_reduce_slices(sl1, dw[0], 72, pchunks * pblocks, 72, accumulate, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(wgrad8x1_kernel, dim3(pblocks, pchunks), dim3(256), 0, st, c3, dy, sl4, planes, S, T, -1);
     if ((e = launch_reduce_slices(sl4, dw[3], 72, pchunks * pblocks, 72, accumulate, st)) != hipSuccess) return e;
     // biases: channel sums of the pre-activation gradients
     const float *gs[4] = {g1, g2, g3, dy};
     const int cs[4] = {8, 32, 8, 1};
+    ChsumArgs ca{};
+    ca.npix = npix;
     for (int k = 0; k < 4; ++k) {
-        hipLaunchKernelGGL(chsum_kernel, dim3(planes * cs[k]), dim3(256), 0, st, gs[k], slb, npix);
-        if ((e = launch_reduce_slices(slb, db[k], cs[k], planes, cs[k], accumulate, st)) != hipSuccess) return e;
+        ca.X[k] = gs[k];
+        ca.slices[k] = slb;
+        ca.first[k + 1] = ca.first[k] + planes * cs[k];
         slb += (size_t)planes * cs[k];
     }
+    hipLaunchKernelGGL(chsum_kernel, dim3(ca.first[4]), dim3(256), 0, st, ca);
+    for (int k = 0; k < 4; ++k)
+        if ((e = launch_reduce_slices(ca.slices[k], db[k], cs[k], planes, cs[k], accumulate, st)) != hipSuccess) return e;
     if ((e = reductions.flush(st)) != hipSuccess) return e;
     return hipGetLastError();
 }
