@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, Dict, Optional
 
-AFT_ABI_VERSION = 7
+AFT_ABI_VERSION = 8
 AFT_ENGINE_PACKED, AFT_ENGINE_GENERAL = 0, 1
 AFT_OK, AFT_ERR_ARG, AFT_ERR_SHAPE, AFT_ERR_HIP = 0, 1, 2, 3
 AFT_ACT_RELU, AFT_ACT_GELU = 0, 1
@@ -144,9 +144,12 @@ EXPORTED_SYMBOLS = (
     "aft_conv_enhancer_fwd_train_f32", "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_fwd_scratch_bytes", "aft_conv_enhancer_bwd_f32",
     "aft_dense_fwd_f32", "aft_dense_bwd_scratch_bytes", "aft_dense_bwd_f32",
     "aft_adapter_fwd_train_f32", "aft_adapter_bwd_f32",
+    "aft_embed_bwd_scratch_bytes", "aft_embed_fwd_train_f32", "aft_embed_bwd_f32",
+    "aft_tail_bwd_scratch_bytes", "aft_tail_fwd_train_f32", "aft_tail_bwd_f32",
 )
 #: size queries (return size_t, not a status code)
 SIZE_SYMBOLS = ("aft_workspace_bytes", "aft_packed_weights_bytes", "aft_encoder_tape_bytes", "aft_encoder_train_scratch_bytes",
-                "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_fwd_scratch_bytes", "aft_dense_bwd_scratch_bytes")
+                "aft_conv_enhancer_scratch_bytes", "aft_conv_enhancer_fwd_scratch_bytes", "aft_dense_bwd_scratch_bytes",
+                "aft_embed_bwd_scratch_bytes", "aft_tail_bwd_scratch_bytes")
 REGION_IDS = {"conv_enhanced": 0, "tokens6": 1, "enc_out": 2}   # aft_workspace_region
 KERNEL_IDS = {"upsample": 0, "embed": 1, "qkv": 2, "attention": 3, "chain": 4, "tail": 5, "chain_last": 6, "encoder_plane": 7, "prologue": 8}

@@ -103,6 +103,15 @@ def load_path(path: str):
     lib.aft_adapter_fwd_train_f32.argtypes = [C.POINTER(p3), C.POINTER(p9), C.POINTER(p9), C.POINTER(i3), C.c_int, C.c_int, vp, vp, vp, vp]
     lib.aft_adapter_bwd_f32.argtypes = [C.POINTER(p3), C.POINTER(p9), C.POINTER(p9), C.POINTER(i3), C.c_int, C.c_int, vp, vp, vp,
                                         vp, vp, C.POINTER(p9), C.POINTER(p9), C.c_int, vp]
+    i6 = [C.c_int] * 6   # planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim
+    lib.aft_embed_bwd_scratch_bytes.restype = C.c_size_t
+    lib.aft_embed_bwd_scratch_bytes.argtypes = i6 + [C.c_int]
+    lib.aft_embed_fwd_train_f32.argtypes = [vp] * 6 + i6 + [vp]
+    lib.aft_embed_bwd_f32.argtypes = [vp] * 9 + [C.c_int, vp, C.c_size_t] + i6 + [vp]
+    lib.aft_tail_bwd_scratch_bytes.restype = C.c_size_t
+    lib.aft_tail_bwd_scratch_bytes.argtypes = i6
+    lib.aft_tail_fwd_train_f32.argtypes = [vp] * 5 + i6 + [vp]
+    lib.aft_tail_bwd_f32.argtypes = [vp] * 6 + [C.c_int, vp, C.c_size_t] + i6 + [vp]
     lib.aft_adam_step_f32.argtypes = [vp, vp, vp, vp, C.c_size_t] + [C.c_float] * 6 + [C.c_int, vp]
     for name in _abi.EXPORTED_SYMBOLS:
         if name not in _abi.SIZE_SYMBOLS + ("aft_version", "aft_last_error", "aft_max_batch"):

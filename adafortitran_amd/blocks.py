@@ -179,6 +179,39 @@ class TransformerEncoderForChannels(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = self.positional_encoding(self.linear_1(x))
+        return self.linear_2(self.run_layers(h))
+
+    #: the two thin ends (patch embedding + linear_1 + positions; linear_2 + inverse patch embedding + residual) as one launch each in
+    #: the HIP training path (training.HipEmbedFunction / HipTailFunction); False = PyTorch's unfold / cat / add around HipLinear (A/B)
+    fused_ends = True
+
+    def positional_table(self) -> torch.Tensor:
+        pe = self.positional_encoding
+        return pe.position_embeddings if hasattr(pe, "position_embeddings") else pe.pe
+
+    def fused_ends_ok(self, conv_enhanced: torch.Tensor, patch) -> bool:
+        """True when the estimator may hand this encoder the conv-enhanced planes themselves (``forward_planes``)."""
+        from . import _lib
+        from .training import HipLinear
+        p = patch[0] * patch[1]
+        l1, l2, d = self.linear_1, self.linear_2, self.linear_1.out_features
+        on = lambda lin: HipLinear.default_hip_training if lin.hip_training is None else lin.hip_training
+        return (self.fused_ends and not _lib.get_switch("AFT_TRAIN_NO_FUSED_ENDS") and conv_enhanced.dim() == 3
+                and conv_enhanced.device.type == "cuda" and torch.is_grad_enabled() and conv_enhanced.dtype == torch.float32
+                and conv_enhanced.shape[0] % 2 == 0 and self.hip_train_gap() is None and on(l1) and on(l2)
+                and l1.bias is not None and l2.bias is not None and l1.weight.dtype == torch.float32
+                and p <= 32 and d % 4 == 0 and d <= 512 and l2.out_features == p and l1.in_features in (p, p + 6))
+
+    def forward_planes(self, conv_enhanced: torch.Tensor, adapter_tokens: Optional[torch.Tensor], patch) -> torch.Tensor:
+        """conv_enhanced [P,S,T] (+ adapter tokens [P,tokens,6]) -> conv_enhanced + InversePatchEmbedding(encoder(tokens)): what the
+        estimator computes around this module (reference fortitran.py:212-227), with both thin ends on the library's kernels."""
+        from .training import HipEmbedFunction, HipTailFunction
+        h = HipEmbedFunction.apply(conv_enhanced, adapter_tokens, self.linear_1.weight, self.linear_1.bias, self.positional_table(),
+                                   tuple(patch))
+        h = self.run_layers(h)
+        return HipTailFunction.apply(h, self.linear_2.weight, self.linear_2.bias, conv_enhanced, tuple(patch))
+
+    def run_layers(self, h: torch.Tensor) -> torch.Tensor:
         if self._hip_train_eligible(h):
             # grad-enabled forward on the HIP device: hand-written forward/backward kernels for the
             # encoder layers (training.py); everything else differentiates through PyTorch-ROCm.
@@ -188,10 +221,8 @@ class TransformerEncoderForChannels(nn.Module):
             cfg = _abi.make_config(ofdm=(h.shape[1], 1), pilot=(1, 1), patch=(1, 1), num_layers=len(self.transformer.layers),
                                    model_dim=h.shape[2], num_head=layer0.self_attn.num_heads,
                                    activation="gelu" if layer0.activation is F.gelu else "relu")
-            h = encoder_stack_train(h, list(self.transformer.layers), cfg, layer0.dropout.p if self.training else 0.0)
-        else:
-            h = self.transformer(h)
-        return self.linear_2(h)
+            return encoder_stack_train(h, list(self.transformer.layers), cfg, layer0.dropout.p if self.training else 0.0)
+        return self.transformer(h)
 
     #: set to False to differentiate the encoder through PyTorch-ROCm autograd instead (A/B tests)
     hip_training = True

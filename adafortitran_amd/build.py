@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ("aft_api.hip", "aft_train.hip", "k_chain.hip", "k_attn.hip", "k_encoder.hip", "k_conv.hip", "k_conv_stream.hip", "k_conv_rows.hip", "k_misc.hip", "k_gemm.hip",
-           "k_attn_train.hip", "k_train.hip", "k_conv_train.hip", "k_chain_bwd.hip")
+           "k_attn_train.hip", "k_train.hip", "k_conv_train.hip", "k_chain_bwd.hip", "k_ends_train.hip")
 LIB = os.path.join(CSRC, "libaft_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -389,6 +389,20 @@ hipError_t launch_adapter_train_bwd(const float *const cond[3], const float *con
                                     const int hidden[3], int tokens, int frames, const float *a0, const float *a1,
                                     const float *dtok, float *da0, float *da1, float *const dw[9], float *const db[9],
                                     bool accumulate, hipStream_t st);
+// k_ends_train.hip: patch embedding + linear_1 + positions, and linear_2 + inverse patch embedding + residual, forward and backward
+bool ends_train_ok(int planes, int S, int T, int p0, int p1, int d, bool adapter);
+size_t embed_bwd_slice_floats(int planes, int S, int T, int p0, int p1, int d, bool adapter);
+size_t tail_bwd_slice_floats(int planes, int S, int T, int p0, int p1, int d);
+// (tok6_per_frame: adapter features [frames][tokens][6] shared by a frame's two INTERLEAVED planes -- the general engine's forward)
+hipError_t launch_embed_train_fwd(const float *conv, const float *tok6, const float *w1, const float *b1, const float *pos, float *x,
+                                  int planes, int S, int T, int p0, int p1, int d, hipStream_t st, bool tok6_per_frame = false);
+hipError_t launch_embed_train_bwd(const float *conv, const float *tok6, const float *w1, const float *dx, float *d_conv, float *d_tok6,
+                                  float *dw1, float *db1, float *dpos, bool accumulate, float *slices, int planes, int S, int T, int p0,
+                                  int p1, int d, hipStream_t st);
+hipError_t launch_tail_train_fwd(const float *x, const float *w2, const float *b2, const float *resid, float *out, int planes, int S, int T,
+                                 int p0, int p1, int d, hipStream_t st);
+hipError_t launch_tail_train_bwd(const float *x, const float *w2, const float *d_out, float *dx, float *dw2, float *db2, bool accumulate,
+                                 float *slices, int planes, int S, int T, int p0, int p1, int d, hipStream_t st);
 hipError_t launch_adam(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps,
                        float wd, float grad_scale, int step, hipStream_t st);
 

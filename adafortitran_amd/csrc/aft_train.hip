@@ -329,6 +329,74 @@ int aft_dense_bwd_f32(const float *x, const float *weight, const float *dy, floa
     return AFT_OK;
 }
 
+size_t aft_embed_bwd_scratch_bytes(int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols, int model_dim,
+                                   int with_tokens6) {
+    return sizeof(float) * embed_bwd_slice_floats(planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim, with_tokens6 != 0);
+}
+
+int aft_embed_fwd_train_f32(const float *conv_enhanced, const float *tokens6, const float *w1, const float *b1, const float *pos,
+                            float *x0, int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols, int model_dim,
+                            void *stream) {
+    if (!conv_enhanced || !w1 || !b1 || !pos || !x0 ||
+        !ends_train_ok(planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim, tokens6 != nullptr)) {
+        set_error("bad embed argument (patch of at most 32 elements, model_dim a multiple of 4 up to 512)");
+        return AFT_ERR_ARG;
+    }
+    STEP("embed forward", launch_embed_train_fwd(conv_enhanced, tokens6, w1, b1, pos, x0, planes, num_scs, num_symbols, patch_scs,
+                                                 patch_symbols, model_dim, static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
+int aft_embed_bwd_f32(const float *conv_enhanced, const float *tokens6, const float *w1, const float *dx0, float *d_conv_enhanced,
+                      float *d_tokens6, float *dw1, float *db1, float *dpos, int accumulate, void *scratch, size_t scratch_bytes,
+                      int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols, int model_dim, void *stream) {
+    if (!conv_enhanced || !w1 || !dx0 || !d_conv_enhanced || !dw1 || !scratch || (tokens6 != nullptr) != (d_tokens6 != nullptr) ||
+        !ends_train_ok(planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim, tokens6 != nullptr)) {
+        set_error("bad embed argument (patch of at most 32 elements, model_dim a multiple of 4 up to 512)");
+        return AFT_ERR_ARG;
+    }
+    if (scratch_bytes < aft_embed_bwd_scratch_bytes(planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim, tokens6 != nullptr)) {
+        set_error("embed scratch too small");
+        return AFT_ERR_ARG;
+    }
+    STEP("embed backward", launch_embed_train_bwd(conv_enhanced, tokens6, w1, dx0, d_conv_enhanced, d_tokens6, dw1, db1, dpos,
+                                                  accumulate != 0, static_cast<float *>(scratch), planes, num_scs, num_symbols, patch_scs,
+                                                  patch_symbols, model_dim, static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
+size_t aft_tail_bwd_scratch_bytes(int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols, int model_dim) {
+    return sizeof(float) * tail_bwd_slice_floats(planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim);
+}
+
+int aft_tail_fwd_train_f32(const float *x, const float *w2, const float *b2, const float *resid, float *out, int planes, int num_scs,
+                           int num_symbols, int patch_scs, int patch_symbols, int model_dim, void *stream) {
+    if (!x || !w2 || !b2 || !resid || !out || !ends_train_ok(planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim, false)) {
+        set_error("bad tail argument (patch of at most 32 elements, model_dim a multiple of 4 up to 512)");
+        return AFT_ERR_ARG;
+    }
+    STEP("tail forward", launch_tail_train_fwd(x, w2, b2, resid, out, planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim,
+                                               static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
+int aft_tail_bwd_f32(const float *x, const float *w2, const float *d_out, float *dx, float *dw2, float *db2, int accumulate,
+                     void *scratch, size_t scratch_bytes, int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols,
+                     int model_dim, void *stream) {
+    if (!x || !w2 || !d_out || !dx || !dw2 || !scratch ||
+        !ends_train_ok(planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim, false)) {
+        set_error("bad tail argument (patch of at most 32 elements, model_dim a multiple of 4 up to 512)");
+        return AFT_ERR_ARG;
+    }
+    if (scratch_bytes < aft_tail_bwd_scratch_bytes(planes, num_scs, num_symbols, patch_scs, patch_symbols, model_dim)) {
+        set_error("tail scratch too small");
+        return AFT_ERR_ARG;
+    }
+    STEP("tail backward", launch_tail_train_bwd(x, w2, d_out, dx, dw2, db2, accumulate != 0, static_cast<float *>(scratch), planes, num_scs,
+                                                num_symbols, patch_scs, patch_symbols, model_dim, static_cast<hipStream_t>(stream)));
+    return AFT_OK;
+}
+
 size_t aft_conv_enhancer_scratch_bytes(int planes, int num_scs, int num_symbols) {
     if (planes <= 0 || num_scs <= 0 || num_symbols <= 0 || !conv_plan_ok(num_scs, num_symbols, 0)) return 0;
     return sizeof(float) * (al64((size_t)planes * 48 * num_scs * num_symbols) + al64(conv_wgrad_slice_floats(planes, num_scs, num_symbols)) +

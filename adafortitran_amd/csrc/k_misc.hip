@@ -515,6 +515,13 @@ hipError_t launch_embed_any(const aft_config &c, const WeightsDev &w, const floa
     a.din = a.p0 * a.p1 + (c.adaptive ? 6 : 0);
     a.planes = 2 * batch;
     if (a.p0 * a.p1 > kMaxPatchGeneral || (c.adaptive && tokens6 == nullptr)) return hipErrorInvalidValue;
+    // Round 6 (late): the training path's embedding kernel (k_ends_train.hip: persistent workgroups, W1^T staged once per workgroup,
+    // 32-row tiles) computes the same sums in the same order -- bias + position first, then the features ascending -- and does not
+    // re-read W1's rows per 8 token rows (embed_any_kernel: 326 us at d = 512 / 128 frames, 0.45 TB/s of a write-bound stage).
+    // AFT_EMBED_ANY_OLD keeps the kernel below (A/B, tests).
+    if (!switch_on("AFT_EMBED_ANY_OLD") && ends_train_ok(a.planes, a.S, a.T, a.p0, a.p1, a.d, c.adaptive != 0))
+        return launch_embed_train_fwd(conv_enhanced, c.adaptive ? tokens6 : nullptr, w.lin1_w, w.lin1_b, w.pos, x, a.planes, a.S, a.T, a.p0,
+                                      a.p1, a.d, st, true);
     const long rows = (long)a.planes * a.tokens;
     hipLaunchKernelGGL(embed_any_kernel, dim3((unsigned)((rows + kEmbAnyRows - 1) / kEmbAnyRows)), dim3(256), 0, st, a);
     return hipGetLastError();

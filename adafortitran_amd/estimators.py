@@ -389,11 +389,17 @@ class BaseFortiTranEstimator(nn.Module):
         B = x.shape[0]
         grid = self.pilot_upsampler(x.reshape(B, -1)).view(B, 1, *self.ofdm_size)
         conv_enhanced = self.initial_enhancer(grid).squeeze(1)
-        tokens = self.patch_embedder(conv_enhanced)
-        if self.use_channel_adaptation and channel_conditions is not None:
-            tokens = torch.cat((tokens, self.channel_adapter(*channel_conditions)), dim=2)
-        encoded = self.transformer_encoder(tokens)
-        combined = conv_enhanced + self.patch_reconstructor(encoded)
+        adaptive = self.use_channel_adaptation and channel_conditions is not None
+        enc, patch = self.transformer_encoder, self.patch_embedder.patch_size
+        if enc.fused_ends_ok(conv_enhanced, patch) and enc.linear_1.in_features == patch[0] * patch[1] + (6 if adaptive else 0):
+            # HIP training path: embedding and reconstruction as one launch each (training.HipEmbedFunction / HipTailFunction)
+            combined = enc.forward_planes(conv_enhanced, self.channel_adapter(*channel_conditions) if adaptive else None, patch)
+        else:
+            tokens = self.patch_embedder(conv_enhanced)
+            if adaptive:
+                tokens = torch.cat((tokens, self.channel_adapter(*channel_conditions)), dim=2)
+            encoded = self.transformer_encoder(tokens)
+            combined = conv_enhanced + self.patch_reconstructor(encoded)
         return self.final_refiner(combined.unsqueeze(1)).squeeze(1)
 
     def get_model_info(self) -> dict:

@@ -292,6 +292,101 @@ class HipLinear(torch.nn.Linear):
         return super().forward(x)
 
 
+class HipEmbedFunction(torch.autograd.Function):
+    """conv_enhanced [P,S,T], adapter tokens [P,tokens,6] | None, linear_1.weight [d,K], linear_1.bias [d], positional table
+    [1,max_len,d] (parameter or buffer) -> x0 [P,tokens,d] = linear_1(cat(PatchEmbedding(conv_enhanced), tokens)) + table[:, :tokens]
+    as ONE launch, and its backward as one launch + the slice reductions (``aft_embed_fwd_train_f32`` / ``aft_embed_bwd_f32``;
+    reference fortitran.py:212-217, blocks/encoders.py:67-68)."""
+
+    @staticmethod
+    def forward(ctx, conv, tok6, weight, bias, pos, patch):
+        lib = _lib.load()
+        conv = conv.contiguous()
+        tok6 = None if tok6 is None else tok6.contiguous()
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        table = pos.detach()
+        table = table[0] if table.dim() == 3 else table
+        P, S, T = conv.shape
+        p0, p1 = patch
+        tokens, d = (S // p0) * (T // p1), w.shape[0]
+        if not table.is_contiguous() or table.shape[0] < tokens or w.shape[1] != p0 * p1 + (0 if tok6 is None else 6):
+            raise ValueError("embed: positional table shorter than the token count, or linear_1's width does not match the patch")
+        x0 = torch.empty((P, tokens, d), dtype=torch.float32, device=conv.device)
+        _lib.check(lib.aft_embed_fwd_train_f32(conv.data_ptr(), None if tok6 is None else tok6.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                               table.data_ptr(), x0.data_ptr(), P, S, T, p0, p1, d, _lib.current_stream_ptr(conv.device)))
+        ctx.save_for_backward(conv, w, *(() if tok6 is None else (tok6,)))
+        ctx.param_objs, ctx.dims = (weight, bias, pos), (P, S, T, p0, p1, d)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        lib = _lib.load()
+        conv, w, *rest = ctx.saved_tensors
+        tok6 = rest[0] if rest else None
+        weight, bias, pos = ctx.param_objs
+        P, S, T, p0, p1, d = ctx.dims
+        dx0 = dx0.contiguous()
+        want_pos = bool(pos.requires_grad)
+        direct = direct_grad_ok((weight, bias) + ((pos,) if want_pos else ()))
+        dw = weight.grad if direct else torch.empty_like(w)
+        db = bias.grad if direct else torch.empty_like(bias)
+        dpos = None
+        if want_pos:
+            dpos = pos.grad if direct else torch.zeros_like(pos)   # the kernel writes the first `tokens` rows
+        d_conv = torch.empty_like(conv)
+        d_tok6 = None if tok6 is None else torch.empty_like(tok6)
+        nbytes = lib.aft_embed_bwd_scratch_bytes(P, S, T, p0, p1, d, int(tok6 is not None))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=conv.device)
+        _lib.check(lib.aft_embed_bwd_f32(conv.data_ptr(), None if tok6 is None else tok6.data_ptr(), w.data_ptr(), dx0.data_ptr(),
+                                         d_conv.data_ptr(), None if d_tok6 is None else d_tok6.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                         None if dpos is None else dpos.data_ptr(), int(direct), scratch.data_ptr(), scratch.numel(),
+                                         P, S, T, p0, p1, d, _lib.current_stream_ptr(conv.device)))
+        if direct:
+            return d_conv, d_tok6, None, None, None, None
+        return d_conv, d_tok6, dw, db, dpos, None
+
+
+class HipTailFunction(torch.autograd.Function):
+    """x [P,tokens,d], linear_2.weight [p,d], linear_2.bias [p], conv_enhanced [P,S,T] -> conv_enhanced +
+    InversePatchEmbedding(linear_2(x)) as ONE launch, backward one launch + the slice reductions (``aft_tail_fwd_train_f32`` /
+    ``aft_tail_bwd_f32``; reference blocks/encoders.py:70, fortitran.py:225-227)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, resid, patch):
+        lib = _lib.load()
+        x, resid = x.contiguous(), resid.contiguous()
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        P, S, T = resid.shape
+        p0, p1 = patch
+        d = x.shape[-1]
+        if w.shape != (p0 * p1, d) or x.shape[0] * x.shape[1] != P * (S // p0) * (T // p1):
+            raise ValueError("tail: linear_2 / token count do not match the patch geometry")
+        out = torch.empty_like(resid)
+        _lib.check(lib.aft_tail_fwd_train_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), resid.data_ptr(), out.data_ptr(), P, S, T, p0, p1, d,
+                                              _lib.current_stream_ptr(x.device)))
+        ctx.save_for_backward(x, w)
+        ctx.param_objs, ctx.dims = (weight, bias), (P, S, T, p0, p1, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        weight, bias = ctx.param_objs
+        P, S, T, p0, p1, d = ctx.dims
+        d_out = d_out.contiguous()
+        direct = direct_grad_ok((weight, bias))
+        dw = weight.grad if direct else torch.empty_like(w)
+        db = bias.grad if direct else torch.empty_like(bias)
+        dx = torch.empty_like(x)
+        scratch = torch.empty(lib.aft_tail_bwd_scratch_bytes(P, S, T, p0, p1, d), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.aft_tail_bwd_f32(x.data_ptr(), w.data_ptr(), d_out.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), int(direct),
+                                        scratch.data_ptr(), scratch.numel(), P, S, T, p0, p1, d, _lib.current_stream_ptr(x.device)))
+        if direct:
+            return dx, None, None, d_out, None
+        return dx, dw, db, d_out, None
+
+
 def layer_params(layer: torch.nn.Module):
     """The twelve parameter tensors of one nn.TransformerEncoderLayer, ABI order (_abi.LAYER_PARAM_NAMES).  Plain attribute reads:
     this runs for every layer of every step, and walking named_parameters() cost 0.2 ms of host time per step."""

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AFT_ABI_VERSION 7   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
+#define AFT_ABI_VERSION 8   /* bump whenever an entry point's meaning, a struct or a scratch size changes */
 
 #define AFT_OK 0
 #define AFT_ERR_ARG 1   /* NULL pointer, bad batch, workspace too small ...          */
@@ -322,6 +322,35 @@ int aft_adapter_bwd_f32(const float *const conditions[3], const float *const wei
                         const int32_t hidden[3], int tokens, int frames, const float *hidden0, const float *hidden1,
                         const float *dtokens6, float *dhidden0, float *dhidden1, float *const dweights[9],
                         float *const dbiases[9], int accumulate, void *stream);
+
+/* The two thin ends of the encoder in the training path (ABI 8), each ONE streaming launch per direction instead of PyTorch's
+ * unfold / cat / broadcast add around a 6- or 12-column GEMM.  `planes` = 2 x frames in the training composite's order
+ * [real planes | imaginary planes]; grid = num_scs x num_symbols, tokens = (num_scs / patch_scs) (num_symbols / patch_symbols),
+ * p = patch_scs patch_symbols <= 32, model_dim a multiple of 4 up to 512.
+ *   embed  (fortitran.py:212-217, blocks/patch_processors.py:22,34-35, blocks/encoders.py:67-68):
+ *     x0[planes*tokens, d] = cat(PatchEmbedding(conv_enhanced), tokens6) W1^T + b1 + pos[:tokens]
+ *     conv_enhanced f32 [planes,S,T]; tokens6 f32 [planes,tokens,6] PER PLANE or NULL (then W1 is [d,p], else [d,p+6]); pos f32
+ *     [>= tokens, d] (the learnable table's or the sinusoid buffer's first rows).
+ *     backward: dx0 -> d_conv_enhanced [planes,S,T] (every element written), d_tokens6 (NULL with tokens6 NULL), dW1, db1, dpos
+ *     [tokens,d] (NULL: no table gradient, e.g. the sinusoid); the parameter gradients are overwritten, or added to when
+ *     accumulate != 0.
+ *   tail   (blocks/encoders.py:70, blocks/patch_processors.py InversePatchEmbedding, fortitran.py:225-227):
+ *     out[planes,S,T] = resid + InversePatchEmbedding(x W2^T + b2),  x f32 [planes*tokens, d], W2 [p,d]
+ *     backward: d_out [planes,S,T] -> dx [planes*tokens,d], dW2, db2 (the residual's gradient IS d_out: nothing to compute). */
+size_t aft_embed_bwd_scratch_bytes(int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols, int model_dim,
+                                   int with_tokens6);
+int aft_embed_fwd_train_f32(const float *conv_enhanced, const float *tokens6, const float *w1, const float *b1, const float *pos,
+                            float *x0, int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols, int model_dim,
+                            void *stream);
+int aft_embed_bwd_f32(const float *conv_enhanced, const float *tokens6, const float *w1, const float *dx0, float *d_conv_enhanced,
+                      float *d_tokens6, float *dw1, float *db1, float *dpos, int accumulate, void *scratch, size_t scratch_bytes,
+                      int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols, int model_dim, void *stream);
+size_t aft_tail_bwd_scratch_bytes(int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols, int model_dim);
+int aft_tail_fwd_train_f32(const float *x, const float *w2, const float *b2, const float *resid, float *out, int planes, int num_scs,
+                           int num_symbols, int patch_scs, int patch_symbols, int model_dim, void *stream);
+int aft_tail_bwd_f32(const float *x, const float *w2, const float *d_out, float *dx, float *dw2, float *db2, int accumulate,
+                     void *scratch, size_t scratch_bytes, int planes, int num_scs, int num_symbols, int patch_scs, int patch_symbols,
+                     int model_dim, void *stream);
 
 /* Replaces torch.optim.Adam.step (reference src/main/trainer.py:407-413; amsgrad off) on one flat
  * float32 shard of n elements: grad is first multiplied by grad_scale (1/world_size after a

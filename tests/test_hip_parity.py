@@ -767,6 +767,36 @@ def test_general_engine_matches_oracle(oracle_lib, adaptive, d, heads):
         xin = dump["layer_out"][layer]
 
 
+@pytest.mark.parametrize("ofdm,pilot,patch,d,heads,adaptive", [((120, 14), (12, 2), (3, 2), 512, 8, True), ((96, 14), (12, 2), (12, 2), 200, 8, True),
+                                                              ((64, 16), (8, 2), (8, 4), 256, 2, False), ((12, 14), (4, 2), (3, 2), 8, 1, True)])
+def test_general_engine_embedding_kernels_give_the_same_bits(ofdm, pilot, patch, d, heads, adaptive, switches):
+    """Late round 6: the general engine's embedding runs the training path's forward kernel (k_ends_train.hip: W1^T staged once per
+    persistent workgroup; 326 -> ~30 us at d = 512) instead of embed_any_kernel (switch AFT_EMBED_ANY_OLD).  Both add bias + position
+    first and then the input features in ascending order: the same bits, through the stage entry point and through a whole forward."""
+    tokens = (ofdm[0] // patch[0]) * (ofdm[1] // patch[1])
+    spec = dict(ofdm=ofdm, pilot=pilot, patch=patch, num_layers=1, model_dim=d, num_head=heads)
+    hid = (5, 11, 2 * tokens) if adaptive else None
+    sd = synth.make_state_dict(**spec, adaptive_hidden=hid, seed=31, head_gain=2.0, max_seq_len=max(64, tokens))
+    cfg = _abi.make_config(**spec, adaptive_hidden=hid)
+    from adafortitran_amd.hip_ops import engine_from_numpy
+    inp = synth.make_inputs(5, ofdm=ofdm, pilot=pilot, seed=32)
+    meta = [(_t(inp[k]) if adaptive else None) for k in ("snr", "ds", "dop")]
+
+    def run():
+        eng = engine_from_numpy(cfg, sd, DEV)
+        out = eng.forward(_t(inp["pilots"]), *meta).clone()
+        x0 = eng.region("x").clone() if hasattr(eng, "region") else None
+        return out, x0
+
+    new, x_new = run()
+    switches.set("AFT_EMBED_ANY_OLD", "1")
+    old, x_old = run()
+    assert torch.isfinite(torch.view_as_real(new)).all()
+    assert torch.equal(torch.view_as_real(new), torch.view_as_real(old))
+    if x_new is not None:
+        assert torch.equal(x_new, x_old)
+
+
 @pytest.mark.parametrize("ofdm,pilot,patch,d,heads,layers", [((96, 14), (12, 2), (12, 2), 128, 4, 2),     # 24-element patch, 56 tokens
                                                             ((64, 16), (8, 2), (8, 4), 64, 2, 1),         # 32-element patch, 32 tokens
                                                             ((60, 20), (6, 4), (5, 5), 512, 8, 1),        # 25 elements at model_dim 512

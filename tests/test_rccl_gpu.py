@@ -100,6 +100,7 @@ def _dp_model_and_data(frames):
 def _dp_train(rank, world, steps=3):
     from adafortitran_amd.optim import ShardedFlatAdam
     frames = 8
+    steps = int(os.environ.get("AFT_DP_STEPS", steps))          # (tools/debug/dp_two_rank_diff.py looks at one and two steps)
     model, pil, meta, tgt = _dp_model_and_data(frames)
     lo, hi = rank * frames // world, (rank + 1) * frames // world
     opt = ShardedFlatAdam(model.parameters(), lr=1e-3) if world > 1 else torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -117,25 +118,39 @@ def _dp_train(rank, world, steps=3):
     return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy(), first_grad
 
 
+def _two_ranks_and_one_process(steps):
+    os.environ["AFT_DP_STEPS"] = str(steps)
+    try:
+        port = _free_port()
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+            got = dict(ret)
+        want, want_grad = _dp_train(0, 1)
+    finally:
+        os.environ.pop("AFT_DP_STEPS", None)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])      # the ranks hold the same bits
+    return got[0][0], got[0][1], want, want_grad
+
+
 def test_two_ranks_sharing_the_gpu_train_like_one_process():
     """SURVEY 8e/8f-1 on hardware at world size 2, as far as a 1-GPU box allows: frames sharded over the ranks, every rank's
     forward + backward on the HIP training kernels, ShardedFlatAdam's reduce-scatter -> fused Adam on the shard -> all-gather
-    on device buffers.  The ranks' averaged first gradient must equal ONE process's gradient on all the frames to 1e-5 of its
-    maximum (fp32 sums in another order); after three steps both ranks hold bit-identical parameters, within 5 % of the distance
-    the parameters travelled of the single process's (Adam's g / sqrt(v) turns rounding noise in near-zero gradients into
-    differences of a fraction of lr, so parameters are compared loosely and the gradient tightly)."""
-    port = _free_port()
-    with mp.Manager() as mgr:
-        ret = mgr.dict()
-        mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
-        got = dict(ret)
-    want, want_grad = _dp_train(0, 1)
-    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
-    gerr = np.abs(got[0][1] - want_grad).max()
+    on device buffers.  What must hold: both ranks keep bit-identical parameters; the ranks' averaged first gradient equals ONE
+    process's gradient on all the frames to 1e-5 of its maximum (fp32 sums in another order; measured 2e-8); after ONE step the
+    parameters agree to 1 % of lr (Adam's g / (sqrt(v) + eps) at |g| ~ eps = 1e-8 turns a relative 1e-4 of rounding noise into a
+    fraction of a percent; measured 0.3 %, all but one in ten thousand within 1e-4 of lr).  After three steps the two runs are two
+    trajectories of a chaotic map started 3e-6 apart -- the distance grows ~10 x per step whatever the kernels (measured maxima after
+    1 / 2 / 3 steps: 2.9e-6 / 9.2e-5 / 2.7e-4; a forward whose roundings differ in the last bit starts the same map somewhere else:
+    9.7e-6 / 1.3e-4 / 8.1e-4 was measured with another bias-add order in the embedding; `tools/debug/dp_two_rank_diff.py` lists
+    the tensors) -- so that comparison is loose by construction: all but one parameter in ten thousand within 5 % of the distance
+    travelled (3 steps x lr; measured 3.2 %), none beyond 20 % (measured 9 %)."""
+    lr = 1e-3
+    par, grad, want, want_grad = _two_ranks_and_one_process(1)
+    gerr = np.abs(grad - want_grad).max()
     assert gerr <= 1e-5 * np.abs(want_grad).max(), (gerr, np.abs(want_grad).max())
-    # parameters after three Adam steps: Adam's g / sqrt(v) turns rounding noise in near-zero gradients (and, from the second step on,
-    # a differing ReLU decision at a near-zero pre-activation: tests/test_train_golden.py) into differences of a fraction of lr for a
-    # FEW elements -- all but one in ten thousand within 5 % of the distance travelled (3 steps x lr 1e-3), none beyond 20 %
-    # (round 6: 3 % -> 5 %; with the 16x16x4 training conv kernel the 99.99th percentile reads 3.5 % -- the first gradient still agrees to 1e-5)
-    dpar = np.abs(got[0][0] - want)
-    assert np.quantile(dpar, 0.9999) <= 0.05 * 3 * 1e-3 and dpar.max() <= 0.2 * 3 * 1e-3, (np.quantile(dpar, 0.9999), dpar.max())
+    d1 = np.abs(par - want)
+    assert np.quantile(d1, 0.9999) <= 1e-3 * lr and d1.max() <= 0.01 * lr, (np.quantile(d1, 0.9999), d1.max())
+    par3, _, want3, _ = _two_ranks_and_one_process(3)
+    d3 = np.abs(par3 - want3)
+    assert np.quantile(d3, 0.9999) <= 0.05 * 3 * lr and d3.max() <= 0.2 * 3 * lr, (np.quantile(d3, 0.9999), d3.max())

@@ -545,6 +545,126 @@ def test_dense_layer_96_row_tiles_have_the_64_row_tiles_bits(rows, in_f, out_f, 
     assert _rel(ref[0], y0.detach()) <= 1e-5 and _rel(ref[1], x.grad) <= 1e-5
 
 
+ENDS_CASES = [((120, 14), (3, 2), 128, True, 4), ((120, 14), (3, 2), 128, False, 2), ((24, 14), (3, 2), 512, True, 2),
+              ((48, 16), (4, 4), 64, True, 6), ((96, 14), (12, 2), 200, False, 2), ((12, 14), (3, 2), 128, True, 256),
+              ((20, 6), (1, 1), 8, True, 2), ((64, 8), (8, 4), 256, True, 4)]
+
+
+@pytest.mark.parametrize("ofdm,patch,d,adaptive,planes", ENDS_CASES)
+def test_fused_embedding_end_matches_autograd(ofdm, patch, d, adaptive, planes):
+    """training.HipEmbedFunction (patch embedding + adapter concat + linear_1 + positional table: one launch each way) against the
+    PyTorch composite it replaces (reference fortitran.py:212-217, encoders.py:67-68): output, d(conv_enhanced), d(adapter tokens),
+    dW1, db1 and the positional table's gradient (rows beyond the token count stay zero).  Grids with partial token blocks, patches of
+    1 / 6 / 16 / 24 / 32 elements, model dims 8 .. 512, 2 .. 256 planes."""
+    from adafortitran_amd.blocks import PatchEmbedding
+    from adafortitran_amd.training import HipEmbedFunction
+    torch.manual_seed(ofdm[0] + d)
+    S, T = ofdm
+    p = patch[0] * patch[1]
+    tokens, K = (S // patch[0]) * (T // patch[1]), p + (6 if adaptive else 0)
+    conv = torch.randn(planes, S, T, device="cuda", requires_grad=True)
+    tok6 = torch.randn(planes, tokens, 6, device="cuda", requires_grad=True) if adaptive else None
+    w = (torch.randn(d, K, device="cuda") / K ** 0.5).requires_grad_(True)
+    b = torch.randn(d, device="cuda", requires_grad=True)
+    pos = torch.randn(1, tokens + 5, d, device="cuda", requires_grad=True)
+    gy = torch.randn(planes, tokens, d, device="cuda")
+    leaves = [t for t in (conv, tok6, w, b, pos) if t is not None]
+
+    def grads(y):
+        for t in leaves:
+            t.grad = None
+        y.backward(gy)
+        return [t.grad.clone() for t in leaves]
+
+    tk = PatchEmbedding(patch)(conv)
+    if adaptive:
+        tk = torch.cat((tk, tok6), dim=2)
+    y0 = torch.nn.functional.linear(tk, w, b) + pos[:, :tokens]
+    g0 = grads(y0)
+    y1 = HipEmbedFunction.apply(conv, tok6, w, b, pos, patch)
+    g1 = grads(y1)
+    assert _rel(y1.detach(), y0.detach()) <= 2e-6
+    for a, c in zip(g1, g0):
+        assert a.shape == c.shape and _rel(a, c) <= 2e-5, _rel(a, c)
+    assert torch.count_nonzero(g1[-1][:, tokens:]) == 0
+    # a table that carries no gradient (the sinusoid's buffer): same output, no table gradient asked for
+    y2 = HipEmbedFunction.apply(conv, tok6, w, b, pos.detach(), patch)
+    assert torch.equal(y2.detach(), y1.detach())
+    for t in leaves:
+        t.grad = None
+    y2.backward(gy)
+    assert pos.grad is None and torch.equal(conv.grad, g1[0]) and torch.equal(w.grad, g1[-3])
+
+
+@pytest.mark.parametrize("ofdm,patch,d,adaptive,planes", ENDS_CASES)
+def test_fused_reconstruction_end_matches_autograd(ofdm, patch, d, adaptive, planes):
+    """training.HipTailFunction (linear_2 + inverse patch embedding + the residual: one launch each way) against the PyTorch composite
+    (reference encoders.py:70, fortitran.py:225-227): output, dx, dW2, db2 and the residual's gradient."""
+    from adafortitran_amd.blocks import InversePatchEmbedding
+    from adafortitran_amd.training import HipTailFunction
+    torch.manual_seed(ofdm[1] + d)
+    S, T = ofdm
+    p = patch[0] * patch[1]
+    tokens = (S // patch[0]) * (T // patch[1])
+    x = torch.randn(planes, tokens, d, device="cuda", requires_grad=True)
+    w = (torch.randn(p, d, device="cuda") / d ** 0.5).requires_grad_(True)
+    b = torch.randn(p, device="cuda", requires_grad=True)
+    resid = torch.randn(planes, S, T, device="cuda", requires_grad=True)
+    gy = torch.randn(planes, S, T, device="cuda")
+    leaves = [x, w, b, resid]
+
+    def grads(y):
+        for t in leaves:
+            t.grad = None
+        y.backward(gy)
+        return [t.grad.clone() for t in leaves]
+
+    y0 = resid + InversePatchEmbedding(ofdm, patch)(torch.nn.functional.linear(x, w, b))
+    g0 = grads(y0)
+    y1 = HipTailFunction.apply(x, w, b, resid, patch)
+    g1 = grads(y1)
+    assert _rel(y1.detach(), y0.detach()) <= 2e-6
+    for a, c in zip(g1, g0):
+        assert a.shape == c.shape and _rel(a, c) <= 2e-5, _rel(a, c)
+
+
+def test_fused_ends_are_what_the_training_step_runs(switches):
+    """The estimator's grad-enabled forward hands the encoder the conv-enhanced planes (fused ends) by default; with the switch
+    AFT_TRAIN_NO_FUSED_ENDS it runs PyTorch's unfold / cat / add around HipLinear as before: same loss and gradients to rounding."""
+    import adafortitran_amd as A
+    from adafortitran_amd import synth
+    sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
+    torch.manual_seed(3)
+    model = A.AdaFortiTranEstimator(sc, A.ModelConfig(model_type="adafortitran", patch_size=(3, 2), num_layers=2, model_dim=128, num_head=4,
+                                                      device="cuda", dropout=0.0, channel_adaptivity_hidden_sizes=[7, 42, 560],
+                                                      adaptive_token_length=6)).train()
+    inp = synth.make_inputs(4, seed=10)
+    pil, tgt = torch.from_numpy(inp["pilots"]), torch.from_numpy(inp["target"]).to("cuda")
+    meta = synth.meta_tuple(inp)
+
+    def run():
+        model.zero_grad()
+        loss = torch.view_as_real(model(pil, meta) - tgt).pow(2).mean()
+        loss.backward()
+        return [loss.detach().clone()] + [p.grad.clone() for p in model.parameters()]
+
+    probe = torch.zeros(8, 120, 14, device="cuda")
+    enc = model.transformer_encoder
+    with torch.enable_grad():
+        assert enc.fused_ends_ok(probe, (3, 2))
+        fused = run()
+        switches.set("AFT_TRAIN_NO_FUSED_ENDS", "1")
+        assert not enc.fused_ends_ok(probe, (3, 2))
+        apart = run()
+    with torch.no_grad():
+        switches.unset("AFT_TRAIN_NO_FUSED_ENDS")
+        assert not enc.fused_ends_ok(probe, (3, 2))          # inference never takes the training kernels
+    for i, (a, c) in enumerate(zip(fused, apart)):
+        # the adapter's first layers are sums of ~1e5 cancelling terms of 1e-4 (2e-4 of |g|max between two summation orders; the
+        # float64 fixtures of test_train_golden.py hold every tensor of the fused path to its measured conditioning)
+        assert _rel(a, c) <= 1e-3, (i, _rel(a, c))
+
+
 def _random_train_specs(n, seed):
     rng = np.random.default_rng(seed)
     out = []

@@ -8,6 +8,7 @@ import numpy as np, torch
 from adafortitran_amd import _abi, _lib, synth
 from adafortitran_amd.hip_ops import engine_from_numpy
 lib = _lib.load_path(os.path.join(os.path.dirname(_lib.lib_path()), "libaft_hip_ldsbug.so"))
+lib.aft_set_switch(b"AFT_EMBED_ANY_OLD", b"1")   # the kernel the bug lived in (since late round 6 the product runs k_ends_train.hip's)
 spec = dict(ofdm=(120, 14), pilot=(12, 2), patch=(3, 2), num_layers=2, model_dim=512, num_head=8)
 sd = synth.make_state_dict(**spec, adaptive_hidden=(7, 42, 560), seed=3)
 cfg = _abi.make_config(**spec, adaptive_hidden=(7, 42, 560))
