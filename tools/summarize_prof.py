@@ -12,7 +12,7 @@ from collections import defaultdict
 def short(name):
     m = re.search(r"(chain_kernel<[^>]*>|chain_split_kernel<[^>]*>|chain_bwd_kernel<[^>]*>|encoder_plane_kernel<[^>]*>|attn_kernel<[^>]*>|attn_split_kernel|"
                   r"conv_stream16_kernel<[^>]*>|conv_stream_kernel<[^>]*>|conv_rows16_kernel<[^>]*>|conv_rows_kernel<[^>]*>|prologue_kernel|conv_stack_kernel<[^>]*>|conv_stack_kernel|embed_kernel<[^>]*>|adapter_kernel|mse_kernel|linear_kernel|pack_weights_kernel)", name)
-    return m.group(1) if m else name[:60]
+    return m.group(1) if m else name.replace("(anonymous namespace)::", "")[:60]
 
 
 for d in sys.argv[1:]:

@@ -19,7 +19,7 @@ if len(adam) < 2:
 win = rows[adam[-2] + 1: adam[-1] + 1]
 agg = defaultdict(lambda: [0, 0.0])
 for s, e, n in win:
-    n = re.sub(r"\(.*", "", n)
+    n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", ""))
     n = re.sub(r"^void ", "", n)[:72]
     agg[n][0] += 1
     agg[n][1] += (e - s) / 1e3
@@ -34,7 +34,7 @@ if "--timeline" in sys.argv:   # every dispatch of the step in launch order: sta
     print("\ntimeline (us): start  duration  gap  kernel")
     prev_end = win[0][0]
     for s, e, n in win:
-        n = re.sub(r"\(.*", "", n)
+        n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", ""))
         n = re.sub(r"^void ", "", n)[:60]
         print(f"  {(s - win[0][0]) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {(s - prev_end) / 1e3:6.1f}  {n}")
         prev_end = e
