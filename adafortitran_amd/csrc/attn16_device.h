@@ -46,9 +46,14 @@ __device__ __forceinline__ float groups_sum(float x) {
     return x + other_half(x);
 }
 
+// HD = 8 (late round 6; `num_head: 16` at `model_dim: 128`): a head is ONE 8-feature slot of the layouts, four heads per block.  The same
+// body with half of every 16-row / 16-deep operand unused: lane groups 2, 3 of the Q^T operand are zero (the logits contract the head's
+// 8 features; K's lane groups 2, 3 re-read groups 0, 1 -- finite, multiplied by zero), V^T's rows 8 .. 15 re-read rows 0 .. 7 and the
+// matching half of O^T is not stored.  Per task the matrix work of a 16-feature head -- half of it idle -- against the 32x32x2 body's
+// 32-feature block per 8-feature head (attn_kernel<8>: three quarters idle).
 // One WAVE walks the tasks first_task, first_task + total_waves, ... < ntasks, then (at most) `tail_task` -- as attn_body.
-// task = (plane * heads + head) * nkt + query tile; head = 2 block + sub.
-template <int TOK = 0>
+// task = (plane * heads + head) * nkt + query tile; head = (32 / HD) block + sub.
+template <int TOK = 0, int HD = 16>
 __device__ __forceinline__ void attn16_body(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ vt,
                                             const float *__restrict__ qbias, float *__restrict__ out, int nblk, int tokens_rt,
                                             int tokpad_rt, int model_dim, float scale_log2e, const int first_task, const int total_waves,
@@ -62,19 +67,24 @@ __device__ __forceinline__ void attn16_body(const float *__restrict__ q, const f
     const int nkt = tokpad / kTile;
     const bool ragged = (tokens & (kTile - 1)) != 0;
     const unsigned blk_bytes = (unsigned)tokpad * kHeadDim * 4;
-    auto first_block = [&](int task) { return (task / nkt) >> 1; };
-    auto sub_of = [&](int task) { return (task / nkt) & 1; };
-    // K or Q^T of 32-token tile `tile`: [half][t] = feature 16 sub + 4 g + t of token 16 half + i: one 16-byte piece per half
+    static_assert(HD == 16 || HD == 8, "heads of 16 or 8 features");
+    constexpr int NSUB = 32 / HD;                                   // heads per 32-feature block
+    auto first_block = [&](int task) { return (task / nkt) / NSUB; };
+    auto sub_of = [&](int task) { return (task / nkt) & (NSUB - 1); };
+    // the 8-feature slot of a block and the lane's feature inside the head: HD 16: slot 2 sub + g / 2; HD 8: slot sub (groups 2, 3 = 0, 1)
+    auto slot_of = [&](int sub) { return HD == 16 ? 2 * sub + (g >> 1) : sub; };
+    const int vfeat = HD == 16 ? i : (i & 7);                      // V^T row of lane i (HD 8: rows 8 .. 15 repeat 0 .. 7, never stored)
+    // K or Q^T of 32-token tile `tile`: [half][t] = feature HD sub + 4 g + t of token 16 half + i: one 16-byte piece per half
     auto load_kq = [&](Srd src, int tile, f32x4 (&dst)[2], unsigned base, int sub) {
 #pragma unroll
         for (int half = 0; half < 2; ++half)
-            dst[half] = srd_load(src, base + (unsigned)(tile * 1024 + (2 * sub + (g >> 1)) * 256 + (32 * (g & 1) + 16 * half + i) * 4) * 4u);
+            dst[half] = srd_load(src, base + (unsigned)(tile * 1024 + slot_of(sub) * 256 + (32 * (g & 1) + 16 * half + i) * 4) * 4u);
     };
-    // V^T of key tile kt: [kb] = keys 16 kb + 4 g + 0..3 of feature 16 sub + i
+    // V^T of key tile kt: [kb] = keys 16 kb + 4 g + 0..3 of feature HD sub + i
     auto load_v = [&](int kt, f32x4 (&dst)[2], unsigned base, int sub) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
-            dst[kb] = srd_load(vs, base + (unsigned)(kt * 1024 + (2 * kb + (g >> 1)) * 256 + (32 * (g & 1) + 16 * sub + i) * 4) * 4u);
+            dst[kb] = srd_load(vs, base + (unsigned)(kt * 1024 + (2 * kb + (g >> 1)) * 256 + (32 * (g & 1) + HD * sub + vfeat) * 4) * 4u);
     };
     auto mask_logits = [&](f32x4 (&sv)[2][2], int kt) {      // padded keys of the ragged last tile
 #pragma unroll
@@ -112,10 +122,10 @@ __device__ __forceinline__ void attn16_body(const float *__restrict__ q, const f
         // Q^T operand: (q + query bias) x log2 e / sqrt(16); padded query lanes of the ragged last query tile are zeroed (their results
         // are never stored, but the reference tests are wave-wide: attn_device.h)
         {
-            const f32x4 bq = *reinterpret_cast<const f32x4 *>(qbias + (pb % nblk) * kHeadDim + 16 * sub + 4 * g);   // features 4 g .. 4 g + 3 of the head
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(qbias + (pb % nblk) * kHeadDim + HD * sub + 4 * (HD == 16 ? g : (g & 1)));   // features 4 g .. 4 g + 3 of the head
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
-                const bool pad = ragged && qt == nkt - 1 && qt * kTile + 16 * qb + i >= tokens;
+                const bool pad = (ragged && qt == nkt - 1 && qt * kTile + 16 * qb + i >= tokens) || (HD == 8 && g >= 2);
                 qreg[qb] = pad ? f32x4{0.f, 0.f, 0.f, 0.f} : (qreg[qb] + bq) * scale_log2e;
             }
         }
@@ -242,10 +252,10 @@ __device__ __forceinline__ void attn16_body(const float *__restrict__ q, const f
         for (int qb = 0; qb < 2; ++qb) {
             const float l_run = groups_sum(lsum[qb][0] + lsum[qb][1]);
             const int qrow = qt * kTile + 16 * qb + i;
-            if (qrow < tokens) {
+            if (qrow < tokens && (HD == 16 || g < 2)) {
                 const float inv = 1.0f / l_run;
                 const unsigned grow = (unsigned)plane * tokens + qrow;
-                const unsigned dst = (((grow >> 5) * (unsigned)nblk + blk) * 1024 + (2 * sub + (g >> 1)) * 256 + ((grow & 31) + 32 * (g & 1)) * 4) * 4;
+                const unsigned dst = (((grow >> 5) * (unsigned)nblk + blk) * 1024 + slot_of(sub) * 256 + ((grow & 31) + 32 * (g & 1)) * 4) * 4;
                 srd_store(os, dst, (oacc[0][qb] + oacc[1][qb]) * inv);
             }
         }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, attn_waves_per_simd(HD)) void attn_kernel(cons
 
 // head dimension 16 on 16x16x4 MFMAs (attn16_device.h, round 6): the value product takes 16-row operands -- a head -- instead of a
 // whole 32-feature block; same task order and hand-out as attn_kernel
-template <int TOK = 0>
+template <int TOK = 0, int HD = 16>
 __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn16_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                       const float *__restrict__ vt, const float *__restrict__ qbias,
                                                                       float *__restrict__ out, int nblk, int tokens, int tokpad, int model_dim,
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256, AFT_ATTN_WAVES) void attn16_kernel(const float
     int vblock = blockIdx.x;
     if ((gridDim.x & 7) == 0) vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int total_waves = gridDim.x * 4, nfull = ntasks / total_waves * total_waves;
-    attn16_body<TOK>(q, k, vt, qbias, out, nblk, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, total_waves, nfull,
-                     partial_round_task(vblock, wave, ntasks));
+    attn16_body<TOK, HD>(q, k, vt, qbias, out, nblk, tokens, tokpad, model_dim, scale_log2e, vblock * 4 + wave, total_waves, nfull,
+                         partial_round_task(vblock, wave, ntasks));
 }
 
 // split-precision tier: K / Q^T / V^T arrive as bf16 hi / lo fragments from chain_split_kernel (attn_device.h)
@@ -137,6 +137,15 @@ hipError_t launch_attention(const aft_config &c, const float *q, const float *k,
         hipLaunchKernelGGL((attn_kernel<HD_>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim, \
                            scale_log2e, ntasks, no_stamps);                                                                           \
         return hipGetLastError();                                                                                                     \
+    }
+    if (hd == 8 && !switch_on("AFT_ATTN_HD8_MFMA32")) {       // late round 6: 16x16x4 MFMAs with half of every operand idle (attn16_device.h)
+        if (tokens == 280 && !switch_on("AFT_ATTN_GENERIC"))
+            hipLaunchKernelGGL((attn16_kernel<280, 8>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
+                               scale_log2e, ntasks);
+        else
+            hipLaunchKernelGGL((attn16_kernel<0, 8>), dim3(blocks), dim3(256), 0, st, q, k, vt, qbias, attn, nblk, tokens, tokpad, c.model_dim,
+                               scale_log2e, ntasks);
+        return hipGetLastError();
     }
     AFT_ATTN_HD(8) AFT_ATTN_HD(24) AFT_ATTN_HD(40) AFT_ATTN_HD(48)   // heads that start anywhere in a block (attn_device.h); covered, not tuned
 #undef AFT_ATTN_HD

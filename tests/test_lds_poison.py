@@ -40,6 +40,7 @@ FORWARD_CASES = {
     "default_B40_two_lanes": (dict(DEFAULT_SPEC), (7, 42, 560), 40),
     "forti_d256_h8": (dict(DEFAULT_SPEC, num_layers=2, model_dim=256, num_head=8), None, 9),
     "hd16_d128_h8": (dict(DEFAULT_SPEC, num_layers=2, num_head=8), (7, 42, 560), 5),
+    "hd8_d128_h16": (dict(DEFAULT_SPEC, num_layers=2, num_head=16), (7, 42, 560), 5),
     "hd48_d192_h4": (dict(DEFAULT_SPEC, num_layers=2, model_dim=192, num_head=4), None, 5),
     "tokens28": (dict(ofdm=(12, 14), pilot=(4, 2), patch=(3, 2), num_layers=2, model_dim=64, num_head=2), (7, 42, 56), 7),
     "grid_66x12_banded_conv": (dict(ofdm=(66, 12), pilot=(11, 3), patch=(3, 3), num_layers=1, model_dim=64, num_head=2), None, 3),
