@@ -630,13 +630,16 @@ def test_fused_reconstruction_end_matches_autograd(ofdm, patch, d, adaptive, pla
 
 def test_fused_ends_are_what_the_training_step_runs(switches):
     """The estimator's grad-enabled forward hands the encoder the conv-enhanced planes (fused ends) by default; with the switch
-    AFT_TRAIN_NO_FUSED_ENDS it runs PyTorch's unfold / cat / add around HipLinear as before: same loss and gradients to rounding."""
+    AFT_TRAIN_NO_FUSED_ENDS it runs PyTorch's unfold / cat / add around HipLinear as before.  The fused kernels keep the rounding
+    sequence of the launches they replace, so the loss and EVERY gradient that flows through them -- conv stacks, adapter, encoder
+    layers, pilot_upsampler -- have the same BITS either way; only the five parameter gradients the fused kernels sum themselves
+    (linear_1 weight / bias, the positional table, linear_2 weight / bias) come out in another summation order."""
     import adafortitran_amd as A
     from adafortitran_amd import synth
     sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
     torch.manual_seed(3)
     model = A.AdaFortiTranEstimator(sc, A.ModelConfig(model_type="adafortitran", patch_size=(3, 2), num_layers=2, model_dim=128, num_head=4,
-                                                      device="cuda", dropout=0.0, channel_adaptivity_hidden_sizes=[7, 42, 560],
+                                                      device="cuda", dropout=0.1, channel_adaptivity_hidden_sizes=[7, 42, 560],
                                                       adaptive_token_length=6)).train()
     inp = synth.make_inputs(4, seed=10)
     pil, tgt = torch.from_numpy(inp["pilots"]), torch.from_numpy(inp["target"]).to("cuda")
@@ -644,9 +647,10 @@ def test_fused_ends_are_what_the_training_step_runs(switches):
 
     def run():
         model.zero_grad()
+        torch.manual_seed(77)            # the same dropout seeds in both runs
         loss = torch.view_as_real(model(pil, meta) - tgt).pow(2).mean()
         loss.backward()
-        return [loss.detach().clone()] + [p.grad.clone() for p in model.parameters()]
+        return {"loss": loss.detach().clone(), **{n: p.grad.clone() for n, p in model.named_parameters()}}
 
     probe = torch.zeros(8, 120, 14, device="cuda")
     enc = model.transformer_encoder
@@ -659,10 +663,13 @@ def test_fused_ends_are_what_the_training_step_runs(switches):
     with torch.no_grad():
         switches.unset("AFT_TRAIN_NO_FUSED_ENDS")
         assert not enc.fused_ends_ok(probe, (3, 2))          # inference never takes the training kernels
-    for i, (a, c) in enumerate(zip(fused, apart)):
-        # the adapter's first layers are sums of ~1e5 cancelling terms of 1e-4 (2e-4 of |g|max between two summation orders; the
-        # float64 fixtures of test_train_golden.py hold every tensor of the fused path to its measured conditioning)
-        assert _rel(a, c) <= 1e-3, (i, _rel(a, c))
+    own = {"transformer_encoder.linear_1.weight", "transformer_encoder.linear_1.bias", "transformer_encoder.linear_2.weight",
+           "transformer_encoder.linear_2.bias", "transformer_encoder.positional_encoding.position_embeddings"}
+    for n in fused:
+        if n in own:
+            assert _rel(fused[n], apart[n]) <= 2e-5, (n, _rel(fused[n], apart[n]))
+        else:
+            assert torch.equal(fused[n], apart[n]), n
 
 
 def _random_train_specs(n, seed):
