@@ -672,6 +672,41 @@ def test_fused_ends_are_what_the_training_step_runs(switches):
             assert torch.equal(fused[n], apart[n]), n
 
 
+@pytest.mark.parametrize("batch,reps", [(128, 40), (64, 40), (6, 60)])
+def test_training_step_soak_same_bits_every_time(batch, reps):
+    """The whole training step (dropout on, same seeds) run `reps` times back to back on one stream: loss and every gradient must come
+    out with the SAME BITS every time -- the hand-overs inside the kernels (LDS exchanges, wave-private regions, the slice reductions'
+    fixed order) leave no room for a timing-dependent result.  128 frames (one conv range, twelve-wave attention backward), 64 frames
+    (two conv ranges, three-wave workgroups), 6 frames (four ranges, partial tiles everywhere).  Differences are counted on the device:
+    one synchronisation at the end."""
+    import adafortitran_amd as A
+    from adafortitran_amd import synth
+    sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
+    torch.manual_seed(12)
+    model = A.AdaFortiTranEstimator(sc, A.ModelConfig(model_type="adafortitran", patch_size=(3, 2), num_layers=6, model_dim=128, num_head=4,
+                                                      device="cuda", dropout=0.1, channel_adaptivity_hidden_sizes=[7, 42, 560],
+                                                      adaptive_token_length=6)).train()
+    inp = synth.make_inputs(batch, seed=13)
+    pil, tgt = torch.from_numpy(inp["pilots"]).cuda(), torch.from_numpy(inp["target"]).cuda()
+    meta = tuple(m.cuda() if hasattr(m, "cuda") else m for m in synth.meta_tuple(inp))
+    params = list(model.parameters())
+
+    def run():
+        for p in params:
+            p.grad = None
+        torch.manual_seed(99)
+        loss = torch.view_as_real(model(pil, meta) - tgt).pow(2).mean()
+        loss.backward()
+        return torch.cat([loss.detach().reshape(1)] + [p.grad.reshape(-1) for p in params])
+
+    ref = run().clone()
+    assert torch.isfinite(ref).all()
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    for _ in range(reps):
+        bad += (run().view(torch.int32) != ref.view(torch.int32)).sum()
+    assert int(bad) == 0, int(bad)
+
+
 def _random_train_specs(n, seed):
     rng = np.random.default_rng(seed)
     out = []
