@@ -663,6 +663,9 @@ def next_rows(wl):
     tr = out["train_bench"].measure(batch=128, steps=10, warmup=3, model_name="adafortitran", dropout=0.1, modes=("hip",))
     rec = {"f1_train_step_ms": round(tr["hip"], 3),
            "f1_frac_of_fp32_roof": round(3 * fl["forward_total"] / (tr["hip"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    # the reference's default batch (src/main/parser.py:81): 64 frames per step
+    tr64 = out["train_bench"].measure(batch=64, steps=10, warmup=3, model_name="adafortitran", dropout=0.1, modes=("hip",))
+    rec["f1_train_step_ms_batch64"] = round(tr64["hip"], 3)
     nr = out["next_rows_bench"].measure(frames=4096, batch=128)
     rec.update({"f2_gather_GBs": nr["f2_pilot_gather"]["GB_per_s"], "f2_gather_hbm_frac": nr["f2_pilot_gather"]["frac_of_hbm_peak"],
                 "f2_loader_fps": nr["f2_packed_loader"]["frames_per_s"],
