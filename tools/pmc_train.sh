@@ -10,7 +10,7 @@ for d in ("gpurun_out/t4/p1", "gpurun_out/t4/p2"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(p)):
-            agg[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(d + "_summary.txt", "w") as f:
         for n, c in sorted(agg.items()):
             if not n.startswith("aft::") and "aft" not in n: continue
