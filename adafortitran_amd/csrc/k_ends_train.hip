@@ -218,6 +218,110 @@ __global__ __launch_bounds__(256) void embed_rows_bwd_kernel(const EmbedBwdArgs 
     }
 }
 
+// ---- embed backward of the default model (d = 128, at most 16 input features): both products of a pass on 16x16x4 MFMAs ----
+// The generic kernel above is bound by its vector ALU and LDS reads (PMC: 3 500 vector instructions per wave, 57 % of the kernel's
+// cycles; as many LDS bank-conflict cycles as LDS instructions): per pass a thread issues ~450 FMAs with two LDS reads each.  An fp32
+// MFMA is that same FMA chain, fed 16 x 4 operands per instruction:
+//     d_in[32 rows][16 f] = dh[32][128] . W1[128][16]      two row blocks (waves 0, 1) x 32 steps over c, ascending
+//     dW1[128 c][16 f]   += dh^T[128][32] . in[32][16]      eight c blocks (two per wave) x 8 steps over the pass's rows, ascending
+// -- 128 matrix instructions per pass and workgroup instead of ~4 700 vector ones per wave, operands read from LDS once per 16 x 4
+// tile (dh rows padded to 132 floats: the d_in reads are conflict-free), the same summation order as the generic kernel: same bits.
+__global__ __launch_bounds__(256) void embed_rows_bwd128_kernel(const EmbedBwdArgs a) {
+    constexpr int D = 128, LDH = D + 4, FP = 16, ROWS = kEmbPass * kEmbTok;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const EndsDims &g = a.g;
+    float *w1t = lds;                // [16][LDH]: W1^T, rows >= din zero
+    float *dhs = w1t + FP * LDH;     // [32][LDH]: the pass's gradient rows (plane-major, 8 tokens each)
+    float *ins = dhs + ROWS * LDH;   // [32][16]: the pass's input features, columns >= din zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int t0 = blockIdx.x * kEmbTok, nrow = min(kEmbTok, g.tokens - t0), nout = D * g.din;
+    const int n0 = blockIdx.y * a.planes_per_chunk, n1 = min(g.planes, n0 + a.planes_per_chunk);
+    const size_t plane_px = (size_t)g.S * g.T;
+    for (int i = tid; i < FP * D; i += 256) {
+        const int f = i >> 7, c = i & (D - 1);
+        w1t[f * LDH + c] = f < g.din ? a.w1[c * g.din + f] : 0.f;
+    }
+    // what does not change from pass to pass: the staging piece (row, quad) of this thread, its gather item (row r, feature f; planes
+    // pl and pl + 2 of the pass) and -- waves 0, 1 -- the four d_in results it stores (rows 4 (g4 & 1) + v of plane 2 wave + g4 / 2)
+    const int srow = tid >> 5, sq = tid & 31;
+    const int gr = (tid >> 4) & 7, gf = tid & 15, gpl = tid >> 7;
+    const bool gvalid = gf < g.din && gr < nrow;
+    const int goff = gf < g.p ? patch_pixel(g, t0 + min(gr, nrow - 1), gf) : (t0 + gr) * 6 + (gf - g.p);
+    const int opl = 2 * wave + (g4 >> 1);
+    int ooff[4];
+    bool ovalid[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = 4 * (g4 & 1) + v;
+        ovalid[v] = wave < 2 && i16 < g.din && r < nrow;
+        ooff[v] = i16 < g.p ? patch_pixel(g, t0 + min(r, nrow - 1), i16) : (t0 + r) * 6 + (i16 - g.p);
+    }
+    f32x4 dpos = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dw[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int nb = n0; nb < n1; nb += kEmbPass) {
+        const int np = min(kEmbPass, n1 - nb);
+        __syncthreads();   // the previous pass's readers are done with dhs / ins
+#pragma unroll
+        for (int pl = 0; pl < kEmbPass; ++pl) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pl < np && srow < nrow) v = *reinterpret_cast<const f32x4 *>(a.dx + ((size_t)(nb + pl) * g.tokens + t0) * D + (size_t)tid * 4);
+            dpos += v;
+            *reinterpret_cast<f32x4 *>(dhs + (pl * kEmbTok + srow) * LDH + 4 * sq) = v;   // (planes beyond the chunk: zero rows)
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int pl = gpl + 2 * m;
+            float v = 0.f;
+            if (gvalid && pl < np) {
+                const size_t n = (size_t)(nb + pl);
+                v = gf < g.p ? a.conv[n * plane_px + goff] : a.tok6[n * g.tokens * 6 + goff];
+            }
+            ins[(pl * kEmbTok + gr) * FP + gf] = v;
+        }
+        __syncthreads();
+        if (wave < 2) {   // d_in rows 16 wave .. 16 wave + 15: A[i][k] = dh[16 wave + i][4 s + k], B[k][j] = W1[4 s + k][j]
+            const float *ap = dhs + (16 * wave + i16) * LDH + g4, *bp = w1t + i16 * LDH + g4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int s = 0; s < D / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], bp[4 * s], acc, 0, 0, 0);
+            if (opl < np) {
+                const size_t n = (size_t)(nb + opl);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {   // D[i = 4 g4 + v][j = i16]
+                    if (!ovalid[v]) continue;
+                    if (i16 < g.p) a.d_conv[n * plane_px + ooff[v]] = acc[v];
+                    else a.d_tok6[n * g.tokens * 6 + ooff[v]] = acc[v];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {   // dW1 rows c = 16 (2 wave + u) + ..: A[i][k] = dh[4 s + k][16 cb + i], B[k][j] = in[4 s + k][j]
+            const float *ap = dhs + g4 * LDH + 16 * (2 * wave + u) + i16, *bp = ins + g4 * FP + i16;
+#pragma unroll
+            for (int s = 0; s < ROWS / 4; ++s) dw[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s * LDH], bp[4 * s * FP], dw[u], 0, 0, 0);
+        }
+    }
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (i16 < g.din) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a.sl_w[wg * nout + (size_t)(16 * (2 * wave + u) + 4 * g4 + v) * g.din + i16] = dw[u][v];
+    }
+    __syncthreads();
+    float *tmp = dhs;   // [8][D]: the table's gradient rows of this chunk, for their column sums (= the bias gradient's share)
+    *reinterpret_cast<f32x4 *>(tmp + tid * 4) = dpos;
+    if (a.sl_pos != nullptr && srow < nrow)
+        *reinterpret_cast<f32x4 *>(a.sl_pos + ((size_t)blockIdx.y * g.tokens + t0) * D + (size_t)tid * 4) = dpos;
+    __syncthreads();
+    if (tid < D) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < kEmbTok; ++r) sum += tmp[r * D + tid];
+        a.sl_b[wg * D + tid] = sum;
+    }
+}
+
 // ---- tail forward: persistent workgroups, W2 in LDS once, 32-row tiles of x through LDS ----
 struct TailFwdArgs {
     EndsDims g;
@@ -417,10 +521,14 @@ hipError_t launch_embed_train_bwd(const float *conv, const float *tok6, const fl
     a.sl_pos = dpos != nullptr ? a.sl_b + al64((size_t)tb * ch * g.d) : nullptr;
     const size_t lds = sizeof(float) * ((size_t)g.din * (g.d + 4) + (size_t)kEmbPass * kEmbTok * (g.d + g.din));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static PerDeviceOnce attr[3];
+    static PerDeviceOnce attr[4];
     const int nout = (g.d * g.din + 255) / 256, npiece = (kEmbTok * (g.d / 4) + 255) / 256;
     hipError_t e;
-    if (nout <= 8 && npiece <= 1) {
+    if (g.d == 128 && g.din <= 16 && !switch_on("AFT_EMBED_BWD_GENERIC")) {   // the default model: both products on MFMAs
+        const size_t lds128 = sizeof(float) * ((16 + kEmbPass * kEmbTok) * (128 + 4) + kEmbPass * kEmbTok * 16);
+        if ((e = ensure_dynamic_lds(attr[3], reinterpret_cast<const void *>(embed_rows_bwd128_kernel), 160 * 1024)) != hipSuccess) return e;
+        hipLaunchKernelGGL(embed_rows_bwd128_kernel, dim3(tb, chunks), dim3(256), lds128, st, a);
+    } else if (nout <= 8 && npiece <= 1) {
         if ((e = ensure_dynamic_lds(attr[0], reinterpret_cast<const void *>(embed_rows_bwd_kernel<8, 1>), 160 * 1024)) != hipSuccess) return e;
         hipLaunchKernelGGL((embed_rows_bwd_kernel<8, 1>), dim3(tb, chunks), dim3(256), lds, st, a);
     } else if (nout <= 24) {

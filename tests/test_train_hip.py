@@ -596,6 +596,41 @@ def test_fused_embedding_end_matches_autograd(ofdm, patch, d, adaptive, planes):
     assert pos.grad is None and torch.equal(conv.grad, g1[0]) and torch.equal(w.grad, g1[-3])
 
 
+@pytest.mark.parametrize("ofdm,patch,adaptive,planes", [((120, 14), (3, 2), True, 4), ((120, 14), (3, 2), False, 2), ((12, 14), (3, 2), True, 256),
+                                                         ((120, 14), (3, 2), True, 256), ((48, 16), (4, 4), False, 6), ((60, 14), (5, 2), True, 18)])
+def test_embedding_backward_on_mfmas_has_the_vector_kernels_bits(ofdm, patch, adaptive, planes, switches):
+    """The default model's embedding backward (model_dim 128, at most 16 input features) runs both of its products on 16x16x4 MFMAs
+    (embed_rows_bwd128_kernel); switch AFT_EMBED_BWD_GENERIC keeps the vector-ALU kernel every other shape runs.  An fp32 MFMA is an
+    FMA chain in k order and the two kernels visit c / the rows in the same order: every output -- d(conv_enhanced),
+    d(adapter tokens), dW1, db1, the table's gradient -- has the same bits.  Full and partial token blocks, 2 .. 256 planes (one to many
+    passes per workgroup, a last pass with fewer than four planes), 6 / 10 / 12 / 16 input features."""
+    from adafortitran_amd.training import HipEmbedFunction
+    torch.manual_seed(planes + ofdm[0])
+    S, T = ofdm
+    p, d = patch[0] * patch[1], 128
+    tokens, K = (S // patch[0]) * (T // patch[1]), p + (6 if adaptive else 0)
+    conv = torch.randn(planes, S, T, device="cuda", requires_grad=True)
+    tok6 = torch.randn(planes, tokens, 6, device="cuda", requires_grad=True) if adaptive else None
+    w = (torch.randn(d, K, device="cuda") / K ** 0.5).requires_grad_(True)
+    b = torch.randn(d, device="cuda", requires_grad=True)
+    pos = torch.randn(1, tokens + 3, d, device="cuda", requires_grad=True)
+    gy = torch.randn(planes, tokens, d, device="cuda")
+    leaves = [t for t in (conv, tok6, w, b, pos) if t is not None]
+
+    def grads():
+        for t in leaves:
+            t.grad = None
+        HipEmbedFunction.apply(conv, tok6, w, b, pos, patch).backward(gy)
+        return [t.grad.clone() for t in leaves]
+
+    switches.unset("AFT_EMBED_BWD_GENERIC")
+    fast = grads()
+    switches.set("AFT_EMBED_BWD_GENERIC", "1")
+    generic = grads()
+    for i, (x, y) in enumerate(zip(fast, generic)):
+        assert torch.isfinite(x).all() and torch.equal(x, y), i
+
+
 @pytest.mark.parametrize("ofdm,patch,d,adaptive,planes", ENDS_CASES)
 def test_fused_reconstruction_end_matches_autograd(ofdm, patch, d, adaptive, planes):
     """training.HipTailFunction (linear_2 + inverse patch embedding + the residual: one launch each way) against the PyTorch composite
