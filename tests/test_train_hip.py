@@ -271,24 +271,25 @@ def test_dropout_keep_rate():
     assert torch.allclose(vals, torch.full_like(vals, 1 / (1 - p)))
 
 
-def _model(name, dropout):
+def _model(name, dropout, pos="learnable"):
     import adafortitran_amd as A
     sc = A.SystemConfig(ofdm=dict(num_scs=120, num_symbols=14), pilot=dict(num_scs=12, num_symbols=2))
     kw = dict(model_type=name, patch_size=(3, 2), num_layers=2, model_dim=128, num_head=4, activation="gelu",
-              max_seq_len=512, pos_encoding_type="learnable", device="cuda", dropout=dropout)
+              max_seq_len=512, pos_encoding_type=pos, device="cuda", dropout=dropout)
     if name == "adafortitran":
         kw.update(channel_adaptivity_hidden_sizes=[7, 42, 560], adaptive_token_length=6)
     cls = A.AdaFortiTranEstimator if name == "adafortitran" else A.FortiTranEstimator
     return cls(sc, A.ModelConfig(**kw))
 
 
-@pytest.mark.parametrize("name", ["fortitran", "adafortitran"])
-def test_full_model_training_step_matches_pytorch_autograd(name):
+@pytest.mark.parametrize("name,pos", [("fortitran", "learnable"), ("adafortitran", "learnable"), ("adafortitran", "sinusoidal")])
+def test_full_model_training_step_matches_pytorch_autograd(name, pos):
     """loss.backward() through the whole estimator: encoder on the HIP training kernels vs the same
-    module differentiated entirely by PyTorch-ROCm, dropout 0, identical parameters and batch."""
+    module differentiated entirely by PyTorch-ROCm, dropout 0, identical parameters and batch.  (sinusoidal: the positional table is
+    a buffer -- the fused embedding end is asked for no table gradient.)"""
     from adafortitran_amd import synth
     torch.manual_seed(0)
-    model = _model(name, 0.0).train()
+    model = _model(name, 0.0, pos).train()
     B = 6
     inp = synth.make_inputs(B, seed=5)
     pil = torch.from_numpy(inp["pilots"]).cuda()
@@ -314,7 +315,9 @@ def test_full_model_training_step_matches_pytorch_autograd(name):
     assert abs(loss_hip - loss_ref) <= 1e-5 * abs(loss_ref)
     assert g_ref.keys() == g_hip.keys()
     for n in g_ref:
-        assert _rel(g_hip[n], g_ref[n]) <= 5e-4, n
+        # (the adapter feeds raw conditions -- Doppler 1400, delay spread 350 -- through three MLPs: every fp32 evaluation of its
+        #  gradients carries ~1e-4 .. 1e-3 of chaotic noise, tests/test_train_golden.py)
+        assert _rel(g_hip[n], g_ref[n]) <= (2e-3 if n.startswith("channel_adapter") else 5e-4), n
 
 
 def test_training_reduces_the_loss_with_dropout():
